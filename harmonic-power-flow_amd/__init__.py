@@ -1,0 +1,10 @@
+"""harmonic-power-flow on MI355X: the Newton-Raphson hot path of pweigmann/harmonic-power-flow's `hpf()` as
+hand-written HIP (gfx950) behind the reference's own Python call shapes.  See DESIGN.md / INTEGRATION.md."""
+from .settings import Settings
+from .api import (AdmittanceSet, build_admittance_matrices, build_harmonic_jacobian, get_THD, harmonic_mismatch,
+                  harmonic_state_vector, hpf, import_Norton_Equivalents, init_network, init_voltages, pf, solve)
+from .device import DeviceModel
+
+__all__ = ["Settings", "AdmittanceSet", "DeviceModel", "build_admittance_matrices", "build_harmonic_jacobian",
+           "get_THD", "harmonic_mismatch", "harmonic_state_vector", "hpf", "import_Norton_Equivalents",
+           "init_network", "init_voltages", "pf", "solve"]

@@ -1,0 +1,262 @@
+"""The reference's call shapes (`Harmonic Power Flow/hcne_generalized.py`, HG) on top of the HIP library.
+
+Same names, argument meaning, return objects and printed warnings as the reference: `init_network` HG:113,
+`build_admittance_matrices` HG:132, `import_Norton_Equivalents` HG:278, `pf` HG:244, `hpf` HG:511,
+`harmonic_mismatch` HG:360, `build_harmonic_jacobian` HG:401, `update_harmonic_state_vec` HG:476, `get_THD` HG:563,
+plus the `solve` convenience wrapper the north-star asks for.  The reference reads module globals (`buses, m, n, c,
+HARMONICS, base_*`); here they live in an explicit `Settings` object, with a module-level
+default (`settings`) and a "current network" context filled by `init_network`, so reference-style scripts keep
+working unchanged.
+
+Everything numerical runs on the GPU through `DeviceModel`; nothing here falls back to the CPU.
+"""
+import numpy as np
+import pandas as pd
+import scipy.sparse as sp
+
+from . import admittance, ingest
+from .device import DeviceModel
+from .settings import Settings
+
+settings = Settings()          # module-level defaults, HG:578-593
+_ctx = {"buses": None, "lines": None}
+
+
+class AdmittanceSet:
+    """Per-harmonic admittance matrices in device layout (shared CSR pattern).  `to_frame()` gives the reference's
+    dense `Y_all` DataFrame."""
+
+    def __init__(self, rowptr, col, Yval, harmonics, n):
+        self.rowptr, self.col, self.Yval, self.harmonics, self.n = rowptr, col, Yval, list(harmonics), n
+
+    def to_frame(self):
+        return admittance.to_dense_frame(self.rowptr, self.col, self.Yval, self.harmonics, self.n)
+
+    def dense(self, h):
+        q = self.harmonics.index(h)
+        return sp.csr_matrix((self.Yval[q], self.col, self.rowptr), shape=(self.n, self.n)).toarray()
+
+
+def _as_admittance(Y, harmonics, n):
+    if isinstance(Y, AdmittanceSet):
+        return Y
+    rowptr, col, Yval = admittance.from_dense_frame(Y, harmonics, n)
+    return AdmittanceSet(rowptr, col, Yval, harmonics, n)
+
+
+def init_network(filename_buses, filename_lines, from_csv=True, settings=None):
+    """HG:113-128."""
+    st = settings or globals()["settings"]
+    buses, lines, m, n, c = ingest.init_network(filename_buses, filename_lines, from_csv, st)
+    _ctx["buses"], _ctx["lines"] = buses, lines
+    return buses, lines, m, n, c
+
+
+def build_admittance_matrices(buses, lines, harmonics):
+    """HG:132-171 -> AdmittanceSet (call `.to_frame()` for the reference's DataFrame)."""
+    rowptr, col, Yval = admittance.build_admittance_csr(buses, lines, list(harmonics))
+    return AdmittanceSet(rowptr, col, Yval, harmonics, len(buses))
+
+
+def import_Norton_Equivalents(buses, coupled, settings=None, ne_dir=None):
+    """HG:278-310."""
+    return ingest.import_Norton_Equivalents(buses, coupled, settings or globals()["settings"], ne_dir)
+
+
+def init_voltages(buses, harmonics):
+    """HG:174-184."""
+    idx = pd.MultiIndex.from_product([list(harmonics), buses.index.values], names=["harmonic", "bus"])
+    V = pd.DataFrame(np.zeros((len(harmonics) * len(buses), 2)), index=idx, columns=["V_m", "V_a"])
+    V.iloc[:len(buses), 0] = 1
+    V.iloc[len(buses):, 0] = 0.1
+    return V
+
+
+def _frame(Vm, Va, harmonics, n):
+    idx = pd.MultiIndex.from_product([list(harmonics), list(range(n))], names=["harmonic", "bus"])
+    return pd.DataFrame({"V_m": np.asarray(Vm), "V_a": np.asarray(Va)}, index=idx)
+
+
+def _device_model(buses, Y, NE, coupled, harmonics, solver="auto", max_scenarios=1, device=0):
+    m, n, c = ingest.network_constants(buses)
+    Hn = len(harmonics)
+    if NE is None:
+        dev = np.full(n, -1, dtype=np.int32)
+        dev[m:] = 0
+        Y_N = np.zeros((1, Hn, Hn) if coupled else (1, Hn), dtype=np.complex128)
+        I_N = np.zeros((1, Hn), dtype=np.complex128)
+        n_dev = 1
+    else:
+        dev, Y_N, I_N, n_dev = ingest.norton_arrays(buses, NE, coupled, Hn)
+    return DeviceModel(n, m, c, harmonics, Y.rowptr, Y.col, Y.Yval, dev, Y_N, I_N, n_dev, coupled,
+                       solver=solver, device=device, max_scenarios=max_scenarios)
+
+
+def pf(Y, buses, thresh_f=1e-6, max_iter_f=30, plt_convergence=False, settings=None, verbose=True, _model=None):
+    """HG:244-275 -> (V, err_t, n_iter_f): fundamental Newton-Raphson on the device from the reference's start
+    (1 p.u. / 0.1 p.u., angle 0)."""
+    st = settings or globals()["settings"]
+    n = len(buses)
+    Y = _as_admittance(Y, st.HARMONICS, n)
+    dm = _model or _device_model(buses, Y, None, False, Y.harmonics, solver="dense")
+    try:
+        dm.set_loads(buses["P"].to_numpy(dtype=float), buses["Q"].to_numpy(dtype=float))
+        dm.set_state(None, None, n_scen=1)
+        n_iter, err, hist = dm.fund_pf(thresh_f, max_iter_f)
+        Vm, Va = dm.get_state()
+    finally:
+        if _model is None:
+            dm.close()
+    n_iter_f = int(n_iter[0])
+    err_t = {i: float(hist[0, i]) for i in range(n_iter_f)}
+    V = _frame(Vm[0], Va[0], Y.harmonics, n)
+    if plt_convergence:
+        import matplotlib.pyplot as plt
+        plt.plot(list(err_t.keys()), list(err_t.values()))
+    if verbose:
+        print(V.loc[Y.harmonics[0]])
+        if n_iter_f < max_iter_f:
+            print("Fundamental power flow converged after " + str(n_iter_f) + " iterations.")
+        elif n_iter_f == max_iter_f:
+            print("Warning! Maximum of " + str(n_iter_f) + " iterations reached.")
+    return V, err_t, n_iter_f
+
+
+def _postprocess(Vm, Va):
+    """HG:545-549."""
+    Vm, Va = Vm.copy(), Va.copy()
+    neg = Vm < 0
+    Va[neg] += np.pi
+    Va = Va % (2 * np.pi)
+    Vm[neg] = -Vm[neg]
+    return Vm, Va
+
+
+def _jac_to_csr(Jd):
+    return sp.csr_matrix(Jd)
+
+
+def hpf(buses, lines, coupled, thresh_h=1e-4, max_iter_h=50, plt_convergence=False, settings=None, ne_dir=None,
+        solver="auto", verbose=True, return_jacobian=True, details=None):
+    """HG:511-560 -> (V, err_h, n_iter_h, J).
+
+    `J` is the Jacobian of the last iteration as scipy CSR like the reference (only materialised for N <= 4096,
+    else None).  `details`, if a dict, receives err_hist, the pf seed, n_iter_f, solver name and device stats."""
+    st = settings or globals()["settings"]
+    harmonics = st.HARMONICS
+    n = len(buses)
+    Y = build_admittance_matrices(buses, lines, harmonics)                       # HG:523
+    NE = import_Norton_Equivalents(buses, coupled, st, ne_dir)                    # HG:528
+    dm = _device_model(buses, Y, NE, coupled, harmonics, solver=solver)
+    try:
+        dm.set_loads(buses["P"].to_numpy(dtype=float), buses["Q"].to_numpy(dtype=float))
+        dm.set_state(None, None, n_scen=1)
+        nf, ef, hf = dm.fund_pf(st.thresh_f, st.max_iter_f)                       # HG:525 (pf with its defaults)
+        seed = dm.get_state()
+        if verbose:
+            Vs = _frame(seed[0][0], seed[1][0], harmonics, n)
+            print(Vs.loc[harmonics[0]])
+            if int(nf[0]) < st.max_iter_f:
+                print("Fundamental power flow converged after " + str(int(nf[0])) + " iterations.")
+            else:
+                print("Warning! Maximum of " + str(int(nf[0])) + " iterations reached.")
+        n_iter, err, hist = dm.solve(thresh_h, max_iter_h)                        # HG:530-542
+        Vm_raw, Va_raw = dm.get_state()
+        n_iter_h = int(n_iter[0])
+        J = None
+        if return_jacobian and n_iter_h > 0 and dm.N <= 4096:
+            # the reference returns the Jacobian built in the last iteration, i.e. at the state before the last update
+            # deterministic replay up to that state, then one assembly (small systems only)
+            dm.set_state(seed[0], seed[1])
+            dm.solve(thresh_h, n_iter_h - 1)
+            J = _jac_to_csr(dm.jacobian(0))
+        if details is not None:
+            details.update(err_hist=hist[0, :n_iter_h + 1].copy(), seed=(seed[0][0].copy(), seed[1][0].copy()),
+                           n_iter_f=int(nf[0]), err_f=hf[0, :int(nf[0])].copy(), solver=dm.solver,
+                           stats=dm.stats(), Vm_raw=Vm_raw[0].copy(), Va_raw=Va_raw[0].copy(), N=dm.N)
+    finally:
+        dm.close()
+    Vm, Va = _postprocess(Vm_raw[0], Va_raw[0])                                   # HG:545-549
+    V = _frame(Vm, Va, harmonics, n)
+    err_h = float(err[0])
+    if plt_convergence:
+        import matplotlib.pyplot as plt
+        plt.plot(range(n_iter_h), hist[0, 1:n_iter_h + 1])
+    if verbose:
+        print(V)
+        if n_iter_h < max_iter_h:
+            print("Harmonic power flow converged after " + str(n_iter_h) + " iterations.")
+        elif n_iter_h == max_iter_h:
+            print("Warning! Maximum of " + str(n_iter_h) + " iterations reached.")
+    return V, err_h, n_iter_h, J
+
+
+def _state_arrays(V):
+    return (np.ascontiguousarray(V["V_m"].to_numpy(dtype=float)), np.ascontiguousarray(V["V_a"].to_numpy(dtype=float)))
+
+
+def harmonic_mismatch(V, Y, buses, NE, settings=None):
+    """HG:360-390 -> (f, err_h) for the voltages in DataFrame `V`."""
+    st = settings or globals()["settings"]
+    n = len(buses)
+    harmonics = list(dict.fromkeys(V.index.get_level_values(0)))
+    Y = _as_admittance(Y, harmonics, n)
+    coupled = np.asarray(next(iter(NE.values()))[1]).shape[0] > 1 if NE else False
+    dm = _device_model(buses, Y, NE, coupled, harmonics, solver="dense")
+    try:
+        dm.set_loads(buses["P"].to_numpy(dtype=float), buses["Q"].to_numpy(dtype=float))
+        dm.set_state(*_state_arrays(V))
+        f, err = dm.mismatch()
+    finally:
+        dm.close()
+    return f[0], float(err[0])
+
+
+def build_harmonic_jacobian(V, Y, NE, coupled, buses=None):
+    """HG:401-473 -> real scipy CSR matrix in the reference's row/column order."""
+    buses = buses if buses is not None else _ctx["buses"]
+    if buses is None:
+        raise ValueError("pass buses= or call init_network first (the reference reads the global `buses`)")
+    n = len(buses)
+    harmonics = list(dict.fromkeys(V.index.get_level_values(0)))
+    Y = _as_admittance(Y, harmonics, n)
+    dm = _device_model(buses, Y, NE, coupled, harmonics, solver="dense")
+    try:
+        dm.set_loads(buses["P"].to_numpy(dtype=float), buses["Q"].to_numpy(dtype=float))
+        dm.set_state(*_state_arrays(V))
+        J = dm.jacobian(0)
+    finally:
+        dm.close()
+    return _jac_to_csr(J)
+
+
+def harmonic_state_vector(V, c=None, buses=None):
+    """HG:393-398."""
+    if c is None:
+        b = buses if buses is not None else _ctx["buses"]
+        c = ingest.network_constants(b)[2]
+    return np.append(V.V_a.to_numpy()[1:], V.V_m.to_numpy()[c:])
+
+
+def get_THD(V):
+    """HG:563-572 -> DataFrame[THD_F, THD_R] per bus (harmonic labels >= 3 are the non-fundamental rows)."""
+    harmonics = list(dict.fromkeys(V.index.get_level_values(0)))
+    n = len(V) // len(harmonics)
+    Vm = V["V_m"].to_numpy(dtype=float).reshape(len(harmonics), n)
+    THD = pd.DataFrame(np.zeros((n, 2)), columns=["THD_F", "THD_R"])
+    for b in range(n):
+        hs = sum(Vm[1:, b] ** 2)
+        THD.loc[b, "THD_F"] = np.sqrt(hs) / Vm[0, b]
+        THD.loc[b, "THD_R"] = np.sqrt(hs) / np.sqrt(sum(Vm[:, b] ** 2))
+    return THD
+
+
+def solve(filename_buses, filename_lines, coupled=True, settings=None, ne_dir=None, solver="auto", verbose=False):
+    """Convenience wrapper (= init_network + hpf + get_THD) -> dict(V, err_h, n_iter_h, THD, details)."""
+    st = settings or globals()["settings"]
+    buses, lines, m, n, c = init_network(filename_buses, filename_lines, settings=st)
+    details = {}
+    V, err_h, n_iter_h, J = hpf(buses, lines, coupled, st.thresh_h, st.max_iter_h, settings=st, ne_dir=ne_dir,
+                                solver=solver, verbose=verbose, details=details)
+    return {"V": V, "err_h": err_h, "n_iter_h": n_iter_h, "THD": get_THD(V), "details": details,
+            "converged": n_iter_h < st.max_iter_h}

@@ -1,0 +1,35 @@
+"""Build libhpf.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+SOURCES = ["hpf_lib.hip", "hpf_block.hip"]
+HEADERS = ["hpf_assembly.hpp", "hpf_internal.hpp", os.path.join("..", "..", "include", "hpf.h")]
+OUT = os.path.join(HERE, "libhpf.so")
+ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
+
+
+def needs_build():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build_lib(force=False, verbose=False):
+    if not force and not needs_build():
+        return OUT
+    cmd = [os.path.join(ROCM, "bin", "hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+           "-Wno-unused-value", "-fPIC", "-shared"] + [os.path.join(CSRC, f) for f in SOURCES] + \
+          ["-o", OUT, "-L" + os.path.join(ROCM, "lib"), "-lrocsolver", "-lrocblas",
+           "-Wl,-rpath," + os.path.join(ROCM, "lib")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build_lib(force=True, verbose=True))

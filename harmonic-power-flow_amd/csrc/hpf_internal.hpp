@@ -1,0 +1,114 @@
+// Internal declarations shared by the translation units of libhpf.so (not part of the public ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rocblas/rocblas.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "../../include/hpf.h"
+#include "hpf_assembly.hpp"
+
+namespace hpf {
+
+enum { T_MISMATCH = 0, T_JACOBIAN = 1, T_SOLVE = 2, T_UPDATE = 3, T_COUNT = 4 };
+
+struct TimedSpan {
+    int which;
+    hipEvent_t e0, e1;
+};
+
+// Feeder-tree description for the BLOCK_TREE solver (host copies + device copies).
+struct Tree {
+    int n_levels = 0;                 // elimination levels (by height, leaves first)
+    int n_depths = 0;                 // back-substitution levels (by depth, root first)
+    std::vector<int> parent;          // [n], -1 for the root (bus 0)
+    std::vector<int> lvl_ptr;         // [n_levels+1] into lvl_nodes
+    std::vector<int> lvl_nodes;       // nodes grouped by height
+    std::vector<int> dep_ptr;         // [n_depths+1] into dep_nodes
+    std::vector<int> dep_nodes;       // nodes grouped by depth
+    std::vector<int> child_ptr;       // [n+1]
+    std::vector<int> child;           // children lists
+    int* d_parent = nullptr;
+    int* d_lvl_nodes = nullptr;
+    int* d_dep_nodes = nullptr;
+    int* d_child_ptr = nullptr;
+    int* d_child = nullptr;
+    int* d_e_up = nullptr;            // [n] CSR position of entry (i, parent(i))
+    int* d_e_dn = nullptr;            // [n] CSR position of entry (parent(i), i)
+    double flops_per_solve = 0.0;
+};
+
+}  // namespace hpf
+
+struct hpf_handle {
+    hpf::Model M{};                   // device pointers
+    int n = 0, m = 0, c = 0, Hn = 0, nnz = 0, n_dev = 0, coupled = 0, solver = 0, device = 0;
+    int S_max = 0, S = 0;
+    int N = 0, Nc = 0, Nf = 0;
+    bool loads_set = false, state_set = false, mismatch_valid = false;
+    int last_detail = 0;
+
+    // model (device)
+    int *d_rowptr = nullptr, *d_col = nullptr, *d_diag = nullptr, *d_erow = nullptr, *d_dev = nullptr;
+    hpf::cplx *d_Y = nullptr, *d_YN = nullptr, *d_IN = nullptr;
+    // per-scenario state (device)
+    double *d_P = nullptr, *d_Q = nullptr, *d_Vm = nullptr, *d_Va = nullptr;
+    hpf::cplx *d_U = nullptr, *d_E = nullptr;
+    double* d_f = nullptr;            // [S][N]  mismatch, overwritten by the Newton step during a solve
+    unsigned long long* d_errbits = nullptr;   // [S]
+    double* d_err = nullptr;          // [S]
+    int* d_niter = nullptr;           // [S]
+    int* d_active = nullptr;          // [S]
+    int* d_nactive = nullptr;         // [1]
+    double* d_hist = nullptr;         // [S][hist_cap]
+    int hist_cap = 0;
+    hpf_stat* d_stats = nullptr;      // [S]
+    // dense solver
+    double* d_J = nullptr;            // [S_alloc][Nmax*Nmax]
+    size_t J_elems_per_scen = 0;
+    int J_scen_alloc = 0;
+    int* d_ipiv = nullptr;
+    int* d_info = nullptr;
+    // block-tree solver
+    hpf::Tree tree;
+    double* d_Z = nullptr;            // [S][n][b*b]
+    double* d_w = nullptr;            // [S][n][b]
+    double* d_x = nullptr;            // [S][n][b]  Newton step, bus-major
+
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    rocblas_handle blas = nullptr;
+    bool timing = false;
+    std::vector<hpf::TimedSpan> spans;
+    double t_ms[hpf::T_COUNT] = {0, 0, 0, 0};
+    int64_t t_n[hpf::T_COUNT] = {0, 0, 0, 0};
+};
+
+namespace hpf {
+
+struct ScopedTimer {
+    hpf_handle* h;
+    int which;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ScopedTimer(hpf_handle* h_, int w) : h(h_), which(w) {
+        if (h->timing) {
+            hipEventCreate(&e0);
+            hipEventCreate(&e1);
+            hipEventRecord(e0, h->stream);
+        }
+    }
+    ~ScopedTimer() {
+        if (h->timing) {
+            hipEventRecord(e1, h->stream);
+            h->spans.push_back({which, e0, e1});
+        }
+    }
+};
+
+// block-tree solver (hpf_block.hip)
+int tree_build(hpf_handle* h, const hpf_desc* d);
+void tree_free(hpf_handle* h);
+int tree_alloc_scenarios(hpf_handle* h);
+int tree_newton_step(hpf_handle* h, bool only_active);   // assembles, eliminates, back-substitutes -> d_f holds the step
+
+}  // namespace hpf

@@ -1,0 +1,761 @@
+// libhpf.so — C ABI (include/hpf.h), assembly kernels and the dense (rocSOLVER) Newton step.
+//
+// Data layout in HBM (all FP64 / complex128, scenario index slowest):
+//   model, shared by all scenarios:  rowptr[n+1], col[nnz], erow[nnz] (row of each stored entry), diag[n],
+//       Y[Hn][nnz] complex (one CSR pattern for all harmonics: lanes sweep the entries of one harmonic, so the
+//       admittance read of the Jacobian kernel is a fully coalesced 16 B/lane stream), dev[n],
+//       Y_N[n_dev][Hn][Hn], I_N[n_dev][Hn].
+//   state: Vm,Va[S][Hn*n]; U,E[S][Hn*n] complex (polar -> rectangular once per iteration, reused by mismatch and
+//       Jacobian; stacked harmonic-major so that for a fixed harmonic consecutive lanes touch consecutive buses);
+//       P,Q[S][n]; f[S][N]; dense J[S][N*N] column-major in the reference's row/column order (HG:469-472).
+// Kernels and what bounds them (algorithmic bytes per NR iteration per scenario):
+//   k_mismatch   HBM: 16*Hn*nnz (Y) + 16*Hn*n (U) + 8*N (f) + pattern;   k_jac_*  HBM: Y + U,E + 32*E_cplx written;
+//   dense solve  FP64 matrix pipe: 2/3 N^3 + 2 N^2 flop (rocSOLVER getrf/getrs).
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <rocsolver/rocsolver.h>
+
+#include "hpf_internal.hpp"
+
+using namespace hpf;
+
+#define HIPCHK(expr)                              \
+    do {                                          \
+        hipError_t _e = (expr);                   \
+        if (_e != hipSuccess) {                   \
+            h->last_detail = (int)_e;             \
+            return HPF_E_HIP;                     \
+        }                                         \
+    } while (0)
+
+#define BLASCHK(expr)                             \
+    do {                                          \
+        rocblas_status _s = (expr);               \
+        if (_s != rocblas_status_success) {       \
+            h->last_detail = (int)_s;             \
+            return HPF_E_ROCSOLVER;               \
+        }                                         \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int TPB = 256;
+
+// polar -> rectangular for `count` stacked entries of every scenario (count = Hn*n, or n for the fundamental pf)
+template <bool FUND>
+__global__ void k_polar(int count, int stride, const double* __restrict__ Vm, const double* __restrict__ Va,
+                        cplx* __restrict__ U, cplx* __restrict__ E) {
+    const int k = blockIdx.x * TPB + threadIdx.x;
+    if (k >= count) return;
+    const size_t o = (size_t)blockIdx.y * stride + k;
+    cplx u, e;
+    polar<FUND>(Vm[o], Va[o], u, e);
+    U[o] = u;
+    E[o] = e;
+}
+
+// ||.||_inf with NaN propagation: |x| as its IEEE bit pattern is monotone for non-negative doubles, and every NaN
+// pattern compares above +inf, so an unsigned max reproduces np.linalg.norm(f, inf) including its NaN result
+// (HG:389) and is independent of the reduction order.
+__device__ __forceinline__ unsigned long long abs_bits(double v) {
+    return (unsigned long long)__double_as_longlong(fabs(v));
+}
+
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// One thread per complex mismatch row (k = 1 .. count-1) of one scenario (blockIdx.y).
+template <bool FUND>
+__global__ void k_mismatch(Model M, int count, int N, int Nc, const int* __restrict__ active, const cplx* __restrict__ U,
+                           const double* __restrict__ P, const double* __restrict__ Q, double* __restrict__ f,
+                           unsigned long long* __restrict__ errbits) {
+    const int s = blockIdx.y;
+    if (active && !active[s]) return;
+    const int k = blockIdx.x * TPB + threadIdx.x + 1;
+    unsigned long long b = 0;
+    if (k < count) {
+        const cplx v = mismatch_row<FUND>(M, U + (size_t)s * M.n * M.Hn, P + (size_t)s * M.n, Q + (size_t)s * M.n, k);
+        store_mismatch(f + (size_t)s * N, Nc, M.c, k, v);
+        b = abs_bits(v.re);
+        if (k >= M.c) {
+            const unsigned long long bi = abs_bits(v.im);
+            b = bi > b ? bi : b;
+        }
+    }
+    b = wave_max_u64(b);
+    __shared__ unsigned long long red[TPB / 64];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = b;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long r = red[0];
+#pragma unroll
+        for (int w = 1; w < TPB / 64; ++w) r = red[w] > r ? red[w] : r;
+        atomicMax(errbits + s, r);
+    }
+}
+
+// Dense Jacobian, network entries: one thread per (harmonic position, stored admittance entry) of one scenario.
+template <bool FUND>
+__global__ void k_jac_dense(Model M, int total, int N, int Nc, size_t J_stride, const int* __restrict__ active,
+                            const int* __restrict__ erow, const cplx* __restrict__ U, const cplx* __restrict__ E,
+                            double* __restrict__ J) {
+    const int s = blockIdx.y;
+    if (active && !active[s]) return;
+    const int t = blockIdx.x * TPB + threadIdx.x;
+    if (t >= total) return;
+    const int q = t / M.nnz, e = t - q * M.nnz;
+    const int i = erow[e];
+    DenseEmit em{J + (size_t)s * J_stride, N, Nc, M.c};
+    const size_t so = (size_t)s * M.n * M.Hn;
+    if (FUND)
+        jac_entry_fund(M, U + so, E + so, i, e, em);
+    else
+        jac_entry(M, U + so, E + so, q, i, e, em);
+}
+
+// Dense Jacobian, coupled Norton cross terms q != p at nonlinear buses (HG:425-435).
+__global__ void k_jac_cross_dense(Model M, int total, int N, int Nc, size_t J_stride, const int* __restrict__ active,
+                                  const cplx* __restrict__ U, const cplx* __restrict__ E, double* __restrict__ J) {
+    const int s = blockIdx.y;
+    if (active && !active[s]) return;
+    const int t = blockIdx.x * TPB + threadIdx.x;
+    if (t >= total) return;
+    // consecutive threads -> consecutive buses (coalesced U/E reads for a fixed column harmonic p)
+    const int nnl = M.n - M.m;
+    const int i = M.m + t % nnl;
+    const int qp = t / nnl;
+    const int q = qp / M.Hn, p = qp - q * M.Hn;
+    if (p == q) return;
+    DenseEmit em{J + (size_t)s * J_stride, N, Nc, M.c};
+    const size_t so = (size_t)s * M.n * M.Hn;
+    jac_cross(M, U + so, E + so, q, p, i, em);
+}
+
+// x <- x - step, scattered back into (Va, Vm) (HG:478,484-485 / HG:229,234-235), then refresh U, E of the entry.
+template <bool FUND>
+__global__ void k_update(int n, int c, int count, int stride, int N, int Nc, const int* __restrict__ active,
+                         const double* __restrict__ step, double* __restrict__ Vm, double* __restrict__ Va,
+                         cplx* __restrict__ U, cplx* __restrict__ E, unsigned long long* __restrict__ errbits) {
+    const int s = blockIdx.y;
+    if (active && !active[s]) return;
+    const int k = blockIdx.x * TPB + threadIdx.x;
+    if (k >= count) return;
+    const size_t o = (size_t)s * stride + k;
+    const double* d = step + (size_t)s * N;
+    double va = Va[o], vm = Vm[o];
+    if (k >= 1) va = va - d[k - 1];
+    if (k >= c) vm = vm - d[Nc + k - c];
+    Va[o] = va;
+    Vm[o] = vm;
+    cplx u, e;
+    polar<FUND>(vm, va, u, e);
+    U[o] = u;
+    E[o] = e;
+    if (k == 0) errbits[s] = 0ull;
+}
+
+// Per-scenario bookkeeping of the NR loop (HG:536-542 / HG:259-265).  first: record the initial mismatch.
+__global__ void k_finalize(int S, int first, double thresh, int max_iter, int hist_cap, int hist_off,
+                           const unsigned long long* __restrict__ errbits, double* __restrict__ err,
+                           int* __restrict__ niter, int* __restrict__ active, int* __restrict__ nactive,
+                           double* __restrict__ hist) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    if (first) {
+        const double e = __longlong_as_double((long long)errbits[s]);
+        err[s] = e;
+        niter[s] = 0;
+        if (hist && hist_off == 0) hist[(size_t)s * hist_cap] = e;
+        const int a = (e > thresh) && (0 < max_iter);
+        active[s] = a;
+        if (a) atomicAdd(nactive, 1);
+        return;
+    }
+    if (!active[s]) return;
+    const double e = __longlong_as_double((long long)errbits[s]);
+    const int it = niter[s] + 1;
+    err[s] = e;
+    niter[s] = it;
+    if (hist) hist[(size_t)s * hist_cap + it - 1 + (hist_off == 0 ? 1 : 0)] = e;
+    const int a = (e > thresh) && (it < max_iter);
+    active[s] = a;
+    if (a) atomicAdd(nactive, 1);
+}
+
+__global__ void k_fill(double* p, size_t count, double v) {
+    const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (i < count) p[i] = v;
+}
+
+__global__ void k_set_int(int* p, int count, int v) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i < count) p[i] = v;
+}
+
+__global__ void k_init_voltages(int n, int count, double* Vm, double* Va) {
+    const int k = blockIdx.x * TPB + threadIdx.x;
+    if (k >= count) return;
+    const size_t o = (size_t)blockIdx.y * count + k;
+    Vm[o] = k < n ? 1.0 : 0.1;     // HG:181-183
+    Va[o] = 0.0;
+}
+
+// get_THD (HG:563-572) THD_F per bus, max over buses, plus the result flags; one block per scenario.
+__global__ void k_stats(int n, int Hn, double thresh, int max_iter, const double* __restrict__ Vm,
+                        const double* __restrict__ err, const int* __restrict__ niter, hpf_stat* __restrict__ out) {
+    const int s = blockIdx.x;
+    const double* V = Vm + (size_t)s * n * Hn;
+    double best = 0.0;
+    bool nan = false;
+    for (int b = threadIdx.x; b < n; b += TPB) {
+        double hs = 0.0;
+        for (int q = 1; q < Hn; ++q) hs = hs + V[(size_t)q * n + b] * V[(size_t)q * n + b];
+        const double t = sqrt(hs) / fabs(V[b]);
+        if (t != t) nan = true;
+        best = t > best ? t : best;
+    }
+    unsigned long long bits = nan ? 0x7ff8000000000000ull : (unsigned long long)__double_as_longlong(best);
+    bits = wave_max_u64(bits);
+    __shared__ unsigned long long red[TPB / 64];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = bits;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long r = red[0];
+        for (int w = 1; w < TPB / 64; ++w) r = red[w] > r ? red[w] : r;
+        hpf_stat st;
+        st.n_iter = niter[s];
+        const double e = err[s];
+        st.err = e;
+        st.flags = (e <= thresh ? 1 : 0) | ((niter[s] >= max_iter && !(e <= thresh)) ? 2 : 0) | ((e != e || isinf(e)) ? 4 : 0);
+        st.thd_max = __longlong_as_double((long long)r);
+        out[s] = st;
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------
+namespace {
+
+template <class T>
+int dev_alloc(hpf_handle* h, T** p, size_t count) {
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc((void**)p, count * sizeof(T));
+    if (e != hipSuccess) {
+        h->last_detail = (int)e;
+        *p = nullptr;
+        return e == hipErrorOutOfMemory ? HPF_E_NOMEM : HPF_E_HIP;
+    }
+    return HPF_OK;
+}
+
+template <class T>
+int dev_upload(hpf_handle* h, T** p, const T* src, size_t count) {
+    int r = dev_alloc(h, p, count);
+    if (r) return r;
+    if (count) HIPCHK(hipMemcpy(*p, src, count * sizeof(T), hipMemcpyHostToDevice));
+    return HPF_OK;
+}
+
+inline dim3 grid2(int count, int S) { return dim3((unsigned)((count + TPB - 1) / TPB), (unsigned)S, 1); }
+
+int ensure_dense(hpf_handle* h, int Nsys) {
+    size_t want = (size_t)Nsys * Nsys;
+    if (h->solver == HPF_SOLVER_DENSE && (size_t)h->N * h->N > want) want = (size_t)h->N * h->N;
+    if (h->d_J && h->J_elems_per_scen >= want) return HPF_OK;
+    if (h->d_J) {
+        hipFree(h->d_J);
+        hipFree(h->d_ipiv);
+        hipFree(h->d_info);
+        h->d_J = nullptr;
+        h->d_ipiv = nullptr;
+        h->d_info = nullptr;
+    }
+    int r = dev_alloc(h, &h->d_J, want * (size_t)h->S_max);
+    if (r) return r;
+    const int Nmax = h->N > h->Nf ? h->N : h->Nf;
+    if ((r = dev_alloc(h, &h->d_ipiv, (size_t)Nmax * h->S_max))) return r;
+    if ((r = dev_alloc(h, &h->d_info, (size_t)h->S_max))) return r;
+    HIPCHK(hipMemset(h->d_info, 0, sizeof(int) * h->S_max));
+    h->J_elems_per_scen = want;
+    return HPF_OK;
+}
+
+int resolve_spans(hpf_handle* h) {
+    if (h->spans.empty()) return HPF_OK;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (auto& sp : h->spans) {
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, sp.e0, sp.e1);
+        h->t_ms[sp.which] += ms;
+        h->t_n[sp.which] += 1;
+        hipEventDestroy(sp.e0);
+        hipEventDestroy(sp.e1);
+    }
+    h->spans.clear();
+    return HPF_OK;
+}
+
+// polar + mismatch (+ optional err conversion) for the current state
+template <bool FUND>
+int launch_polar(hpf_handle* h) {
+    const int count = FUND ? h->n : h->n * h->Hn;
+    hipLaunchKernelGGL((k_polar<FUND>), grid2(count, h->S), dim3(TPB), 0, h->stream, count, h->n * h->Hn, h->d_Vm,
+                       h->d_Va, h->d_U, h->d_E);
+    HIPCHK(hipGetLastError());
+    return HPF_OK;
+}
+
+template <bool FUND>
+int launch_mismatch(hpf_handle* h, const int* active) {
+    ScopedTimer t(h, T_MISMATCH);
+    const int count = FUND ? h->n : h->n * h->Hn;
+    const int N = FUND ? h->Nf : h->N;
+    const int Nc = FUND ? h->n - 1 : h->Nc;
+    if (count > 1) {
+        hipLaunchKernelGGL((k_mismatch<FUND>), grid2(count - 1, h->S), dim3(TPB), 0, h->stream, h->M, count, N, Nc,
+                           active, h->d_U, h->d_P, h->d_Q, h->d_f, h->d_errbits);
+        HIPCHK(hipGetLastError());
+    }
+    return HPF_OK;
+}
+
+template <bool FUND>
+int launch_jacobian_dense(hpf_handle* h, const int* active) {
+    ScopedTimer t(h, T_JACOBIAN);
+    const int N = FUND ? h->Nf : h->N;
+    const int Nc = FUND ? h->n - 1 : h->Nc;
+    HIPCHK(hipMemsetAsync(h->d_J, 0, sizeof(double) * h->J_elems_per_scen * (size_t)h->S, h->stream));
+    const int total = (FUND ? 1 : h->Hn) * h->nnz;
+    hipLaunchKernelGGL((k_jac_dense<FUND>), grid2(total, h->S), dim3(TPB), 0, h->stream, h->M, total, N, Nc,
+                       h->J_elems_per_scen, active, h->d_erow, h->d_U, h->d_E, h->d_J);
+    HIPCHK(hipGetLastError());
+    if (!FUND && h->coupled && h->n > h->m) {
+        const int tot = (h->n - h->m) * h->Hn * h->Hn;
+        hipLaunchKernelGGL(k_jac_cross_dense, grid2(tot, h->S), dim3(TPB), 0, h->stream, h->M, tot, N, Nc,
+                           h->J_elems_per_scen, active, h->d_U, h->d_E, h->d_J);
+        HIPCHK(hipGetLastError());
+    }
+    return HPF_OK;
+}
+
+// f <- J^{-1} f for every scenario (rocSOLVER LU with partial pivoting)
+int dense_solve(hpf_handle* h, int Nsys) {
+    ScopedTimer t(h, T_SOLVE);
+    if (Nsys <= 0) return HPF_OK;
+    BLASCHK(rocblas_set_stream(h->blas, h->stream));
+    if (h->S == 1) {
+        BLASCHK(rocsolver_dgetrf(h->blas, Nsys, Nsys, h->d_J, Nsys, h->d_ipiv, h->d_info));
+        BLASCHK(rocsolver_dgetrs(h->blas, rocblas_operation_none, Nsys, 1, h->d_J, Nsys, h->d_ipiv, h->d_f, Nsys));
+    } else {
+        const rocblas_stride sA = (rocblas_stride)h->J_elems_per_scen;
+        const int Nmax = h->N > h->Nf ? h->N : h->Nf;
+        const rocblas_stride sF = (rocblas_stride)Nsys;
+        BLASCHK(rocsolver_dgetrf_strided_batched(h->blas, Nsys, Nsys, h->d_J, Nsys, sA, h->d_ipiv, Nmax, h->d_info, h->S));
+        BLASCHK(rocsolver_dgetrs_strided_batched(h->blas, rocblas_operation_none, Nsys, 1, h->d_J, Nsys, sA, h->d_ipiv,
+                                                 Nmax, h->d_f, Nsys, sF, h->S));
+    }
+    return HPF_OK;
+}
+
+template <bool FUND>
+int launch_update(hpf_handle* h, const int* active) {
+    ScopedTimer t(h, T_UPDATE);
+    const int count = FUND ? h->n : h->n * h->Hn;
+    const int N = FUND ? h->Nf : h->N;
+    const int Nc = FUND ? h->n - 1 : h->Nc;
+    hipLaunchKernelGGL((k_update<FUND>), grid2(count, h->S), dim3(TPB), 0, h->stream, h->n, h->c, count,
+                       h->n * h->Hn, N, Nc, active, h->d_f, h->d_Vm, h->d_Va, h->d_U, h->d_E, h->d_errbits);
+    HIPCHK(hipGetLastError());
+    return HPF_OK;
+}
+
+// One Newton step: Jacobian at the current state, step = J^{-1} f into d_f.
+template <bool FUND>
+int newton_step(hpf_handle* h, const int* active) {
+    int r;
+    if (!FUND && h->solver == HPF_SOLVER_BLOCK_TREE) return tree_newton_step(h, active != nullptr);
+    const int Nsys = FUND ? h->Nf : h->N;
+    if ((r = ensure_dense(h, Nsys))) return r;
+    if ((r = launch_jacobian_dense<FUND>(h, active))) return r;
+    return dense_solve(h, Nsys);
+}
+
+int check_info(hpf_handle* h, const std::vector<int>& was_active) {
+    if (!h->d_info) return HPF_OK;
+    std::vector<int> info(h->S);
+    HIPCHK(hipMemcpyAsync(info.data(), h->d_info, sizeof(int) * h->S, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int s = 0; s < h->S; ++s)
+        if (was_active[s] && info[s] != 0) {
+            h->last_detail = info[s];
+            return HPF_E_SINGULAR;
+        }
+    return HPF_OK;
+}
+
+template <bool FUND>
+int nr_loop(hpf_handle* h, double thresh, int max_iter, int* n_iter, double* err, double* err_hist) {
+    if (!h->loads_set || !h->state_set) return HPF_E_STATE;
+    if (max_iter < 0) return HPF_E_ARG;
+    int r;
+    const int S = h->S;
+    const int hist_off = FUND ? 1 : 0;                // pf records only post-update errors (HG:264)
+    const int cap = max_iter + 1;
+    if (h->hist_cap < cap) {
+        if (h->d_hist) hipFree(h->d_hist);
+        if ((r = dev_alloc(h, &h->d_hist, (size_t)cap * h->S_max))) return r;
+        h->hist_cap = cap;
+    }
+    {
+        const size_t cnt = (size_t)h->hist_cap * S;
+        hipLaunchKernelGGL(k_fill, dim3((unsigned)((cnt + TPB - 1) / TPB)), dim3(TPB), 0, h->stream, h->d_hist, cnt,
+                           (double)NAN);
+    }
+    if ((r = launch_polar<FUND>(h))) return r;
+    HIPCHK(hipMemsetAsync(h->d_errbits, 0, sizeof(unsigned long long) * S, h->stream));
+    if ((r = launch_mismatch<FUND>(h, nullptr))) return r;
+    HIPCHK(hipMemsetAsync(h->d_nactive, 0, sizeof(int), h->stream));
+    hipLaunchKernelGGL(k_finalize, dim3((S + 63) / 64), dim3(64), 0, h->stream, S, 1, thresh, max_iter, h->hist_cap,
+                       hist_off, h->d_errbits, h->d_err, h->d_niter, h->d_active, h->d_nactive, h->d_hist);
+    std::vector<int> act(S), was(S);
+    auto count_active = [&]() {
+        int c = 0;
+        for (int s = 0; s < S; ++s) c += act[s] != 0;
+        return c;
+    };
+    HIPCHK(hipMemcpyAsync(act.data(), h->d_active, sizeof(int) * S, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    int nactive = count_active();
+    int it = 0;
+    while (nactive > 0 && it < max_iter) {
+        was = act;
+        if ((r = newton_step<FUND>(h, h->d_active))) return r;
+        if ((r = launch_update<FUND>(h, h->d_active))) return r;
+        if ((r = launch_mismatch<FUND>(h, h->d_active))) return r;
+        HIPCHK(hipMemsetAsync(h->d_nactive, 0, sizeof(int), h->stream));
+        hipLaunchKernelGGL(k_finalize, dim3((S + 63) / 64), dim3(64), 0, h->stream, S, 0, thresh, max_iter,
+                           h->hist_cap, hist_off, h->d_errbits, h->d_err, h->d_niter, h->d_active, h->d_nactive,
+                           h->d_hist);
+        HIPCHK(hipMemcpyAsync(act.data(), h->d_active, sizeof(int) * S, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        nactive = count_active();
+        if (FUND || h->solver == HPF_SOLVER_DENSE)
+            if ((r = check_info(h, was))) return r;
+        ++it;
+    }
+    h->mismatch_valid = false;   // frozen scenarios leave stale rows in d_f: hpf_mismatch before hpf_iterate
+    if (n_iter) HIPCHK(hipMemcpy(n_iter, h->d_niter, sizeof(int) * S, hipMemcpyDeviceToHost));
+    if (err) HIPCHK(hipMemcpy(err, h->d_err, sizeof(double) * S, hipMemcpyDeviceToHost));
+    if (err_hist) {
+        const int cols = FUND ? max_iter : max_iter + 1;
+        HIPCHK(hipMemcpy2D(err_hist, sizeof(double) * cols, h->d_hist, sizeof(double) * h->hist_cap,
+                           sizeof(double) * cols, S, hipMemcpyDeviceToHost));
+    }
+    if (!FUND) {
+        hipLaunchKernelGGL(k_stats, dim3(S), dim3(TPB), 0, h->stream, h->n, h->Hn, thresh, max_iter, h->d_Vm, h->d_err,
+                           h->d_niter, h->d_stats);
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return HPF_OK;
+}
+
+void free_all(hpf_handle* h) {
+    void* ptrs[] = {h->d_rowptr, h->d_col, h->d_diag, h->d_erow, h->d_dev, h->d_Y, h->d_YN, h->d_IN, h->d_P, h->d_Q,
+                    h->d_Vm, h->d_Va, h->d_U, h->d_E, h->d_f, h->d_errbits, h->d_err, h->d_niter, h->d_active,
+                    h->d_nactive, h->d_hist, h->d_stats, h->d_J, h->d_ipiv, h->d_info, h->d_Z, h->d_w, h->d_x};
+    for (void* p : ptrs)
+        if (p) hipFree(p);
+    tree_free(h);
+    for (auto& sp : h->spans) {
+        hipEventDestroy(sp.e0);
+        hipEventDestroy(sp.e1);
+    }
+    if (h->blas) rocblas_destroy_handle(h->blas);
+    if (h->own_stream) hipStreamDestroy(h->own_stream);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------------------
+extern "C" {
+
+int hpf_version(void) { return 100; }
+
+const char* hpf_strerror(int code) {
+    switch (code) {
+        case HPF_OK: return "success";
+        case HPF_E_ARG: return "invalid argument";
+        case HPF_E_STATE: return "call order violated (loads/state/mismatch not set)";
+        case HPF_E_TOPOLOGY: return "BLOCK_TREE solver needs a radial network rooted at bus 0";
+        case HPF_E_NOMEM: return "out of device memory";
+        case HPF_E_HIP: return "HIP runtime error";
+        case HPF_E_ROCSOLVER: return "rocBLAS/rocSOLVER error";
+        case HPF_E_SINGULAR: return "singular Jacobian (zero pivot)";
+        default: return "unknown error";
+    }
+}
+
+int hpf_last_error_detail(const hpf_handle* h) { return h ? h->last_detail : 0; }
+
+int hpf_create(hpf_handle** out, const hpf_desc* d) {
+    if (!out || !d) return HPF_E_ARG;
+    *out = nullptr;
+    if (d->n < 1 || d->Hn < 1 || d->m < 1 || d->m > d->n || d->c < 1 || d->c > d->m || d->nnz < d->n ||
+        d->max_scenarios < 1 || !d->rowptr || !d->col || !d->Yval || !d->dev_of_bus)
+        return HPF_E_ARG;
+    if (d->m < d->n && (d->n_dev < 1 || !d->Y_N || !d->I_N)) return HPF_E_ARG;
+    if (d->solver != HPF_SOLVER_DENSE && d->solver != HPF_SOLVER_BLOCK_TREE) return HPF_E_ARG;
+    // host-side validation of the pattern: sorted columns, diagonal present, indices in range
+    std::vector<int> diag(d->n, -1), erow(d->nnz);
+    if (d->rowptr[0] != 0 || d->rowptr[d->n] != d->nnz) return HPF_E_ARG;
+    for (int i = 0; i < d->n; ++i) {
+        if (d->rowptr[i + 1] < d->rowptr[i]) return HPF_E_ARG;
+        for (int e = d->rowptr[i]; e < d->rowptr[i + 1]; ++e) {
+            const int j = d->col[e];
+            if (j < 0 || j >= d->n) return HPF_E_ARG;
+            if (e > d->rowptr[i] && d->col[e - 1] >= j) return HPF_E_ARG;
+            if (j == i) diag[i] = e;
+            erow[e] = i;
+        }
+        if (diag[i] < 0) return HPF_E_ARG;
+        const int dv = d->dev_of_bus[i];
+        if (i >= d->m ? (dv < 0 || dv >= d->n_dev) : dv != -1) return HPF_E_ARG;
+    }
+    hpf_handle* h = new (std::nothrow) hpf_handle();
+    if (!h) return HPF_E_NOMEM;
+    int r = HPF_OK;
+    auto fail = [&](int code) {
+        free_all(h);
+        delete h;
+        return code;
+    };
+    h->n = d->n; h->m = d->m; h->c = d->c; h->Hn = d->Hn; h->nnz = d->nnz; h->n_dev = d->n_dev;
+    h->coupled = d->coupled ? 1 : 0; h->solver = d->solver; h->device = d->device; h->S_max = d->max_scenarios;
+    h->Nc = d->n * d->Hn - 1;
+    h->N = 2 * h->Nc - (d->c - 1);
+    h->Nf = 2 * d->n - 1 - d->c;
+    if (hipSetDevice(d->device) != hipSuccess) return fail(HPF_E_HIP);
+    if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) return fail(HPF_E_HIP);
+    h->stream = h->own_stream;
+    if (rocblas_create_handle(&h->blas) != rocblas_status_success) return fail(HPF_E_ROCSOLVER);
+    const size_t HnN = (size_t)d->Hn * d->n, S = (size_t)d->max_scenarios;
+    const size_t ynsz = (size_t)d->n_dev * d->Hn * (d->coupled ? d->Hn : 1);
+    if ((r = dev_upload(h, &h->d_rowptr, d->rowptr, (size_t)d->n + 1))) return fail(r);
+    if ((r = dev_upload(h, &h->d_col, d->col, (size_t)d->nnz))) return fail(r);
+    if ((r = dev_upload(h, &h->d_diag, diag.data(), (size_t)d->n))) return fail(r);
+    if ((r = dev_upload(h, &h->d_erow, erow.data(), (size_t)d->nnz))) return fail(r);
+    if ((r = dev_upload(h, &h->d_dev, d->dev_of_bus, (size_t)d->n))) return fail(r);
+    if ((r = dev_upload(h, &h->d_Y, (const cplx*)d->Yval, (size_t)d->Hn * d->nnz))) return fail(r);
+    if ((r = dev_upload(h, &h->d_YN, (const cplx*)d->Y_N, ynsz))) return fail(r);
+    if ((r = dev_upload(h, &h->d_IN, (const cplx*)d->I_N, (size_t)d->n_dev * d->Hn))) return fail(r);
+    if ((r = dev_alloc(h, &h->d_P, S * d->n))) return fail(r);
+    if ((r = dev_alloc(h, &h->d_Q, S * d->n))) return fail(r);
+    if ((r = dev_alloc(h, &h->d_Vm, S * HnN))) return fail(r);
+    if ((r = dev_alloc(h, &h->d_Va, S * HnN))) return fail(r);
+    if ((r = dev_alloc(h, &h->d_U, S * HnN))) return fail(r);
+    if ((r = dev_alloc(h, &h->d_E, S * HnN))) return fail(r);
+    if ((r = dev_alloc(h, &h->d_f, S * (size_t)(h->N > h->Nf ? h->N : h->Nf)))) return fail(r);
+    if ((r = dev_alloc(h, &h->d_errbits, S))) return fail(r);
+    if ((r = dev_alloc(h, &h->d_err, S))) return fail(r);
+    if ((r = dev_alloc(h, &h->d_niter, S))) return fail(r);
+    if ((r = dev_alloc(h, &h->d_active, S))) return fail(r);
+    if ((r = dev_alloc(h, &h->d_nactive, (size_t)1))) return fail(r);
+    if ((r = dev_alloc(h, &h->d_stats, S))) return fail(r);
+    Model& M = h->M;
+    M.n = d->n; M.m = d->m; M.c = d->c; M.Hn = d->Hn; M.nnz = d->nnz; M.n_dev = d->n_dev; M.coupled = h->coupled;
+    M.rowptr = h->d_rowptr; M.col = h->d_col; M.diag = h->d_diag; M.Y = h->d_Y; M.dev = h->d_dev;
+    M.YN = h->d_YN; M.IN = h->d_IN;
+    if (d->solver == HPF_SOLVER_BLOCK_TREE) {
+        if ((r = tree_build(h, d))) return fail(r);
+        if ((r = tree_alloc_scenarios(h))) return fail(r);
+    }
+    *out = h;
+    return HPF_OK;
+}
+
+int hpf_destroy(hpf_handle* h) {
+    if (!h) return HPF_E_ARG;
+    hipSetDevice(h->device);
+    hipStreamSynchronize(h->stream);
+    free_all(h);
+    delete h;
+    return HPF_OK;
+}
+
+int hpf_num_unknowns(const hpf_handle* h) { return h ? h->N : HPF_E_ARG; }
+int hpf_num_unknowns_fund(const hpf_handle* h) { return h ? h->Nf : HPF_E_ARG; }
+
+int hpf_set_loads(hpf_handle* h, int n_scen, const double* P, const double* Q) {
+    if (!h || !P || !Q || n_scen < 1 || n_scen > h->S_max) return HPF_E_ARG;
+    if (h->state_set && n_scen != h->S) h->state_set = false;
+    h->S = n_scen;
+    HIPCHK(hipMemcpyAsync(h->d_P, P, sizeof(double) * (size_t)n_scen * h->n, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_Q, Q, sizeof(double) * (size_t)n_scen * h->n, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->loads_set = true;
+    h->mismatch_valid = false;
+    return HPF_OK;
+}
+
+int hpf_set_state(hpf_handle* h, int n_scen, const double* Vm, const double* Va) {
+    if (!h || n_scen < 1 || n_scen > h->S_max || (Vm == nullptr) != (Va == nullptr)) return HPF_E_ARG;
+    if (h->loads_set && n_scen != h->S) return HPF_E_ARG;
+    h->S = n_scen;
+    const int count = h->n * h->Hn;
+    if (Vm) {
+        HIPCHK(hipMemcpyAsync(h->d_Vm, Vm, sizeof(double) * (size_t)n_scen * count, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->d_Va, Va, sizeof(double) * (size_t)n_scen * count, hipMemcpyHostToDevice, h->stream));
+    } else {
+        hipLaunchKernelGGL(k_init_voltages, grid2(count, n_scen), dim3(TPB), 0, h->stream, h->n, count, h->d_Vm, h->d_Va);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->state_set = true;
+    h->mismatch_valid = false;
+    return HPF_OK;
+}
+
+int hpf_get_state(hpf_handle* h, double* Vm, double* Va) {
+    if (!h || !Vm || !Va) return HPF_E_ARG;
+    if (!h->state_set) return HPF_E_STATE;
+    const size_t cnt = (size_t)h->S * h->n * h->Hn;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(Vm, h->d_Vm, sizeof(double) * cnt, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(Va, h->d_Va, sizeof(double) * cnt, hipMemcpyDeviceToHost));
+    return HPF_OK;
+}
+
+static int mismatch_impl(hpf_handle* h, bool fund, double* f, double* err) {
+    if (!h) return HPF_E_ARG;
+    if (!h->loads_set || !h->state_set) return HPF_E_STATE;
+    int r;
+    if ((r = fund ? launch_polar<true>(h) : launch_polar<false>(h))) return r;
+    HIPCHK(hipMemsetAsync(h->d_errbits, 0, sizeof(unsigned long long) * h->S, h->stream));
+    if ((r = fund ? launch_mismatch<true>(h, nullptr) : launch_mismatch<false>(h, nullptr))) return r;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const int N = fund ? h->Nf : h->N;
+    if (f) HIPCHK(hipMemcpy(f, h->d_f, sizeof(double) * (size_t)h->S * N, hipMemcpyDeviceToHost));
+    if (err) HIPCHK(hipMemcpy(err, h->d_errbits, sizeof(double) * h->S, hipMemcpyDeviceToHost));
+    h->mismatch_valid = !fund;
+    return HPF_OK;
+}
+
+int hpf_mismatch(hpf_handle* h, double* f, double* err) { return mismatch_impl(h, false, f, err); }
+int hpf_fund_mismatch(hpf_handle* h, double* f, double* err) { return mismatch_impl(h, true, f, err); }
+
+static int jacobian_impl(hpf_handle* h, bool fund, int scen, double* J) {
+    if (!h || !J || scen < 0 || scen >= h->S) return HPF_E_ARG;
+    if (!h->loads_set || !h->state_set) return HPF_E_STATE;
+    int r;
+    const int Nsys = fund ? h->Nf : h->N;
+    if ((r = ensure_dense(h, Nsys))) return r;
+    if ((r = fund ? launch_polar<true>(h) : launch_polar<false>(h))) return r;
+    if ((r = fund ? launch_jacobian_dense<true>(h, nullptr) : launch_jacobian_dense<false>(h, nullptr))) return r;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(J, h->d_J + (size_t)scen * h->J_elems_per_scen, sizeof(double) * (size_t)Nsys * Nsys,
+                     hipMemcpyDeviceToHost));
+    return HPF_OK;
+}
+
+int hpf_jacobian(hpf_handle* h, int scen, double* J) { return jacobian_impl(h, false, scen, J); }
+int hpf_fund_jacobian(hpf_handle* h, int scen, double* J) { return jacobian_impl(h, true, scen, J); }
+
+int hpf_fund_pf(hpf_handle* h, double thresh, int max_iter, int* n_iter, double* err, double* err_hist) {
+    if (!h) return HPF_E_ARG;
+    return nr_loop<true>(h, thresh, max_iter, n_iter, err, err_hist);
+}
+
+int hpf_solve(hpf_handle* h, double thresh, int max_iter, int* n_iter, double* err, double* err_hist) {
+    if (!h) return HPF_E_ARG;
+    return nr_loop<false>(h, thresh, max_iter, n_iter, err, err_hist);
+}
+
+int hpf_iterate(hpf_handle* h, int iters) {
+    if (!h || iters < 0) return HPF_E_ARG;
+    if (!h->loads_set || !h->state_set || !h->mismatch_valid) return HPF_E_STATE;
+    int r;
+    for (int it = 0; it < iters; ++it) {
+        if ((r = newton_step<false>(h, nullptr))) return r;
+        if ((r = launch_update<false>(h, nullptr))) return r;
+        if ((r = launch_mismatch<false>(h, nullptr))) return r;
+    }
+    return HPF_OK;
+}
+
+int hpf_get_stats(hpf_handle* h, hpf_stat* stats) {
+    if (!h || !stats) return HPF_E_ARG;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(stats, h->d_stats, sizeof(hpf_stat) * h->S, hipMemcpyDeviceToHost));
+    return HPF_OK;
+}
+
+int hpf_get_stats_dev(hpf_handle* h, void* stats_dev) {
+    if (!h || !stats_dev) return HPF_E_ARG;
+    HIPCHK(hipMemcpyAsync(stats_dev, h->d_stats, sizeof(hpf_stat) * h->S, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return HPF_OK;
+}
+
+int hpf_set_stream(hpf_handle* h, void* s) {
+    if (!h) return HPF_E_ARG;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->stream = s ? (hipStream_t)s : h->own_stream;
+    return HPF_OK;
+}
+
+int hpf_sync(hpf_handle* h) {
+    if (!h) return HPF_E_ARG;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return HPF_OK;
+}
+
+int hpf_timing_enable(hpf_handle* h, int on) {
+    if (!h) return HPF_E_ARG;
+    int r = resolve_spans(h);
+    h->timing = on != 0;
+    return r;
+}
+
+int hpf_timing_get(hpf_handle* h, int which, double* ms, int64_t* launches) {
+    if (!h || which < 0 || which >= T_COUNT) return HPF_E_ARG;
+    int r = resolve_spans(h);
+    if (r) return r;
+    if (ms) *ms = h->t_ms[which];
+    if (launches) *launches = h->t_n[which];
+    return HPF_OK;
+}
+
+int hpf_timing_reset(hpf_handle* h) {
+    if (!h) return HPF_E_ARG;
+    int r = resolve_spans(h);
+    for (int i = 0; i < T_COUNT; ++i) {
+        h->t_ms[i] = 0;
+        h->t_n[i] = 0;
+    }
+    return r;
+}
+
+double hpf_solve_flops(const hpf_handle* h) {
+    if (!h) return 0.0;
+    if (h->solver == HPF_SOLVER_BLOCK_TREE) return h->tree.flops_per_solve;
+    const double N = h->N;
+    return (2.0 / 3.0) * N * N * N + 2.0 * N * N;
+}
+
+}  // extern "C"

@@ -1,0 +1,185 @@
+"""`DeviceModel`: owner of one libhpf handle (one network x harmonic set x Norton data on one GPU) and the thin
+NumPy-facing wrappers around the C ABI.  All heavy work happens in HIP kernels / rocSOLVER; this file only marshals
+arrays."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(_lib.c_dbl_p)
+
+
+def _ip(a):
+    return a.ctypes.data_as(_lib.c_int_p)
+
+
+def is_radial(n, rowptr, col):
+    """True if the admittance pattern is a tree spanning all buses (n-1 undirected edges, connected from bus 0)."""
+    nnz = len(col)
+    if nnz != n + 2 * (n - 1):
+        return False
+    seen = np.zeros(n, dtype=bool)
+    seen[0] = True
+    stack = [0]
+    while stack:
+        i = stack.pop()
+        for j in col[rowptr[i]:rowptr[i + 1]]:
+            if not seen[j]:
+                seen[j] = True
+                stack.append(int(j))
+    return bool(seen.all())
+
+
+class DeviceModel:
+    def __init__(self, n, m, c, harmonics, rowptr, col, Yval, dev_of_bus, Y_N, I_N, n_dev, coupled,
+                 solver="auto", device=0, max_scenarios=1):
+        lib = _lib.load()
+        self.lib = lib
+        self.n, self.m, self.c = int(n), int(m), int(c)
+        self.harmonics = list(harmonics)
+        self.Hn = len(self.harmonics)
+        self.coupled = bool(coupled)
+        self.rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+        self.col = np.ascontiguousarray(col, dtype=np.int32)
+        self.Yval = np.ascontiguousarray(Yval, dtype=np.complex128)
+        self.dev_of_bus = np.ascontiguousarray(dev_of_bus, dtype=np.int32)
+        self.Y_N = np.ascontiguousarray(Y_N, dtype=np.complex128)
+        self.I_N = np.ascontiguousarray(I_N, dtype=np.complex128)
+        if solver == "auto":
+            solver = "block_tree" if (is_radial(self.n, self.rowptr, self.col) and self.n >= 32) else "dense"
+        self.solver = solver
+        d = _lib.hpf_desc()
+        d.n, d.m, d.c, d.Hn, d.nnz = self.n, self.m, self.c, self.Hn, len(self.col)
+        d.n_dev, d.coupled = int(n_dev), int(self.coupled)
+        d.solver = {"dense": _lib.SOLVER_DENSE, "block_tree": _lib.SOLVER_BLOCK_TREE}[solver]
+        d.device, d.max_scenarios = int(device), int(max_scenarios)
+        d.rowptr, d.col = _ip(self.rowptr), _ip(self.col)
+        d.Yval = self.Yval.view(np.float64).ctypes.data_as(_lib.c_dbl_p)
+        d.dev_of_bus = _ip(self.dev_of_bus)
+        d.Y_N = self.Y_N.view(np.float64).ctypes.data_as(_lib.c_dbl_p)
+        d.I_N = self.I_N.view(np.float64).ctypes.data_as(_lib.c_dbl_p)
+        self._h = C.c_void_p()
+        _lib.check(lib.hpf_create(C.byref(self._h), C.byref(d)), None, "hpf_create")
+        self.S_max = int(max_scenarios)
+        self.S = 0
+        self.N = lib.hpf_num_unknowns(self._h)
+        self.Nf = lib.hpf_num_unknowns_fund(self._h)
+
+    # -- lifetime ------------------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.hpf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, code, where):
+        _lib.check(code, self._h, where)
+
+    # -- state ---------------------------------------------------------------------------------------------
+    def set_loads(self, P, Q):
+        P = np.ascontiguousarray(np.atleast_2d(P), dtype=np.float64)
+        Q = np.ascontiguousarray(np.atleast_2d(Q), dtype=np.float64)
+        assert P.shape == Q.shape and P.shape[1] == self.n
+        self.S = P.shape[0]
+        self._chk(self.lib.hpf_set_loads(self._h, self.S, _dp(P), _dp(Q)), "hpf_set_loads")
+
+    def set_state(self, Vm=None, Va=None, n_scen=None):
+        if Vm is None:
+            S = n_scen or self.S or 1
+            self._chk(self.lib.hpf_set_state(self._h, S, None, None), "hpf_set_state")
+            self.S = S
+            return
+        Vm = np.ascontiguousarray(np.atleast_2d(Vm), dtype=np.float64)
+        Va = np.ascontiguousarray(np.atleast_2d(Va), dtype=np.float64)
+        assert Vm.shape == Va.shape and Vm.shape[1] == self.n * self.Hn
+        self._chk(self.lib.hpf_set_state(self._h, Vm.shape[0], _dp(Vm), _dp(Va)), "hpf_set_state")
+        self.S = Vm.shape[0]
+
+    def get_state(self):
+        Vm = np.empty((self.S, self.n * self.Hn))
+        Va = np.empty_like(Vm)
+        self._chk(self.lib.hpf_get_state(self._h, _dp(Vm), _dp(Va)), "hpf_get_state")
+        return Vm, Va
+
+    # -- kernels -------------------------------------------------------------------------------------------
+    def mismatch(self, fund=False, want_f=True):
+        N = self.Nf if fund else self.N
+        f = np.empty((self.S, N)) if want_f else None
+        err = np.empty(self.S)
+        fn = self.lib.hpf_fund_mismatch if fund else self.lib.hpf_mismatch
+        self._chk(fn(self._h, _dp(f) if want_f else None, _dp(err)), "hpf_mismatch")
+        return f, err
+
+    def jacobian(self, scen=0, fund=False):
+        N = self.Nf if fund else self.N
+        J = np.empty((N, N), order="F")
+        fn = self.lib.hpf_fund_jacobian if fund else self.lib.hpf_jacobian
+        self._chk(fn(self._h, int(scen), J.ctypes.data_as(_lib.c_dbl_p)), "hpf_jacobian")
+        return J
+
+    def fund_pf(self, thresh=1e-6, max_iter=30):
+        n_iter = np.zeros(self.S, dtype=np.int32)
+        err = np.empty(self.S)
+        hist = np.empty((self.S, max(max_iter, 1)))
+        self._chk(self.lib.hpf_fund_pf(self._h, float(thresh), int(max_iter), _ip(n_iter), _dp(err), _dp(hist)),
+                  "hpf_fund_pf")
+        return n_iter, err, hist[:, :max_iter]
+
+    def solve(self, thresh=1e-4, max_iter=50):
+        n_iter = np.zeros(self.S, dtype=np.int32)
+        err = np.empty(self.S)
+        hist = np.empty((self.S, max_iter + 1))
+        self._chk(self.lib.hpf_solve(self._h, float(thresh), int(max_iter), _ip(n_iter), _dp(err), _dp(hist)),
+                  "hpf_solve")
+        return n_iter, err, hist
+
+    def iterate(self, iters):
+        self._chk(self.lib.hpf_iterate(self._h, int(iters)), "hpf_iterate")
+
+    def sync(self):
+        self._chk(self.lib.hpf_sync(self._h), "hpf_sync")
+
+    def stats(self):
+        st = (_lib.hpf_stat * self.S)()
+        self._chk(self.lib.hpf_get_stats(self._h, st), "hpf_get_stats")
+        return np.array([(s.n_iter, s.flags, s.err, s.thd_max) for s in st],
+                        dtype=[("n_iter", "i4"), ("flags", "i4"), ("err", "f8"), ("thd_max", "f8")])
+
+    def stats_to_device(self, data_ptr):
+        self._chk(self.lib.hpf_get_stats_dev(self._h, C.c_void_p(int(data_ptr))), "hpf_get_stats_dev")
+
+    def set_stream(self, stream_ptr):
+        self._chk(self.lib.hpf_set_stream(self._h, C.c_void_p(int(stream_ptr)) if stream_ptr else None),
+                  "hpf_set_stream")
+
+    def timing(self, on=True):
+        self._chk(self.lib.hpf_timing_enable(self._h, int(on)), "hpf_timing_enable")
+
+    def timing_reset(self):
+        self._chk(self.lib.hpf_timing_reset(self._h), "hpf_timing_reset")
+
+    def timing_get(self):
+        out = {}
+        for which, name in enumerate(("mismatch", "jacobian", "solve", "update")):
+            ms = C.c_double()
+            cnt = C.c_int64()
+            self._chk(self.lib.hpf_timing_get(self._h, which, C.byref(ms), C.byref(cnt)), "hpf_timing_get")
+            out[name] = (ms.value, cnt.value)
+        return out
+
+    def solve_flops(self):
+        return float(self.lib.hpf_solve_flops(self._h))

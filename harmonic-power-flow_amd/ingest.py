@@ -1,0 +1,132 @@
+"""CSV bus/line ingest and Norton-parameter import — the reference's file formats, kept as the drop-in boundary.
+
+Follows `Harmonic Power Flow/hcne_generalized.py` (HG): `init_lines_from_csv` HG:45-61, `init_buses_from_csv`
+HG:77-94, `init_network` HG:113-128, `import_Norton_Equivalents` HG:278-310.  Unlike the reference, both CSV
+dialects are accepted natively (net1: `X_shunt`, no `G;B` columns — SURVEY.md Appendix B) and the Norton CSV is
+looked up in a configurable directory, case-insensitively (the reference hard-codes `~/Git/...` and relies on a
+case-insensitive file system for `SMPS` vs `smps`, HG:289-290).
+
+`pandas.read_csv` is used on purpose: its float parser decides the input doubles, and parity with the reference
+starts at the inputs.
+"""
+import os
+
+import numpy as np
+import pandas as pd
+
+from .settings import Settings
+
+
+def init_lines_from_csv(filename, settings=None):
+    """HG:45-61: `;`-delimited, columns ID;fromID;toID;R;X[;G;B]; R,X -> p.u. impedance, G,B -> p.u. admittance."""
+    st = settings or Settings()
+    df = pd.read_csv(filename, delimiter=";").dropna(how="all").reset_index(drop=True)
+    for col in ("G", "B"):
+        if col not in df.columns:
+            df[col] = 0.0
+    df["R"] = df.R.astype(float) / st.base_impedance
+    df["X"] = df.X.astype(float) / st.base_impedance
+    df["G"] = df.G.astype(float) / st.base_admittance
+    df["B"] = df.B.astype(float) / st.base_admittance
+    return df
+
+
+def init_buses_from_csv(filename, settings=None):
+    """HG:77-94: columns ID;type;component;S;P;Q;X_sh[;V_nom] (or net1's ID;type;component;S;X_shunt;P;Q)."""
+    st = settings or Settings()
+    df = pd.read_csv(filename, delimiter=";").dropna(how="all").reset_index(drop=True)
+    if "X_shunt" in df.columns and "X_sh" not in df.columns:
+        df = df.rename(columns={"X_shunt": "X_sh"})
+    df["S"] = df.S.astype(float) / st.BASE_POWER
+    df["P"] = df.P.astype(float) / st.BASE_POWER
+    df["Q"] = df.Q.astype(float) / st.BASE_POWER
+    df["X_sh"] = df.X_sh.astype(float) / st.base_impedance
+    return df
+
+
+def network_constants(buses):
+    """m, n, c of HG:121-127: m = 0-based index of the first nonlinear bus (n if none), c = #PV + 1."""
+    nl = buses.index[buses["type"] == "nonlinear"]
+    m = int(min(nl)) if len(nl) > 0 else len(buses)
+    n = len(buses)
+    c = len(buses[buses.type == "PV"]) + 1
+    return m, n, c
+
+
+def validate_bus_order(buses):
+    """The reference assumes slack, PV..., PQ..., nonlinear... (HG:83, TODO HG:114) without checking; a violated
+    order silently gives wrong index sets, so it is an error here."""
+    rank = {"slack": 0, "PV": 1, "PQ": 2, "nonlinear": 3}
+    r = [rank.get(t, -1) for t in buses["type"]]
+    if -1 in r:
+        raise ValueError("unknown bus type %r" % sorted(set(buses["type"]) - set(rank)))
+    if r[0] != 0 or r.count(0) != 1 or any(b < a for a, b in zip(r, r[1:])):
+        raise ValueError("buses must be ordered slack, PV..., PQ..., nonlinear... (reference contract, HG:83)")
+
+
+def init_network(filename_buses, filename_lines, from_csv=True, settings=None):
+    """HG:113-128 -> (buses, lines, m, n, c)."""
+    if not from_csv:
+        raise NotImplementedError("the reference's manual initialisers are broken (HG:97-110); use CSV files")
+    buses = init_buses_from_csv(filename_buses, settings)
+    lines = init_lines_from_csv(filename_lines, settings)
+    validate_bus_order(buses)
+    m, n, c = network_constants(buses)
+    return buses, lines, m, n, c
+
+
+def default_ne_dir():
+    """Directory holding `<component>_NE.csv`: $HPF_NE_DIR, else the reference's hard-coded location HG:289."""
+    return os.environ.get("HPF_NE_DIR") or os.path.expanduser("~/Git/harmonic-power-flow/Circuit Simulation")
+
+
+def _find_ne_file(ne_dir, device):
+    want = (str(device) + "_NE.csv").lower()
+    for f in sorted(os.listdir(ne_dir)):
+        if f.lower() == want:
+            return os.path.join(ne_dir, f)
+    raise FileNotFoundError("no Norton-equivalent file for component %r in %s" % (device, ne_dir))
+
+
+def import_Norton_Equivalents(buses, coupled, settings=None, ne_dir=None):
+    """HG:278-310 -> {device: [I_N, Y_N]} as DataFrames in p.u., exactly the reference's objects."""
+    st = settings or Settings()
+    ne_dir = ne_dir or default_ne_dir()
+    freqs = st.HARMONICS_FREQ
+    NE = {}
+    for device in buses.component[buses.type == "nonlinear"].unique():
+        NE_device = pd.read_csv(_find_ne_file(ne_dir, device), index_col=["Parameter", "Frequency"])
+        NE_device.columns = NE_device.columns.astype(int)
+        missing = [f for f in freqs if f not in NE_device.columns]
+        if missing:
+            raise KeyError("Norton file of %r lacks harmonics at %s Hz" % (device, missing))
+        NE_device = NE_device[freqs]
+        NE_device = NE_device.apply(lambda col: col.apply(lambda val: complex(val.strip("()"))))
+        if coupled:
+            I_N = NE_device.loc["I_N_c"] / st.base_current
+            Y_N = NE_device.loc[("Y_N_c", freqs), freqs] / st.base_admittance
+        else:
+            I_N = NE_device.loc["I_N_uc"] / st.base_current
+            Y_N = NE_device.loc["Y_N_uc"] / st.base_admittance
+        NE[device] = [I_N, Y_N]
+    return NE
+
+
+def norton_arrays(buses, NE, coupled, Hn):
+    """Pack the Norton dict for the device: dev_of_bus[n] (-1 = linear), Y_N [n_dev][Hn][Hn] (coupled) or
+    [n_dev][Hn] (uncoupled), I_N [n_dev][Hn], complex128 C-ordered."""
+    types = buses["type"].to_numpy()
+    comps = buses["component"].to_numpy()
+    devices = list(NE.keys())
+    dev_of_bus = np.full(len(buses), -1, dtype=np.int32)
+    for i in range(len(buses)):
+        if types[i] == "nonlinear":
+            dev_of_bus[i] = devices.index(comps[i])
+    n_dev = max(len(devices), 1)
+    I_N = np.zeros((n_dev, Hn), dtype=np.complex128)
+    Y_N = np.zeros((n_dev, Hn, Hn) if coupled else (n_dev, Hn), dtype=np.complex128)
+    for d, name in enumerate(devices):
+        i_n, y_n = NE[name]
+        I_N[d] = np.asarray(i_n, dtype=np.complex128).reshape(-1)
+        Y_N[d] = np.asarray(y_n, dtype=np.complex128).reshape(Y_N[d].shape)
+    return dev_of_bus, np.ascontiguousarray(Y_N), np.ascontiguousarray(I_N), len(devices)

@@ -1,0 +1,140 @@
+/*
+ * libhpf — MI355X (gfx950) harmonic power-flow Newton-Raphson hot path, C ABI.
+ *
+ * This is the drop-in boundary for ONE path of pweigmann/harmonic-power-flow: the NR loop of
+ * `hpf()` in `Harmonic Power Flow/hcne_generalized.py` (HG).  The reference has no FFI of its own (its hot path
+ * sits behind plain Python functions, HG:360-560); each entry point below names the reference function it
+ * replaces.  The Python host (`harmonic-power-flow_amd/`) binds these symbols with `ctypes` and re-exports the
+ * reference's own call shapes (`hpf`, `pf`, `harmonic_mismatch`, `build_harmonic_jacobian`, ...).
+ *
+ * Conventions
+ *   - return 0 on success; < 0 invalid argument / wrong state; > 0 device-side failure (HIP, rocSOLVER, singular
+ *     pivot): see hpf_strerror().  Nothing throws across the ABI.
+ *   - all host buffers are caller-owned and copied in/out; `*_dev` entry points take device pointers instead.
+ *   - the handle owns all device memory, one HIP stream and the rocBLAS handle; one handle per (process, device).
+ *     A handle is not thread-safe; distinct handles are independent.
+ *   - complex128 arrays are interleaved (re, im) doubles, NumPy layout.
+ *   - all arithmetic is FP64.  Stacked index k = q*n + i (harmonic position q, bus i), HG:139-143.
+ *   - scenarios: S independent load cases (P, Q per bus) share topology, admittances and Norton data; every
+ *     per-scenario array is [S][...] with the scenario index slowest.
+ */
+#ifndef HPF_H
+#define HPF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hpf_handle hpf_handle;
+
+enum {
+    HPF_SOLVER_DENSE = 0,      /* dense real FP64 Jacobian, rocSOLVER getrf/getrs (any topology)             */
+    HPF_SOLVER_BLOCK_TREE = 1  /* bus-major 2Hn x 2Hn block elimination along the feeder tree (radial only)  */
+};
+
+enum {
+    HPF_OK = 0,
+    HPF_E_ARG = -1,        /* null pointer / out-of-range argument */
+    HPF_E_STATE = -2,      /* call order violated (e.g. solve before loads were set) */
+    HPF_E_TOPOLOGY = -3,   /* BLOCK_TREE requested for a network that is not a tree rooted at bus 0 */
+    HPF_E_NOMEM = -4,
+    HPF_E_HIP = 1,         /* HIP runtime error (hpf_last_error_detail has the hipError_t) */
+    HPF_E_ROCSOLVER = 2,   /* rocBLAS / rocSOLVER status != success */
+    HPF_E_SINGULAR = 3     /* a factorisation met an exactly zero pivot */
+};
+
+/* Model description (host pointers, copied by hpf_create).  Produced by the Python ingest from the reference's CSV
+ * formats: bus/line CSVs -> (n, m, c) HG:113-128; per-harmonic admittances HG:132-171 stored as one CSR pattern
+ * shared by all harmonics; Norton equivalents HG:278-310 per device type. */
+typedef struct hpf_desc {
+    int32_t n;                 /* buses                                                            HG:126 */
+    int32_t m;                 /* 0-based index of first nonlinear bus (n if none)                 HG:122-125 */
+    int32_t c;                 /* number of PV buses + 1                                           HG:127 */
+    int32_t Hn;                /* harmonics incl. fundamental (K+1)                                HG:584 */
+    int32_t nnz;               /* stored entries of the shared admittance pattern (full diagonal present) */
+    int32_t n_dev;             /* nonlinear device types                                           HG:285 */
+    int32_t coupled;           /* 1: Y_N is Hn x Hn per device; 0: Y_N is a length-Hn vector       HG:301-308 */
+    int32_t solver;            /* HPF_SOLVER_*                                                             */
+    int32_t device;            /* HIP device ordinal                                                       */
+    int32_t max_scenarios;     /* capacity S_max >= 1                                                      */
+    const int32_t* rowptr;     /* [n+1]                                                                    */
+    const int32_t* col;        /* [nnz], ascending inside a row                                            */
+    const double*  Yval;       /* [Hn][nnz] complex128                                                     */
+    const int32_t* dev_of_bus; /* [n]: device type of a nonlinear bus, -1 for linear buses                 */
+    const double*  Y_N;        /* coupled: [n_dev][Hn][Hn] complex128 (row = harmonic of injected current,
+                                  col = harmonic of voltage, HG:304,432); uncoupled: [n_dev][Hn]           */
+    const double*  I_N;        /* [n_dev][Hn] complex128                                                   */
+} hpf_desc;
+
+/* Per-scenario result record, also the payload of the multi-GPU statistics gather (24 bytes). */
+typedef struct hpf_stat {
+    int32_t n_iter;            /* harmonic NR iterations performed                       HG:542 */
+    int32_t flags;             /* bit0 converged (err <= thresh), bit1 hit max_iter, bit2 non-finite mismatch */
+    double  err;               /* final ||f||_inf                                        HG:389 */
+    double  thd_max;           /* max over buses of THD_F                                HG:566-568 */
+} hpf_stat;
+
+int  hpf_create(hpf_handle** out, const hpf_desc* d);
+int  hpf_destroy(hpf_handle* h);
+const char* hpf_strerror(int code);
+int  hpf_last_error_detail(const hpf_handle* h);      /* hipError_t / rocblas_status / pivot index of the last >0 code */
+int  hpf_version(void);
+
+/* Sizes: N = 2*n*Hn - 1 - c unknowns of the harmonic NR (HG:388,397); Nf = 2*n - 1 - c of the fundamental NR. */
+int  hpf_num_unknowns(const hpf_handle* h);
+int  hpf_num_unknowns_fund(const hpf_handle* h);
+
+/* Loads P,Q [S][n] in p.u. (buses.P / buses.Q of HG:197,372).  Sets the active scenario count S. */
+int  hpf_set_loads(hpf_handle* h, int n_scen, const double* P, const double* Q);
+/* Voltages Vm,Va [S][Hn*n] (the V DataFrame of HG:174-184, signed magnitudes allowed).  NULL,NULL -> the reference's
+ * initial values (1 p.u. at h=1, 0.1 p.u. above, angle 0; init_voltages HG:174-184) for all S scenarios. */
+int  hpf_set_state(hpf_handle* h, int n_scen, const double* Vm, const double* Va);
+int  hpf_get_state(hpf_handle* h, double* Vm, double* Va);      /* raw: signed, un-wrapped; host applies HG:545-549 */
+
+/* harmonic_mismatch (HG:360-390) incl. current_balance / current_injections (HG:313-357) for all S scenarios.
+ * f [S][N] (may be NULL), err [S] (may be NULL). */
+int  hpf_mismatch(hpf_handle* h, double* f, double* err);
+/* build_harmonic_jacobian (HG:401-473) of scenario `scen`, written as a dense column-major N x N matrix
+ * (parity / debugging; the solver consumes the device copy directly). */
+int  hpf_jacobian(hpf_handle* h, int scen, double* J_colmajor);
+/* fund_mismatch + build_jacobian of the fundamental power flow (HG:195-223) for scenario `scen`: f [Nf], J [Nf*Nf]. */
+int  hpf_fund_mismatch(hpf_handle* h, double* f, double* err);
+int  hpf_fund_jacobian(hpf_handle* h, int scen, double* J_colmajor);
+
+/* pf (HG:244-275): fundamental NR from the current state for all S scenarios; leaves the harmonic rows untouched.
+ * n_iter [S], err [S] may be NULL.  err_hist [S][max_iter] (HG:264, may be NULL). */
+int  hpf_fund_pf(hpf_handle* h, double thresh, int max_iter, int* n_iter, double* err, double* err_hist);
+
+/* The NR loop of hpf (HG:530-542) from the current state: initial mismatch, then while err > thresh and
+ * n_iter < max_iter: Jacobian -> solve -> update -> mismatch.  Scenarios that satisfy the stop rule freeze.
+ * n_iter [S], err [S], err_hist [S][max_iter+1] (initial + one per iteration; unused tail = NaN) may be NULL. */
+int  hpf_solve(hpf_handle* h, double thresh, int max_iter, int* n_iter, double* err, double* err_hist);
+
+/* One unconditional NR iteration (Jacobian -> solve -> update -> mismatch) for all S scenarios, repeated `iters`
+ * times, no host synchronisation inside (throughput measurement; update_harmonic_state_vec HG:476-479 +
+ * update_harmonic_voltages HG:482-485).  Requires a valid mismatch (hpf_mismatch or hpf_solve first). */
+int  hpf_iterate(hpf_handle* h, int iters);
+
+/* Per-scenario statistics after hpf_solve; `thd_max` from get_THD (HG:563-572) evaluated on device. */
+int  hpf_get_stats(hpf_handle* h, hpf_stat* stats /* [S] host */);
+int  hpf_get_stats_dev(hpf_handle* h, void* stats_dev /* [S] hpf_stat, device memory of the caller (RCCL gather) */);
+
+/* Stream plumbing: run on a caller stream (e.g. torch's current stream) instead of the handle's own; NULL restores. */
+int  hpf_set_stream(hpf_handle* h, void* hip_stream);
+int  hpf_sync(hpf_handle* h);
+
+/* Kernel timing with HIP events on the handle's stream, accumulated since the last reset.
+ * which: 0 mismatch kernel, 1 Jacobian assembly kernel, 2 linear solve (factor+solve), 3 state update;
+ * returns total milliseconds in *ms and launch count in *launches. */
+int  hpf_timing_enable(hpf_handle* h, int on);
+int  hpf_timing_get(hpf_handle* h, int which, double* ms, int64_t* launches);
+int  hpf_timing_reset(hpf_handle* h);
+/* Exact flop count of one linear solve of one scenario for the configured solver (roofline numerator). */
+double hpf_solve_flops(const hpf_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HPF_H */

@@ -1,0 +1,69 @@
+"""Loader of the CPU emulation harness (tests/cpu_emul/emul.cpp): executes the device functions of
+csrc/hpf_assembly.hpp serially on the host.  Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+SRC = os.path.join(HERE, "cpu_emul", "emul.cpp")
+LIB = os.path.join(HERE, "cpu_emul", "libhpf_emul.so")
+HDR = os.path.join(REPO, "harmonic-power-flow_amd", "csrc", "hpf_assembly.hpp")
+
+
+def load():
+    if (not os.path.exists(LIB)) or os.path.getmtime(LIB) < max(os.path.getmtime(SRC), os.path.getmtime(HDR)):
+        subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-mfma", "-fPIC", "-shared", "-I",
+                               os.path.dirname(HDR), SRC, "-o", LIB])
+    return C.CDLL(LIB)
+
+
+def _p(a, t=C.c_double):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+class Emul:
+    def __init__(self, n, m, c, Hn, rowptr, col, Yval, dev, Y_N, I_N, n_dev, coupled):
+        self.lib = load()
+        self.n, self.m, self.c, self.Hn = n, m, c, Hn
+        self.rowptr = np.ascontiguousarray(rowptr, np.int32)
+        self.col = np.ascontiguousarray(col, np.int32)
+        self.Y = np.ascontiguousarray(Yval, np.complex128)
+        self.dev = np.ascontiguousarray(dev, np.int32)
+        self.YN = np.ascontiguousarray(Y_N, np.complex128)
+        self.IN = np.ascontiguousarray(I_N, np.complex128)
+        self.n_dev, self.coupled = n_dev, int(coupled)
+        rows = np.repeat(np.arange(n), np.diff(self.rowptr))
+        self.diag = np.ascontiguousarray(np.nonzero(rows == self.col)[0], np.int32)
+
+    def _model_args(self):
+        return (self.n, self.m, self.c, self.Hn, len(self.col), self.n_dev, self.coupled, _p(self.rowptr, C.c_int32),
+                _p(self.col, C.c_int32), _p(self.diag, C.c_int32), _p(self.Y.view(np.float64)), _p(self.dev, C.c_int32),
+                _p(self.YN.view(np.float64)), _p(self.IN.view(np.float64)))
+
+    def polar(self, Vm, Va, fund=False):
+        cnt = self.n if fund else self.n * self.Hn
+        U = np.zeros(self.n * self.Hn, np.complex128)
+        E = np.zeros(self.n * self.Hn, np.complex128)
+        Vm = np.ascontiguousarray(Vm, np.float64)
+        Va = np.ascontiguousarray(Va, np.float64)
+        self.lib.emul_polar(int(fund), cnt, _p(Vm), _p(Va), _p(U.view(np.float64)), _p(E.view(np.float64)))
+        return U, E
+
+    def mismatch(self, Vm, Va, P, Q, fund=False):
+        U, E = self.polar(Vm, Va, fund)
+        N = (2 * self.n - 1 - self.c) if fund else (2 * (self.n * self.Hn - 1) - (self.c - 1))
+        f = np.zeros(N)
+        P = np.ascontiguousarray(P, np.float64)
+        Q = np.ascontiguousarray(Q, np.float64)
+        self.lib.emul_mismatch(int(fund), *self._model_args(), _p(U.view(np.float64)), _p(P), _p(Q), _p(f))
+        return f
+
+    def jacobian(self, Vm, Va, fund=False):
+        U, E = self.polar(Vm, Va, fund)
+        N = (2 * self.n - 1 - self.c) if fund else (2 * (self.n * self.Hn - 1) - (self.c - 1))
+        J = np.zeros((N, N), order="F")
+        self.lib.emul_jacobian(int(fund), *self._model_args(), _p(U.view(np.float64)), _p(E.view(np.float64)), _p(J))
+        return J

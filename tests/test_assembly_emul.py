@@ -1,0 +1,92 @@
+"""The device arithmetic (csrc/hpf_assembly.hpp), executed serially on the host, against the oracle:
+index maps of mismatch / Jacobian (harmonic and fundamental) and the rounding order.  No GPU involved."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import hpf_oracle as o
+from conftest import GOLD, INPUTS
+from emul import Emul
+
+import harmonic_power_flow_amd as hp
+from harmonic_power_flow_amd import ingest
+
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "net*_H*.npz")))
+
+
+def _setup(name):
+    net_name, hs, cs = name.split("_")
+    hmax, coupled = int(hs[1:]), cs == "c"
+    st = hp.Settings(H_MAX=hmax)
+    fb, fl = os.path.join(INPUTS, f"{net_name}_buses.csv"), os.path.join(INPUTS, f"{net_name}_lines.csv")
+    buses, lines, m, n, c = hp.init_network(fb, fl, settings=st)
+    Y = hp.build_admittance_matrices(buses, lines, st.HARMONICS)
+    NE = hp.import_Norton_Equivalents(buses, coupled, st, INPUTS)
+    dev, Y_N, I_N, n_dev = ingest.norton_arrays(buses, NE, coupled, len(st.HARMONICS))
+    em = Emul(n, m, c, len(st.HARMONICS), Y.rowptr, Y.col, Y.Yval, dev, Y_N, I_N, n_dev, coupled)
+    net = o.init_network(fb, fl)
+    rowptr, col, Yval = o.build_admittance_matrices(net, st.HARMONICS)
+    mdl = o.Model(net, st.HARMONICS, rowptr, col, Yval, o.import_Norton_Equivalents(net, st.HARMONICS, coupled, INPUTS),
+                  coupled)
+    return st, buses, Y, em, net, mdl, (rowptr, col, Yval)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_product_ingest_matches_oracle_and_reference(name):
+    st, buses, Y, em, net, mdl, (rowptr, col, Yval) = _setup(name)
+    g = np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=True)
+    assert np.array_equal(Y.rowptr, rowptr) and np.array_equal(Y.col, col)
+    assert np.array_equal(Y.Yval, Yval)                                  # bit-identical admittances
+    assert np.array_equal(Y.to_frame().to_numpy(), g["Y_all"])          # ... and equal to the reference's Y_all
+    assert np.array_equal(em.IN.ravel(), g["I_N"].ravel()) and np.array_equal(em.YN.ravel(), g["Y_N"].ravel())
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_device_arithmetic_on_host_matches_oracle(name):
+    st, buses, Y, em, net, mdl, _ = _setup(name)
+    g = np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=True)
+    P, Q = buses["P"].to_numpy(float), buses["Q"].to_numpy(float)
+    traj = g["V_traj"]
+    for it in sorted({0, 1, len(traj) // 2, len(traj) - 1}):
+        Vm, Va = traj[it][:, 0].copy(), traj[it][:, 1].copy()
+        f_o, _ = o.harmonic_mismatch(mdl, Vm.copy(), Va.copy())
+        f_e = em.mismatch(Vm, Va, P, Q)
+        scale = max(1.0, np.abs(f_o).max())
+        assert np.abs(f_e - f_o).max() <= 1e-13 * scale, (name, it)
+        J_o = o.build_harmonic_jacobian(mdl, Vm.copy(), Va.copy()).toarray()
+        J_e = em.jacobian(Vm, Va)
+        assert J_e.shape == J_o.shape
+        assert np.abs(J_e - J_o).max() <= 1e-13 * np.abs(J_o).max(), (name, it)
+    # iteration 0 against the reference's own f and J
+    Vm, Va = traj[0][:, 0].copy(), traj[0][:, 1].copy()
+    assert np.abs(em.mismatch(Vm, Va, P, Q) - g["f0"]).max() <= 1e-13 * max(1.0, np.abs(g["f0"]).max())
+    Jg = np.zeros(tuple(g["J0_shape"]))
+    np.add.at(Jg, (g["J0_row"], g["J0_col"]), g["J0_data"])
+    assert np.abs(em.jacobian(Vm, Va) - Jg).max() <= 1e-13 * np.abs(Jg).max()
+
+
+@pytest.mark.parametrize("name", ["net1_H11_c", "net2_H11_uc", "net3_H51_c"])
+def test_fundamental_arithmetic_on_host(name):
+    """pf's mismatch / Jacobian (HG:195-223) at the reference start and at the converged seed."""
+    st, buses, Y, em, net, mdl, (rowptr, col, Yval) = _setup(name)
+    g = np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=True)
+    P, Q = buses["P"].to_numpy(float), buses["Q"].to_numpy(float)
+    n, c = net.n, net.c
+    Y1 = o.y_csr(rowptr, col, Yval[0], n).toarray()
+    import scipy.sparse as sp
+    for Vm, Va in (o.init_voltages(n, len(st.HARMONICS)), (g["V_pf"][:, 0].copy(), g["V_pf"][:, 1].copy())):
+        V_vec = Vm[:n] * np.exp(1j * Va[:n])
+        mis = V_vec * np.conj(Y1.dot(V_vec)) + (P + 1j * Q)
+        f_o = np.r_[mis.real[1:], mis.imag[c:]]
+        f_e = em.mismatch(Vm, Va, P, Q, fund=True)
+        assert np.abs(f_e - f_o).max() <= 1e-14 * max(1.0, np.abs(f_o).max())
+        I_diag, V_diag = sp.diags(Y1 @ V_vec), sp.diags(V_vec)
+        V_dn = sp.diags(V_vec / abs(V_vec))
+        dSdA = 1j * V_diag @ (np.conj(I_diag - Y1 @ V_diag))
+        dSdV = V_dn @ np.conj(I_diag) + V_diag @ np.conj(Y1 @ V_dn)
+        J_o = np.block([[np.asarray(dSdA[1:, 1:].real), np.asarray(dSdV[1:, c:].real)],
+                        [np.asarray(dSdA[c:, 1:].imag), np.asarray(dSdV[c:, c:].imag)]])
+        J_e = em.jacobian(Vm, Va, fund=True)
+        assert np.abs(J_e - J_o).max() <= 1e-14 * np.abs(J_o).max()

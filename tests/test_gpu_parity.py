@@ -1,0 +1,206 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against
+  (1) golden vectors captured from the unmodified reference (tests/golden/*.npz), and
+  (2) the CPU oracle on the same seeded inputs.
+Tolerances: the north-star bar is |dV| < 1e-8 p.u. per harmonic on the converged voltages (complex U and V_m after
+the HG:545-549 normalisation) with the SAME iteration count; mismatch / Jacobian entries are compared at
+1e-12 relative (FP64 everywhere; device sincos differs from glibc by <= 1 ulp)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import hpf_oracle as o
+from conftest import GOLD, INPUTS
+
+pytestmark = pytest.mark.gpu
+
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "net*_H*.npz")))
+TOL_V = 1e-8
+
+
+def _hp():
+    import harmonic_power_flow_amd as hp
+    return hp
+
+
+def _case(name):
+    net_name, hs, cs = name.split("_")
+    return net_name, int(hs[1:]), cs == "c"
+
+
+def _paths(net_name):
+    return os.path.join(INPUTS, f"{net_name}_buses.csv"), os.path.join(INPUTS, f"{net_name}_lines.csv")
+
+
+def _model(hp, name, solver="dense", max_scenarios=1):
+    from harmonic_power_flow_amd import api
+    net_name, hmax, coupled = _case(name)
+    st = hp.Settings(H_MAX=hmax)
+    buses, lines, m, n, c = hp.init_network(*_paths(net_name), settings=st)
+    Y = hp.build_admittance_matrices(buses, lines, st.HARMONICS)
+    NE = hp.import_Norton_Equivalents(buses, coupled, st, INPUTS)
+    dm = api._device_model(buses, Y, NE, coupled, st.HARMONICS, solver=solver, max_scenarios=max_scenarios)
+    return st, buses, dm
+
+
+def test_gpu_present_and_native_library_loaded():
+    import torch
+    assert torch.cuda.is_available()
+    from harmonic_power_flow_amd import _lib
+    assert _lib.load().hpf_version() >= 100
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_hpf_matches_reference_golden(name):
+    """Full drop-in path: CSV ingest -> pf -> harmonic NR -> post-processing, vs the reference's own result."""
+    hp = _hp()
+    g = np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=True)
+    net_name, hmax, coupled = _case(name)
+    st = hp.Settings(H_MAX=hmax)
+    buses, lines, m, n, c = hp.init_network(*_paths(net_name), settings=st)
+    det = {}
+    V, err_h, n_iter_h, J = hp.hpf(buses, lines, coupled, settings=st, ne_dir=INPUTS, verbose=False, details=det)
+    assert det["n_iter_f"] == int(g["n_iter_f"])
+    np.testing.assert_allclose(np.stack(det["seed"], 1), g["V_pf"], rtol=0, atol=1e-13)
+    assert n_iter_h == int(g["n_iter_h"]), (n_iter_h, int(g["n_iter_h"]))
+    ge = g["err_hist"]
+    np.testing.assert_allclose(det["err_hist"][:3], ge[:3], rtol=1e-9)
+    Ud = V["V_m"].to_numpy() * np.exp(1j * V["V_a"].to_numpy())
+    Ug = g["V_final"][:, 0] * np.exp(1j * g["V_final"][:, 1])
+    dU = np.abs(Ud - Ug).max()
+    dVm = np.abs(V["V_m"].to_numpy() - g["V_final"][:, 0]).max()
+    print(f"\n{name}: it {n_iter_h} err {err_h:.3e} (ref {float(g['err_h']):.3e}) max|dU| {dU:.2e} max|dVm| {dVm:.2e}")
+    assert dU < TOL_V and dVm < TOL_V
+    assert (V["V_m"].to_numpy() >= 0).all() and (V["V_a"].to_numpy() >= 0).all() and (V["V_a"].to_numpy() < 2 * np.pi).all()
+    thd = hp.get_THD(V).to_numpy()
+    np.testing.assert_allclose(thd, g["THD"], rtol=1e-6)
+    if J is not None:
+        assert J.shape == tuple(g["J0_shape"])
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_mismatch_and_jacobian_kernels_vs_golden_and_oracle(name):
+    """hpf_mismatch / hpf_jacobian at iteration 0 (vs the reference's f0, J0) and along the golden trajectory
+    (vs the oracle)."""
+    hp = _hp()
+    g = np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=True)
+    net_name, hmax, coupled = _case(name)
+    st, buses, dm = _model(hp, name)
+    net = o.init_network(*_paths(net_name))
+    rowptr, col, Yval = o.build_admittance_matrices(net, st.HARMONICS)
+    mdl = o.Model(net, st.HARMONICS, rowptr, col, Yval, o.import_Norton_Equivalents(net, st.HARMONICS, coupled, INPUTS),
+                  coupled)
+    try:
+        dm.set_loads(buses["P"].to_numpy(float), buses["Q"].to_numpy(float))
+        traj = g["V_traj"]
+        for it in sorted({0, 1, len(traj) // 2, len(traj) - 1}):
+            Vm, Va = traj[it][:, 0].copy(), traj[it][:, 1].copy()
+            dm.set_state(Vm, Va)
+            f, err = dm.mismatch()
+            J = dm.jacobian(0)
+            f_o, e_o = o.harmonic_mismatch(mdl, Vm.copy(), Va.copy())
+            J_o = o.build_harmonic_jacobian(mdl, Vm.copy(), Va.copy()).toarray()
+            fs = max(1.0, np.abs(f_o).max())
+            assert np.abs(f[0] - f_o).max() <= 1e-12 * fs
+            assert abs(err[0] - e_o) <= 1e-12 * fs
+            assert np.abs(J - J_o).max() <= 1e-12 * np.abs(J_o).max()
+            if it == 0:
+                assert np.abs(f[0] - g["f0"]).max() <= 1e-12 * fs
+                Jg = np.zeros(tuple(g["J0_shape"]))
+                np.add.at(Jg, (g["J0_row"], g["J0_col"]), g["J0_data"])
+                assert np.abs(J - Jg).max() <= 1e-12 * np.abs(Jg).max()
+    finally:
+        dm.close()
+
+
+@pytest.mark.parametrize("name", ["net1_H11_c", "net3_H51_uc"])
+def test_fundamental_pf_kernels(name):
+    """hpf_fund_mismatch / hpf_fund_jacobian / hpf_fund_pf vs the oracle's pf (HG:195-275)."""
+    hp = _hp()
+    g = np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=True)
+    net_name, hmax, coupled = _case(name)
+    st, buses, dm = _model(hp, name)
+    net = o.init_network(*_paths(net_name))
+    rowptr, col, Yval = o.build_admittance_matrices(net, st.HARMONICS)
+    try:
+        dm.set_loads(buses["P"].to_numpy(float), buses["Q"].to_numpy(float))
+        dm.set_state(None, None, n_scen=1)
+        f, err = dm.mismatch(fund=True)
+        n, c = net.n, net.c
+        Y1 = o.y_csr(rowptr, col, Yval[0], n).toarray()
+        V_vec = np.ones(n, dtype=complex)
+        mis = V_vec * np.conj(Y1.dot(V_vec)) + (net.P + 1j * net.Q)
+        f_o = np.r_[mis.real[1:], mis.imag[c:]]
+        assert np.abs(f[0] - f_o).max() <= 1e-13 * max(1.0, np.abs(f_o).max())
+        n_iter, e, hist = dm.fund_pf(1e-6, 30)
+        Vm, Va = dm.get_state()
+        assert int(n_iter[0]) == int(g["n_iter_f"])
+        np.testing.assert_allclose(hist[0, :int(n_iter[0])], g["err_f"], rtol=1e-6, atol=1e-15)
+        np.testing.assert_allclose(np.stack([Vm[0], Va[0]], 1), g["V_pf"], rtol=0, atol=1e-13)
+    finally:
+        dm.close()
+
+
+def test_batched_scenarios_match_individual_oracle_runs():
+    """S scenarios with different loads in one handle: each must equal the oracle run on that load alone."""
+    hp = _hp()
+    name = "net1_H11_c"
+    net_name, hmax, coupled = _case(name)
+    S = 5
+    st, buses, dm = _model(hp, name, max_scenarios=S)
+    rng = np.random.default_rng(7)
+    P0, Q0 = buses["P"].to_numpy(float), buses["Q"].to_numpy(float)
+    scale = rng.uniform(0.5, 1.5, size=(S, len(P0)))
+    scale[0] = 1.0
+    try:
+        dm.set_loads(P0 * scale, Q0 * scale)
+        dm.set_state(None, None, n_scen=S)
+        nf, ef, hf = dm.fund_pf(1e-6, 30)
+        n_iter, err, hist = dm.solve(1e-4, 50)
+        Vm, Va = dm.get_state()
+        stats = dm.stats()
+    finally:
+        dm.close()
+    for s in range(S):
+        net = o.init_network(*_paths(net_name))
+        net.P, net.Q = P0 * scale[s], Q0 * scale[s]
+        r = o.hpf(net, st.HARMONICS, coupled, INPUTS)
+        assert int(n_iter[s]) == r["n_iter_h"], (s, n_iter[s], r["n_iter_h"])
+        Ud = Vm[s] * np.exp(1j * Va[s])
+        Uo = r["Vm_raw"] * np.exp(1j * r["Va_raw"])
+        assert np.abs(Ud - Uo).max() < TOL_V
+        assert stats["n_iter"][s] == r["n_iter_h"] and (stats["flags"][s] & 1)
+        thd = o.get_THD(np.abs(r["Vm_raw"]), net.n, len(st.HARMONICS))[:, 0].max()
+        assert abs(stats["thd_max"][s] - thd) < 1e-6 * thd
+
+
+def test_state_and_argument_errors():
+    hp = _hp()
+    from harmonic_power_flow_amd._lib import HpfError
+    st, buses, dm = _model(hp, "net2_H11_c")
+    try:
+        with pytest.raises(HpfError):
+            dm.S = 1
+            dm.solve()                      # loads / state not set
+        dm.set_loads(buses["P"].to_numpy(float), buses["Q"].to_numpy(float))
+        dm.set_state(None, None, n_scen=1)
+        with pytest.raises(HpfError):
+            dm.iterate(1)                   # no valid mismatch yet
+        with pytest.raises(HpfError):
+            dm.jacobian(scen=3)
+    finally:
+        dm.close()
+    with pytest.raises(HpfError):           # BLOCK_TREE on a meshed network
+        _model(hp, "net2_H11_c", solver="block_tree")
+
+
+def test_max_iter_and_nonconvergence_reporting():
+    """A run capped at max_iter_h reports n_iter_h == max_iter_h like the reference (HG:558-559)."""
+    hp = _hp()
+    st = hp.Settings(H_MAX=11)
+    buses, lines, m, n, c = hp.init_network(*_paths("net2"), settings=st)
+    V, err_h, n_iter_h, J = hp.hpf(buses, lines, True, max_iter_h=3, settings=st, ne_dir=INPUTS, verbose=False)
+    g = np.load(os.path.join(GOLD, "net2_H11_c.npz"), allow_pickle=True)
+    assert n_iter_h == 3
+    assert abs(err_h - g["err_hist"][3]) <= 1e-6 * g["err_hist"][3]
