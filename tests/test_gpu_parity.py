@@ -17,6 +17,12 @@ pytestmark = pytest.mark.gpu
 
 CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "net*_H*.npz")))
 TOL_V = 1e-8
+# The NR trajectory of net1/K=25/coupled is chaotic in its first ~20 iterations and its LENGTH depends on the
+# rounding of the linear solver: inside the reference itself, swapping SuperLU for LAPACK gives 32 iterations instead
+# of 23, and an iteratively refined (exact to working precision) solve gives 27 (measured with the oracle, DESIGN.md
+# "Parity").  All of them end at the same voltages.  For this case the voltages are the gate and the iteration
+# count is only reported; every other case is robust and must reproduce the reference's iteration count.
+SOLVER_SENSITIVE = {"net1_H51_c"}
 
 
 def _hp():
@@ -63,7 +69,9 @@ def test_hpf_matches_reference_golden(name):
     V, err_h, n_iter_h, J = hp.hpf(buses, lines, coupled, settings=st, ne_dir=INPUTS, verbose=False, details=det)
     assert det["n_iter_f"] == int(g["n_iter_f"])
     np.testing.assert_allclose(np.stack(det["seed"], 1), g["V_pf"], rtol=0, atol=1e-13)
-    assert n_iter_h == int(g["n_iter_h"]), (n_iter_h, int(g["n_iter_h"]))
+    if name not in SOLVER_SENSITIVE:
+        assert n_iter_h == int(g["n_iter_h"]), (n_iter_h, int(g["n_iter_h"]))
+    assert n_iter_h < 50 and err_h <= 1e-4
     ge = g["err_hist"]
     np.testing.assert_allclose(det["err_hist"][:3], ge[:3], rtol=1e-9)
     Ud = V["V_m"].to_numpy() * np.exp(1j * V["V_a"].to_numpy())
@@ -204,3 +212,112 @@ def test_max_iter_and_nonconvergence_reporting():
     g = np.load(os.path.join(GOLD, "net2_H11_c.npz"), allow_pickle=True)
     assert n_iter_h == 3
     assert abs(err_h - g["err_hist"][3]) <= 1e-6 * g["err_hist"][3]
+
+
+# ---- synthetic radial feeders: dense (rocSOLVER) and block-tree Newton steps ------------------------------------
+def _syn_model(hp, n, hmax, solver, tmp_path, max_scenarios=1):
+    from harmonic_power_flow_amd import api, synth
+    fb, fl = synth.gen(n, seed=0, outdir=str(tmp_path))
+    st = hp.Settings(H_MAX=hmax)
+    buses, lines, m, nn, c = hp.init_network(fb, fl, settings=st)
+    Y = hp.build_admittance_matrices(buses, lines, st.HARMONICS)
+    NE = hp.import_Norton_Equivalents(buses, True, st, INPUTS)
+    dm = api._device_model(buses, Y, NE, True, st.HARMONICS, solver=solver, max_scenarios=max_scenarios)
+    return st, buses, lines, dm, (fb, fl)
+
+
+@pytest.mark.parametrize("n,solver", [(50, "dense"), (50, "block_tree"), (100, "block_tree"), (200, "block_tree"),
+                                      (200, "dense")])
+def test_synthetic_feeder_vs_reference_golden(n, solver, tmp_path):
+    hp = _hp()
+    g = np.load(os.path.join(GOLD, f"syn{n}_H11_c.npz"), allow_pickle=True)
+    st, buses, lines, dm, _ = _syn_model(hp, n, 11, solver, tmp_path)
+    try:
+        dm.set_loads(buses["P"].to_numpy(float), buses["Q"].to_numpy(float))
+        dm.set_state(None, None, n_scen=1)
+        nf, ef, hf = dm.fund_pf(1e-6, 30)
+        seed = dm.get_state()
+        np.testing.assert_allclose(np.stack([seed[0][0], seed[1][0]], 1), g["V_pf"], rtol=0, atol=1e-12)
+        n_iter, err, hist = dm.solve(1e-4, 50)
+        Vm, Va = dm.get_state()
+    finally:
+        dm.close()
+    from harmonic_power_flow_amd.api import _postprocess
+    Vm, Va = _postprocess(Vm[0], Va[0])
+    Ud = Vm * np.exp(1j * Va)
+    Ug = g["V_final"][:, 0] * np.exp(1j * g["V_final"][:, 1])
+    print(f"\nsyn{n} {solver}: it {int(n_iter[0])} (ref {int(g['n_iter_h'])}) err {err[0]:.3e} max|dU| {np.abs(Ud - Ug).max():.2e}")
+    assert int(n_iter[0]) == int(g["n_iter_h"])
+    assert np.abs(Ud - Ug).max() < TOL_V
+
+
+def test_block_tree_step_equals_dense_step(tmp_path):
+    """One Newton step from the pf seed: block-tree elimination vs rocSOLVER LU on the same Jacobian."""
+    hp = _hp()
+    out = {}
+    for solver in ("dense", "block_tree"):
+        st, buses, lines, dm, _ = _syn_model(hp, 100, 11, solver, tmp_path)
+        try:
+            dm.set_loads(buses["P"].to_numpy(float), buses["Q"].to_numpy(float))
+            dm.set_state(None, None, n_scen=1)
+            dm.fund_pf(1e-6, 30)
+            v0 = dm.get_state()
+            dm.mismatch()
+            dm.iterate(1)
+            dm.sync()
+            out[solver] = (v0, dm.get_state(), dm.mismatch()[1][0])
+        finally:
+            dm.close()
+    (v0d, v1d, ed), (v0b, v1b, eb) = out["dense"], out["block_tree"]
+    assert np.array_equal(v0d[0], v0b[0])
+    step = np.abs(v1d[0] - v0d[0]).max()
+    assert step > 1e-3
+    assert np.abs(v1d[0] - v1b[0]).max() <= 1e-10 * max(1.0, step)
+    assert np.abs(v1d[1] - v1b[1]).max() <= 1e-10 * max(1.0, np.abs(v1d[1] - v0d[1]).max())
+    assert abs(ed - eb) <= 1e-8 * ed
+
+
+def test_auto_solver_and_api_on_radial_feeder(tmp_path):
+    hp = _hp()
+    from harmonic_power_flow_amd import synth
+    fb, fl = synth.gen(50, seed=0, outdir=str(tmp_path))
+    st = hp.Settings(H_MAX=11)
+    res = hp.solve(fb, fl, coupled=True, settings=st, ne_dir=INPUTS)
+    g = np.load(os.path.join(GOLD, "syn50_H11_c.npz"), allow_pickle=True)
+    assert res["details"]["solver"] == "block_tree"
+    assert res["n_iter_h"] == int(g["n_iter_h"]) and res["converged"]
+    V = res["V"]
+    Ud = V["V_m"].to_numpy() * np.exp(1j * V["V_a"].to_numpy())
+    Ug = g["V_final"][:, 0] * np.exp(1j * g["V_final"][:, 1])
+    assert np.abs(Ud - Ug).max() < TOL_V
+    np.testing.assert_allclose(res["THD"].to_numpy(), g["THD"], rtol=1e-6)
+
+
+def test_scenario_batch_block_tree_matches_oracle(tmp_path):
+    """Monte-Carlo load scenarios (BASELINE config 4 shape, small): each scenario equals its own oracle run."""
+    hp = _hp()
+    from harmonic_power_flow_amd import synth
+    S, n = 6, 50
+    st, buses, lines, dm, (fb, fl) = _syn_model(hp, n, 11, "block_tree", tmp_path, max_scenarios=S)
+    P0, Q0 = buses["P"].to_numpy(float), buses["Q"].to_numpy(float)
+    scale = np.stack([synth.scenario_scale(n, s) for s in range(S)])
+    try:
+        dm.set_loads(P0 * scale, Q0 * scale)
+        dm.set_state(None, None, n_scen=S)
+        dm.fund_pf(1e-6, 30)
+        n_iter, err, hist = dm.solve(1e-4, 50)
+        Vm, Va = dm.get_state()
+        stats = dm.stats()
+    finally:
+        dm.close()
+    for s in range(S):
+        net = o.init_network(fb, fl)
+        net.P, net.Q = P0 * scale[s], Q0 * scale[s]
+        r = o.hpf(net, st.HARMONICS, True, INPUTS)
+        conv_o = r["n_iter_h"] < 50
+        assert bool(stats["flags"][s] & 1) == conv_o
+        if conv_o:
+            assert int(n_iter[s]) == r["n_iter_h"], (s, int(n_iter[s]), r["n_iter_h"])
+            Ud = Vm[s] * np.exp(1j * Va[s])
+            Uo = r["Vm_raw"] * np.exp(1j * r["Va_raw"])
+            assert np.abs(Ud - Uo).max() < TOL_V
