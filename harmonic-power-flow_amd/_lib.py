@@ -35,6 +35,8 @@ SYMBOLS = {
     "hpf_version": (C.c_int, []),
     "hpf_num_unknowns": (C.c_int, [_H]),
     "hpf_num_unknowns_fund": (C.c_int, [_H]),
+    "hpf_tree_levels": (C.c_int, [_H]),
+    "hpf_tree_depths": (C.c_int, [_H]),
     "hpf_set_loads": (C.c_int, [_H, C.c_int, c_dbl_p, c_dbl_p]),
     "hpf_set_state": (C.c_int, [_H, C.c_int, c_dbl_p, c_dbl_p]),
     "hpf_get_state": (C.c_int, [_H, c_dbl_p, c_dbl_p]),

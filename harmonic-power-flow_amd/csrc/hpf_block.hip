@@ -433,12 +433,15 @@ int tree_build(hpf_handle* h, const hpf_desc* d) {
         for (int i = 1; i < n; ++i) T.child[pos[T.parent[i]]++] = i;   // children in ascending bus index
     }
     const double bd = b;
-    T.flops_per_solve = 0.0;
+    // exact flop count of the elimination: per bus 2 b^3 (Gauss-Jordan), (4 b^2 + 4 b) per child pulled,
+    // 2 b^2 (w = D^-1 y); per non-root bus 4 b^2 (Z = D^-1 A(k,parent)) and 2 b^2 in the back sweep
+    T.flops_factor = 0.0;
     for (int i = 0; i < n; ++i) {
         const int nch = T.child_ptr[i + 1] - T.child_ptr[i];
-        T.flops_per_solve += 2.0 * bd * bd * bd + (4.0 * bd * bd + 4.0 * bd) * nch + 2.0 * bd * bd;
-        if (i > 0) T.flops_per_solve += 4.0 * bd * bd + 2.0 * bd * bd;
+        T.flops_factor += 2.0 * bd * bd * bd + (4.0 * bd * bd + 4.0 * bd) * nch + 2.0 * bd * bd;
+        if (i > 0) T.flops_factor += 4.0 * bd * bd;
     }
+    T.flops_per_solve = T.flops_factor + 2.0 * bd * bd * (n - 1);
     int r;
     if ((r = upload(h, &T.d_parent, T.parent))) return r;
     if ((r = upload(h, &T.d_lvl_nodes, T.lvl_nodes))) return r;
@@ -475,6 +478,7 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
     const TreeDev td{T.d_parent, T.d_child_ptr, T.d_child, T.d_e_up, T.d_e_dn};
     const int b = 2 * h->Hn;
     const int R = (b + 15) / 16;
+    {
     ScopedTimer t(h, T_SOLVE);
     for (int l = 0; l < T.n_levels; ++l) {
         const int cnt = T.lvl_ptr[l + 1] - T.lvl_ptr[l];
@@ -493,6 +497,8 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
         }
         if (r) return r;
     }
+    }
+    ScopedTimer tb(h, T_BACK);
     for (int dl = 0; dl < T.n_depths; ++dl) {
         const int cnt = T.dep_ptr[dl + 1] - T.dep_ptr[dl];
         if (cnt == 0) continue;

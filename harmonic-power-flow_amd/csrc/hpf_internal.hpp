@@ -11,7 +11,7 @@
 
 namespace hpf {
 
-enum { T_MISMATCH = 0, T_JACOBIAN = 1, T_SOLVE = 2, T_UPDATE = 3, T_COUNT = 4 };
+enum { T_MISMATCH = 0, T_JACOBIAN = 1, T_SOLVE = 2, T_UPDATE = 3, T_BACK = 4, T_COUNT = 5 };
 
 struct TimedSpan {
     int which;
@@ -36,7 +36,8 @@ struct Tree {
     int* d_child = nullptr;
     int* d_e_up = nullptr;            // [n] CSR position of entry (i, parent(i))
     int* d_e_dn = nullptr;            // [n] CSR position of entry (parent(i), i)
-    double flops_per_solve = 0.0;
+    double flops_per_solve = 0.0;     // factor sweep + back sweep
+    double flops_factor = 0.0;        // factor sweep only (k_tree_factor, all levels)
 };
 
 }  // namespace hpf
@@ -80,8 +81,8 @@ struct hpf_handle {
     rocblas_handle blas = nullptr;
     bool timing = false;
     std::vector<hpf::TimedSpan> spans;
-    double t_ms[hpf::T_COUNT] = {0, 0, 0, 0};
-    int64_t t_n[hpf::T_COUNT] = {0, 0, 0, 0};
+    double t_ms[hpf::T_COUNT] = {0, 0, 0, 0, 0};
+    int64_t t_n[hpf::T_COUNT] = {0, 0, 0, 0, 0};
 };
 
 namespace hpf {

@@ -600,6 +600,8 @@ int hpf_destroy(hpf_handle* h) {
 
 int hpf_num_unknowns(const hpf_handle* h) { return h ? h->N : HPF_E_ARG; }
 int hpf_num_unknowns_fund(const hpf_handle* h) { return h ? h->Nf : HPF_E_ARG; }
+int hpf_tree_levels(const hpf_handle* h) { return h ? h->tree.n_levels : HPF_E_ARG; }
+int hpf_tree_depths(const hpf_handle* h) { return h ? h->tree.n_depths : HPF_E_ARG; }
 
 int hpf_set_loads(hpf_handle* h, int n_scen, const double* P, const double* Q) {
     if (!h || !P || !Q || n_scen < 1 || n_scen > h->S_max) return HPF_E_ARG;
@@ -753,7 +755,7 @@ int hpf_timing_reset(hpf_handle* h) {
 
 double hpf_solve_flops(const hpf_handle* h) {
     if (!h) return 0.0;
-    if (h->solver == HPF_SOLVER_BLOCK_TREE) return h->tree.flops_per_solve;
+    if (h->solver == HPF_SOLVER_BLOCK_TREE) return h->tree.flops_factor;
     const double N = h->N;
     return (2.0 / 3.0) * N * N * N + 2.0 * N * N;
 }

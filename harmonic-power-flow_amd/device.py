@@ -67,6 +67,8 @@ class DeviceModel:
         self.S = 0
         self.N = lib.hpf_num_unknowns(self._h)
         self.Nf = lib.hpf_num_unknowns_fund(self._h)
+        self.n_levels = lib.hpf_tree_levels(self._h)
+        self.n_depths = lib.hpf_tree_depths(self._h)
 
     # -- lifetime ------------------------------------------------------------------------------------------
     def close(self):
@@ -174,7 +176,7 @@ class DeviceModel:
 
     def timing_get(self):
         out = {}
-        for which, name in enumerate(("mismatch", "jacobian", "solve", "update")):
+        for which, name in enumerate(("mismatch", "jacobian", "solve", "update", "back")):
             ms = C.c_double()
             cnt = C.c_int64()
             self._chk(self.lib.hpf_timing_get(self._h, which, C.byref(ms), C.byref(cnt)), "hpf_timing_get")

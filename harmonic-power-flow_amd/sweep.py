@@ -1,0 +1,46 @@
+"""Scenario sweeps across GPUs: one process per GPU, scenarios dealt round-robin, NO collective on the data path —
+independent feeders / Monte-Carlo load cases share nothing during the NR loop.  The only exchange
+is one all-gather of the 24-byte per-scenario records (`hpf_stat`: n_iter, flags, err, thd_max) at the end of a
+sweep (`torch.distributed`, backend "nccl" = RCCL on ROCm; "gloo" in the CPU tests)."""
+import numpy as np
+
+STAT_DTYPE = np.dtype([("n_iter", "<i4"), ("flags", "<i4"), ("err", "<f8"), ("thd_max", "<f8")])
+assert STAT_DTYPE.itemsize == 24
+
+
+def scenario_ids(rank, world, per_rank):
+    """Round-robin deal: iteration counts differ per scenario, interleaving balances the ranks."""
+    return rank + world * np.arange(per_rank)
+
+
+def gather_stats(rec, world):
+    """rec: uint8 tensor [S_local, 24] on this rank's device -> uint8 tensor [S_local*world, 24] ordered by global
+    scenario id (id = rank + world*i)."""
+    if world == 1:
+        return rec
+    import torch
+    import torch.distributed as dist
+    parts = [torch.empty_like(rec) for _ in range(world)]
+    dist.all_gather(parts, rec.contiguous())
+    return torch.stack(parts, dim=1).reshape(-1, rec.shape[1])
+
+
+def summarize(raw):
+    """raw: uint8 array [n, 24] -> convergence statistics of the sweep."""
+    st = np.ascontiguousarray(raw).view(STAT_DTYPE).reshape(-1)
+    conv = (st["flags"] & 1) != 0
+    out = {"scenarios": int(len(st)), "converged": int(conv.sum()), "hit_max_iter": int(((st["flags"] & 2) != 0).sum()),
+           "non_finite": int(((st["flags"] & 4) != 0).sum()),
+           "iters_min": int(st["n_iter"].min()), "iters_max": int(st["n_iter"].max()),
+           "iters_mean": float(st["n_iter"].mean()), "iters_total": int(st["n_iter"].sum())}
+    if conv.any():
+        out["err_max_converged"] = float(st["err"][conv].max())
+        out["thd_max"] = float(np.nanmax(st["thd_max"][conv]))
+    return out
+
+
+def pack_stats(n_iter, flags, err, thd):
+    """Host-side packing of the record layout (tests)."""
+    st = np.zeros(len(n_iter), dtype=STAT_DTYPE)
+    st["n_iter"], st["flags"], st["err"], st["thd_max"] = n_iter, flags, err, thd
+    return st.view(np.uint8).reshape(len(n_iter), 24)

@@ -85,6 +85,10 @@ int  hpf_version(void);
 /* Sizes: N = 2*n*Hn - 1 - c unknowns of the harmonic NR (HG:388,397); Nf = 2*n - 1 - c of the fundamental NR. */
 int  hpf_num_unknowns(const hpf_handle* h);
 int  hpf_num_unknowns_fund(const hpf_handle* h);
+/* BLOCK_TREE: number of elimination levels (= k_tree_factor launches per Newton step) / of back-substitution
+ * levels (= k_tree_back launches); 0 for DENSE. */
+int  hpf_tree_levels(const hpf_handle* h);
+int  hpf_tree_depths(const hpf_handle* h);
 
 /* Loads P,Q [S][n] in p.u. (buses.P / buses.Q of HG:197,372).  Sets the active scenario count S. */
 int  hpf_set_loads(hpf_handle* h, int n_scen, const double* P, const double* Q);
@@ -126,12 +130,15 @@ int  hpf_set_stream(hpf_handle* h, void* hip_stream);
 int  hpf_sync(hpf_handle* h);
 
 /* Kernel timing with HIP events on the handle's stream, accumulated since the last reset.
- * which: 0 mismatch kernel, 1 Jacobian assembly kernel, 2 linear solve (factor+solve), 3 state update;
- * returns total milliseconds in *ms and launch count in *launches. */
+ * which: 0 mismatch kernel, 1 Jacobian assembly kernels (DENSE only; BLOCK_TREE assembles inside the factor kernel),
+ * 2 linear solve (DENSE: getrf+getrs; BLOCK_TREE: the factor sweep = one k_tree_factor launch per tree level),
+ * 3 state update, 4 back-substitution sweep (BLOCK_TREE only; one k_tree_back launch per tree depth).
+ * Returns total milliseconds in *ms and the number of timed spans (one per Newton step) in *launches. */
 int  hpf_timing_enable(hpf_handle* h, int on);
 int  hpf_timing_get(hpf_handle* h, int which, double* ms, int64_t* launches);
 int  hpf_timing_reset(hpf_handle* h);
-/* Exact flop count of one linear solve of one scenario for the configured solver (roofline numerator). */
+/* Exact FP64 flop count of the span `which == 2` for ONE scenario and ONE Newton step (roofline numerator):
+ * DENSE 2/3 N^3 + 2 N^2; BLOCK_TREE sum over buses of 2 b^3 + (4 b^2 + 4 b) per child + 2 b^2 (+ 4 b^2 non-root). */
 double hpf_solve_flops(const hpf_handle* h);
 
 #ifdef __cplusplus

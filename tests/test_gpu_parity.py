@@ -321,3 +321,34 @@ def test_scenario_batch_block_tree_matches_oracle(tmp_path):
             Ud = Vm[s] * np.exp(1j * Va[s])
             Uo = r["Vm_raw"] * np.exp(1j * r["Va_raw"])
             assert np.abs(Ud - Uo).max() < TOL_V
+
+
+def test_headline_feeder_syn1000_vs_reference_golden(tmp_path):
+    """BASELINE config 3: 1 000 buses x 25 harmonics, coupled, one scenario, block-tree Newton step, against the
+    reference's own converged voltages (captured by oracle/make_golden.py; 27 iterations, err 7.047e-10)."""
+    hp = _hp()
+    g = np.load(os.path.join(GOLD, "syn1000_H51_c.npz"), allow_pickle=True)
+    st, buses, lines, dm, _ = _syn_model(hp, 1000, 51, "block_tree", tmp_path)
+    try:
+        dm.set_loads(buses["P"].to_numpy(float), buses["Q"].to_numpy(float))
+        dm.set_state(None, None, n_scen=1)
+        nf, ef, hf = dm.fund_pf(1e-6, 30)
+        seed = dm.get_state()
+        np.testing.assert_allclose(np.stack([seed[0][0], seed[1][0]], 1), g["V_pf"], rtol=0, atol=1e-12)
+        f, err0 = dm.mismatch()
+        assert np.abs(f[0] - g["f0"]).max() <= 1e-12 * np.abs(g["f0"]).max()
+        n_iter, err, hist = dm.solve(1e-4, 50)
+        Vm, Va = dm.get_state()
+    finally:
+        dm.close()
+    from harmonic_power_flow_amd.api import _postprocess
+    Vm, Va = _postprocess(Vm[0], Va[0])
+    Ud = Vm * np.exp(1j * Va)
+    Ug = g["V_final"][:, 0] * np.exp(1j * g["V_final"][:, 1])
+    ge = g["err_hist"]
+    print(f"\nsyn1000 block_tree: it {int(n_iter[0])} (ref {int(g['n_iter_h'])}) err {err[0]:.3e} "
+          f"max|dU| {np.abs(Ud - Ug).max():.2e}; err_hist rel dev first 5: "
+          + " ".join("%.1e" % (abs(hist[0, i] - ge[i]) / ge[i]) for i in range(5)))
+    assert int(n_iter[0]) < 50 and err[0] <= 1e-4
+    assert np.abs(Ud - Ug).max() < TOL_V
+    assert np.abs(Vm - g["V_final"][:, 0]).max() < TOL_V
