@@ -17,6 +17,7 @@
 // broadcast through LDS (2 barriers per step); Z_k (b x b) and w_k (b) are the only HBM writes.
 // Bound: FP64 FMA rate (2 b^3 flop per bus) against 24 b^2 bytes of Z traffic per bus -> ~4.3 flop/B at b = 52.
 #include "hpf_internal.hpp"
+#include "hpf_gj.hpp"
 
 using namespace hpf;
 
@@ -325,6 +326,228 @@ __global__ __launch_bounds__(256) void k_tree_back(int n, int c, int Hn, TreeDev
     }
 }
 
+
+// =============================================================================================================
+// Wave-per-bus kernels (b <= 52): one 64-lane wavefront owns one (bus, scenario) pair, lane = matrix row.
+//
+//  * D_k lives in registers, one row per lane (a[c], c static).  No workgroup barrier, no inter-wave traffic.
+//  * Gauss-Jordan without row scaling and without row swaps (implicit partial pivoting): at step j the pivot lane r is
+//    the not-yet-used lane with the largest |a[.][j]| (wave-wide max of the IEEE bit pattern, lane id in the low bits);
+//    it broadcasts its row through LDS, every other lane subtracts g = a[j]/pivot times that row.  Column j is replaced
+//    in place by the j-th column of the inverse.  The register array ROTATES by one position per step (the FMA writes
+//    logical column c+1 into physical register c), so that the current column is always register 0 and the loop body
+//    is the same for every j: a rolled loop with static register indices, ~1.5 KB of code instead of B unrolled steps.
+//    Each lane is the pivot exactly once (step myj); at the end lane x holds row myj(x) of the inverse times its
+//    pivot, register j being the column r_j (the lane that was pivot at step j).
+//  * Output is the TRANSPOSED inverse AinvT[c][i] = D_k^{-1}[i][c] (b x b, stored B x B) and w = D_k^{-1} y: for a
+//    fixed register j all lanes store into one row r_j of AinvT -> one coalesced 8*B-byte store per register.
+//    The parent applies the harmonic-diagonal coupling blocks on the fly:
+//        D_p -= A(p,k) D_k^{-1} A(k,p):   v = g0*Ainv[2q][:] + g1*Ainv[2q+1][:]  (16-B pair loads, coalesced)
+//                                          D_p[i][2p+t'] -= v[2p]*Bup[p][0][t'] + v[2p+1]*Bup[p][1][t'].
+// =============================================================================================================
+// 2x2 coupling block A(row bus i, col bus j) at harmonic p, masked to existing equations / unknowns -> out[tr*2+tc]
+__device__ __forceinline__ void coupling_block(const Model& M, const cplx* U, const cplx* E, int p, int i, int j, int e,
+                                               double out[4]) {
+    const Blk2 blk = offdiag_block(M, U, E, p, i, j, e);
+#pragma unroll
+    for (int tr = 0; tr < 2; ++tr)
+#pragma unroll
+        for (int tc = 0; tc < 2; ++tc)
+            out[tr * 2 + tc] = (loc_valid(M.n, M.c, i, 2 * p + tr) && loc_valid(M.n, M.c, j, 2 * p + tc))
+                                   ? pick(blk, tr, tc) : 0.0;
+}
+
+template <int B>
+__global__ __launch_bounds__(64) void k_factor_w(Model M, TreeDev T, const int* __restrict__ nodes, int b, int N, int Nc,
+                                                 const int* __restrict__ active, const cplx* __restrict__ Uall,
+                                                 const cplx* __restrict__ Eall, const double* __restrict__ fall,
+                                                 double* __restrict__ Aall, double* __restrict__ wall, int ablate) {
+    const int s = blockIdx.y;
+    if (active && !active[s]) return;
+    const int k = nodes[blockIdx.x];
+    const int lane = threadIdx.x;
+    const int n = M.n, c = M.c, Hn = M.Hn;
+    const size_t so = (size_t)s * n * Hn;
+    const cplx* U = Uall + so;
+    const cplx* E = Eall + so;
+    const double* f = fall + (size_t)s * N;
+    constexpr size_t BB = (size_t)B * B;
+    double* As = Aall + (size_t)s * n * BB;
+    double* ws = wall + (size_t)s * n * B;
+
+    __shared__ double bup[(B / 2) * 4];
+    __shared__ int rj[B];
+
+    const int q = lane >> 1, t = lane & 1;
+    const bool rowvalid = lane < b && loc_valid(n, c, k, lane);
+
+    // ---- A. assemble row `lane` of D_k --------------------------------------------------------------------------
+    double a[B];
+    {
+        const int diag_e = M.diag[k];
+        const bool nl = k >= M.m && M.coupled;
+#pragma unroll
+        for (int p = 0; p < B / 2; ++p) {
+            double v0 = 0.0, v1 = 0.0;
+            if (rowvalid && p < Hn && !(ablate & 4)) {
+                if (p == q) {
+                    const Blk2 blk = (q == 0 && k < M.m) ? jac_power_entry<false>(M, U, E, k, k, diag_e)
+                                                          : jac_current_entry(M, U, E, q, k, k, diag_e);
+                    v0 = pick(blk, t, 0);
+                    v1 = pick(blk, t, 1);
+                } else if (nl) {
+                    const Blk2 blk = jac_norton_cross(M, U, E, q, p, k);
+                    v0 = pick(blk, t, 0);
+                    v1 = pick(blk, t, 1);
+                }
+            }
+            a[2 * p] = v0;
+            a[2 * p + 1] = v1;
+        }
+#pragma unroll
+        for (int cc = 0; cc < B; ++cc) {
+            const bool cv = cc < b && loc_valid(n, c, k, cc);
+            if (!cv || !rowvalid) a[cc] = (cc == lane) ? 1.0 : 0.0;     // identity padding
+        }
+    }
+    double y = 0.0;
+    if (rowvalid) {
+        const int kst = q * n + k;
+        y = t ? f[Nc + kst - c] : f[kst - 1];
+    }
+
+    // ---- B. pull the children's Schur complements (fixed order) ------------------------------------------------
+    for (int cp = T.child_ptr[k]; cp < ((ablate & 2) ? 0 : T.child_ptr[k + 1]); ++cp) {
+        const int ch = T.child[cp];
+        __syncthreads();
+        if (lane < Hn) {
+            double blk4[4];
+            coupling_block(M, U, E, lane, ch, k, T.e_up[ch], blk4);      // A(child, parent) at harmonic `lane`
+            bup[lane * 4 + 0] = blk4[0];
+            bup[lane * 4 + 1] = blk4[1];
+            bup[lane * 4 + 2] = blk4[2];
+            bup[lane * 4 + 3] = blk4[3];
+        }
+        double g0 = 0.0, g1 = 0.0;
+        if (rowvalid) {
+            const Blk2 blk = offdiag_block(M, U, E, q, k, ch, T.e_dn[ch]);   // A(parent, child) at my harmonic
+            g0 = pick(blk, t, 0);
+            g1 = loc_valid(n, c, ch, 2 * q + 1) ? pick(blk, t, 1) : 0.0;
+        }
+        const double* Ac = As + (size_t)ch * BB;
+        const double* wc = ws + (size_t)ch * B;
+        const int qq = q < B / 2 ? q : 0;
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < B / 2; ++p) {
+            const double2 z0 = *reinterpret_cast<const double2*>(Ac + (size_t)(2 * p) * B + 2 * qq);
+            const double2 z1 = *reinterpret_cast<const double2*>(Ac + (size_t)(2 * p + 1) * B + 2 * qq);
+            const double v0 = fma(g1, z0.y, g0 * z0.x);       // (A(p,k) Ainv)[i][2p]
+            const double v1 = fma(g1, z1.y, g0 * z1.x);       // (A(p,k) Ainv)[i][2p+1]
+            a[2 * p] = fma(-v0, bup[p * 4 + 0], a[2 * p]);
+            a[2 * p] = fma(-v1, bup[p * 4 + 2], a[2 * p]);
+            a[2 * p + 1] = fma(-v0, bup[p * 4 + 1], a[2 * p + 1]);
+            a[2 * p + 1] = fma(-v1, bup[p * 4 + 3], a[2 * p + 1]);
+        }
+        y = fma(-g0, wc[2 * qq], y);
+        y = fma(-g1, wc[2 * qq + 1], y);
+    }
+
+    // ---- C. Gauss-Jordan with implicit partial pivoting, rotating registers (hpf_gj.hpp) -------------------------
+    int myj = 0;
+    double mypiv = 1.0;
+    if (ablate & 1) ablate |= 8;
+    gauss_jordan_wave_rl<B>(a, y, lane, (ablate & 1) ? 0 : B, rj, myj, mypiv);
+
+    // ---- D. store the transposed inverse and w -----------------------------------------------------------------
+    __syncthreads();
+    if (lane < B && !(ablate & 8)) {
+        const double invp = 1.0 / mypiv;
+        double* Ak = As + (size_t)k * BB;
+#pragma unroll
+        for (int j = 0; j < B; ++j) Ak[(size_t)rj[j] * B + myj] = a[j] * invp;
+        ws[(size_t)k * B + myj] = y * invp;
+    }
+}
+
+// root -> leaves: x_k = w_k - D_k^{-1} (A(k,parent) x_parent); one wave per (bus, scenario), lane = row
+template <int B>
+__global__ __launch_bounds__(64) void k_back_w(Model M, TreeDev T, const int* __restrict__ nodes, int b, int N, int Nc,
+                                               const int* __restrict__ active, const cplx* __restrict__ Uall,
+                                               const cplx* __restrict__ Eall, const double* __restrict__ Aall,
+                                               const double* __restrict__ wall, double* __restrict__ xall,
+                                               double* __restrict__ step) {
+    const int s = blockIdx.y;
+    if (active && !active[s]) return;
+    const int k = nodes[blockIdx.x];
+    const int lane = threadIdx.x;
+    const int n = M.n, c = M.c, Hn = M.Hn;
+    constexpr size_t BB = (size_t)B * B;
+    const double* Ak = Aall + ((size_t)s * n + k) * BB;
+    const double* wk = wall + ((size_t)s * n + k) * B;
+    double* xs = xall + (size_t)s * n * B;
+    __shared__ double tb[B];
+    const int par = T.parent[k];
+    double x = 0.0;
+    if (lane < B) x = wk[lane];
+    if (par >= 0) {
+        const size_t so = (size_t)s * n * Hn;
+        const double* xp = xs + (size_t)par * B;
+        double tv = 0.0;
+        const int p = lane >> 1, tr = lane & 1;
+        if (lane < b && p < Hn) {
+            double blk4[4];
+            coupling_block(M, Uall + so, Eall + so, p, k, par, T.e_up[k], blk4);
+            tv = fma(blk4[tr * 2 + 1], xp[2 * p + 1], blk4[tr * 2] * xp[2 * p]);
+        }
+        if (lane < B) tb[lane] = tv;
+        __syncthreads();
+        if (lane < B) {
+#pragma unroll 4
+            for (int cc = 0; cc < B; ++cc) x = fma(-Ak[(size_t)cc * B + lane], tb[cc], x);
+        }
+    }
+    if (lane < B) {
+        xs[(size_t)k * B + lane] = x;
+        if (lane < b) {
+            const int kst = (lane >> 1) * n + k;
+            double* st = step + (size_t)s * N;
+            if (lane & 1) {
+                if (kst >= c) st[Nc + kst - c] = x;
+            } else {
+                if (kst >= 1) st[kst - 1] = x;
+            }
+        }
+    }
+}
+
+template <int B>
+int launch_factor_w(hpf_handle* h, const TreeDev& T, const int* nodes, int count, const int* active) {
+    hipLaunchKernelGGL((k_factor_w<B>), dim3((unsigned)count, (unsigned)h->S), dim3(64), 0, h->stream, h->M, T, nodes,
+                       2 * h->Hn, h->N, h->Nc, active, h->d_U, h->d_E, h->d_f, h->d_Z, h->d_w, h->debug_ablate);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        h->last_detail = (int)e;
+        return HPF_E_HIP;
+    }
+    return HPF_OK;
+}
+
+template <int B>
+int launch_back_w(hpf_handle* h, const TreeDev& T, const int* nodes, int count, const int* active) {
+    hipLaunchKernelGGL((k_back_w<B>), dim3((unsigned)count, (unsigned)h->S), dim3(64), 0, h->stream, h->M, T, nodes,
+                       2 * h->Hn, h->N, h->Nc, active, h->d_U, h->d_E, h->d_Z, h->d_w, h->d_x, h->d_f);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        h->last_detail = (int)e;
+        return HPF_E_HIP;
+    }
+    return HPF_OK;
+}
+
+// padded block size of the wave-per-bus path (0: use the 256-thread generic kernels)
+int wave_block_size(int b) { return b <= 12 ? 12 : (b <= 28 ? 28 : (b <= 52 ? 52 : 0)); }
+
 template <class T>
 int upload(hpf_handle* h, T** dst, const std::vector<T>& v) {
     const size_t cnt = v.empty() ? 1 : v.size();
@@ -461,7 +684,8 @@ void tree_free(hpf_handle* h) {
 }
 
 int tree_alloc_scenarios(hpf_handle* h) {
-    const size_t b = 2 * (size_t)h->Hn, S = h->S_max, n = h->n;
+    const int bw = wave_block_size(2 * h->Hn);
+    const size_t b = bw ? (size_t)bw : 2 * (size_t)h->Hn, S = h->S_max, n = h->n;
     hipError_t e;
     if ((e = hipMalloc((void**)&h->d_Z, sizeof(double) * S * n * b * b)) != hipSuccess ||
         (e = hipMalloc((void**)&h->d_w, sizeof(double) * S * n * b)) != hipSuccess ||
@@ -478,37 +702,51 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
     const TreeDev td{T.d_parent, T.d_child_ptr, T.d_child, T.d_e_up, T.d_e_dn};
     const int b = 2 * h->Hn;
     const int R = (b + 15) / 16;
+    const int BW = wave_block_size(b);
     {
-    ScopedTimer t(h, T_SOLVE);
-    for (int l = 0; l < T.n_levels; ++l) {
-        const int cnt = T.lvl_ptr[l + 1] - T.lvl_ptr[l];
-        if (cnt == 0) continue;
-        const int* nodes = T.d_lvl_nodes + T.lvl_ptr[l];
-        int r;
-        switch (R) {
-            case 1: r = launch_factor<1>(h, td, nodes, cnt, active); break;
-            case 2: r = launch_factor<2>(h, td, nodes, cnt, active); break;
-            case 3: r = launch_factor<3>(h, td, nodes, cnt, active); break;
-            case 4: r = launch_factor<4>(h, td, nodes, cnt, active); break;
-            case 5: r = launch_factor<5>(h, td, nodes, cnt, active); break;
-            case 6: r = launch_factor<6>(h, td, nodes, cnt, active); break;
-            case 7: r = launch_factor<7>(h, td, nodes, cnt, active); break;
-            default: return HPF_E_ARG;
+        ScopedTimer t(h, T_SOLVE);
+        for (int l = 0; l < T.n_levels; ++l) {
+            const int cnt = T.lvl_ptr[l + 1] - T.lvl_ptr[l];
+            if (cnt == 0) continue;
+            const int* nodes = T.d_lvl_nodes + T.lvl_ptr[l];
+            int r;
+            switch (BW) {
+                case 12: r = launch_factor_w<12>(h, td, nodes, cnt, active); break;
+                case 28: r = launch_factor_w<28>(h, td, nodes, cnt, active); break;
+                case 52: r = launch_factor_w<52>(h, td, nodes, cnt, active); break;
+                default:
+                    switch (R) {
+                        case 4: r = launch_factor<4>(h, td, nodes, cnt, active); break;
+                        case 5: r = launch_factor<5>(h, td, nodes, cnt, active); break;
+                        case 6: r = launch_factor<6>(h, td, nodes, cnt, active); break;
+                        case 7: r = launch_factor<7>(h, td, nodes, cnt, active); break;
+                        default: return HPF_E_ARG;
+                    }
+            }
+            if (r) return r;
         }
-        if (r) return r;
-    }
     }
     ScopedTimer tb(h, T_BACK);
     for (int dl = 0; dl < T.n_depths; ++dl) {
         const int cnt = T.dep_ptr[dl + 1] - T.dep_ptr[dl];
         if (cnt == 0) continue;
-        hipLaunchKernelGGL(k_tree_back, dim3((unsigned)cnt, (unsigned)h->S), dim3(256), 0, h->stream, h->n, h->c, h->Hn, td,
-                           T.d_dep_nodes + T.dep_ptr[dl], b, h->N, h->Nc, active, h->d_Z, h->d_w, h->d_x, h->d_f);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) {
-            h->last_detail = (int)e;
-            return HPF_E_HIP;
+        const int* nodes = T.d_dep_nodes + T.dep_ptr[dl];
+        int r = HPF_OK;
+        switch (BW) {
+            case 12: r = launch_back_w<12>(h, td, nodes, cnt, active); break;
+            case 28: r = launch_back_w<28>(h, td, nodes, cnt, active); break;
+            case 52: r = launch_back_w<52>(h, td, nodes, cnt, active); break;
+            default: {
+                hipLaunchKernelGGL(k_tree_back, dim3((unsigned)cnt, (unsigned)h->S), dim3(256), 0, h->stream, h->n, h->c,
+                                   h->Hn, td, nodes, b, h->N, h->Nc, active, h->d_Z, h->d_w, h->d_x, h->d_f);
+                hipError_t e = hipGetLastError();
+                if (e != hipSuccess) {
+                    h->last_detail = (int)e;
+                    return HPF_E_HIP;
+                }
+            }
         }
+        if (r) return r;
     }
     return HPF_OK;
 }

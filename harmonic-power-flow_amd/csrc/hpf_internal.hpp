@@ -49,6 +49,7 @@ struct hpf_handle {
     int N = 0, Nc = 0, Nf = 0;
     bool loads_set = false, state_set = false, mismatch_valid = false;
     int last_detail = 0;
+    int debug_ablate = 0;             // HPF_DEBUG_ABLATE: timing-only ablation of factor-kernel phases (results invalid)
 
     // model (device)
     int *d_rowptr = nullptr, *d_col = nullptr, *d_diag = nullptr, *d_erow = nullptr, *d_dev = nullptr;

@@ -13,6 +13,7 @@
 //   dense solve  FP64 matrix pipe: 2/3 N^3 + 2 N^2 flop (rocSOLVER getrf/getrs).
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <rocsolver/rocsolver.h>
@@ -550,6 +551,7 @@ int hpf_create(hpf_handle** out, const hpf_desc* d) {
     h->Nc = d->n * d->Hn - 1;
     h->N = 2 * h->Nc - (d->c - 1);
     h->Nf = 2 * d->n - 1 - d->c;
+    if (const char* ab = getenv("HPF_DEBUG_ABLATE")) h->debug_ablate = atoi(ab);
     if (hipSetDevice(d->device) != hipSuccess) return fail(HPF_E_HIP);
     if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) return fail(HPF_E_HIP);
     h->stream = h->own_stream;
