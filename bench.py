@@ -92,9 +92,16 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    # one rank per GPU; HPF_BENCH_BACKEND=gloo + fewer GPUs than ranks is a rehearsal mode for a 1-GPU box only
+    backend = os.environ.get("HPF_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % max(ndev, 1) if backend != "nccl" else local_rank
+    torch.cuda.set_device(dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
     import harmonic_power_flow_amd as hp
 
     inp = build_inputs(args, hp)
@@ -107,7 +114,7 @@ def main():
     scale = np.stack([synth.scenario_scale(n, int(s)) for s in scen_ids])
     dm = hp.DeviceModel(n, inp["m"], inp["c"], inp["st"].HARMONICS, inp["Y"].rowptr, inp["Y"].col, inp["Y"].Yval,
                         inp["dev"], inp["Y_N"], inp["I_N"], inp["n_dev"], True, solver=args.solver,
-                        device=local_rank, max_scenarios=S)
+                        device=dev_index, max_scenarios=S)
     dm.set_loads(P0 * scale, Q0 * scale)
     dm.set_state(None, None, n_scen=S)
     nf, _, _ = dm.fund_pf(inp["st"].thresh_f, inp["st"].max_iter_f)
@@ -130,7 +137,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     tim = dm.timing_get()
@@ -143,7 +150,7 @@ def main():
         n_iter, err, _ = dm.solve(inp["st"].thresh_h, inp["st"].max_iter_h)
         rec = torch.empty((S, 24), dtype=torch.uint8, device="cuda")
         dm.stats_to_device(rec.data_ptr())
-        allrec = gather_stats(rec, world)
+        allrec = gather_stats(rec if backend == "nccl" else rec.cpu(), world)
         sweep = summarize(allrec.cpu().numpy())
 
     if rank != 0:
@@ -170,6 +177,7 @@ def main():
     bytes_update = 8 * dm.N + 2 * 16 * Hn * n + 4 * 8 * Hn * n
     shared_bytes = 16 * Hn * nnz + 4 * (nnz + n + 1) + 16 * (Hn * Hn + Hn) + 4 * n
     step_bytes = S * (bytes_mismatch + bytes_factor + bytes_back + bytes_update) + 4 * shared_bytes
+    traffic, traffic_note = pmc_traffic(args, S)
     out = {
         "metric": "NR iterations/sec + ms/iter, 1 000-bus x 25-harmonic feeder; |dV| vs reference",
         "value": value, "unit": "NR iterations/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
@@ -183,10 +191,11 @@ def main():
                    "solver": dm.solver, "step": "one NR iteration of every scenario (HG:537-540)",
                    "pf_iterations": int(nf.max())},
         "ms_per_iter_per_scenario": ms_step / S,
-        "roofline": {"bound": "mfma", "kernel": "k_tree_factor (one sweep = %d launches, one per tree level)"
+        "roofline": {"bound": "mfma", "kernel": "k_factor_w<52> (one sweep = %d launches, one per tree level)"
                                                 % dm_levels(dm) if args.solver == "block_tree" else "rocsolver getrf+getrs",
                      "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": (achieved / FP64_PEAK_TFLOPS) if achieved else None, "traffic": None,
+                     "frac": (achieved / FP64_PEAK_TFLOPS) if achieved else None, "traffic": traffic,
+                     "traffic_note": traffic_note,
                      "flop_per_launch": flops, "avg_ms": solve_ms / max(solve_n, 1)},
         "roofline_hbm_step": {"bound": "hbm", "achieved": step_bytes / (ms_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                               "unit": "GB/s", "frac": step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -206,6 +215,20 @@ def main():
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(args, S):
+    """HBM bytes of one factor sweep from the committed PMC passes (tools/pmc_traffic.py); only valid for the default
+    workload they were collected on."""
+    path = os.path.join(REPO, "profiles", "pmc_traffic_latest.json")
+    if not os.path.exists(path) or (args.buses, args.hmax, S, args.solver) != (1000, 51, 128, "block_tree"):
+        return None, "no PMC pass for this workload"
+    d = json.load(open(path))["per_step_bytes"].get("k_factor_w")
+    if not d:
+        return None, "no PMC pass for this kernel"
+    return d["fetch_raw"] + d["write"], ("bytes per factor sweep = FETCH_SIZE*1024 (raw; %.3g B if the gfx950 x2 wide-stream "
+                                         "correction applied) + WRITE_SIZE*1024, separate rocprofv3 --pmc passes, see "
+                                         "profiles/pmc_traffic_latest.json" % d["fetch_x2_gfx950_wide_stream_correction"])
 
 
 def dm_levels(dm):

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""HBM traffic of the bench kernels from rocprofv3 PMC passes.
+
+On the GPU box (two separate passes, counters only with --kernel-trace, as MI355X_MICROARCH.md / the pool rules require):
+    cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+    for c in FETCH_SIZE WRITE_SIZE; do rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_$c -- \
+        python3 bench.py --steps 3 --warmup 1 --cpu-iters 0 --no-finish; done
+Then here:  python tools/pmc_traffic.py profiles/r01/pmc_traffic.json [steps_profiled=4]
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = ("k_factor_w", "k_back_w", "k_mismatch", "k_update", "k_tree_factor", "k_tree_back")
+
+
+def main():
+    out_path = sys.argv[1]
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    res = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        f = sorted(glob.glob(os.path.join(REPO, "gpurun_out", f"pmc_{c}", "*", "*counter_collection.csv")))[-1]
+        agg = collections.defaultdict(lambda: [0, 0.0])
+        for r in csv.DictReader(open(f)):
+            for key in KEYS:
+                if key in r["Kernel_Name"]:
+                    agg[key][0] += 1
+                    agg[key][1] += float(r["Counter_Value"])
+        res[c] = {k: {"dispatches": v[0], "sum_counter_KB": v[1]} for k, v in agg.items()}
+    out = {"command": "rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-trace -- python3 bench.py --steps 3 --warmup 1 "
+                      "--cpu-iters 0 --no-finish (two separate passes)",
+           "steps_profiled": steps, "raw": res, "per_step_bytes": {}}
+    for k in res["FETCH_SIZE"]:
+        fe = res["FETCH_SIZE"][k]["sum_counter_KB"] / steps * 1024
+        wr = res["WRITE_SIZE"].get(k, {"sum_counter_KB": 0.0})["sum_counter_KB"] / steps * 1024
+        out["per_step_bytes"][k] = {"fetch_raw": fe, "fetch_x2_gfx950_wide_stream_correction": 2 * fe, "write": wr}
+    out["note"] = ("FETCH_SIZE/WRITE_SIZE are KB. MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reads exactly 1/2 of the bytes of a "
+                   "wide coalesced 16 B/lane stream and other widths are uncalibrated; the factor kernel reads 16-byte pairs "
+                   "shared by two lanes, the back sweep 8 B/lane, so raw and doubled values are both given.")
+    json.dump(out, open(out_path, "w"), indent=1)
+    print(json.dumps(out["per_step_bytes"], indent=1))
+
+
+if __name__ == "__main__":
+    main()
