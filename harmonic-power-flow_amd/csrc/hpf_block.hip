@@ -18,6 +18,7 @@
 // Bound: FP64 FMA rate (2 b^3 flop per bus) against 24 b^2 bytes of Z traffic per bus -> ~4.3 flop/B at b = 52.
 #include "hpf_internal.hpp"
 #include "hpf_gj.hpp"
+#include "hpf_gj_mfma.hpp"
 
 using namespace hpf;
 
@@ -357,8 +358,8 @@ __device__ __forceinline__ void coupling_block(const Model& M, const cplx* U, co
                                    ? pick(blk, tr, tc) : 0.0;
 }
 
-template <int B>
-__global__ __launch_bounds__(64) void k_factor_w(Model M, TreeDev T, const int* __restrict__ nodes, int b, int N, int Nc,
+template <int B, int MODE>
+__global__ __launch_bounds__(64, MODE == 1 ? 2 : 1) void k_factor_w(Model M, TreeDev T, const int* __restrict__ nodes, int b, int N, int Nc,
                                                  const int* __restrict__ active, const cplx* __restrict__ Uall,
                                                  const cplx* __restrict__ Eall, const double* __restrict__ fall,
                                                  double* __restrict__ Aall, double* __restrict__ wall, int ablate) {
@@ -453,20 +454,32 @@ __global__ __launch_bounds__(64) void k_factor_w(Model M, TreeDev T, const int* 
         y = fma(-g1, wc[2 * qq + 1], y);
     }
 
-    // ---- C. Gauss-Jordan with implicit partial pivoting, rotating registers (hpf_gj.hpp) -------------------------
-    int myj = 0;
-    double mypiv = 1.0;
-    if (ablate & 1) ablate |= 8;
-    gauss_jordan_wave_rl<B>(a, y, lane, (ablate & 1) ? 0 : B, rj, myj, mypiv);
+    if constexpr (MODE == 1) {
+        // ---- C'. FP64 matrix cores: row-per-lane -> accumulator tiles (LDS), blocked Gauss-Jordan with static 4x4
+        //      pivot blocks (hpf_gj_mfma.hpp), tiles -> coalesced transposed inverse + w --------------------------------
+        constexpr int NT = (B + 16) / 16;
+        __shared__ double tbuf[64 * 17];
+        __shared__ double panel[NT * 64 + 16];
+        d4_t ct[NT][NT];
+        rows_to_tiles<B, NT>(a, y, lane, ct, tbuf);
+        gauss_jordan_mfma<NT>(ct, (b + 3) / 4, panel);
+        tiles_to_global<B, NT>(ct, lane, tbuf, As + (size_t)k * BB, ws + (size_t)k * B);
+    } else {
+        // ---- C. Gauss-Jordan with implicit partial pivoting, rotating registers (hpf_gj.hpp) ---------------------
+        int myj = 0;
+        double mypiv = 1.0;
+        if (ablate & 1) ablate |= 8;
+        gauss_jordan_wave_rl<B>(a, y, lane, (ablate & 1) ? 0 : B, rj, myj, mypiv);
 
-    // ---- D. store the transposed inverse and w -----------------------------------------------------------------
-    __syncthreads();
-    if (lane < B && !(ablate & 8)) {
-        const double invp = 1.0 / mypiv;
-        double* Ak = As + (size_t)k * BB;
+        // ---- D. store the transposed inverse and w -------------------------------------------------------------
+        __syncthreads();
+        if (lane < B && !(ablate & 8)) {
+            const double invp = 1.0 / mypiv;
+            double* Ak = As + (size_t)k * BB;
 #pragma unroll
-        for (int j = 0; j < B; ++j) Ak[(size_t)rj[j] * B + myj] = a[j] * invp;
-        ws[(size_t)k * B + myj] = y * invp;
+            for (int j = 0; j < B; ++j) Ak[(size_t)rj[j] * B + myj] = a[j] * invp;
+            ws[(size_t)k * B + myj] = y * invp;
+        }
     }
 }
 
@@ -521,9 +534,9 @@ __global__ __launch_bounds__(64) void k_back_w(Model M, TreeDev T, const int* __
     }
 }
 
-template <int B>
+template <int B, int MODE>
 int launch_factor_w(hpf_handle* h, const TreeDev& T, const int* nodes, int count, const int* active) {
-    hipLaunchKernelGGL((k_factor_w<B>), dim3((unsigned)count, (unsigned)h->S), dim3(64), 0, h->stream, h->M, T, nodes,
+    hipLaunchKernelGGL((k_factor_w<B, MODE>), dim3((unsigned)count, (unsigned)h->S), dim3(64), 0, h->stream, h->M, T, nodes,
                        2 * h->Hn, h->N, h->Nc, active, h->d_U, h->d_E, h->d_f, h->d_Z, h->d_w, h->debug_ablate);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -711,9 +724,9 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
             const int* nodes = T.d_lvl_nodes + T.lvl_ptr[l];
             int r;
             switch (BW) {
-                case 12: r = launch_factor_w<12>(h, td, nodes, cnt, active); break;
-                case 28: r = launch_factor_w<28>(h, td, nodes, cnt, active); break;
-                case 52: r = launch_factor_w<52>(h, td, nodes, cnt, active); break;
+                case 12: r = h->gj_mode ? launch_factor_w<12, 1>(h, td, nodes, cnt, active) : launch_factor_w<12, 0>(h, td, nodes, cnt, active); break;
+                case 28: r = h->gj_mode ? launch_factor_w<28, 1>(h, td, nodes, cnt, active) : launch_factor_w<28, 0>(h, td, nodes, cnt, active); break;
+                case 52: r = h->gj_mode ? launch_factor_w<52, 1>(h, td, nodes, cnt, active) : launch_factor_w<52, 0>(h, td, nodes, cnt, active); break;
                 default:
                     switch (R) {
                         case 4: r = launch_factor<4>(h, td, nodes, cnt, active); break;

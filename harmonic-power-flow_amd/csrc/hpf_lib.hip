@@ -552,6 +552,7 @@ int hpf_create(hpf_handle** out, const hpf_desc* d) {
     h->N = 2 * h->Nc - (d->c - 1);
     h->Nf = 2 * d->n - 1 - d->c;
     if (const char* ab = getenv("HPF_DEBUG_ABLATE")) h->debug_ablate = atoi(ab);
+    if (const char* gm = getenv("HPF_GJ_MODE")) h->gj_mode = atoi(gm) ? 1 : 0;
     if (hipSetDevice(d->device) != hipSuccess) return fail(HPF_E_HIP);
     if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) return fail(HPF_E_HIP);
     h->stream = h->own_stream;
@@ -714,6 +715,15 @@ int hpf_get_stats_dev(hpf_handle* h, void* stats_dev) {
     HIPCHK(hipMemcpyAsync(stats_dev, h->d_stats, sizeof(hpf_stat) * h->S, hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return HPF_OK;
+}
+
+int hpf_set_option(hpf_handle* h, const char* name, int value) {
+    if (!h || !name) return HPF_E_ARG;
+    if (!strcmp(name, "block_pivoting")) {          // 1: partial pivoting (wave Gauss-Jordan), 0: static 4x4 blocks on MFMA
+        h->gj_mode = value ? 0 : 1;
+        return HPF_OK;
+    }
+    return HPF_E_ARG;
 }
 
 int hpf_set_stream(hpf_handle* h, void* s) {

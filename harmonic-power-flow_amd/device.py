@@ -164,6 +164,9 @@ class DeviceModel:
     def stats_to_device(self, data_ptr):
         self._chk(self.lib.hpf_get_stats_dev(self._h, C.c_void_p(int(data_ptr))), "hpf_get_stats_dev")
 
+    def set_option(self, name, value):
+        self._chk(self.lib.hpf_set_option(self._h, name.encode(), int(value)), "hpf_set_option")
+
     def set_stream(self, stream_ptr):
         self._chk(self.lib.hpf_set_stream(self._h, C.c_void_p(int(stream_ptr)) if stream_ptr else None),
                   "hpf_set_stream")

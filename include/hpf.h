@@ -125,6 +125,12 @@ int  hpf_iterate(hpf_handle* h, int iters);
 int  hpf_get_stats(hpf_handle* h, hpf_stat* stats /* [S] host */);
 int  hpf_get_stats_dev(hpf_handle* h, void* stats_dev /* [S] hpf_stat, device memory of the caller (RCCL gather) */);
 
+/* Options.  "block_pivoting" (BLOCK_TREE only): 0 (default) inverts the 2Hn x 2Hn bus blocks on the FP64 matrix cores with
+ * a static pivot order (4x4 blocks = two harmonics, 2x2 Schur inside); 1 uses wave-level Gauss-Jordan with partial pivoting
+ * over the whole block (slower, for networks whose bus blocks are not block-diagonally dominant).  Env HPF_GJ_MODE=0 selects
+ * the pivoted variant process-wide. */
+int  hpf_set_option(hpf_handle* h, const char* name, int value);
+
 /* Stream plumbing: run on a caller stream (e.g. torch's current stream) instead of the handle's own; NULL restores. */
 int  hpf_set_stream(hpf_handle* h, void* hip_stream);
 int  hpf_sync(hpf_handle* h);

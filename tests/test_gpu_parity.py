@@ -352,3 +352,24 @@ def test_headline_feeder_syn1000_vs_reference_golden(tmp_path):
     assert int(n_iter[0]) < 50 and err[0] <= 1e-4
     assert np.abs(Ud - Ug).max() < TOL_V
     assert np.abs(Vm - g["V_final"][:, 0]).max() < TOL_V
+
+
+def test_block_pivoting_option_gives_same_solution(tmp_path):
+    """BLOCK_TREE with partial pivoting (wave Gauss-Jordan) vs the default MFMA static-block inversion: same voltages."""
+    hp = _hp()
+    res = {}
+    for piv in (0, 1):
+        st, buses, lines, dm, _ = _syn_model(hp, 100, 11, "block_tree", tmp_path)
+        try:
+            dm.set_option("block_pivoting", piv)
+            dm.set_loads(buses["P"].to_numpy(float), buses["Q"].to_numpy(float))
+            dm.set_state(None, None, n_scen=1)
+            dm.fund_pf(1e-6, 30)
+            n_iter, err, _ = dm.solve(1e-4, 50)
+            res[piv] = (int(n_iter[0]), dm.get_state())
+        finally:
+            dm.close()
+    assert res[0][0] == res[1][0] == 17
+    U0 = res[0][1][0][0] * np.exp(1j * res[0][1][1][0])
+    U1 = res[1][1][0][0] * np.exp(1j * res[1][1][1][0])
+    assert np.abs(U0 - U1).max() < 1e-10

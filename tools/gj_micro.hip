@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include "hpf_gj.hpp"
+#include "hpf_gj_mfma.hpp"
 
 #ifndef GJB
 #define GJB 52
@@ -49,12 +50,55 @@ __global__ __launch_bounds__(64) void k_gj(const double* __restrict__ Ain, doubl
     if (lane == 0 && cyc) cyc[blk] = t1 - t0;
 }
 
+
+// MFMA variant: matrix in accumulator layout, static 4x4 pivot blocks
+template <int B>
+__global__ __launch_bounds__(64) void k_gj_mfma(const double* __restrict__ Ain, double* __restrict__ Aout, long long* cyc, int nsteps) {
+    constexpr int NT = (B + 15) / 16;
+    const int lane = threadIdx.x, lg = lane >> 4, jj = lane & 15;
+    const size_t blk = blockIdx.x;
+    __shared__ double panel[NT * 64 + 16];
+    d4_t c[NT][NT];
+    const double* A = Ain + blk * B * B;
+#pragma unroll
+    for (int tr = 0; tr < NT; ++tr)
+#pragma unroll
+        for (int tc = 0; tc < NT; ++tc)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int i = 16 * tr + lg + 4 * reg, cc = 16 * tc + jj;
+                c[tr][tc][reg] = (i < B && cc < B) ? A[(size_t)cc * B + i] : (i == cc ? 1.0 : 0.0);
+            }
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    gauss_jordan_mfma<NT>(c, nsteps == B ? (B + 3) / 4 : (nsteps < 0 ? -nsteps : 0), panel);
+    const long long t1 = __builtin_amdgcn_s_memtime();
+    double* O = Aout + blk * B * B;
+#pragma unroll
+    for (int tr = 0; tr < NT; ++tr)
+#pragma unroll
+        for (int tc = 0; tc < NT; ++tc)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int i = 16 * tr + lg + 4 * reg, cc = 16 * tc + jj;
+                if (i < B && cc < B) O[(size_t)cc * B + i] = c[tr][tc][reg];       // AinvT[c][i]
+            }
+    if (lane == 0 && cyc) cyc[blk] = t1 - t0;
+}
+
+#if GJVAR == 2
+#define KGJ k_gj_mfma
+#else
+#define KGJ k_gj
+#endif
+
 int main(int argc, char** argv) {
     constexpr int B = GJB;
-    const int nblk = argc > 1 ? atoi(argv[1]) : 131072;
+    const int nblk = argc > 1 ? std::max(1, atoi(argv[1])) : 131072;
     std::vector<double> A((size_t)nblk * B * B);
     srand(1);
     for (size_t i = 0; i < A.size(); ++i) A[i] = (rand() / (double)RAND_MAX) - 0.5;
+    for (int blk = 0; blk < nblk; ++blk)
+        for (int d = 0; d < B; ++d) A[(size_t)blk * B * B + (size_t)d * B + d] += 0.5 * B;   // diagonally dominant (static-pivot variants need it; the feeder blocks are block-dominant)
     double *dA, *dO;
     long long* dC;
     hipMalloc(&dA, A.size() * 8);
@@ -65,7 +109,7 @@ int main(int argc, char** argv) {
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     // correctness on block 0
-    hipLaunchKernelGGL((k_gj<B>), dim3(1), dim3(64), 0, 0, dA, dO, dC, B);
+    hipLaunchKernelGGL((KGJ<B>), dim3(1), dim3(64), 0, 0, dA, dO, dC, B);
     std::vector<double> O((size_t)B * B);
     hipMemcpy(O.data(), dO, O.size() * 8, hipMemcpyDeviceToHost);
     double maxerr = 0;
@@ -76,10 +120,22 @@ int main(int argc, char** argv) {
             maxerr = std::max(maxerr, std::fabs(s - (i == j)));
         }
     printf("B=%d variant %d  |A*Ainv - I|max = %.3e\n", B, GJVAR, maxerr);
+    if (const char* dbg = getenv("GJ_NBS")) {   // debug: run only GJ_NBS block steps on matrix 0 and dump input + state
+        hipLaunchKernelGGL((KGJ<B>), dim3(1), dim3(64), 0, 0, dA, dO, dC, -atoi(dbg));
+        hipMemcpy(O.data(), dO, O.size() * 8, hipMemcpyDeviceToHost);
+        FILE* f = fopen("gpurun_out/gj_dump.bin", "wb");
+        if (f) {
+            fwrite(A.data(), 8, (size_t)B * B, f);
+            fwrite(O.data(), 8, (size_t)B * B, f);
+            fclose(f);
+        }
+        return 0;
+    }
     for (int grid : {1, 256, 1024, 2048, 4096, nblk}) {
+        if (grid > nblk) continue;   // never launch more blocks than matrices were allocated
         for (int rep = 0; rep < 2; ++rep) {
             hipEventRecord(e0);
-            hipLaunchKernelGGL((k_gj<B>), dim3(grid), dim3(64), 0, 0, dA, dO, dC, B);
+            hipLaunchKernelGGL((KGJ<B>), dim3(grid), dim3(64), 0, 0, dA, dO, dC, B);
             hipEventRecord(e1);
             hipEventSynchronize(e1);
         }
@@ -93,7 +149,7 @@ int main(int argc, char** argv) {
     }
     // zero steps: load/store overhead only
     hipEventRecord(e0);
-    hipLaunchKernelGGL((k_gj<B>), dim3(nblk), dim3(64), 0, 0, dA, dO, (long long*)nullptr, 0);
+    hipLaunchKernelGGL((KGJ<B>), dim3(nblk), dim3(64), 0, 0, dA, dO, (long long*)nullptr, 0);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
