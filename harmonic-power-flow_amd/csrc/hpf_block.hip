@@ -30,6 +30,9 @@ struct TreeDev {
     const int* child;
     const int* e_up;
     const int* e_dn;
+    const int* child_mid;   // children [child_ptr, child_mid) have all-linear subtrees, [child_mid, child_ptr+1) are dense
+    const int* lin_ptr;
+    const int* lin_post;
 };
 
 // validity of local index l = 2q+t of bus i as an unknown / equation (same rule for both, see hpf_assembly.hpp)
@@ -362,7 +365,8 @@ template <int B, int MODE>
 __global__ __launch_bounds__(64, MODE == 1 ? 2 : 1) void k_factor_w(Model M, TreeDev T, const int* __restrict__ nodes, int b, int N, int Nc,
                                                  const int* __restrict__ active, const cplx* __restrict__ Uall,
                                                  const cplx* __restrict__ Eall, const double* __restrict__ fall,
-                                                 double* __restrict__ Aall, double* __restrict__ wall, int ablate) {
+                                                 double* __restrict__ Aall, double* __restrict__ wall,
+                                                 const double* __restrict__ linAall, int ablate) {
     const int s = blockIdx.y;
     if (active && !active[s]) return;
     const int k = nodes[blockIdx.x];
@@ -383,19 +387,48 @@ __global__ __launch_bounds__(64, MODE == 1 ? 2 : 1) void k_factor_w(Model M, Tre
     const bool rowvalid = lane < b && loc_valid(n, c, k, lane);
 
     // ---- A. assemble row `lane` of D_k --------------------------------------------------------------------------
+    // Row i = 2q+t.  The 2x2 block on the harmonic diagonal (d0, d1) comes from the network entry (k,k) (+ the p == q
+    // Norton term) minus the Schur complements of the children whose whole subtree is linear: those are harmonic-
+    // diagonal (2x2 per harmonic, inverted by k_lin_factor), so they only touch (d0, d1) and y.
+    double y = 0.0;
+    if (rowvalid) {
+        const int kst = q * n + k;
+        y = t ? f[Nc + kst - c] : f[kst - 1];
+    }
     double a[B];
     {
-        const int diag_e = M.diag[k];
+        double d0 = 0.0, d1 = 0.0;
+        if (rowvalid && !(ablate & 4)) {
+            const int diag_e = M.diag[k];
+            const Blk2 blk = (q == 0 && k < M.m) ? jac_power_entry<false>(M, U, E, k, k, diag_e)
+                                                  : jac_current_entry(M, U, E, q, k, k, diag_e);
+            d0 = pick(blk, t, 0);
+            d1 = pick(blk, t, 1);
+            const double* linA = linAall + (size_t)s * n * Hn * 4;
+            for (int cp = T.child_ptr[k]; cp < T.child_mid[k]; ++cp) {
+                const int ch = T.child[cp];
+                const Blk2 g = offdiag_block(M, U, E, q, k, ch, T.e_dn[ch]);     // A(parent, child), my harmonic
+                const double g0 = pick(g, t, 0);
+                const double g1 = loc_valid(n, c, ch, 2 * q + 1) ? pick(g, t, 1) : 0.0;
+                double h4[4];
+                coupling_block(M, U, E, q, ch, k, T.e_up[ch], h4);               // A(child, parent)
+                const double* ic = linA + ((size_t)ch * Hn + q) * 4;
+                const double v0 = fma(g1, ic[2], g0 * ic[0]), v1 = fma(g1, ic[3], g0 * ic[1]);
+                d0 -= fma(v1, h4[2], v0 * h4[0]);
+                d1 -= fma(v1, h4[3], v0 * h4[1]);
+                const double* wc = ws + (size_t)ch * B;
+                y = fma(-g0, wc[2 * q], y);
+                y = fma(-g1, wc[2 * q + 1], y);
+            }
+        }
         const bool nl = k >= M.m && M.coupled;
 #pragma unroll
         for (int p = 0; p < B / 2; ++p) {
             double v0 = 0.0, v1 = 0.0;
             if (rowvalid && p < Hn && !(ablate & 4)) {
                 if (p == q) {
-                    const Blk2 blk = (q == 0 && k < M.m) ? jac_power_entry<false>(M, U, E, k, k, diag_e)
-                                                          : jac_current_entry(M, U, E, q, k, k, diag_e);
-                    v0 = pick(blk, t, 0);
-                    v1 = pick(blk, t, 1);
+                    v0 = d0;
+                    v1 = d1;
                 } else if (nl) {
                     const Blk2 blk = jac_norton_cross(M, U, E, q, p, k);
                     v0 = pick(blk, t, 0);
@@ -411,14 +444,9 @@ __global__ __launch_bounds__(64, MODE == 1 ? 2 : 1) void k_factor_w(Model M, Tre
             if (!cv || !rowvalid) a[cc] = (cc == lane) ? 1.0 : 0.0;     // identity padding
         }
     }
-    double y = 0.0;
-    if (rowvalid) {
-        const int kst = q * n + k;
-        y = t ? f[Nc + kst - c] : f[kst - 1];
-    }
 
-    // ---- B. pull the children's Schur complements (fixed order) ------------------------------------------------
-    for (int cp = T.child_ptr[k]; cp < ((ablate & 2) ? 0 : T.child_ptr[k + 1]); ++cp) {
+    // ---- B. pull the dense children's Schur complements (fixed order) ------------------------------------------
+    for (int cp = T.child_mid[k]; cp < ((ablate & 2) ? 0 : T.child_ptr[k + 1]); ++cp) {
         const int ch = T.child[cp];
         __syncthreads();
         if (lane < Hn) {
@@ -534,10 +562,117 @@ __global__ __launch_bounds__(64) void k_back_w(Model M, TreeDev T, const int* __
     }
 }
 
+
+// =============================================================================================================
+// Buses whose whole subtree is linear (no nonlinear bus below them; with uncoupled Norton data: every bus): their
+// Schur-complemented diagonal block stays harmonic-diagonal, i.e. Hn independent 2x2 systems.  One thread per
+// (maximal linear subtree, harmonic, scenario) walks the subtree in post-order (factor) / reverse post-order (back).
+// =============================================================================================================
+__device__ __forceinline__ void diag2x2(const Model& M, const cplx* U, const cplx* E, int q, int k, double m2[4]) {
+    const Blk2 blk = (q == 0 && k < M.m) ? jac_power_entry<false>(M, U, E, k, k, M.diag[k])
+                                          : jac_current_entry(M, U, E, q, k, k, M.diag[k]);
+    const bool v0 = loc_valid(M.n, M.c, k, 2 * q), v1 = loc_valid(M.n, M.c, k, 2 * q + 1);
+    m2[0] = v0 ? blk.dA.re : 1.0;
+    m2[1] = (v0 && v1) ? blk.dV.re : 0.0;
+    m2[2] = (v0 && v1) ? blk.dA.im : 0.0;
+    m2[3] = v1 ? blk.dV.im : 1.0;
+}
+
+__global__ __launch_bounds__(128) void k_lin_factor(Model M, TreeDev T, int nroots, int N, int Nc, int Bst,
+                                                    const int* __restrict__ active, const cplx* __restrict__ Uall,
+                                                    const cplx* __restrict__ Eall, const double* __restrict__ fall,
+                                                    double* __restrict__ linAall, double* __restrict__ wall) {
+    const int s = blockIdx.y;
+    if (active && !active[s]) return;
+    const int tix = blockIdx.x * 128 + threadIdx.x;
+    if (tix >= nroots * M.Hn) return;
+    const int q = tix % M.Hn, r = tix / M.Hn;                      // consecutive threads: consecutive harmonics
+    const int n = M.n, c = M.c, Hn = M.Hn;
+    const size_t so = (size_t)s * n * Hn;
+    const cplx* U = Uall + so;
+    const cplx* E = Eall + so;
+    const double* f = fall + (size_t)s * N;
+    double* linA = linAall + so * 4;
+    double* ws = wall + (size_t)s * n * Bst;
+    for (int idx = T.lin_ptr[r]; idx < T.lin_ptr[r + 1]; ++idx) {
+        const int k = T.lin_post[idx];
+        double m2[4];
+        diag2x2(M, U, E, q, k, m2);
+        const int kst = q * n + k;
+        double y0 = kst >= 1 ? f[kst - 1] : 0.0;
+        double y1 = kst >= c ? f[Nc + kst - c] : 0.0;
+        for (int cp = T.child_ptr[k]; cp < T.child_ptr[k + 1]; ++cp) {      // all children of a linear-subtree bus are linear
+            const int ch = T.child[cp];
+            double g4[4], h4[4];
+            coupling_block(M, U, E, q, k, ch, T.e_dn[ch], g4);               // A(k, child)
+            coupling_block(M, U, E, q, ch, k, T.e_up[ch], h4);               // A(child, k)
+            const double* ic = linA + ((size_t)ch * Hn + q) * 4;
+            const double gi0 = fma(g4[1], ic[2], g4[0] * ic[0]), gi1 = fma(g4[1], ic[3], g4[0] * ic[1]);
+            const double gi2 = fma(g4[3], ic[2], g4[2] * ic[0]), gi3 = fma(g4[3], ic[3], g4[2] * ic[1]);
+            m2[0] -= fma(gi1, h4[2], gi0 * h4[0]);
+            m2[1] -= fma(gi1, h4[3], gi0 * h4[1]);
+            m2[2] -= fma(gi3, h4[2], gi2 * h4[0]);
+            m2[3] -= fma(gi3, h4[3], gi2 * h4[1]);
+            const double* wc = ws + (size_t)ch * Bst + 2 * q;
+            y0 -= fma(g4[1], wc[1], g4[0] * wc[0]);
+            y1 -= fma(g4[3], wc[1], g4[2] * wc[0]);
+        }
+        double i0, i1, i2, i3;
+        inv2(m2[0], m2[1], m2[2], m2[3], i0, i1, i2, i3);
+        double* ik = linA + ((size_t)k * Hn + q) * 4;
+        ik[0] = i0;
+        ik[1] = i1;
+        ik[2] = i2;
+        ik[3] = i3;
+        double* wk = ws + (size_t)k * Bst + 2 * q;
+        wk[0] = fma(i1, y1, i0 * y0);
+        wk[1] = fma(i3, y1, i2 * y0);
+    }
+}
+
+__global__ __launch_bounds__(128) void k_lin_back(Model M, TreeDev T, int nroots, int N, int Nc, int Bst,
+                                                  const int* __restrict__ active, const cplx* __restrict__ Uall,
+                                                  const cplx* __restrict__ Eall, const double* __restrict__ linAall,
+                                                  const double* __restrict__ wall, double* __restrict__ xall,
+                                                  double* __restrict__ step) {
+    const int s = blockIdx.y;
+    if (active && !active[s]) return;
+    const int tix = blockIdx.x * 128 + threadIdx.x;
+    if (tix >= nroots * M.Hn) return;
+    const int q = tix % M.Hn, r = tix / M.Hn;
+    const int n = M.n, c = M.c, Hn = M.Hn;
+    const size_t so = (size_t)s * n * Hn;
+    const double* linA = linAall + so * 4;
+    const double* ws = wall + (size_t)s * n * Bst;
+    double* xs = xall + (size_t)s * n * Bst;
+    double* st = step + (size_t)s * N;
+    for (int idx = T.lin_ptr[r + 1] - 1; idx >= T.lin_ptr[r]; --idx) {      // reverse post-order: parents first
+        const int k = T.lin_post[idx];
+        const int par = T.parent[k];
+        const double* wk = ws + (size_t)k * Bst + 2 * q;
+        double x0 = wk[0], x1 = wk[1];
+        if (par >= 0) {
+            double h4[4];
+            coupling_block(M, Uall + so, Eall + so, q, k, par, T.e_up[k], h4);   // A(k, parent)
+            const double* xp = xs + (size_t)par * Bst + 2 * q;
+            const double t0 = fma(h4[1], xp[1], h4[0] * xp[0]), t1 = fma(h4[3], xp[1], h4[2] * xp[0]);
+            const double* ik = linA + ((size_t)k * Hn + q) * 4;
+            x0 -= fma(ik[1], t1, ik[0] * t0);
+            x1 -= fma(ik[3], t1, ik[2] * t0);
+        }
+        double* xk = xs + (size_t)k * Bst + 2 * q;
+        xk[0] = x0;
+        xk[1] = x1;
+        const int kst = q * n + k;
+        if (kst >= 1) st[kst - 1] = x0;
+        if (kst >= c) st[Nc + kst - c] = x1;
+    }
+}
+
 template <int B, int MODE>
 int launch_factor_w(hpf_handle* h, const TreeDev& T, const int* nodes, int count, const int* active) {
     hipLaunchKernelGGL((k_factor_w<B, MODE>), dim3((unsigned)count, (unsigned)h->S), dim3(64), 0, h->stream, h->M, T, nodes,
-                       2 * h->Hn, h->N, h->Nc, active, h->d_U, h->d_E, h->d_f, h->d_Z, h->d_w, h->debug_ablate);
+                       2 * h->Hn, h->N, h->Nc, active, h->d_U, h->d_E, h->d_f, h->d_Z, h->d_w, h->d_linA, h->debug_ablate);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         h->last_detail = (int)e;
@@ -639,45 +774,95 @@ int tree_build(hpf_handle* h, const hpf_desc* d) {
             if (d->col[e] == p) e_up[i] = e;
         if (e_up[i] < 0 || e_dn[i] < 0) return HPF_E_TOPOLOGY;  // pattern not symmetric
     }
+    // buses whose whole subtree is linear: 2x2-per-harmonic algebra (wave-per-bus path only)
+    const bool use_lin = wave_block_size(b) != 0;
+    T.lin.assign(n, 0);
+    if (use_lin) {
+        for (int i = 0; i < n; ++i) T.lin[i] = (i < d->m || !d->coupled) ? 1 : 0;
+        for (int oi = n - 1; oi > 0; --oi) {
+            const int i = order[oi];
+            if (!T.lin[i]) T.lin[T.parent[i]] = 0;
+        }
+    }
+    // heights over the DENSE buses only (linear subtrees are finished before the first dense level)
     for (int oi = n - 1; oi > 0; --oi) {
         const int i = order[oi], p = T.parent[i];
+        if (T.lin[i]) continue;
         if (height[i] + 1 > height[p]) height[p] = height[i] + 1;
     }
     int maxh = 0, maxd = 0;
+    T.n_dense = 0;
     for (int i = 0; i < n; ++i) {
+        if (T.lin[i]) continue;
+        ++T.n_dense;
         maxh = height[i] > maxh ? height[i] : maxh;
         maxd = depth[i] > maxd ? depth[i] : maxd;
     }
-    T.n_levels = maxh + 1;
-    T.n_depths = maxd + 1;
+    T.n_levels = T.n_dense ? maxh + 1 : 0;
+    T.n_depths = T.n_dense ? maxd + 1 : 0;
     auto bucket = [&](const std::vector<int>& key, int nb, std::vector<int>& ptr, std::vector<int>& items) {
         ptr.assign(nb + 1, 0);
-        for (int i = 0; i < n; ++i) ptr[key[i] + 1]++;
+        for (int i = 0; i < n; ++i)
+            if (!T.lin[i]) ptr[key[i] + 1]++;
         for (int l = 0; l < nb; ++l) ptr[l + 1] += ptr[l];
-        items.assign(n, 0);
+        items.assign(T.n_dense, 0);
         std::vector<int> pos(ptr.begin(), ptr.end() - 1);
-        for (int i = 0; i < n; ++i) items[pos[key[i]]++] = i;   // ascending bus index inside a level
+        for (int i = 0; i < n; ++i)
+            if (!T.lin[i]) items[pos[key[i]]++] = i;             // ascending bus index inside a level
     };
     bucket(height, T.n_levels, T.lvl_ptr, T.lvl_nodes);
     bucket(depth, T.n_depths, T.dep_ptr, T.dep_nodes);
+    // children lists: linear-subtree children first, then dense children, ascending bus index inside each group
     T.child_ptr.assign(n + 1, 0);
     for (int i = 1; i < n; ++i) T.child_ptr[T.parent[i] + 1]++;
     for (int i = 0; i < n; ++i) T.child_ptr[i + 1] += T.child_ptr[i];
     T.child.assign(n > 1 ? n - 1 : 0, 0);
+    T.child_mid.assign(n, 0);
     {
         std::vector<int> pos(T.child_ptr.begin(), T.child_ptr.end() - 1);
-        for (int i = 1; i < n; ++i) T.child[pos[T.parent[i]]++] = i;   // children in ascending bus index
+        for (int i = 1; i < n; ++i)
+            if (T.lin[i]) T.child[pos[T.parent[i]]++] = i;
+        for (int i = 0; i < n; ++i) T.child_mid[i] = pos[i];
+        for (int i = 1; i < n; ++i)
+            if (!T.lin[i]) T.child[pos[T.parent[i]]++] = i;
+    }
+    // maximal linear subtrees, post-order (children before parents; iterative DFS)
+    T.lin_ptr.assign(1, 0);
+    T.lin_post.clear();
+    T.n_lin_roots = 0;
+    for (int r0 = 0; r0 < n; ++r0) {
+        if (!T.lin[r0] || (T.parent[r0] >= 0 && T.lin[T.parent[r0]])) continue;
+        std::vector<std::pair<int, int>> stack;                  // (node, next child position)
+        stack.push_back({r0, T.child_ptr[r0]});
+        while (!stack.empty()) {
+            const int node = stack.back().first;
+            if (stack.back().second < T.child_ptr[node + 1]) {
+                const int ch = T.child[stack.back().second++];
+                stack.push_back({ch, T.child_ptr[ch]});
+            } else {
+                T.lin_post.push_back(node);
+                stack.pop_back();
+            }
+        }
+        T.lin_ptr.push_back((int)T.lin_post.size());
+        ++T.n_lin_roots;
     }
     const double bd = b;
-    // exact flop count of the elimination: per bus 2 b^3 (Gauss-Jordan), (4 b^2 + 4 b) per child pulled,
-    // 2 b^2 (w = D^-1 y); per non-root bus 4 b^2 (Z = D^-1 A(k,parent)) and 2 b^2 in the back sweep
+    // exact FP64 flop count of the dense part of the elimination: per dense bus 2 b^3 (block inversion), (4 b^2 + 4 b)
+    // per dense child pulled, 2 b^2 (w = D^-1 y); per non-root dense bus 4 b^2 (D^-1 A(k,parent)) in the parent's pull
+    // and 2 b^2 in the back sweep.  The 2x2 work of the linear subtrees (~60 flop per bus and harmonic) is not counted.
     T.flops_factor = 0.0;
+    int n_dense_nonroot = 0;
     for (int i = 0; i < n; ++i) {
-        const int nch = T.child_ptr[i + 1] - T.child_ptr[i];
+        if (T.lin[i]) continue;
+        const int nch = T.child_ptr[i + 1] - T.child_mid[i];
         T.flops_factor += 2.0 * bd * bd * bd + (4.0 * bd * bd + 4.0 * bd) * nch + 2.0 * bd * bd;
-        if (i > 0) T.flops_factor += 4.0 * bd * bd;
+        if (i > 0) {
+            T.flops_factor += 4.0 * bd * bd;
+            ++n_dense_nonroot;
+        }
     }
-    T.flops_per_solve = T.flops_factor + 2.0 * bd * bd * (n - 1);
+    T.flops_per_solve = T.flops_factor + 2.0 * bd * bd * n_dense_nonroot;
     int r;
     if ((r = upload(h, &T.d_parent, T.parent))) return r;
     if ((r = upload(h, &T.d_lvl_nodes, T.lvl_nodes))) return r;
@@ -686,12 +871,17 @@ int tree_build(hpf_handle* h, const hpf_desc* d) {
     if ((r = upload(h, &T.d_child, T.child))) return r;
     if ((r = upload(h, &T.d_e_up, e_up))) return r;
     if ((r = upload(h, &T.d_e_dn, e_dn))) return r;
+    if ((r = upload(h, &T.d_child_mid, T.child_mid))) return r;
+    if ((r = upload(h, &T.d_lin, T.lin))) return r;
+    if ((r = upload(h, &T.d_lin_ptr, T.lin_ptr))) return r;
+    if ((r = upload(h, &T.d_lin_post, T.lin_post))) return r;
     return HPF_OK;
 }
 
 void tree_free(hpf_handle* h) {
     Tree& T = h->tree;
-    void* ptrs[] = {T.d_parent, T.d_lvl_nodes, T.d_dep_nodes, T.d_child_ptr, T.d_child, T.d_e_up, T.d_e_dn};
+    void* ptrs[] = {T.d_parent, T.d_lvl_nodes, T.d_dep_nodes, T.d_child_ptr, T.d_child, T.d_e_up, T.d_e_dn,
+                    T.d_child_mid, T.d_lin, T.d_lin_ptr, T.d_lin_post};
     for (void* p : ptrs)
         if (p) hipFree(p);
 }
@@ -702,7 +892,8 @@ int tree_alloc_scenarios(hpf_handle* h) {
     hipError_t e;
     if ((e = hipMalloc((void**)&h->d_Z, sizeof(double) * S * n * b * b)) != hipSuccess ||
         (e = hipMalloc((void**)&h->d_w, sizeof(double) * S * n * b)) != hipSuccess ||
-        (e = hipMalloc((void**)&h->d_x, sizeof(double) * S * n * b)) != hipSuccess) {
+        (e = hipMalloc((void**)&h->d_x, sizeof(double) * S * n * b)) != hipSuccess ||
+        (e = hipMalloc((void**)&h->d_linA, sizeof(double) * S * n * (size_t)h->Hn * 4)) != hipSuccess) {
         h->last_detail = (int)e;
         return e == hipErrorOutOfMemory ? HPF_E_NOMEM : HPF_E_HIP;
     }
@@ -712,12 +903,24 @@ int tree_alloc_scenarios(hpf_handle* h) {
 int tree_newton_step(hpf_handle* h, bool only_active) {
     Tree& T = h->tree;
     const int* active = only_active ? h->d_active : nullptr;
-    const TreeDev td{T.d_parent, T.d_child_ptr, T.d_child, T.d_e_up, T.d_e_dn};
+    const TreeDev td{T.d_parent, T.d_child_ptr, T.d_child, T.d_e_up, T.d_e_dn, T.d_child_mid, T.d_lin_ptr, T.d_lin_post};
     const int b = 2 * h->Hn;
     const int R = (b + 15) / 16;
     const int BW = wave_block_size(b);
+    const int lin_threads = T.n_lin_roots * h->Hn;
+    const int Bst = BW ? BW : b;
     {
         ScopedTimer t(h, T_SOLVE);
+        if (lin_threads > 0) {
+            hipLaunchKernelGGL(k_lin_factor, dim3((unsigned)((lin_threads + 127) / 128), (unsigned)h->S), dim3(128), 0,
+                               h->stream, h->M, td, T.n_lin_roots, h->N, h->Nc, Bst, active, h->d_U, h->d_E, h->d_f,
+                               h->d_linA, h->d_w);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) {
+                h->last_detail = (int)e;
+                return HPF_E_HIP;
+            }
+        }
         for (int l = 0; l < T.n_levels; ++l) {
             const int cnt = T.lvl_ptr[l + 1] - T.lvl_ptr[l];
             if (cnt == 0) continue;
@@ -760,6 +963,16 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
             }
         }
         if (r) return r;
+    }
+    if (lin_threads > 0) {
+        hipLaunchKernelGGL(k_lin_back, dim3((unsigned)((lin_threads + 127) / 128), (unsigned)h->S), dim3(128), 0, h->stream,
+                           h->M, td, T.n_lin_roots, h->N, h->Nc, Bst, active, h->d_U, h->d_E, h->d_linA, h->d_w, h->d_x,
+                           h->d_f);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) {
+            h->last_detail = (int)e;
+            return HPF_E_HIP;
+        }
     }
     return HPF_OK;
 }

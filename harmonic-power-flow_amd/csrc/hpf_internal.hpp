@@ -28,7 +28,13 @@ struct Tree {
     std::vector<int> dep_ptr;         // [n_depths+1] into dep_nodes
     std::vector<int> dep_nodes;       // nodes grouped by depth
     std::vector<int> child_ptr;       // [n+1]
-    std::vector<int> child;           // children lists
+    std::vector<int> child;           // children lists: all-linear-subtree children first, then dense children
+    std::vector<int> child_mid;       // [n] end of the linear children inside a node's child list
+    std::vector<int> lin;             // [n] 1: the whole subtree of the bus is linear -> harmonic-diagonal 2x2 algebra
+    std::vector<int> lin_ptr;         // [n_lin_roots+1] into lin_post
+    std::vector<int> lin_post;        // post-order node lists of the maximal linear subtrees
+    int n_lin_roots = 0;
+    int n_dense = 0;
     int* d_parent = nullptr;
     int* d_lvl_nodes = nullptr;
     int* d_dep_nodes = nullptr;
@@ -36,6 +42,10 @@ struct Tree {
     int* d_child = nullptr;
     int* d_e_up = nullptr;            // [n] CSR position of entry (i, parent(i))
     int* d_e_dn = nullptr;            // [n] CSR position of entry (parent(i), i)
+    int* d_child_mid = nullptr;
+    int* d_lin = nullptr;
+    int* d_lin_ptr = nullptr;
+    int* d_lin_post = nullptr;
     double flops_per_solve = 0.0;     // factor sweep + back sweep
     double flops_factor = 0.0;        // factor sweep only (k_tree_factor, all levels)
 };
@@ -78,6 +88,7 @@ struct hpf_handle {
     double* d_Z = nullptr;            // [S][n][b*b]
     double* d_w = nullptr;            // [S][n][b]
     double* d_x = nullptr;            // [S][n][b]  Newton step, bus-major
+    double* d_linA = nullptr;         // [S][n][Hn][4] inverse 2x2 blocks of the all-linear-subtree buses
 
     hipStream_t own_stream = nullptr, stream = nullptr;
     rocblas_handle blas = nullptr;

@@ -215,14 +215,14 @@ def test_max_iter_and_nonconvergence_reporting():
 
 
 # ---- synthetic radial feeders: dense (rocSOLVER) and block-tree Newton steps ------------------------------------
-def _syn_model(hp, n, hmax, solver, tmp_path, max_scenarios=1):
+def _syn_model(hp, n, hmax, solver, tmp_path, max_scenarios=1, coupled=True):
     from harmonic_power_flow_amd import api, synth
     fb, fl = synth.gen(n, seed=0, outdir=str(tmp_path))
     st = hp.Settings(H_MAX=hmax)
     buses, lines, m, nn, c = hp.init_network(fb, fl, settings=st)
     Y = hp.build_admittance_matrices(buses, lines, st.HARMONICS)
-    NE = hp.import_Norton_Equivalents(buses, True, st, INPUTS)
-    dm = api._device_model(buses, Y, NE, True, st.HARMONICS, solver=solver, max_scenarios=max_scenarios)
+    NE = hp.import_Norton_Equivalents(buses, coupled, st, INPUTS)
+    dm = api._device_model(buses, Y, NE, coupled, st.HARMONICS, solver=solver, max_scenarios=max_scenarios)
     return st, buses, lines, dm, (fb, fl)
 
 
@@ -251,12 +251,14 @@ def test_synthetic_feeder_vs_reference_golden(n, solver, tmp_path):
     assert np.abs(Ud - Ug).max() < TOL_V
 
 
-def test_block_tree_step_equals_dense_step(tmp_path):
-    """One Newton step from the pf seed: block-tree elimination vs rocSOLVER LU on the same Jacobian."""
+@pytest.mark.parametrize("coupled,hmax", [(True, 11), (False, 11), (True, 27)])
+def test_block_tree_step_equals_dense_step(tmp_path, coupled, hmax):
+    """Three Newton steps from the pf seed: block-tree elimination (dense MFMA blocks + 2x2 linear subtrees; uncoupled =
+    everything 2x2) vs rocSOLVER LU on the same Jacobian."""
     hp = _hp()
     out = {}
     for solver in ("dense", "block_tree"):
-        st, buses, lines, dm, _ = _syn_model(hp, 100, 11, solver, tmp_path)
+        st, buses, lines, dm, _ = _syn_model(hp, 100, hmax, solver, tmp_path, coupled=coupled)
         try:
             dm.set_loads(buses["P"].to_numpy(float), buses["Q"].to_numpy(float))
             dm.set_state(None, None, n_scen=1)
@@ -265,16 +267,21 @@ def test_block_tree_step_equals_dense_step(tmp_path):
             dm.mismatch()
             dm.iterate(1)
             dm.sync()
-            out[solver] = (v0, dm.get_state(), dm.mismatch()[1][0])
+            v1 = dm.get_state()
+            e1 = dm.mismatch()[1][0]
+            dm.iterate(2)
+            dm.sync()
+            out[solver] = (v0, v1, e1, dm.get_state())
         finally:
             dm.close()
-    (v0d, v1d, ed), (v0b, v1b, eb) = out["dense"], out["block_tree"]
+    (v0d, v1d, ed, v3d), (v0b, v1b, eb, v3b) = out["dense"], out["block_tree"]
     assert np.array_equal(v0d[0], v0b[0])
     step = np.abs(v1d[0] - v0d[0]).max()
     assert step > 1e-3
     assert np.abs(v1d[0] - v1b[0]).max() <= 1e-10 * max(1.0, step)
     assert np.abs(v1d[1] - v1b[1]).max() <= 1e-10 * max(1.0, np.abs(v1d[1] - v0d[1]).max())
     assert abs(ed - eb) <= 1e-8 * ed
+    assert np.abs(v3d[0] - v3b[0]).max() <= 1e-7 * max(1.0, np.abs(v3d[0]).max())
 
 
 def test_auto_solver_and_api_on_radial_feeder(tmp_path):
