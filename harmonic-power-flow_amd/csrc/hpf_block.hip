@@ -56,8 +56,8 @@ __global__ __launch_bounds__(256) void k_tree_factor(Model M, TreeDev T, const i
                                                      int Nc, const int* __restrict__ active,
                                                      const cplx* __restrict__ Uall, const cplx* __restrict__ Eall,
                                                      const double* __restrict__ fall, double* __restrict__ Zall,
-                                                     double* __restrict__ wall) {
-    const int s = blockIdx.y;
+                                                     double* __restrict__ wall, int s0) {
+    const int s = blockIdx.y + s0;
     if (active && !active[s]) return;
     const int k = nodes[blockIdx.x];
     const int tid = threadIdx.x, tr = tid >> 4, tc = tid & 15;
@@ -298,8 +298,8 @@ __global__ __launch_bounds__(256) void k_tree_factor(Model M, TreeDev T, const i
 __global__ __launch_bounds__(256) void k_tree_back(int n, int c, int Hn, TreeDev T, const int* __restrict__ nodes, int b,
                                                    int N, int Nc, const int* __restrict__ active,
                                                    const double* __restrict__ Zall, const double* __restrict__ wall,
-                                                   double* __restrict__ xall, double* __restrict__ step) {
-    const int s = blockIdx.y;
+                                                   double* __restrict__ xall, double* __restrict__ step, int s0) {
+    const int s = blockIdx.y + s0;
     if (active && !active[s]) return;
     const int k = nodes[blockIdx.x];
     const size_t bb = (size_t)b * b;
@@ -366,8 +366,9 @@ __global__ __launch_bounds__(64, MODE == 1 ? 2 : 1) void k_factor_w(Model M, Tre
                                                  const int* __restrict__ active, const cplx* __restrict__ Uall,
                                                  const cplx* __restrict__ Eall, const double* __restrict__ fall,
                                                  double* __restrict__ Aall, double* __restrict__ wall,
-                                                 const double* __restrict__ linAall, int ablate) {
-    const int s = blockIdx.y;
+                                                 const double* __restrict__ linAall, double* __restrict__ Call,
+                                                 int ablate, int s0) {
+    const int s = blockIdx.y + s0;
     if (active && !active[s]) return;
     const int k = nodes[blockIdx.x];
     const int lane = threadIdx.x;
@@ -445,8 +446,22 @@ __global__ __launch_bounds__(64, MODE == 1 ? 2 : 1) void k_factor_w(Model M, Tre
         }
     }
 
-    // ---- B. pull the dense children's Schur complements (fixed order) ------------------------------------------
-    for (int cp = T.child_mid[k]; cp < ((ablate & 2) ? 0 : T.child_ptr[k + 1]); ++cp) {
+    // ---- B. dense children (fixed order).  MODE 1: every dense child has already formed its Schur complement
+    //      C = A(k,ch) D_ch^-1 A(ch,k) (+ the right-hand-side column) in its own wave (schur_tiles): just subtract. -------
+    constexpr size_t CB = (size_t)(B + 1) * B;
+    if constexpr (MODE == 1) {
+        const double* Cs = Call + (size_t)s * n * CB;
+        for (int cp = T.child_mid[k]; cp < ((ablate & 2) ? 0 : T.child_ptr[k + 1]); ++cp) {
+            const double* Cc = Cs + (size_t)T.child[cp] * CB;
+            if (lane < B) {
+#pragma unroll
+                for (int cc = 0; cc < B; ++cc) a[cc] -= Cc[(size_t)cc * B + lane];
+                y -= Cc[(size_t)B * B + lane];
+            }
+        }
+    }
+    // MODE 0: pull from the children's transposed inverses
+    for (int cp = T.child_mid[k]; cp < ((MODE == 1 || (ablate & 2)) ? 0 : T.child_ptr[k + 1]); ++cp) {
         const int ch = T.child[cp];
         __syncthreads();
         if (lane < Hn) {
@@ -492,6 +507,27 @@ __global__ __launch_bounds__(64, MODE == 1 ? 2 : 1) void k_factor_w(Model M, Tre
         rows_to_tiles<B, NT>(a, y, lane, ct, tbuf);
         gauss_jordan_mfma<NT>(ct, (b + 3) / 4, panel);
         tiles_to_global<B, NT>(ct, lane, tbuf, As + (size_t)k * BB, ws + (size_t)k * B);
+        const int par = T.parent[k];
+        if (par >= 0) {
+            // ---- E. push: Schur complement of this bus for its parent ------------------------------------------
+            __shared__ double gl[NT * 8 * 4], hl[NT * 8 * 4];
+            __syncthreads();
+            if (lane < NT * 8) {
+                double g4[4] = {0.0, 0.0, 0.0, 0.0}, h4[4] = {0.0, 0.0, 0.0, 0.0};
+                if (lane < Hn) {
+                    coupling_block(M, U, E, lane, par, k, T.e_dn[k], g4);       // A(parent, k)
+                    coupling_block(M, U, E, lane, k, par, T.e_up[k], h4);       // A(k, parent)
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    gl[lane * 4 + e] = g4[e];
+                    hl[lane * 4 + e] = h4[e];
+                }
+            }
+            __syncthreads();
+            schur_tiles<B, NT>(ct, lane, gl, hl);
+            tiles_to_global_aug<B, NT>(ct, lane, tbuf, Call + ((size_t)s * n + k) * CB);
+        }
     } else {
         // ---- C. Gauss-Jordan with implicit partial pivoting, rotating registers (hpf_gj.hpp) ---------------------
         int myj = 0;
@@ -517,8 +553,8 @@ __global__ __launch_bounds__(64) void k_back_w(Model M, TreeDev T, const int* __
                                                const int* __restrict__ active, const cplx* __restrict__ Uall,
                                                const cplx* __restrict__ Eall, const double* __restrict__ Aall,
                                                const double* __restrict__ wall, double* __restrict__ xall,
-                                               double* __restrict__ step) {
-    const int s = blockIdx.y;
+                                               double* __restrict__ step, int s0) {
+    const int s = blockIdx.y + s0;
     if (active && !active[s]) return;
     const int k = nodes[blockIdx.x];
     const int lane = threadIdx.x;
@@ -581,8 +617,8 @@ __device__ __forceinline__ void diag2x2(const Model& M, const cplx* U, const cpl
 __global__ __launch_bounds__(128) void k_lin_factor(Model M, TreeDev T, int nroots, int N, int Nc, int Bst,
                                                     const int* __restrict__ active, const cplx* __restrict__ Uall,
                                                     const cplx* __restrict__ Eall, const double* __restrict__ fall,
-                                                    double* __restrict__ linAall, double* __restrict__ wall) {
-    const int s = blockIdx.y;
+                                                    double* __restrict__ linAall, double* __restrict__ wall, int s0) {
+    const int s = blockIdx.y + s0;
     if (active && !active[s]) return;
     const int tix = blockIdx.x * 128 + threadIdx.x;
     if (tix >= nroots * M.Hn) return;
@@ -634,8 +670,8 @@ __global__ __launch_bounds__(128) void k_lin_back(Model M, TreeDev T, int nroots
                                                   const int* __restrict__ active, const cplx* __restrict__ Uall,
                                                   const cplx* __restrict__ Eall, const double* __restrict__ linAall,
                                                   const double* __restrict__ wall, double* __restrict__ xall,
-                                                  double* __restrict__ step) {
-    const int s = blockIdx.y;
+                                                  double* __restrict__ step, int s0) {
+    const int s = blockIdx.y + s0;
     if (active && !active[s]) return;
     const int tix = blockIdx.x * 128 + threadIdx.x;
     if (tix >= nroots * M.Hn) return;
@@ -671,8 +707,8 @@ __global__ __launch_bounds__(128) void k_lin_back(Model M, TreeDev T, int nroots
 
 template <int B, int MODE>
 int launch_factor_w(hpf_handle* h, const TreeDev& T, const int* nodes, int count, const int* active) {
-    hipLaunchKernelGGL((k_factor_w<B, MODE>), dim3((unsigned)count, (unsigned)h->S), dim3(64), 0, h->stream, h->M, T, nodes,
-                       2 * h->Hn, h->N, h->Nc, active, h->d_U, h->d_E, h->d_f, h->d_Z, h->d_w, h->d_linA, h->debug_ablate);
+    hipLaunchKernelGGL((k_factor_w<B, MODE>), dim3((unsigned)count, (unsigned)h->cur_S), dim3(64), 0, h->cur_stream, h->M, T, nodes,
+                       2 * h->Hn, h->N, h->Nc, active, h->d_U, h->d_E, h->d_f, h->d_Z, h->d_w, h->d_linA, h->d_C, h->debug_ablate, h->cur_s0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         h->last_detail = (int)e;
@@ -683,8 +719,8 @@ int launch_factor_w(hpf_handle* h, const TreeDev& T, const int* nodes, int count
 
 template <int B>
 int launch_back_w(hpf_handle* h, const TreeDev& T, const int* nodes, int count, const int* active) {
-    hipLaunchKernelGGL((k_back_w<B>), dim3((unsigned)count, (unsigned)h->S), dim3(64), 0, h->stream, h->M, T, nodes,
-                       2 * h->Hn, h->N, h->Nc, active, h->d_U, h->d_E, h->d_Z, h->d_w, h->d_x, h->d_f);
+    hipLaunchKernelGGL((k_back_w<B>), dim3((unsigned)count, (unsigned)h->cur_S), dim3(64), 0, h->cur_stream, h->M, T, nodes,
+                       2 * h->Hn, h->N, h->Nc, active, h->d_U, h->d_E, h->d_Z, h->d_w, h->d_x, h->d_f, h->cur_s0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         h->last_detail = (int)e;
@@ -729,8 +765,8 @@ int launch_factor(hpf_handle* h, const TreeDev& T, const int* nodes, int count, 
                             (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_tree_factor<R>), dim3((unsigned)count, (unsigned)h->S), dim3(256), lds, h->stream, h->M, T,
-                       nodes, b, h->N, h->Nc, active, h->d_U, h->d_E, h->d_f, h->d_Z, h->d_w);
+    hipLaunchKernelGGL((k_tree_factor<R>), dim3((unsigned)count, (unsigned)h->cur_S), dim3(256), lds, h->cur_stream, h->M, T,
+                       nodes, b, h->N, h->Nc, active, h->d_U, h->d_E, h->d_f, h->d_Z, h->d_w, h->cur_s0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         h->last_detail = (int)e;
@@ -893,7 +929,8 @@ int tree_alloc_scenarios(hpf_handle* h) {
     if ((e = hipMalloc((void**)&h->d_Z, sizeof(double) * S * n * b * b)) != hipSuccess ||
         (e = hipMalloc((void**)&h->d_w, sizeof(double) * S * n * b)) != hipSuccess ||
         (e = hipMalloc((void**)&h->d_x, sizeof(double) * S * n * b)) != hipSuccess ||
-        (e = hipMalloc((void**)&h->d_linA, sizeof(double) * S * n * (size_t)h->Hn * 4)) != hipSuccess) {
+        (e = hipMalloc((void**)&h->d_linA, sizeof(double) * S * n * (size_t)h->Hn * 4)) != hipSuccess ||
+        (bw && (e = hipMalloc((void**)&h->d_C, sizeof(double) * S * n * (b + 1) * b)) != hipSuccess)) {
         h->last_detail = (int)e;
         return e == hipErrorOutOfMemory ? HPF_E_NOMEM : HPF_E_HIP;
     }
@@ -912,9 +949,9 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
     {
         ScopedTimer t(h, T_SOLVE);
         if (lin_threads > 0) {
-            hipLaunchKernelGGL(k_lin_factor, dim3((unsigned)((lin_threads + 127) / 128), (unsigned)h->S), dim3(128), 0,
-                               h->stream, h->M, td, T.n_lin_roots, h->N, h->Nc, Bst, active, h->d_U, h->d_E, h->d_f,
-                               h->d_linA, h->d_w);
+            hipLaunchKernelGGL(k_lin_factor, dim3((unsigned)((lin_threads + 127) / 128), (unsigned)h->cur_S), dim3(128), 0,
+                               h->cur_stream, h->M, td, T.n_lin_roots, h->N, h->Nc, Bst, active, h->d_U, h->d_E, h->d_f,
+                               h->d_linA, h->d_w, h->cur_s0);
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) {
                 h->last_detail = (int)e;
@@ -953,8 +990,8 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
             case 28: r = launch_back_w<28>(h, td, nodes, cnt, active); break;
             case 52: r = launch_back_w<52>(h, td, nodes, cnt, active); break;
             default: {
-                hipLaunchKernelGGL(k_tree_back, dim3((unsigned)cnt, (unsigned)h->S), dim3(256), 0, h->stream, h->n, h->c,
-                                   h->Hn, td, nodes, b, h->N, h->Nc, active, h->d_Z, h->d_w, h->d_x, h->d_f);
+                hipLaunchKernelGGL(k_tree_back, dim3((unsigned)cnt, (unsigned)h->cur_S), dim3(256), 0, h->cur_stream, h->n, h->c,
+                                   h->Hn, td, nodes, b, h->N, h->Nc, active, h->d_Z, h->d_w, h->d_x, h->d_f, h->cur_s0);
                 hipError_t e = hipGetLastError();
                 if (e != hipSuccess) {
                     h->last_detail = (int)e;
@@ -965,9 +1002,9 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
         if (r) return r;
     }
     if (lin_threads > 0) {
-        hipLaunchKernelGGL(k_lin_back, dim3((unsigned)((lin_threads + 127) / 128), (unsigned)h->S), dim3(128), 0, h->stream,
+        hipLaunchKernelGGL(k_lin_back, dim3((unsigned)((lin_threads + 127) / 128), (unsigned)h->cur_S), dim3(128), 0, h->cur_stream,
                            h->M, td, T.n_lin_roots, h->N, h->Nc, Bst, active, h->d_U, h->d_E, h->d_linA, h->d_w, h->d_x,
-                           h->d_f);
+                           h->d_f, h->cur_s0);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) {
             h->last_detail = (int)e;

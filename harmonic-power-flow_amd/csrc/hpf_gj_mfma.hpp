@@ -188,4 +188,84 @@ __device__ __forceinline__ void tiles_to_global(const d4_t (&c)[NT][NT], int lan
     }
 }
 
+
+// Cross-lane partner values in the accumulator layout: lane ^ 1 holds the neighbouring column, lane ^ 16 the neighbouring row.
+__device__ __forceinline__ double xor1_f64(double v) {          // DPP quad_perm [1,0,3,2]
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double xor16_f64(double v) {         // ds_swizzle, bit mode: and 0x1f, or 0, xor 0x10
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_ds_swizzle(lo, 0x401F);
+    hi = __builtin_amdgcn_ds_swizzle(hi, 0x401F);
+    return __hiloint2double(hi, lo);
+}
+
+// Child -> parent Schur complement in the accumulator layout.  With the inverse Ainv (and w = Ainv y in column B) in the
+// tiles, overwrite them by   C = G Ainv H   (columns < B)   and   G w   (column B),   where G = A(parent, child) and
+// H = A(child, parent) are harmonic-diagonal: gl[q*4 + 2*t + t1] = G_q[t][t1], hl[q*4 + 2*t2 + tc] = H_q[t2][tc] (LDS,
+// zero for q >= Hn).  Element (i, c) needs the 2x2 block of Ainv around it: own, row partner (lane^16), column partner
+// (lane^1) and the diagonal partner.
+template <int B, int NT>
+__device__ __forceinline__ void schur_tiles(d4_t (&c)[NT][NT], int lane, const double* gl, const double* hl) {
+    const int lg = lane >> 4, jj = lane & 15;
+    const int ti = lg & 1, tcn = jj & 1;
+    constexpr int tcB = B >> 4, jjB = B & 15;
+    double ha[NT], hb[NT];
+#pragma unroll
+    for (int tc = 0; tc < NT; ++tc) {
+        const int p = 8 * tc + (jj >> 1);
+        ha[tc] = hl[p * 4 + 2 * tcn + tcn];             // H[tcn][tcn]
+        hb[tc] = hl[p * 4 + 2 * (tcn ^ 1) + tcn];       // H[tcn^1][tcn]
+        if (tc == tcB && jj == jjB) {                   // right-hand-side column: C = G w
+            ha[tc] = 1.0;
+            hb[tc] = 0.0;
+        }
+        if (16 * tc + jj > B) {
+            ha[tc] = 0.0;
+            hb[tc] = 0.0;
+        }
+    }
+#pragma unroll
+    for (int tr = 0; tr < NT; ++tr)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int q = 8 * tr + 2 * reg + (lg >> 1);
+            const double ga = gl[q * 4 + 2 * ti + ti];          // G[ti][ti]
+            const double gb = gl[q * 4 + 2 * ti + (ti ^ 1)];    // G[ti][ti^1]
+#pragma unroll
+            for (int tc = 0; tc < NT; ++tc) {
+                const double own = c[tr][tc][reg];
+                const double rowp = xor16_f64(own);
+                const double colp = xor1_f64(own);
+                const double both = xor1_f64(rowp);
+                c[tr][tc][reg] = fma(gb, fma(both, hb[tc], rowp * ha[tc]), ga * fma(colp, hb[tc], own * ha[tc]));
+            }
+        }
+}
+
+// Accumulator tiles -> global, B+1 columns (columns 0..B-1 and the right-hand-side column B), column-major [col][row].
+template <int B, int NT>
+__device__ __forceinline__ void tiles_to_global_aug(const d4_t (&c)[NT][NT], int lane, double* tbuf, double* __restrict__ C) {
+    const int lg = lane >> 4, jj = lane & 15;
+#pragma unroll
+    for (int tc = 0; tc < NT; ++tc) {
+        __syncthreads();
+#pragma unroll
+        for (int tr = 0; tr < NT; ++tr)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) tbuf[jj * 65 + 16 * tr + lg + 4 * reg] = c[tr][tc][reg];
+        __syncthreads();
+        if (lane < B) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int col = 16 * tc + j;
+                if (col <= B) C[(size_t)col * B + lane] = tbuf[j * 65 + lane];
+            }
+        }
+    }
+}
+
 }  // namespace hpf

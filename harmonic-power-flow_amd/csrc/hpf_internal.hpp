@@ -88,9 +88,17 @@ struct hpf_handle {
     double* d_Z = nullptr;            // [S][n][b*b]
     double* d_w = nullptr;            // [S][n][b]
     double* d_x = nullptr;            // [S][n][b]  Newton step, bus-major
+    double* d_C = nullptr;            // [S][n][(B+1)*B] Schur complements pushed by dense children (MFMA mode)
     double* d_linA = nullptr;         // [S][n][Hn][4] inverse 2x2 blocks of the all-linear-subtree buses
 
     hipStream_t own_stream = nullptr, stream = nullptr;
+    // launch context: stream and scenario slice the launch helpers currently target (scenario groups run as independent
+    // pipelines on their own streams so that the latency-bound upper tree levels of one group overlap the others)
+    hipStream_t cur_stream = nullptr;
+    int cur_s0 = 0, cur_S = 0;
+    int n_groups = 4;
+    hipStream_t gstream[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t fork_ev = nullptr, join_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     rocblas_handle blas = nullptr;
     bool timing = false;
     std::vector<hpf::TimedSpan> spans;
@@ -108,12 +116,12 @@ struct ScopedTimer {
         if (h->timing) {
             hipEventCreate(&e0);
             hipEventCreate(&e1);
-            hipEventRecord(e0, h->stream);
+            hipEventRecord(e0, h->cur_stream);
         }
     }
     ~ScopedTimer() {
         if (h->timing) {
-            hipEventRecord(e1, h->stream);
+            hipEventRecord(e1, h->cur_stream);
             h->spans.push_back({which, e0, e1});
         }
     }

@@ -80,8 +80,8 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
 template <bool FUND>
 __global__ void k_mismatch(Model M, int count, int N, int Nc, const int* __restrict__ active, const cplx* __restrict__ U,
                            const double* __restrict__ P, const double* __restrict__ Q, double* __restrict__ f,
-                           unsigned long long* __restrict__ errbits) {
-    const int s = blockIdx.y;
+                           unsigned long long* __restrict__ errbits, int s0) {
+    const int s = blockIdx.y + s0;
     if (active && !active[s]) return;
     const int k = blockIdx.x * TPB + threadIdx.x + 1;
     unsigned long long b = 0;
@@ -147,8 +147,8 @@ __global__ void k_jac_cross_dense(Model M, int total, int N, int Nc, size_t J_st
 template <bool FUND>
 __global__ void k_update(int n, int c, int count, int stride, int N, int Nc, const int* __restrict__ active,
                          const double* __restrict__ step, double* __restrict__ Vm, double* __restrict__ Va,
-                         cplx* __restrict__ U, cplx* __restrict__ E, unsigned long long* __restrict__ errbits) {
-    const int s = blockIdx.y;
+                         cplx* __restrict__ U, cplx* __restrict__ E, unsigned long long* __restrict__ errbits, int s0) {
+    const int s = blockIdx.y + s0;
     if (active && !active[s]) return;
     const int k = blockIdx.x * TPB + threadIdx.x;
     if (k >= count) return;
@@ -310,9 +310,48 @@ int resolve_spans(hpf_handle* h) {
     return HPF_OK;
 }
 
+
+// launch context = (stream, first scenario, scenario count) used by the launch helpers
+inline void set_ctx(hpf_handle* h, hipStream_t st, int s0, int cnt) {
+    h->cur_stream = st;
+    h->cur_s0 = s0;
+    h->cur_S = cnt;
+}
+inline void full_ctx(hpf_handle* h) { set_ctx(h, h->stream, 0, h->S); }
+
+inline int groups_for(const hpf_handle* h) {
+    if (h->solver != HPF_SOLVER_BLOCK_TREE) return 1;
+    int g = h->n_groups;
+    while (g > 1 && h->S < 8 * g) --g;         // at least 8 scenarios per group
+    return g < 1 ? 1 : g;
+}
+
+// Run body() once per scenario group, each group on its own stream between a fork and a join with the main stream.
+template <class F>
+int for_groups(hpf_handle* h, F body) {
+    const int G = groups_for(h);
+    if (G == 1) {
+        full_ctx(h);
+        return body();
+    }
+    HIPCHK(hipEventRecord(h->fork_ev, h->stream));
+    int rc = HPF_OK;
+    for (int g = 0; g < G && rc == HPF_OK; ++g) {
+        const int s0 = (int)((long long)h->S * g / G), s1 = (int)((long long)h->S * (g + 1) / G);
+        HIPCHK(hipStreamWaitEvent(h->gstream[g], h->fork_ev, 0));
+        set_ctx(h, h->gstream[g], s0, s1 - s0);
+        rc = body();
+        HIPCHK(hipEventRecord(h->join_ev[g], h->gstream[g]));
+    }
+    for (int g = 0; g < G; ++g) HIPCHK(hipStreamWaitEvent(h->stream, h->join_ev[g], 0));
+    full_ctx(h);
+    return rc;
+}
+
 // polar + mismatch (+ optional err conversion) for the current state
 template <bool FUND>
 int launch_polar(hpf_handle* h) {
+    full_ctx(h);
     const int count = FUND ? h->n : h->n * h->Hn;
     hipLaunchKernelGGL((k_polar<FUND>), grid2(count, h->S), dim3(TPB), 0, h->stream, count, h->n * h->Hn, h->d_Vm,
                        h->d_Va, h->d_U, h->d_E);
@@ -327,8 +366,8 @@ int launch_mismatch(hpf_handle* h, const int* active) {
     const int N = FUND ? h->Nf : h->N;
     const int Nc = FUND ? h->n - 1 : h->Nc;
     if (count > 1) {
-        hipLaunchKernelGGL((k_mismatch<FUND>), grid2(count - 1, h->S), dim3(TPB), 0, h->stream, h->M, count, N, Nc,
-                           active, h->d_U, h->d_P, h->d_Q, h->d_f, h->d_errbits);
+        hipLaunchKernelGGL((k_mismatch<FUND>), grid2(count - 1, h->cur_S), dim3(TPB), 0, h->cur_stream, h->M, count, N, Nc,
+                           active, h->d_U, h->d_P, h->d_Q, h->d_f, h->d_errbits, h->cur_s0);
         HIPCHK(hipGetLastError());
     }
     return HPF_OK;
@@ -378,8 +417,8 @@ int launch_update(hpf_handle* h, const int* active) {
     const int count = FUND ? h->n : h->n * h->Hn;
     const int N = FUND ? h->Nf : h->N;
     const int Nc = FUND ? h->n - 1 : h->Nc;
-    hipLaunchKernelGGL((k_update<FUND>), grid2(count, h->S), dim3(TPB), 0, h->stream, h->n, h->c, count,
-                       h->n * h->Hn, N, Nc, active, h->d_f, h->d_Vm, h->d_Va, h->d_U, h->d_E, h->d_errbits);
+    hipLaunchKernelGGL((k_update<FUND>), grid2(count, h->cur_S), dim3(TPB), 0, h->cur_stream, h->n, h->c, count,
+                       h->n * h->Hn, N, Nc, active, h->d_f, h->d_Vm, h->d_Va, h->d_U, h->d_E, h->d_errbits, h->cur_s0);
     HIPCHK(hipGetLastError());
     return HPF_OK;
 }
@@ -444,9 +483,19 @@ int nr_loop(hpf_handle* h, double thresh, int max_iter, int* n_iter, double* err
     int it = 0;
     while (nactive > 0 && it < max_iter) {
         was = act;
-        if ((r = newton_step<FUND>(h, h->d_active))) return r;
-        if ((r = launch_update<FUND>(h, h->d_active))) return r;
-        if ((r = launch_mismatch<FUND>(h, h->d_active))) return r;
+        auto body = [&]() -> int {
+            int rr;
+            if ((rr = newton_step<FUND>(h, h->d_active))) return rr;
+            if ((rr = launch_update<FUND>(h, h->d_active))) return rr;
+            return launch_mismatch<FUND>(h, h->d_active);
+        };
+        if (FUND) {
+            full_ctx(h);
+            r = body();
+        } else {
+            r = for_groups(h, body);
+        }
+        if (r) return r;
         HIPCHK(hipMemsetAsync(h->d_nactive, 0, sizeof(int), h->stream));
         hipLaunchKernelGGL(k_finalize, dim3((S + 63) / 64), dim3(64), 0, h->stream, S, 0, thresh, max_iter,
                            h->hist_cap, hist_off, h->d_errbits, h->d_err, h->d_niter, h->d_active, h->d_nactive,
@@ -477,7 +526,7 @@ int nr_loop(hpf_handle* h, double thresh, int max_iter, int* n_iter, double* err
 void free_all(hpf_handle* h) {
     void* ptrs[] = {h->d_rowptr, h->d_col, h->d_diag, h->d_erow, h->d_dev, h->d_Y, h->d_YN, h->d_IN, h->d_P, h->d_Q,
                     h->d_Vm, h->d_Va, h->d_U, h->d_E, h->d_f, h->d_errbits, h->d_err, h->d_niter, h->d_active,
-                    h->d_nactive, h->d_hist, h->d_stats, h->d_J, h->d_ipiv, h->d_info, h->d_Z, h->d_w, h->d_x, h->d_linA};
+                    h->d_nactive, h->d_hist, h->d_stats, h->d_J, h->d_ipiv, h->d_info, h->d_Z, h->d_w, h->d_x, h->d_linA, h->d_C};
     for (void* p : ptrs)
         if (p) hipFree(p);
     tree_free(h);
@@ -485,6 +534,11 @@ void free_all(hpf_handle* h) {
         hipEventDestroy(sp.e0);
         hipEventDestroy(sp.e1);
     }
+    for (int g = 0; g < 8; ++g) {
+        if (h->gstream[g]) hipStreamDestroy(h->gstream[g]);
+        if (h->join_ev[g]) hipEventDestroy(h->join_ev[g]);
+    }
+    if (h->fork_ev) hipEventDestroy(h->fork_ev);
     if (h->blas) rocblas_destroy_handle(h->blas);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
 }
@@ -556,6 +610,13 @@ int hpf_create(hpf_handle** out, const hpf_desc* d) {
     if (hipSetDevice(d->device) != hipSuccess) return fail(HPF_E_HIP);
     if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) return fail(HPF_E_HIP);
     h->stream = h->own_stream;
+    if (const char* gs = getenv("HPF_GROUPS")) h->n_groups = atoi(gs) < 1 ? 1 : (atoi(gs) > 8 ? 8 : atoi(gs));
+    for (int g = 0; g < 8; ++g) {
+        if (hipStreamCreateWithFlags(&h->gstream[g], hipStreamNonBlocking) != hipSuccess) return fail(HPF_E_HIP);
+        if (hipEventCreateWithFlags(&h->join_ev[g], hipEventDisableTiming) != hipSuccess) return fail(HPF_E_HIP);
+    }
+    if (hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming) != hipSuccess) return fail(HPF_E_HIP);
+    set_ctx(h, h->stream, 0, 0);
     if (rocblas_create_handle(&h->blas) != rocblas_status_success) return fail(HPF_E_ROCSOLVER);
     const size_t HnN = (size_t)d->Hn * d->n, S = (size_t)d->max_scenarios;
     const size_t ynsz = (size_t)d->n_dev * d->Hn * (d->coupled ? d->Hn : 1);
@@ -694,13 +755,33 @@ int hpf_solve(hpf_handle* h, double thresh, int max_iter, int* n_iter, double* e
 int hpf_iterate(hpf_handle* h, int iters) {
     if (!h || iters < 0) return HPF_E_ARG;
     if (!h->loads_set || !h->state_set || !h->mismatch_valid) return HPF_E_STATE;
-    int r;
-    for (int it = 0; it < iters; ++it) {
-        if ((r = newton_step<false>(h, nullptr))) return r;
-        if ((r = launch_update<false>(h, nullptr))) return r;
-        if ((r = launch_mismatch<false>(h, nullptr))) return r;
+    // iteration-major enqueue order (all groups' step i before any group's step i+1) keeps the group pipelines in phase
+    const int G = groups_for(h);
+    int r = HPF_OK;
+    if (G > 1) {
+        HIPCHK(hipEventRecord(h->fork_ev, h->stream));
+        for (int g = 0; g < G; ++g) HIPCHK(hipStreamWaitEvent(h->gstream[g], h->fork_ev, 0));
     }
-    return HPF_OK;
+    for (int it = 0; it < iters && r == HPF_OK; ++it) {
+        for (int g = 0; g < G && r == HPF_OK; ++g) {
+            if (G > 1)
+                set_ctx(h, h->gstream[g], (int)((long long)h->S * g / G),
+                        (int)((long long)h->S * (g + 1) / G) - (int)((long long)h->S * g / G));
+            else
+                full_ctx(h);
+            if ((r = newton_step<false>(h, nullptr))) break;
+            if ((r = launch_update<false>(h, nullptr))) break;
+            r = launch_mismatch<false>(h, nullptr);
+        }
+    }
+    if (G > 1) {
+        for (int g = 0; g < G; ++g) {
+            HIPCHK(hipEventRecord(h->join_ev[g], h->gstream[g]));
+            HIPCHK(hipStreamWaitEvent(h->stream, h->join_ev[g], 0));
+        }
+    }
+    full_ctx(h);
+    return r;
 }
 
 int hpf_get_stats(hpf_handle* h, hpf_stat* stats) {
@@ -719,6 +800,11 @@ int hpf_get_stats_dev(hpf_handle* h, void* stats_dev) {
 
 int hpf_set_option(hpf_handle* h, const char* name, int value) {
     if (!h || !name) return HPF_E_ARG;
+    if (!strcmp(name, "scenario_groups")) {         // independent scenario pipelines on separate streams (1..8)
+        if (value < 1 || value > 8) return HPF_E_ARG;
+        h->n_groups = value;
+        return HPF_OK;
+    }
     if (!strcmp(name, "block_pivoting")) {          // 1: partial pivoting (wave Gauss-Jordan), 0: static 4x4 blocks on MFMA
         h->gj_mode = value ? 0 : 1;
         return HPF_OK;
@@ -730,6 +816,7 @@ int hpf_set_stream(hpf_handle* h, void* s) {
     if (!h) return HPF_E_ARG;
     HIPCHK(hipStreamSynchronize(h->stream));
     h->stream = s ? (hipStream_t)s : h->own_stream;
+    full_ctx(h);
     return HPF_OK;
 }
 

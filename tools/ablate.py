@@ -16,6 +16,7 @@ for m in masks:
     try:
         d = json.loads(out.stdout.strip().splitlines()[-1])
         ph = d["phase_ms_per_step"]
-        print("ablate %2d: factor %.3f ms  back %.3f ms  step %.3f ms" % (m, ph["solve"], ph.get("back", 0), d["ms_per_step"]), flush=True)
+        print("ablate %2d groups %s: factor %.3f ms  back %.3f ms  step %.3f ms  -> %.0f it/s" % (
+            m, d["roofline"].get("concurrent_groups"), ph["solve"], ph.get("back", 0), d["ms_per_step"], d["value"]), flush=True)
     except Exception as e:
         print("ablate", m, "failed", e, out.stderr[-500:], flush=True)
