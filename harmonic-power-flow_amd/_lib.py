@@ -49,6 +49,7 @@ SYMBOLS = {
     "hpf_iterate": (C.c_int, [_H, C.c_int]),
     "hpf_get_stats": (C.c_int, [_H, C.POINTER(hpf_stat)]),
     "hpf_get_stats_dev": (C.c_int, [_H, C.c_void_p]),
+    "hpf_debug_stamps": (C.c_int, [_H, C.POINTER(C.c_longlong), C.c_int]),
     "hpf_set_option": (C.c_int, [_H, C.c_char_p, C.c_int]),
     "hpf_set_stream": (C.c_int, [_H, C.c_void_p]),
     "hpf_sync": (C.c_int, [_H]),

@@ -361,6 +361,117 @@ __device__ __forceinline__ void coupling_block(const Model& M, const cplx* U, co
                                    ? pick(blk, tr, tc) : 0.0;
 }
 
+
+// Row `lane` (= 2q+t) of the un-eliminated diagonal block D_k and its right-hand side y: network entry (k,k) on the harmonic
+// diagonal (+ the p == q Norton term) minus the Schur complements of the children whose whole subtree is linear (harmonic-
+// diagonal, inverted by k_lin_factor), and, at a nonlinear bus, the Norton cross-coupling -Y_N[q,p]*(E | jU)_{p,k}
+// (HG:425-435) with the bus voltages staged once in LDS.  Identity padding for missing unknowns / equations.
+template <int B>
+__device__ __forceinline__ void assemble_row(const Model& M, const TreeDev& T, const cplx* U, const cplx* E,
+                                             const double* f, const double* ws, const double* linA, int k, int lane,
+                                             int b, int Nc, int ablate, double* ue /*LDS (B/2)*8*/, double (&a)[B],
+                                             double& y) {
+    const int n = M.n, c = M.c, Hn = M.Hn;
+    const int q = lane >> 1, t = lane & 1;
+    const bool rowvalid = lane < b && loc_valid(n, c, k, lane);
+    y = 0.0;
+    if (rowvalid) {
+        const int kst = q * n + k;
+        y = t ? f[Nc + kst - c] : f[kst - 1];
+    }
+    double d0 = 0.0, d1 = 0.0;
+    if (rowvalid && !(ablate & 4)) {
+        const int diag_e = M.diag[k];
+        const Blk2 blk = (q == 0 && k < M.m) ? jac_power_entry<false>(M, U, E, k, k, diag_e)
+                                              : jac_current_entry(M, U, E, q, k, k, diag_e);
+        d0 = pick(blk, t, 0);
+        d1 = pick(blk, t, 1);
+        for (int cp = T.child_ptr[k]; cp < T.child_mid[k]; ++cp) {
+            const int ch = T.child[cp];
+            const Blk2 g = offdiag_block(M, U, E, q, k, ch, T.e_dn[ch]);     // A(parent, child), my harmonic
+            const double g0 = pick(g, t, 0);
+            const double g1 = loc_valid(n, c, ch, 2 * q + 1) ? pick(g, t, 1) : 0.0;
+            double h4[4];
+            coupling_block(M, U, E, q, ch, k, T.e_up[ch], h4);               // A(child, parent)
+            const double* ic = linA + ((size_t)ch * Hn + q) * 4;
+            const double v0 = fma(g1, ic[2], g0 * ic[0]), v1 = fma(g1, ic[3], g0 * ic[1]);
+            d0 -= fma(v1, h4[2], v0 * h4[0]);
+            d1 -= fma(v1, h4[3], v0 * h4[1]);
+            const double* wc = ws + (size_t)ch * B;
+            y = fma(-g0, wc[2 * q], y);
+            y = fma(-g1, wc[2 * q + 1], y);
+        }
+    }
+    // Norton cross-coupling of a nonlinear bus (HG:425-435): entry [2q+t][2p+t'] = -(Y_N[q,p] * (jU | E)_{p,k}) picked Re/Im.
+    // Written out per component, with the exact rounding of the reference expression (every product and the final sum
+    // rounded once, a negation is exact):   v = yi*P + yr*Q   with (P,Q) a signed selection of the bus voltage parts that
+    // depends only on (t, t') -> staged per harmonic in LDS as tab[t][p] = {P0, Q0, P1, Q1}:
+    //   t=0: dA.re = yi*ur + yr*ui,      dV.re = yi*ei + yr*(-er);     t=1: dA.im = yi*ui + yr*(-ur),  dV.im = yi*(-er) + yr*(-ei).
+    const bool nl = k >= M.m && M.coupled && !(ablate & 4);
+    if (nl) {
+        __syncthreads();
+        if (lane < Hn) {
+            const cplx u = U[(size_t)lane * n + k], e = E[(size_t)lane * n + k];
+            double* t0 = ue + lane * 4;
+            double* t1 = ue + (B / 2) * 4 + lane * 4;
+            t0[0] = u.re;  t0[1] = u.im;   t0[2] = e.im;   t0[3] = -e.re;
+            t1[0] = u.im;  t1[1] = -u.re;  t1[2] = -e.re;  t1[3] = -e.im;
+        }
+        __syncthreads();
+        const cplx* ynrow = M.YN + ((size_t)M.dev[k] * Hn + (rowvalid ? q : 0)) * Hn;
+        const double* tab = ue + t * (B / 2) * 4;
+#pragma unroll
+        for (int p = 0; p < B / 2; ++p) {
+            const cplx yn = ynrow[p < Hn ? p : 0];
+            const double v0 = yn.im * tab[p * 4 + 0] + yn.re * tab[p * 4 + 1];
+            const double v1 = yn.im * tab[p * 4 + 2] + yn.re * tab[p * 4 + 3];
+            a[2 * p] = (p == q) ? d0 : v0;
+            a[2 * p + 1] = (p == q) ? d1 : v1;
+        }
+    } else {
+#pragma unroll
+        for (int p = 0; p < B / 2; ++p) {
+            a[2 * p] = (p == q) ? d0 : 0.0;
+            a[2 * p + 1] = (p == q) ? d1 : 0.0;
+        }
+    }
+    // identity padding: missing unknowns / equations exist only at the slack and PV buses (harmonic position 0) and, when the
+    // block is padded (b < B), beyond b -> wave-uniform rare branch
+    if (k < c || b < B) {
+#pragma unroll
+        for (int cc = 0; cc < B; ++cc) {
+            const bool cv = cc < b && loc_valid(n, c, k, cc);
+            if (!cv || !rowvalid) a[cc] = (cc == lane) ? 1.0 : 0.0;
+        }
+    }
+}
+
+// Assembly of all dense buses of all scenarios in one launch (no dependence on the elimination): the row image is parked
+// in the bus's own Schur-complement slot C[k] ([B+1][B], column-major), where k_factor_w picks it up.
+template <int B>
+__global__ __launch_bounds__(64) void k_assemble_w(Model M, TreeDev T, const int* __restrict__ nodes, int b, int N, int Nc,
+                                                   const int* __restrict__ active, const cplx* __restrict__ Uall,
+                                                   const cplx* __restrict__ Eall, const double* __restrict__ fall,
+                                                   const double* __restrict__ wall, const double* __restrict__ linAall,
+                                                   double* __restrict__ Call, int ablate, int s0) {
+    const int s = blockIdx.y + s0;
+    if (active && !active[s]) return;
+    const int k = nodes[blockIdx.x];
+    const int lane = threadIdx.x;
+    const int n = M.n, Hn = M.Hn;
+    const size_t so = (size_t)s * n * Hn;
+    __shared__ double ue[(B / 2) * 8];
+    double a[B], y;
+    assemble_row<B>(M, T, Uall + so, Eall + so, fall + (size_t)s * N, wall + (size_t)s * n * B, linAall + so * 4, k, lane, b,
+                    Nc, ablate, ue, a, y);
+    if (lane < B) {
+        double* Ck = Call + ((size_t)s * n + k) * ((size_t)(B + 1) * B);
+#pragma unroll
+        for (int cc = 0; cc < B; ++cc) Ck[(size_t)cc * B + lane] = a[cc];
+        Ck[(size_t)B * B + lane] = y;
+    }
+}
+
 template <int B, int MODE>
 __global__ __launch_bounds__(64, MODE == 1 ? 2 : 1) void k_factor_w(Model M, TreeDev T, const int* __restrict__ nodes, int b, int N, int Nc,
                                                  const int* __restrict__ active, const cplx* __restrict__ Uall,
@@ -381,74 +492,27 @@ __global__ __launch_bounds__(64, MODE == 1 ? 2 : 1) void k_factor_w(Model M, Tre
     double* As = Aall + (size_t)s * n * BB;
     double* ws = wall + (size_t)s * n * B;
 
-    __shared__ double bup[(B / 2) * 4];
+    __shared__ double bup[(B / 2) * 8];
     __shared__ int rj[B];
 
     const int q = lane >> 1, t = lane & 1;
     const bool rowvalid = lane < b && loc_valid(n, c, k, lane);
 
-    // ---- A. assemble row `lane` of D_k --------------------------------------------------------------------------
-    // Row i = 2q+t.  The 2x2 block on the harmonic diagonal (d0, d1) comes from the network entry (k,k) (+ the p == q
-    // Norton term) minus the Schur complements of the children whose whole subtree is linear: those are harmonic-
-    // diagonal (2x2 per harmonic, inverted by k_lin_factor), so they only touch (d0, d1) and y.
-    double y = 0.0;
-    if (rowvalid) {
-        const int kst = q * n + k;
-        y = t ? f[Nc + kst - c] : f[kst - 1];
-    }
-    double a[B];
-    {
-        double d0 = 0.0, d1 = 0.0;
-        if (rowvalid && !(ablate & 4)) {
-            const int diag_e = M.diag[k];
-            const Blk2 blk = (q == 0 && k < M.m) ? jac_power_entry<false>(M, U, E, k, k, diag_e)
-                                                  : jac_current_entry(M, U, E, q, k, k, diag_e);
-            d0 = pick(blk, t, 0);
-            d1 = pick(blk, t, 1);
-            const double* linA = linAall + (size_t)s * n * Hn * 4;
-            for (int cp = T.child_ptr[k]; cp < T.child_mid[k]; ++cp) {
-                const int ch = T.child[cp];
-                const Blk2 g = offdiag_block(M, U, E, q, k, ch, T.e_dn[ch]);     // A(parent, child), my harmonic
-                const double g0 = pick(g, t, 0);
-                const double g1 = loc_valid(n, c, ch, 2 * q + 1) ? pick(g, t, 1) : 0.0;
-                double h4[4];
-                coupling_block(M, U, E, q, ch, k, T.e_up[ch], h4);               // A(child, parent)
-                const double* ic = linA + ((size_t)ch * Hn + q) * 4;
-                const double v0 = fma(g1, ic[2], g0 * ic[0]), v1 = fma(g1, ic[3], g0 * ic[1]);
-                d0 -= fma(v1, h4[2], v0 * h4[0]);
-                d1 -= fma(v1, h4[3], v0 * h4[1]);
-                const double* wc = ws + (size_t)ch * B;
-                y = fma(-g0, wc[2 * q], y);
-                y = fma(-g1, wc[2 * q + 1], y);
-            }
-        }
-        const bool nl = k >= M.m && M.coupled;
+    // ---- A. row `lane` of D_k and y: MODE 0 assembles here; MODE 1 loads the image k_assemble_w parked in this bus's
+    //      own Schur-complement slot --------------------------------------------------------------------------------
+    constexpr size_t CB = (size_t)(B + 1) * B;
+    double a[B], y;
+    if constexpr (MODE == 1) {
+        const double* Ck = Call + ((size_t)s * n + k) * CB;
 #pragma unroll
-        for (int p = 0; p < B / 2; ++p) {
-            double v0 = 0.0, v1 = 0.0;
-            if (rowvalid && p < Hn && !(ablate & 4)) {
-                if (p == q) {
-                    v0 = d0;
-                    v1 = d1;
-                } else if (nl) {
-                    const Blk2 blk = jac_norton_cross(M, U, E, q, p, k);
-                    v0 = pick(blk, t, 0);
-                    v1 = pick(blk, t, 1);
-                }
-            }
-            a[2 * p] = v0;
-            a[2 * p + 1] = v1;
-        }
-#pragma unroll
-        for (int cc = 0; cc < B; ++cc) {
-            const bool cv = cc < b && loc_valid(n, c, k, cc);
-            if (!cv || !rowvalid) a[cc] = (cc == lane) ? 1.0 : 0.0;     // identity padding
-        }
+        for (int cc = 0; cc < B; ++cc) a[cc] = lane < B ? Ck[(size_t)cc * B + lane] : 0.0;
+        y = lane < B ? Ck[(size_t)B * B + lane] : 0.0;
+    } else {
+        assemble_row<B>(M, T, U, E, f, ws, linAall + (size_t)s * n * Hn * 4, k, lane, b, Nc, ablate, bup, a, y);
     }
 
     // ---- B. dense children (fixed order).  MODE 1: every dense child has already formed its Schur complement
     //      C = A(k,ch) D_ch^-1 A(ch,k) (+ the right-hand-side column) in its own wave (schur_tiles): just subtract. -------
-    constexpr size_t CB = (size_t)(B + 1) * B;
     if constexpr (MODE == 1) {
         const double* Cs = Call + (size_t)s * n * CB;
         for (int cp = T.child_mid[k]; cp < ((ablate & 2) ? 0 : T.child_ptr[k + 1]); ++cp) {
@@ -952,6 +1016,22 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
             hipLaunchKernelGGL(k_lin_factor, dim3((unsigned)((lin_threads + 127) / 128), (unsigned)h->cur_S), dim3(128), 0,
                                h->cur_stream, h->M, td, T.n_lin_roots, h->N, h->Nc, Bst, active, h->d_U, h->d_E, h->d_f,
                                h->d_linA, h->d_w, h->cur_s0);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) {
+                h->last_detail = (int)e;
+                return HPF_E_HIP;
+            }
+        }
+        if (BW && h->gj_mode && T.n_dense > 0) {
+            // un-eliminated blocks of ALL dense buses in one launch (independent of the elimination order)
+            const dim3 grid((unsigned)T.n_dense, (unsigned)h->cur_S);
+#define HPF_LAUNCH_ASM(BB_)                                                                                              \
+    hipLaunchKernelGGL((k_assemble_w<BB_>), grid, dim3(64), 0, h->cur_stream, h->M, td, T.d_lvl_nodes, b, h->N, h->Nc, active, \
+                       h->d_U, h->d_E, h->d_f, h->d_w, h->d_linA, h->d_C, h->debug_ablate, h->cur_s0)
+            if (BW == 12) HPF_LAUNCH_ASM(12);
+            else if (BW == 28) HPF_LAUNCH_ASM(28);
+            else HPF_LAUNCH_ASM(52);
+#undef HPF_LAUNCH_ASM
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) {
                 h->last_detail = (int)e;

@@ -88,6 +88,7 @@ struct hpf_handle {
     double* d_Z = nullptr;            // [S][n][b*b]
     double* d_w = nullptr;            // [S][n][b]
     double* d_x = nullptr;            // [S][n][b]  Newton step, bus-major
+    long long* d_dbg = nullptr;       // [S][n][8] diagnostic phase stamps of the factor kernel (HPF_DEBUG_ABLATE & 16)
     double* d_C = nullptr;            // [S][n][(B+1)*B] Schur complements pushed by dense children (MFMA mode)
     double* d_linA = nullptr;         // [S][n][Hn][4] inverse 2x2 blocks of the all-linear-subtree buses
 

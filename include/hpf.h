@@ -125,6 +125,11 @@ int  hpf_iterate(hpf_handle* h, int iters);
 int  hpf_get_stats(hpf_handle* h, hpf_stat* stats /* [S] host */);
 int  hpf_get_stats_dev(hpf_handle* h, void* stats_dev /* [S] hpf_stat, device memory of the caller (RCCL gather) */);
 
+/* Diagnostics: with env HPF_DEBUG_ABLATE & 16 the BLOCK_TREE factor kernel records shader-cycle stamps per (scenario, bus):
+ * out[(s*n + k)*8 + 0..5] = assembly, children sums, rows->tiles, MFMA Gauss-Jordan, store, Schur push; [6] dense children,
+ * [7] nonlinear bus.  Timing-only; never read by any kernel. */
+int  hpf_debug_stamps(hpf_handle* h, long long* out, int count);
+
 /* Options.  "block_pivoting" (BLOCK_TREE only): 0 (default) inverts the 2Hn x 2Hn bus blocks on the FP64 matrix cores with
  * a static pivot order (4x4 blocks = two harmonics, 2x2 Schur inside); 1 uses wave-level Gauss-Jordan with partial pivoting
  * over the whole block (slower, for networks whose bus blocks are not block-diagonally dominant).  Env HPF_GJ_MODE=0 selects

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Phase breakdown of the block-tree factor kernel from in-kernel cycle stamps (diagnostic build path, HPF_DEBUG_ABLATE=16).
+Run on the GPU box: HPF_DEBUG_ABLATE=16 HPF_GROUPS=1 python tools/stamps.py [scenarios]"""
+import ctypes as C
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+os.environ.setdefault("HPF_DEBUG_ABLATE", "16")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import harmonic_power_flow_amd as hp
+from harmonic_power_flow_amd import ingest, synth
+
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+INPUTS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "inputs")
+tmp = tempfile.mkdtemp()
+fb, fl = synth.gen(1000, seed=0, outdir=tmp)
+st = hp.Settings(H_MAX=51)
+buses, lines, m, n, c = hp.init_network(fb, fl, settings=st)
+Y = hp.build_admittance_matrices(buses, lines, st.HARMONICS)
+NE = hp.import_Norton_Equivalents(buses, True, st, INPUTS)
+dev, Y_N, I_N, n_dev = ingest.norton_arrays(buses, NE, True, len(st.HARMONICS))
+dm = hp.DeviceModel(n, m, c, st.HARMONICS, Y.rowptr, Y.col, Y.Yval, dev, Y_N, I_N, n_dev, True, solver="block_tree", max_scenarios=S)
+P0, Q0 = buses["P"].to_numpy(float), buses["Q"].to_numpy(float)
+scale = np.stack([synth.scenario_scale(n, s) for s in range(S)])
+dm.set_loads(P0 * scale, Q0 * scale)
+dm.set_state(None, None, n_scen=S)
+dm.fund_pf()
+dm.mismatch(want_f=False)
+dm.iterate(3)
+dm.sync()
+buf = np.zeros(S * n * 8, dtype=np.int64)
+dm._chk(dm.lib.hpf_debug_stamps(dm._h, buf.ctypes.data_as(C.POINTER(C.c_longlong)), buf.size), "hpf_debug_stamps")
+d = buf.reshape(S, n, 8)
+dense = d[:, :, 3].sum(axis=0) > 0
+names = ["assembly", "child sums", "rows->tiles", "MFMA GJ", "store", "push"]
+print("dense buses: %d; cycles per block (median over scenarios and buses)" % dense.sum())
+for label, sel in (("nonlinear leaf (0 dense children)", dense & (d[0, :, 6] == 0) & (d[0, :, 7] == 1)),
+                   ("1-2 dense children", dense & (d[0, :, 6] >= 1) & (d[0, :, 6] <= 2)),
+                   (">=4 dense children", dense & (d[0, :, 6] >= 4))):
+    if sel.sum() == 0:
+        continue
+    x = d[:, sel, :6].reshape(-1, 6)
+    med = np.median(x, axis=0)
+    print("%-36s n=%4d  " % (label, sel.sum()) + "  ".join("%s %7.0f" % (nm, v) for nm, v in zip(names, med)) + "   total %8.0f" % med.sum())
