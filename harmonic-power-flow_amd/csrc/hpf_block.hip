@@ -498,11 +498,11 @@ __global__ __launch_bounds__(64, MODE == 1 ? 2 : 1) void k_factor_w(Model M, Tre
     const int q = lane >> 1, t = lane & 1;
     const bool rowvalid = lane < b && loc_valid(n, c, k, lane);
 
-    // ---- A. row `lane` of D_k and y: MODE 0 assembles here; MODE 1 loads the image k_assemble_w parked in this bus's
-    //      own Schur-complement slot --------------------------------------------------------------------------------
+    // ---- A. row `lane` of D_k and y (assemble_row).  Diagnostic variant HPF_DEBUG_ABLATE&32: load the image that a separate
+    //      k_assemble_w launch parked in this bus's own Schur-complement slot (measured slower: +0.6 ms store/reload) ------
     constexpr size_t CB = (size_t)(B + 1) * B;
     double a[B], y;
-    if constexpr (MODE == 1) {
+    if (MODE == 1 && (ablate & 32)) {        // split assembly (k_assemble_w ran before): diagnostic variant, slower
         const double* Ck = Call + ((size_t)s * n + k) * CB;
 #pragma unroll
         for (int cc = 0; cc < B; ++cc) a[cc] = lane < B ? Ck[(size_t)cc * B + lane] : 0.0;
@@ -1022,7 +1022,7 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
                 return HPF_E_HIP;
             }
         }
-        if (BW && h->gj_mode && T.n_dense > 0) {
+        if (BW && h->gj_mode && T.n_dense > 0 && (h->debug_ablate & 32)) {
             // un-eliminated blocks of ALL dense buses in one launch (independent of the elimination order)
             const dim3 grid((unsigned)T.n_dense, (unsigned)h->cur_S);
 #define HPF_LAUNCH_ASM(BB_)                                                                                              \

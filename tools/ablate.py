@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Timing-only ablation of the block-tree factor kernel phases (HPF_DEBUG_ABLATE bitmask: 1 skip Gauss-Jordan loop,
-2 skip children pull, 4 skip block assembly, 8 skip the A^-1 store).  Results of ablated runs are numerically invalid;
+2 skip children pull, 4 skip block assembly, 8 skip the A^-1 store, 16 phase stamps, 32 split assembly kernel).  Results of ablated runs are numerically invalid;
 only the phase times are read.  Usage: python tools/ablate.py [masks...]"""
 import json
 import os
