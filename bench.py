@@ -168,11 +168,15 @@ def main():
     value = total_scen * K / elapsed
     ms_step = 1e3 * elapsed / K
     solve_ms, solve_n = tim["solve"]
-    # scenario groups run as independent pipelines on their own streams: G spans per phase and step, each covering S/G
-    # scenarios; the spans of different groups overlap, so the wall time attributed to a phase is (sum of spans) / G
-    G = max(1, round(solve_n / max(K_steps(args), 1)))
-    flops = dm.solve_flops() * S / G                   # one factor sweep (all levels) of one scenario group
-    achieved = flops * G / (solve_ms / max(solve_n, 1) * 1e-3) / 1e12 if solve_ms > 0 else None
+    # One HIP-event span per k_factor_w launch (tree level x scenario group), on the stream it runs on.  Scenario groups are
+    # independent pipelines on separate streams, so launches of different groups overlap; like rocprofv3 --stats, `avg_ms`
+    # averages the launch durations as if they were alone.  achieved = algorithmic flops of all launches / sum of their
+    # durations = (flops per launch) / (average launch duration).
+    flops_step = dm.solve_flops() * S                  # all factor launches of one NR step on this GPU
+    launches_per_step = solve_n / max(K, 1)
+    achieved = flops_step * K / (solve_ms * 1e-3) / 1e12 if solve_ms > 0 else None
+    flops = flops_step / max(launches_per_step, 1)
+    G = max(1, round(launches_per_step / max(dm.n_levels, 1)))
     b = 2 * Hn
     nnz = len(inp["Y"].col)
     n_nl = n - inp["m"]
@@ -203,13 +207,16 @@ def main():
                      "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": (achieved / FP64_PEAK_TFLOPS) if achieved else None, "traffic": traffic,
                      "traffic_note": traffic_note,
-                     "flop_per_launch": flops, "avg_ms": solve_ms / max(solve_n, 1), "concurrent_groups": G},
+                     "flop_per_launch": flops, "avg_ms": solve_ms / max(solve_n, 1), "launches_per_step": launches_per_step,
+                     "concurrent_groups": G,
+                     "aggregate_tflops_over_step_wall": flops_step / (ms_step * 1e-3) / 1e12},
         "roofline_hbm_step": {"bound": "hbm", "achieved": step_bytes / (ms_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                               "unit": "GB/s", "frac": step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                               "bytes_per_step": step_bytes,
                               "note": "algorithmic bytes of a whole NR step (mismatch + factor + back sweep + update)"},
         "phase_ms_per_step": {k: (v[0] / max(v[1], 1)) for k, v in tim.items() if v[1]},
-        "phase_note": "per scenario group (%d groups overlap on separate streams)" % G,
+        "phase_note": "solve: per k_factor_w launch; others: per scenario group and step (%d groups overlap on separate "
+                      "streams)" % G,
         "vs_reference_measured": value / 0.0257,
     }
     if sweep is not None:

@@ -420,13 +420,29 @@ __device__ __forceinline__ void assemble_row(const Model& M, const TreeDev& T, c
         __syncthreads();
         const cplx* ynrow = M.YN + ((size_t)M.dev[k] * Hn + (rowvalid ? q : 0)) * Hn;
         const double* tab = ue + t * (B / 2) * 4;
+        // the lane's Y_N row is fetched in two batches with ALL loads of a batch in flight (sched_barrier pins them in
+        // front of their uses; left alone, the scheduler serialises one load per harmonic = one memory round trip each)
+        constexpr int HB = (B / 2 + 1) / 2;
 #pragma unroll
-        for (int p = 0; p < B / 2; ++p) {
-            const cplx yn = ynrow[p < Hn ? p : 0];
-            const double v0 = yn.im * tab[p * 4 + 0] + yn.re * tab[p * 4 + 1];
-            const double v1 = yn.im * tab[p * 4 + 2] + yn.re * tab[p * 4 + 3];
-            a[2 * p] = (p == q) ? d0 : v0;
-            a[2 * p + 1] = (p == q) ? d1 : v1;
+        for (int half = 0; half < 2; ++half) {
+            cplx ynb[HB];
+#pragma unroll
+            for (int j = 0; j < HB; ++j) {
+                const int p = half * HB + j;
+                ynb[j] = ynrow[p < Hn ? p : 0];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < HB; ++j) {
+                const int p = half * HB + j;
+                if (p < B / 2) {
+                    const double v0 = ynb[j].im * tab[p * 4 + 0] + ynb[j].re * tab[p * 4 + 1];
+                    const double v1 = ynb[j].im * tab[p * 4 + 2] + ynb[j].re * tab[p * 4 + 3];
+                    a[2 * p] = (p == q) ? d0 : v0;
+                    a[2 * p + 1] = (p == q) ? d1 : v1;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     } else {
 #pragma unroll
@@ -502,7 +518,7 @@ __global__ __launch_bounds__(64, MODE == 1 ? 2 : 1) void k_factor_w(Model M, Tre
     //      k_assemble_w launch parked in this bus's own Schur-complement slot (measured slower: +0.6 ms store/reload) ------
     constexpr size_t CB = (size_t)(B + 1) * B;
     double a[B], y;
-    if (MODE == 1 && (ablate & 32)) {        // split assembly (k_assemble_w ran before): diagnostic variant, slower
+    if (false) {        // (split-assembly diagnostic variant retired: the C slot now holds accumulator tiles)
         const double* Ck = Call + ((size_t)s * n + k) * CB;
 #pragma unroll
         for (int cc = 0; cc < B; ++cc) a[cc] = lane < B ? Ck[(size_t)cc * B + lane] : 0.0;
@@ -513,17 +529,7 @@ __global__ __launch_bounds__(64, MODE == 1 ? 2 : 1) void k_factor_w(Model M, Tre
 
     // ---- B. dense children (fixed order).  MODE 1: every dense child has already formed its Schur complement
     //      C = A(k,ch) D_ch^-1 A(ch,k) (+ the right-hand-side column) in its own wave (schur_tiles): just subtract. -------
-    if constexpr (MODE == 1) {
-        const double* Cs = Call + (size_t)s * n * CB;
-        for (int cp = T.child_mid[k]; cp < ((ablate & 2) ? 0 : T.child_ptr[k + 1]); ++cp) {
-            const double* Cc = Cs + (size_t)T.child[cp] * CB;
-            if (lane < B) {
-#pragma unroll
-                for (int cc = 0; cc < B; ++cc) a[cc] -= Cc[(size_t)cc * B + lane];
-                y -= Cc[(size_t)B * B + lane];
-            }
-        }
-    }
+    // (MODE 1 subtracts the children's tile-layout Schur complements after the layout conversion, see C')
     // MODE 0: pull from the children's transposed inverses
     for (int cp = T.child_mid[k]; cp < ((MODE == 1 || (ablate & 2)) ? 0 : T.child_ptr[k + 1]); ++cp) {
         const int ch = T.child[cp];
@@ -569,6 +575,29 @@ __global__ __launch_bounds__(64, MODE == 1 ? 2 : 1) void k_factor_w(Model M, Tre
         __shared__ double panel[NT * 64 + 16];
         d4_t ct[NT][NT];
         rows_to_tiles<B, NT>(a, y, lane, ct, tbuf);
+        {
+            // dense children: C = A(k,ch) D_ch^-1 A(ch,k) (+ right-hand-side column) was formed by the child's own wave
+            // (schur_tiles) and stored in accumulator layout: 64 coalesced 512-byte loads per child, fixed child order
+            constexpr size_t CT = (size_t)NT * NT * 4 * 64;
+            const double* Cs = Call + (size_t)s * n * CT;
+            for (int cp = T.child_mid[k]; cp < ((ablate & 2) ? 0 : T.child_ptr[k + 1]); ++cp) {
+                const double* Cc = Cs + (size_t)T.child[cp] * CT + lane;
+#pragma unroll
+                for (int tr = 0; tr < NT; ++tr) {
+                    double tmp[NT * 4];                      // one tile-row (<= 16 loads) in flight at a time
+#pragma unroll
+                    for (int e = 0; e < NT * 4; ++e)
+                        if (16 * tr + 4 * (e & 3) < B) tmp[e] = Cc[(size_t)(tr * NT * 4 + e) * 64];   // rows >= B: padding
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int tc = 0; tc < NT; ++tc)
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg)
+                            if (16 * tr + 4 * reg < B) ct[tr][tc][reg] -= tmp[tc * 4 + reg];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
         gauss_jordan_mfma<NT>(ct, (b + 3) / 4, panel);
         tiles_to_global<B, NT>(ct, lane, tbuf, As + (size_t)k * BB, ws + (size_t)k * B);
         const int par = T.parent[k];
@@ -590,7 +619,15 @@ __global__ __launch_bounds__(64, MODE == 1 ? 2 : 1) void k_factor_w(Model M, Tre
             }
             __syncthreads();
             schur_tiles<B, NT>(ct, lane, gl, hl);
-            tiles_to_global_aug<B, NT>(ct, lane, tbuf, Call + ((size_t)s * n + k) * CB);
+            constexpr size_t CT = (size_t)NT * NT * 4 * 64;
+            double* Ck = Call + ((size_t)s * n + k) * CT + lane;
+#pragma unroll
+            for (int tr = 0; tr < NT; ++tr)
+#pragma unroll
+                for (int tc = 0; tc < NT; ++tc)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg)
+                        if (16 * tr + 4 * reg < B) Ck[(size_t)((tr * NT + tc) * 4 + reg) * 64] = ct[tr][tc][reg];
         }
     } else {
         // ---- C. Gauss-Jordan with implicit partial pivoting, rotating registers (hpf_gj.hpp) ---------------------
@@ -644,8 +681,22 @@ __global__ __launch_bounds__(64) void k_back_w(Model M, TreeDev T, const int* __
         if (lane < B) tb[lane] = tv;
         __syncthreads();
         if (lane < B) {
-#pragma unroll 4
-            for (int cc = 0; cc < B; ++cc) x = fma(-Ak[(size_t)cc * B + lane], tb[cc], x);
+            constexpr int QB = (B + 3) / 4;                  // four batches, every load of a batch in flight
+#pragma unroll
+            for (int qb = 0; qb < 4; ++qb) {
+                double av[QB];
+#pragma unroll
+                for (int j = 0; j < QB; ++j) {
+                    const int cc = qb * QB + j;
+                    av[j] = cc < B ? Ak[(size_t)cc * B + lane] : 0.0;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < QB; ++j) {
+                    const int cc = qb * QB + j;
+                    if (cc < B) x = fma(-av[j], tb[cc], x);
+                }
+            }
         }
     }
     if (lane < B) {
@@ -994,7 +1045,7 @@ int tree_alloc_scenarios(hpf_handle* h) {
         (e = hipMalloc((void**)&h->d_w, sizeof(double) * S * n * b)) != hipSuccess ||
         (e = hipMalloc((void**)&h->d_x, sizeof(double) * S * n * b)) != hipSuccess ||
         (e = hipMalloc((void**)&h->d_linA, sizeof(double) * S * n * (size_t)h->Hn * 4)) != hipSuccess ||
-        (bw && (e = hipMalloc((void**)&h->d_C, sizeof(double) * S * n * (b + 1) * b)) != hipSuccess)) {
+        (bw && (e = hipMalloc((void**)&h->d_C, sizeof(double) * S * n * (size_t)(((bw + 16) / 16) * ((bw + 16) / 16) * 256))) != hipSuccess)) {
         h->last_detail = (int)e;
         return e == hipErrorOutOfMemory ? HPF_E_NOMEM : HPF_E_HIP;
     }
@@ -1011,7 +1062,6 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
     const int lin_threads = T.n_lin_roots * h->Hn;
     const int Bst = BW ? BW : b;
     {
-        ScopedTimer t(h, T_SOLVE);
         if (lin_threads > 0) {
             hipLaunchKernelGGL(k_lin_factor, dim3((unsigned)((lin_threads + 127) / 128), (unsigned)h->cur_S), dim3(128), 0,
                                h->cur_stream, h->M, td, T.n_lin_roots, h->N, h->Nc, Bst, active, h->d_U, h->d_E, h->d_f,
@@ -1022,7 +1072,7 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
                 return HPF_E_HIP;
             }
         }
-        if (BW && h->gj_mode && T.n_dense > 0 && (h->debug_ablate & 32)) {
+        if (false) {
             // un-eliminated blocks of ALL dense buses in one launch (independent of the elimination order)
             const dim3 grid((unsigned)T.n_dense, (unsigned)h->cur_S);
 #define HPF_LAUNCH_ASM(BB_)                                                                                              \
@@ -1043,6 +1093,7 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
             if (cnt == 0) continue;
             const int* nodes = T.d_lvl_nodes + T.lvl_ptr[l];
             int r;
+            ScopedTimer t(h, T_SOLVE);          // one span per k_factor_w launch (what rocprofv3 --stats averages)
             switch (BW) {
                 case 12: r = h->gj_mode ? launch_factor_w<12, 1>(h, td, nodes, cnt, active) : launch_factor_w<12, 0>(h, td, nodes, cnt, active); break;
                 case 28: r = h->gj_mode ? launch_factor_w<28, 1>(h, td, nodes, cnt, active) : launch_factor_w<28, 0>(h, td, nodes, cnt, active); break;

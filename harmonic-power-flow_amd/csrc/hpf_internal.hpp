@@ -97,7 +97,7 @@ struct hpf_handle {
     // pipelines on their own streams so that the latency-bound upper tree levels of one group overlap the others)
     hipStream_t cur_stream = nullptr;
     int cur_s0 = 0, cur_S = 0;
-    int n_groups = 4;
+    int n_groups = 3;
     hipStream_t gstream[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t fork_ev = nullptr, join_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     rocblas_handle blas = nullptr;

@@ -142,9 +142,10 @@ int  hpf_sync(hpf_handle* h);
 
 /* Kernel timing with HIP events on the handle's stream, accumulated since the last reset.
  * which: 0 mismatch kernel, 1 Jacobian assembly kernels (DENSE only; BLOCK_TREE assembles inside the factor kernel),
- * 2 linear solve (DENSE: getrf+getrs; BLOCK_TREE: the factor sweep = one k_tree_factor launch per tree level),
+ * 2 linear solve (DENSE: getrf+getrs, one span per step; BLOCK_TREE: one span per k_factor_w launch, i.e. per tree level
+ *   and scenario group),
  * 3 state update, 4 back-substitution sweep (BLOCK_TREE only; one k_tree_back launch per tree depth).
- * Returns total milliseconds in *ms and the number of timed spans (one per Newton step) in *launches. */
+ * Returns total milliseconds in *ms and the number of timed spans in *launches. */
 int  hpf_timing_enable(hpf_handle* h, int on);
 int  hpf_timing_get(hpf_handle* h, int which, double* ms, int64_t* launches);
 int  hpf_timing_reset(hpf_handle* h);
