@@ -494,7 +494,7 @@ __global__ __launch_bounds__(64, MODE == 1 ? 2 : 1) void k_factor_w(Model M, Tre
                                                  const cplx* __restrict__ Eall, const double* __restrict__ fall,
                                                  double* __restrict__ Aall, double* __restrict__ wall,
                                                  const double* __restrict__ linAall, double* __restrict__ Call,
-                                                 int ablate, int s0) {
+                                                 double* __restrict__ Hall, int ablate, int s0) {
     const int s = blockIdx.y + s0;
     if (active && !active[s]) return;
     const int k = nodes[blockIdx.x];
@@ -616,6 +616,11 @@ __global__ __launch_bounds__(64, MODE == 1 ? 2 : 1) void k_factor_w(Model M, Tre
                     gl[lane * 4 + e] = g4[e];
                     hl[lane * 4 + e] = h4[e];
                 }
+                if (lane < Hn) {       // A(k, parent) is needed again by the back sweep: keep it (32 B per harmonic)
+                    double* Hk = Hall + ((size_t)s * n + k) * Hn * 4 + lane * 4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) Hk[e] = h4[e];
+                }
             }
             __syncthreads();
             schur_tiles<B, NT>(ct, lane, gl, hl);
@@ -654,7 +659,7 @@ __global__ __launch_bounds__(64) void k_back_w(Model M, TreeDev T, const int* __
                                                const int* __restrict__ active, const cplx* __restrict__ Uall,
                                                const cplx* __restrict__ Eall, const double* __restrict__ Aall,
                                                const double* __restrict__ wall, double* __restrict__ xall,
-                                               double* __restrict__ step, int s0) {
+                                               double* __restrict__ step, const double* __restrict__ Hall, int s0) {
     const int s = blockIdx.y + s0;
     if (active && !active[s]) return;
     const int k = nodes[blockIdx.x];
@@ -674,9 +679,14 @@ __global__ __launch_bounds__(64) void k_back_w(Model M, TreeDev T, const int* __
         double tv = 0.0;
         const int p = lane >> 1, tr = lane & 1;
         if (lane < b && p < Hn) {
-            double blk4[4];
-            coupling_block(M, Uall + so, Eall + so, p, k, par, T.e_up[k], blk4);
-            tv = fma(blk4[tr * 2 + 1], xp[2 * p + 1], blk4[tr * 2] * xp[2 * p]);
+            if (Hall) {                                      // stored by the factor kernel's push phase
+                const double* hk = Hall + ((size_t)s * n + k) * Hn * 4 + p * 4 + tr * 2;
+                tv = fma(hk[1], xp[2 * p + 1], hk[0] * xp[2 * p]);
+            } else {
+                double blk4[4];
+                coupling_block(M, Uall + so, Eall + so, p, k, par, T.e_up[k], blk4);
+                tv = fma(blk4[tr * 2 + 1], xp[2 * p + 1], blk4[tr * 2] * xp[2 * p]);
+            }
         }
         if (lane < B) tb[lane] = tv;
         __syncthreads();
@@ -823,7 +833,7 @@ __global__ __launch_bounds__(128) void k_lin_back(Model M, TreeDev T, int nroots
 template <int B, int MODE>
 int launch_factor_w(hpf_handle* h, const TreeDev& T, const int* nodes, int count, const int* active) {
     hipLaunchKernelGGL((k_factor_w<B, MODE>), dim3((unsigned)count, (unsigned)h->cur_S), dim3(64), 0, h->cur_stream, h->M, T, nodes,
-                       2 * h->Hn, h->N, h->Nc, active, h->d_U, h->d_E, h->d_f, h->d_Z, h->d_w, h->d_linA, h->d_C, h->debug_ablate, h->cur_s0);
+                       2 * h->Hn, h->N, h->Nc, active, h->d_U, h->d_E, h->d_f, h->d_Z, h->d_w, h->d_linA, h->d_C, h->d_H, h->debug_ablate, h->cur_s0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         h->last_detail = (int)e;
@@ -835,7 +845,8 @@ int launch_factor_w(hpf_handle* h, const TreeDev& T, const int* nodes, int count
 template <int B>
 int launch_back_w(hpf_handle* h, const TreeDev& T, const int* nodes, int count, const int* active) {
     hipLaunchKernelGGL((k_back_w<B>), dim3((unsigned)count, (unsigned)h->cur_S), dim3(64), 0, h->cur_stream, h->M, T, nodes,
-                       2 * h->Hn, h->N, h->Nc, active, h->d_U, h->d_E, h->d_Z, h->d_w, h->d_x, h->d_f, h->cur_s0);
+                       2 * h->Hn, h->N, h->Nc, active, h->d_U, h->d_E, h->d_Z, h->d_w, h->d_x, h->d_f,
+                       h->gj_mode ? h->d_H : nullptr, h->cur_s0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         h->last_detail = (int)e;
@@ -1045,6 +1056,7 @@ int tree_alloc_scenarios(hpf_handle* h) {
         (e = hipMalloc((void**)&h->d_w, sizeof(double) * S * n * b)) != hipSuccess ||
         (e = hipMalloc((void**)&h->d_x, sizeof(double) * S * n * b)) != hipSuccess ||
         (e = hipMalloc((void**)&h->d_linA, sizeof(double) * S * n * (size_t)h->Hn * 4)) != hipSuccess ||
+        (e = hipMalloc((void**)&h->d_H, sizeof(double) * S * n * (size_t)h->Hn * 4)) != hipSuccess ||
         (bw && (e = hipMalloc((void**)&h->d_C, sizeof(double) * S * n * (size_t)(((bw + 16) / 16) * ((bw + 16) / 16) * 256))) != hipSuccess)) {
         h->last_detail = (int)e;
         return e == hipErrorOutOfMemory ? HPF_E_NOMEM : HPF_E_HIP;

@@ -90,6 +90,7 @@ struct hpf_handle {
     double* d_x = nullptr;            // [S][n][b]  Newton step, bus-major
     long long* d_dbg = nullptr;       // [S][n][8] diagnostic phase stamps of the factor kernel (HPF_DEBUG_ABLATE & 16)
     double* d_C = nullptr;            // [S][n][(B+1)*B] Schur complements pushed by dense children (MFMA mode)
+    double* d_H = nullptr;            // [S][n][Hn][4] A(k,parent) blocks of the dense buses, kept for the back sweep
     double* d_linA = nullptr;         // [S][n][Hn][4] inverse 2x2 blocks of the all-linear-subtree buses
 
     hipStream_t own_stream = nullptr, stream = nullptr;
