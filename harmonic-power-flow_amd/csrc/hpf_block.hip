@@ -494,7 +494,8 @@ __global__ __launch_bounds__(64, MODE == 1 ? 2 : 1) void k_factor_w(Model M, Tre
                                                  const cplx* __restrict__ Eall, const double* __restrict__ fall,
                                                  double* __restrict__ Aall, double* __restrict__ wall,
                                                  const double* __restrict__ linAall, double* __restrict__ Call,
-                                                 double* __restrict__ Hall, int ablate, int s0) {
+                                                 double* __restrict__ Hall, long long* __restrict__ dbg, int ablate,
+                                                 int s0) {
     const int s = blockIdx.y + s0;
     if (active && !active[s]) return;
     const int k = nodes[blockIdx.x];
@@ -510,6 +511,9 @@ __global__ __launch_bounds__(64, MODE == 1 ? 2 : 1) void k_factor_w(Model M, Tre
 
     __shared__ double bup[(B / 2) * 8];
     __shared__ int rj[B];
+    // diagnostic stamps (HPF_DEBUG_ABLATE & 16): phase boundaries in shader cycles, written to a buffer nothing else reads
+    long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, st5 = 0, st6 = 0;
+    if (ablate & 16) st0 = __builtin_amdgcn_s_memtime();
 
     const int q = lane >> 1, t = lane & 1;
     const bool rowvalid = lane < b && loc_valid(n, c, k, lane);
@@ -574,7 +578,9 @@ __global__ __launch_bounds__(64, MODE == 1 ? 2 : 1) void k_factor_w(Model M, Tre
         __shared__ double tbuf[64 * 17];
         __shared__ double panel[NT * 64 + 16];
         d4_t ct[NT][NT];
+        if (ablate & 16) st1 = __builtin_amdgcn_s_memtime();
         rows_to_tiles<B, NT>(a, y, lane, ct, tbuf);
+        if (ablate & 16) st2 = __builtin_amdgcn_s_memtime();
         {
             // dense children: C = A(k,ch) D_ch^-1 A(ch,k) (+ right-hand-side column) was formed by the child's own wave
             // (schur_tiles) and stored in accumulator layout: 64 coalesced 512-byte loads per child, fixed child order
@@ -598,8 +604,11 @@ __global__ __launch_bounds__(64, MODE == 1 ? 2 : 1) void k_factor_w(Model M, Tre
                 }
             }
         }
+        if (ablate & 16) st3 = __builtin_amdgcn_s_memtime();
         gauss_jordan_mfma<NT>(ct, (b + 3) / 4, panel);
+        if (ablate & 16) st4 = __builtin_amdgcn_s_memtime();
         tiles_to_global<B, NT>(ct, lane, tbuf, As + (size_t)k * BB, ws + (size_t)k * B);
+        if (ablate & 16) st5 = __builtin_amdgcn_s_memtime();
         const int par = T.parent[k];
         if (par >= 0) {
             // ---- E. push: Schur complement of this bus for its parent ------------------------------------------
@@ -633,6 +642,18 @@ __global__ __launch_bounds__(64, MODE == 1 ? 2 : 1) void k_factor_w(Model M, Tre
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg)
                         if (16 * tr + 4 * reg < B) Ck[(size_t)((tr * NT + tc) * 4 + reg) * 64] = ct[tr][tc][reg];
+        }
+        if ((ablate & 16) && lane == 0 && dbg) {
+            st6 = __builtin_amdgcn_s_memtime();
+            long long* o = dbg + ((size_t)s * n + k) * 8;
+            o[0] = st1 - st0;   // assembly (+ linear children)
+            o[1] = st2 - st1;   // rows -> tiles
+            o[2] = st3 - st2;   // dense children sums
+            o[3] = st4 - st3;   // MFMA Gauss-Jordan
+            o[4] = st5 - st4;   // tiles -> A^-T, w
+            o[5] = st6 - st5;   // Schur push
+            o[6] = T.child_ptr[k + 1] - T.child_mid[k];
+            o[7] = (k >= M.m) | ((T.child_mid[k] - T.child_ptr[k]) << 1);
         }
     } else {
         // ---- C. Gauss-Jordan with implicit partial pivoting, rotating registers (hpf_gj.hpp) ---------------------
@@ -833,7 +854,7 @@ __global__ __launch_bounds__(128) void k_lin_back(Model M, TreeDev T, int nroots
 template <int B, int MODE>
 int launch_factor_w(hpf_handle* h, const TreeDev& T, const int* nodes, int count, const int* active) {
     hipLaunchKernelGGL((k_factor_w<B, MODE>), dim3((unsigned)count, (unsigned)h->cur_S), dim3(64), 0, h->cur_stream, h->M, T, nodes,
-                       2 * h->Hn, h->N, h->Nc, active, h->d_U, h->d_E, h->d_f, h->d_Z, h->d_w, h->d_linA, h->d_C, h->d_H, h->debug_ablate, h->cur_s0);
+                       2 * h->Hn, h->N, h->Nc, active, h->d_U, h->d_E, h->d_f, h->d_Z, h->d_w, h->d_linA, h->d_C, h->d_H, h->d_dbg, h->debug_ablate, h->cur_s0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         h->last_detail = (int)e;
@@ -1057,10 +1078,12 @@ int tree_alloc_scenarios(hpf_handle* h) {
         (e = hipMalloc((void**)&h->d_x, sizeof(double) * S * n * b)) != hipSuccess ||
         (e = hipMalloc((void**)&h->d_linA, sizeof(double) * S * n * (size_t)h->Hn * 4)) != hipSuccess ||
         (e = hipMalloc((void**)&h->d_H, sizeof(double) * S * n * (size_t)h->Hn * 4)) != hipSuccess ||
+        ((h->debug_ablate & 16) && (e = hipMalloc((void**)&h->d_dbg, sizeof(long long) * S * n * 8)) != hipSuccess) ||
         (bw && (e = hipMalloc((void**)&h->d_C, sizeof(double) * S * n * (size_t)(((bw + 16) / 16) * ((bw + 16) / 16) * 256))) != hipSuccess)) {
         h->last_detail = (int)e;
         return e == hipErrorOutOfMemory ? HPF_E_NOMEM : HPF_E_HIP;
     }
+    if (h->d_dbg) hipMemset(h->d_dbg, 0, sizeof(long long) * S * n * 8);
     return HPF_OK;
 }
 

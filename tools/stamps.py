@@ -35,13 +35,14 @@ buf = np.zeros(S * n * 8, dtype=np.int64)
 dm._chk(dm.lib.hpf_debug_stamps(dm._h, buf.ctypes.data_as(C.POINTER(C.c_longlong)), buf.size), "hpf_debug_stamps")
 d = buf.reshape(S, n, 8)
 dense = d[:, :, 3].sum(axis=0) > 0
-names = ["assembly", "child sums", "rows->tiles", "MFMA GJ", "store", "push"]
+names = ["assembly", "rows->tiles", "child sums", "MFMA GJ", "store", "push"]
 print("dense buses: %d; cycles per block (median over scenarios and buses)" % dense.sum())
 for label, sel in (("nonlinear leaf (0 dense children)", dense & (d[0, :, 6] == 0) & (d[0, :, 7] == 1)),
-                   ("1-2 dense children", dense & (d[0, :, 6] >= 1) & (d[0, :, 6] <= 2)),
+                   ("linear dense bus, 1-2 dense children", dense & (d[0, :, 6] >= 1) & (d[0, :, 6] <= 2) & ((d[0, :, 7] & 1) == 0)),
+                   ("nonlinear bus, 1-2 dense children", dense & (d[0, :, 6] >= 1) & (d[0, :, 6] <= 2) & ((d[0, :, 7] & 1) == 1)),
                    (">=4 dense children", dense & (d[0, :, 6] >= 4))):
     if sel.sum() == 0:
         continue
     x = d[:, sel, :6].reshape(-1, 6)
     med = np.median(x, axis=0)
-    print("%-36s n=%4d  " % (label, sel.sum()) + "  ".join("%s %7.0f" % (nm, v) for nm, v in zip(names, med)) + "   total %8.0f" % med.sum())
+    print("%-38s n=%4d  " % (label, sel.sum()) + "  ".join("%s %7.0f" % (nm, v) for nm, v in zip(names, med)) + "   total %8.0f" % med.sum())
