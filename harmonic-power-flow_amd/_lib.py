@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhpf.so")
+LIB_PATH = os.environ.get("HPF_LIB_PATH") or os.path.join(_HERE, "libhpf.so")   # HPF_LIB_PATH: diagnostic builds
 
 SOLVER_DENSE = 0
 SOLVER_BLOCK_TREE = 1

@@ -18,18 +18,22 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build_lib(force=False, verbose=False):
-    if not force and not needs_build():
+def build_lib(force=False, verbose=False, stamps=False):
+    """stamps=True builds the diagnostic variant libhpf_stamps.so (in-kernel phase stamps, tools/stamps.py)."""
+    out = os.path.join(HERE, "libhpf_stamps.so") if stamps else OUT
+    if not stamps and not force and not needs_build():
         return OUT
     cmd = [os.path.join(ROCM, "bin", "hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
-           "-Wno-unused-value", "-fPIC", "-shared"] + [os.path.join(CSRC, f) for f in SOURCES] + \
-          ["-o", OUT, "-L" + os.path.join(ROCM, "lib"), "-lrocsolver", "-lrocblas",
+           "-Wno-unused-value", "-fPIC", "-shared"] + (["-DHPF_FACTOR_STAMPS"] if stamps else []) + \
+          [os.path.join(CSRC, f) for f in SOURCES] + \
+          ["-o", out, "-L" + os.path.join(ROCM, "lib"), "-lrocsolver", "-lrocblas",
            "-Wl,-rpath," + os.path.join(ROCM, "lib")]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":
-    print(build_lib(force=True, verbose=True))
+    import sys
+    print(build_lib(force=True, verbose=True, stamps="--stamps" in sys.argv))

@@ -22,6 +22,15 @@
 
 using namespace hpf;
 
+#ifdef HPF_FACTOR_STAMPS
+#define HPF_STAMP_DECL long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, st5 = 0, st6 = 0
+#define HPF_STAMP(v) \
+    if (ablate & 16) v = __builtin_amdgcn_s_memtime()
+#else
+#define HPF_STAMP_DECL
+#define HPF_STAMP(v)
+#endif
+
 namespace {
 
 struct TreeDev {
@@ -511,9 +520,10 @@ __global__ __launch_bounds__(64, MODE == 1 ? 2 : 1) void k_factor_w(Model M, Tre
 
     __shared__ double bup[(B / 2) * 8];
     __shared__ int rj[B];
-    // diagnostic stamps (HPF_DEBUG_ABLATE & 16): phase boundaries in shader cycles, written to a buffer nothing else reads
-    long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, st5 = 0, st6 = 0;
-    if (ablate & 16) st0 = __builtin_amdgcn_s_memtime();
+    // diagnostic stamps: compiled only into the -DHPF_FACTOR_STAMPS build (build.py --stamps -> libhpf_stamps.so); even
+    // disabled at run time they cost ~15 % through register allocation, so the product build has none
+    HPF_STAMP_DECL;
+    HPF_STAMP(st0);
 
     const int q = lane >> 1, t = lane & 1;
     const bool rowvalid = lane < b && loc_valid(n, c, k, lane);
@@ -578,9 +588,9 @@ __global__ __launch_bounds__(64, MODE == 1 ? 2 : 1) void k_factor_w(Model M, Tre
         __shared__ double tbuf[64 * 17];
         __shared__ double panel[NT * 64 + 16];
         d4_t ct[NT][NT];
-        if (ablate & 16) st1 = __builtin_amdgcn_s_memtime();
+        HPF_STAMP(st1);
         rows_to_tiles<B, NT>(a, y, lane, ct, tbuf);
-        if (ablate & 16) st2 = __builtin_amdgcn_s_memtime();
+        HPF_STAMP(st2);
         {
             // dense children: C = A(k,ch) D_ch^-1 A(ch,k) (+ right-hand-side column) was formed by the child's own wave
             // (schur_tiles) and stored in accumulator layout: 64 coalesced 512-byte loads per child, fixed child order
@@ -604,11 +614,11 @@ __global__ __launch_bounds__(64, MODE == 1 ? 2 : 1) void k_factor_w(Model M, Tre
                 }
             }
         }
-        if (ablate & 16) st3 = __builtin_amdgcn_s_memtime();
+        HPF_STAMP(st3);
         gauss_jordan_mfma<NT>(ct, (b + 3) / 4, panel);
-        if (ablate & 16) st4 = __builtin_amdgcn_s_memtime();
+        HPF_STAMP(st4);
         tiles_to_global<B, NT>(ct, lane, tbuf, As + (size_t)k * BB, ws + (size_t)k * B);
-        if (ablate & 16) st5 = __builtin_amdgcn_s_memtime();
+        HPF_STAMP(st5);
         const int par = T.parent[k];
         if (par >= 0) {
             // ---- E. push: Schur complement of this bus for its parent ------------------------------------------
@@ -643,6 +653,7 @@ __global__ __launch_bounds__(64, MODE == 1 ? 2 : 1) void k_factor_w(Model M, Tre
                     for (int reg = 0; reg < 4; ++reg)
                         if (16 * tr + 4 * reg < B) Ck[(size_t)((tr * NT + tc) * 4 + reg) * 64] = ct[tr][tc][reg];
         }
+#ifdef HPF_FACTOR_STAMPS
         if ((ablate & 16) && lane == 0 && dbg) {
             st6 = __builtin_amdgcn_s_memtime();
             long long* o = dbg + ((size_t)s * n + k) * 8;
@@ -655,6 +666,7 @@ __global__ __launch_bounds__(64, MODE == 1 ? 2 : 1) void k_factor_w(Model M, Tre
             o[6] = T.child_ptr[k + 1] - T.child_mid[k];
             o[7] = (k >= M.m) | ((T.child_mid[k] - T.child_ptr[k]) << 1);
         }
+#endif
     } else {
         // ---- C. Gauss-Jordan with implicit partial pivoting, rotating registers (hpf_gj.hpp) ---------------------
         int myj = 0;

@@ -9,6 +9,8 @@ import tempfile
 import numpy as np
 
 os.environ.setdefault("HPF_DEBUG_ABLATE", "16")
+os.environ.setdefault("HPF_LIB_PATH", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                   "harmonic-power-flow_amd", "libhpf_stamps.so"))   # build.py --stamps
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import harmonic_power_flow_amd as hp
 from harmonic_power_flow_amd import ingest, synth
