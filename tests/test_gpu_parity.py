@@ -381,3 +381,29 @@ def test_block_pivoting_option_gives_same_solution(tmp_path):
     U0 = res[0][1][0][0] * np.exp(1j * res[0][1][1][0])
     U1 = res[1][1][0][0] * np.exp(1j * res[1][1][1][0])
     assert np.abs(U0 - U1).max() < 1e-10
+
+
+def test_k49_generic_block_path_matches_dense(tmp_path):
+    """BASELINE config 5 shape in small: K = 49 harmonics (block size 100 > 52 -> generic 256-thread block kernels, no MFMA,
+    no linear-subtree shortcut) against the dense rocSOLVER step on a 60-bus feeder."""
+    hp = _hp()
+    out = {}
+    for solver in ("dense", "block_tree"):
+        st, buses, lines, dm, _ = _syn_model(hp, 60, 99, solver, tmp_path)
+        try:
+            assert dm.Hn == 50
+            dm.set_loads(buses["P"].to_numpy(float), buses["Q"].to_numpy(float))
+            dm.set_state(None, None, n_scen=1)
+            dm.fund_pf(1e-6, 30)
+            v0 = dm.get_state()
+            dm.mismatch()
+            dm.iterate(1)
+            dm.sync()
+            out[solver] = (v0, dm.get_state())
+        finally:
+            dm.close()
+    (v0d, v1d), (v0b, v1b) = out["dense"], out["block_tree"]
+    step = np.abs(v1d[0] - v0d[0]).max()
+    assert step > 1e-3
+    assert np.abs(v1d[0] - v1b[0]).max() <= 1e-9 * max(1.0, step)
+    assert np.abs(v1d[1] - v1b[1]).max() <= 1e-9 * max(1.0, np.abs(v1d[1] - v0d[1]).max())
