@@ -15,7 +15,7 @@ Shims (no edits to reference source):
   4. net1 is fed as a header-normalised copy (`X_shunt`->`X_sh`, `;G;B` = `;0;0` appended) because
      HG cannot read net1's dialect (AttributeError: X_sh).
 
-Usage:  python oracle/make_golden.py [nets] [syn] [syn1000] [hf]      (default: nets syn hf)
+Usage:  python oracle/make_golden.py [nets] [quirks] [syn] [syn1000] [hf]      (default: nets syn hf)
 """
 import contextlib
 import io
@@ -174,7 +174,7 @@ def run_case(g, buses_csv, lines_csv, h_max, coupled, full=True):
         out["Y_all"] = rec["Y"]
     else:
         out["V_it0"], out["V_it1"] = rec["V"][0], rec["V"][1]
-    for d, (i_n, y_n) in rec["NE"].items():
+    for d, (i_n, y_n) in (rec["NE"] or {}).items():
         out["NE_dev"] = d
         out["I_N"], out["Y_N"] = i_n, y_n             # single device type in all shipped nets
     return out
@@ -195,6 +195,20 @@ def main(argv):
                 for coupled in (False, True):
                     name = f"{net}_H{h_max}_{'c' if coupled else 'uc'}"
                     out = run_case(g, b, l, h_max, coupled)
+                    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+                    summary[name] = (out["n_iter_h"], out["err_h"], out["n_iter_f"])
+                    print(name, summary[name], flush=True)
+    if "quirks" in what:
+        # fixtures authored for this build (tests/golden/inputs): parallel lines (overwrite, HG:151-155), pi-model shunts with the
+        # reference's off-by-one (HG:163-168), a bus shunt away from the slack (HG:158-161), a PV bus; and a network without any
+        # nonlinear bus (m == n, empty Norton dict)
+        for net, hs in (("quirk5", (11,)), ("lin4", (11,))):
+            for f in (net + "_buses.csv", net + "_lines.csv"):
+                shutil.copy(os.path.join(GOLD, "inputs", f), os.path.join(work, f))
+            for h_max in hs:
+                for coupled in (False, True):
+                    name = f"{net}_H{h_max}_{'c' if coupled else 'uc'}"
+                    out = run_case(g, net + "_buses.csv", net + "_lines.csv", h_max, coupled)
                     np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
                     summary[name] = (out["n_iter_h"], out["err_h"], out["n_iter_f"])
                     print(name, summary[name], flush=True)

@@ -13,7 +13,8 @@ from emul import Emul
 import harmonic_power_flow_amd as hp
 from harmonic_power_flow_amd import ingest
 
-CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "net*_H*.npz")))
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "*_H*.npz"))
+                   if not os.path.basename(p).startswith("syn"))
 
 
 def _setup(name):
@@ -40,7 +41,8 @@ def test_product_ingest_matches_oracle_and_reference(name):
     assert np.array_equal(Y.rowptr, rowptr) and np.array_equal(Y.col, col)
     assert np.array_equal(Y.Yval, Yval)                                  # bit-identical admittances
     assert np.array_equal(Y.to_frame().to_numpy(), g["Y_all"])          # ... and equal to the reference's Y_all
-    assert np.array_equal(em.IN.ravel(), g["I_N"].ravel()) and np.array_equal(em.YN.ravel(), g["Y_N"].ravel())
+    if "I_N" in g.files:
+        assert np.array_equal(em.IN.ravel(), g["I_N"].ravel()) and np.array_equal(em.YN.ravel(), g["Y_N"].ravel())
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -58,7 +60,11 @@ def test_device_arithmetic_on_host_matches_oracle(name):
         J_o = o.build_harmonic_jacobian(mdl, Vm.copy(), Va.copy()).toarray()
         J_e = em.jacobian(Vm, Va)
         assert J_e.shape == J_o.shape
-        assert np.abs(J_e - J_o).max() <= 1e-13 * np.abs(J_o).max(), (name, it)
+        # lin4 ends with harmonic magnitudes of exactly 0: U/V_m is 0/0 there in the reference formula as well (HG:405); the
+        # reference never builds J at that state because the loop has stopped.  NaN patterns must agree, the rest must match.
+        assert np.array_equal(np.isnan(J_e), np.isnan(J_o)), (name, it)
+        fin = ~np.isnan(J_o)
+        assert np.abs(J_e[fin] - J_o[fin]).max() <= 1e-13 * np.abs(J_o[fin]).max(), (name, it)
     # iteration 0 against the reference's own f and J
     Vm, Va = traj[0][:, 0].copy(), traj[0][:, 1].copy()
     assert np.abs(em.mismatch(Vm, Va, P, Q) - g["f0"]).max() <= 1e-13 * max(1.0, np.abs(g["f0"]).max())

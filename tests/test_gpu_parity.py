@@ -15,7 +15,8 @@ from conftest import GOLD, INPUTS
 
 pytestmark = pytest.mark.gpu
 
-CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "net*_H*.npz")))
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "*_H*.npz"))
+                   if not os.path.basename(p).startswith("syn"))
 TOL_V = 1e-8
 # The NR trajectory of net1/K=25/coupled is chaotic in its first ~20 iterations and its LENGTH depends on the
 # rounding of the linear solver: inside the reference itself, swapping SuperLU for LAPACK gives 32 iterations instead
