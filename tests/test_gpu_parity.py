@@ -74,16 +74,16 @@ def test_hpf_matches_reference_golden(name):
         assert n_iter_h == int(g["n_iter_h"]), (n_iter_h, int(g["n_iter_h"]))
     assert n_iter_h < 50 and err_h <= 1e-4
     ge = g["err_hist"]
-    np.testing.assert_allclose(det["err_hist"][:3], ge[:3], rtol=1e-9)
+    np.testing.assert_allclose(det["err_hist"][:3], ge[:3], rtol=1e-9, atol=1e-12 * ge[0])   # atol: round-off floor (lin4)
     Ud = V["V_m"].to_numpy() * np.exp(1j * V["V_a"].to_numpy())
     Ug = g["V_final"][:, 0] * np.exp(1j * g["V_final"][:, 1])
     dU = np.abs(Ud - Ug).max()
     dVm = np.abs(V["V_m"].to_numpy() - g["V_final"][:, 0]).max()
     print(f"\n{name}: it {n_iter_h} err {err_h:.3e} (ref {float(g['err_h']):.3e}) max|dU| {dU:.2e} max|dVm| {dVm:.2e}")
     assert dU < TOL_V and dVm < TOL_V
-    assert (V["V_m"].to_numpy() >= 0).all() and (V["V_a"].to_numpy() >= 0).all() and (V["V_a"].to_numpy() < 2 * np.pi).all()
+    assert (V["V_m"].to_numpy() >= 0).all() and (V["V_a"].to_numpy() >= 0).all() and (V["V_a"].to_numpy() <= 2 * np.pi).all()   # np.mod(-tiny, 2pi) rounds to 2pi, in the reference as well
     thd = hp.get_THD(V).to_numpy()
-    np.testing.assert_allclose(thd, g["THD"], rtol=1e-6)
+    np.testing.assert_allclose(thd, g["THD"], rtol=1e-6, atol=1e-12)   # atol: lin4 has harmonic magnitudes at round-off level
     if J is not None:
         assert J.shape == tuple(g["J0_shape"])
 
@@ -113,7 +113,10 @@ def test_mismatch_and_jacobian_kernels_vs_golden_and_oracle(name):
             fs = max(1.0, np.abs(f_o).max())
             assert np.abs(f[0] - f_o).max() <= 1e-12 * fs
             assert abs(err[0] - e_o) <= 1e-12 * fs
-            assert np.abs(J - J_o).max() <= 1e-12 * np.abs(J_o).max()
+            # (lin4 ends with harmonic magnitudes of exactly 0 -> U/V_m = 0/0 in the reference formula too, HG:405)
+            assert np.array_equal(np.isnan(J), np.isnan(J_o))
+            fin = ~np.isnan(J_o)
+            assert np.abs(J[fin] - J_o[fin]).max() <= 1e-12 * np.abs(J_o[fin]).max()
             if it == 0:
                 assert np.abs(f[0] - g["f0"]).max() <= 1e-12 * fs
                 Jg = np.zeros(tuple(g["J0_shape"]))
