@@ -358,6 +358,16 @@ __global__ __launch_bounds__(256) void k_tree_back(int n, int c, int Hn, TreeDev
 //        D_p -= A(p,k) D_k^{-1} A(k,p):   v = g0*Ainv[2q][:] + g1*Ainv[2q+1][:]  (16-B pair loads, coalesced)
 //                                          D_p[i][2p+t'] -= v[2p]*Bup[p][0][t'] + v[2p+1]*Bup[p][1][t'].
 // =============================================================================================================
+// fundamental power flow (HG:205-223): every bus is a power row, E = U/|U|
+__device__ __forceinline__ void coupling_block_fund(const Model& M, const cplx* U, const cplx* E, int i, int j, int e, double out[4]) {
+    const Blk2 blk = jac_power_entry<true>(M, U, E, i, j, e);
+#pragma unroll
+    for (int tr = 0; tr < 2; ++tr)
+#pragma unroll
+        for (int tc = 0; tc < 2; ++tc)
+            out[tr * 2 + tc] = (loc_valid(M.n, M.c, i, tr) && loc_valid(M.n, M.c, j, tc)) ? pick(blk, tr, tc) : 0.0;
+}
+
 // 2x2 coupling block A(row bus i, col bus j) at harmonic p, masked to existing equations / unknowns -> out[tr*2+tc]
 __device__ __forceinline__ void coupling_block(const Model& M, const cplx* U, const cplx* E, int p, int i, int j, int e,
                                                double out[4]) {
@@ -762,9 +772,11 @@ __global__ __launch_bounds__(64) void k_back_w(Model M, TreeDev T, const int* __
 // Schur-complemented diagonal block stays harmonic-diagonal, i.e. Hn independent 2x2 systems.  One thread per
 // (maximal linear subtree, harmonic, scenario) walks the subtree in post-order (factor) / reverse post-order (back).
 // =============================================================================================================
+template <bool FUND>
 __device__ __forceinline__ void diag2x2(const Model& M, const cplx* U, const cplx* E, int q, int k, double m2[4]) {
-    const Blk2 blk = (q == 0 && k < M.m) ? jac_power_entry<false>(M, U, E, k, k, M.diag[k])
-                                          : jac_current_entry(M, U, E, q, k, k, M.diag[k]);
+    const Blk2 blk = FUND ? jac_power_entry<true>(M, U, E, k, k, M.diag[k])
+                          : ((q == 0 && k < M.m) ? jac_power_entry<false>(M, U, E, k, k, M.diag[k])
+                                                  : jac_current_entry(M, U, E, q, k, k, M.diag[k]));
     const bool v0 = loc_valid(M.n, M.c, k, 2 * q), v1 = loc_valid(M.n, M.c, k, 2 * q + 1);
     m2[0] = v0 ? blk.dA.re : 1.0;
     m2[1] = (v0 && v1) ? blk.dV.re : 0.0;
@@ -772,6 +784,7 @@ __device__ __forceinline__ void diag2x2(const Model& M, const cplx* U, const cpl
     m2[3] = v1 ? blk.dV.im : 1.0;
 }
 
+template <bool FUND>
 __global__ __launch_bounds__(128) void k_lin_factor(Model M, TreeDev T, int nroots, int N, int Nc, int Bst,
                                                     const int* __restrict__ active, const cplx* __restrict__ Uall,
                                                     const cplx* __restrict__ Eall, const double* __restrict__ fall,
@@ -779,8 +792,9 @@ __global__ __launch_bounds__(128) void k_lin_factor(Model M, TreeDev T, int nroo
     const int s = blockIdx.y + s0;
     if (active && !active[s]) return;
     const int tix = blockIdx.x * 128 + threadIdx.x;
-    if (tix >= nroots * M.Hn) return;
-    const int q = tix % M.Hn, r = tix / M.Hn;                      // consecutive threads: consecutive harmonics
+    const int HnE = FUND ? 1 : M.Hn;                               // FUND: harmonic position 0 only
+    if (tix >= nroots * HnE) return;
+    const int q = tix % HnE, r = tix / HnE;                        // consecutive threads: consecutive harmonics
     const int n = M.n, c = M.c, Hn = M.Hn;
     const size_t so = (size_t)s * n * Hn;
     const cplx* U = Uall + so;
@@ -791,15 +805,20 @@ __global__ __launch_bounds__(128) void k_lin_factor(Model M, TreeDev T, int nroo
     for (int idx = T.lin_ptr[r]; idx < T.lin_ptr[r + 1]; ++idx) {
         const int k = T.lin_post[idx];
         double m2[4];
-        diag2x2(M, U, E, q, k, m2);
+        diag2x2<FUND>(M, U, E, q, k, m2);
         const int kst = q * n + k;
         double y0 = kst >= 1 ? f[kst - 1] : 0.0;
         double y1 = kst >= c ? f[Nc + kst - c] : 0.0;
         for (int cp = T.child_ptr[k]; cp < T.child_ptr[k + 1]; ++cp) {      // all children of a linear-subtree bus are linear
             const int ch = T.child[cp];
             double g4[4], h4[4];
-            coupling_block(M, U, E, q, k, ch, T.e_dn[ch], g4);               // A(k, child)
-            coupling_block(M, U, E, q, ch, k, T.e_up[ch], h4);               // A(child, k)
+            if (FUND) {
+                coupling_block_fund(M, U, E, k, ch, T.e_dn[ch], g4);
+                coupling_block_fund(M, U, E, ch, k, T.e_up[ch], h4);
+            } else {
+                coupling_block(M, U, E, q, k, ch, T.e_dn[ch], g4);           // A(k, child)
+                coupling_block(M, U, E, q, ch, k, T.e_up[ch], h4);           // A(child, k)
+            }
             const double* ic = linA + ((size_t)ch * Hn + q) * 4;
             const double gi0 = fma(g4[1], ic[2], g4[0] * ic[0]), gi1 = fma(g4[1], ic[3], g4[0] * ic[1]);
             const double gi2 = fma(g4[3], ic[2], g4[2] * ic[0]), gi3 = fma(g4[3], ic[3], g4[2] * ic[1]);
@@ -824,6 +843,7 @@ __global__ __launch_bounds__(128) void k_lin_factor(Model M, TreeDev T, int nroo
     }
 }
 
+template <bool FUND>
 __global__ __launch_bounds__(128) void k_lin_back(Model M, TreeDev T, int nroots, int N, int Nc, int Bst,
                                                   const int* __restrict__ active, const cplx* __restrict__ Uall,
                                                   const cplx* __restrict__ Eall, const double* __restrict__ linAall,
@@ -832,8 +852,9 @@ __global__ __launch_bounds__(128) void k_lin_back(Model M, TreeDev T, int nroots
     const int s = blockIdx.y + s0;
     if (active && !active[s]) return;
     const int tix = blockIdx.x * 128 + threadIdx.x;
-    if (tix >= nroots * M.Hn) return;
-    const int q = tix % M.Hn, r = tix / M.Hn;
+    const int HnE = FUND ? 1 : M.Hn;
+    if (tix >= nroots * HnE) return;
+    const int q = tix % HnE, r = tix / HnE;
     const int n = M.n, c = M.c, Hn = M.Hn;
     const size_t so = (size_t)s * n * Hn;
     const double* linA = linAall + so * 4;
@@ -847,7 +868,10 @@ __global__ __launch_bounds__(128) void k_lin_back(Model M, TreeDev T, int nroots
         double x0 = wk[0], x1 = wk[1];
         if (par >= 0) {
             double h4[4];
-            coupling_block(M, Uall + so, Eall + so, q, k, par, T.e_up[k], h4);   // A(k, parent)
+            if (FUND)
+                coupling_block_fund(M, Uall + so, Eall + so, k, par, T.e_up[k], h4);
+            else
+                coupling_block(M, Uall + so, Eall + so, q, k, par, T.e_up[k], h4);   // A(k, parent)
             const double* xp = xs + (size_t)par * Bst + 2 * q;
             const double t0 = fma(h4[1], xp[1], h4[0] * xp[0]), t1 = fma(h4[3], xp[1], h4[2] * xp[0]);
             const double* ik = linA + ((size_t)k * Hn + q) * 4;
@@ -1042,6 +1066,23 @@ int tree_build(hpf_handle* h, const hpf_desc* d) {
         T.lin_ptr.push_back((int)T.lin_post.size());
         ++T.n_lin_roots;
     }
+    // post-order of the whole tree (children lists as built above): used by the fundamental power-flow step
+    T.all_ptr = {0, n};
+    T.all_post.clear();
+    {
+        std::vector<std::pair<int, int>> stack;
+        stack.push_back({0, T.child_ptr[0]});
+        while (!stack.empty()) {
+            const int node = stack.back().first;
+            if (stack.back().second < T.child_ptr[node + 1]) {
+                const int ch = T.child[stack.back().second++];
+                stack.push_back({ch, T.child_ptr[ch]});
+            } else {
+                T.all_post.push_back(node);
+                stack.pop_back();
+            }
+        }
+    }
     const double bd = b;
     // exact FP64 flop count of the dense part of the elimination: per dense bus 2 b^3 (block inversion), (4 b^2 + 4 b)
     // per dense child pulled, 2 b^2 (w = D^-1 y); per non-root dense bus 4 b^2 (D^-1 A(k,parent)) in the parent's pull
@@ -1070,13 +1111,15 @@ int tree_build(hpf_handle* h, const hpf_desc* d) {
     if ((r = upload(h, &T.d_lin, T.lin))) return r;
     if ((r = upload(h, &T.d_lin_ptr, T.lin_ptr))) return r;
     if ((r = upload(h, &T.d_lin_post, T.lin_post))) return r;
+    if ((r = upload(h, &T.d_all_ptr, T.all_ptr))) return r;
+    if ((r = upload(h, &T.d_all_post, T.all_post))) return r;
     return HPF_OK;
 }
 
 void tree_free(hpf_handle* h) {
     Tree& T = h->tree;
     void* ptrs[] = {T.d_parent, T.d_lvl_nodes, T.d_dep_nodes, T.d_child_ptr, T.d_child, T.d_e_up, T.d_e_dn,
-                    T.d_child_mid, T.d_lin, T.d_lin_ptr, T.d_lin_post};
+                    T.d_child_mid, T.d_lin, T.d_lin_ptr, T.d_lin_post, T.d_all_ptr, T.d_all_post};
     for (void* p : ptrs)
         if (p) hipFree(p);
 }
@@ -1099,6 +1142,29 @@ int tree_alloc_scenarios(hpf_handle* h) {
     return HPF_OK;
 }
 
+
+// Fundamental power-flow Newton step on a radial network (pf, HG:244-275): every bus is a plain power bus there, so the whole
+// tree is one "linear subtree" at harmonic position 0 -> the same 2x2 elimination, one thread per scenario walking the post-order.
+int tree_fund_step(hpf_handle* h, bool only_active) {
+    Tree& T = h->tree;
+    const int* active = only_active ? h->d_active : nullptr;
+    const TreeDev td{T.d_parent, T.d_child_ptr, T.d_child, T.d_e_up, T.d_e_dn, T.d_child_mid, T.d_all_ptr, T.d_all_post};
+    const int b = 2 * h->Hn;
+    const int BW = wave_block_size(b);
+    const int Bst = BW ? BW : b;
+    ScopedTimer t(h, T_SOLVE);
+    hipLaunchKernelGGL((k_lin_factor<true>), dim3(1, (unsigned)h->cur_S), dim3(128), 0, h->cur_stream, h->M, td, 1, h->Nf,
+                       h->n - 1, Bst, active, h->d_U, h->d_E, h->d_f, h->d_linA, h->d_w, h->cur_s0);
+    hipLaunchKernelGGL((k_lin_back<true>), dim3(1, (unsigned)h->cur_S), dim3(128), 0, h->cur_stream, h->M, td, 1, h->Nf,
+                       h->n - 1, Bst, active, h->d_U, h->d_E, h->d_linA, h->d_w, h->d_x, h->d_f, h->cur_s0);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        h->last_detail = (int)e;
+        return HPF_E_HIP;
+    }
+    return HPF_OK;
+}
+
 int tree_newton_step(hpf_handle* h, bool only_active) {
     Tree& T = h->tree;
     const int* active = only_active ? h->d_active : nullptr;
@@ -1110,7 +1176,7 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
     const int Bst = BW ? BW : b;
     {
         if (lin_threads > 0) {
-            hipLaunchKernelGGL(k_lin_factor, dim3((unsigned)((lin_threads + 127) / 128), (unsigned)h->cur_S), dim3(128), 0,
+            hipLaunchKernelGGL((k_lin_factor<false>), dim3((unsigned)((lin_threads + 127) / 128), (unsigned)h->cur_S), dim3(128), 0,
                                h->cur_stream, h->M, td, T.n_lin_roots, h->N, h->Nc, Bst, active, h->d_U, h->d_E, h->d_f,
                                h->d_linA, h->d_w, h->cur_s0);
             hipError_t e = hipGetLastError();
@@ -1180,7 +1246,7 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
         if (r) return r;
     }
     if (lin_threads > 0) {
-        hipLaunchKernelGGL(k_lin_back, dim3((unsigned)((lin_threads + 127) / 128), (unsigned)h->cur_S), dim3(128), 0, h->cur_stream,
+        hipLaunchKernelGGL((k_lin_back<false>), dim3((unsigned)((lin_threads + 127) / 128), (unsigned)h->cur_S), dim3(128), 0, h->cur_stream,
                            h->M, td, T.n_lin_roots, h->N, h->Nc, Bst, active, h->d_U, h->d_E, h->d_linA, h->d_w, h->d_x,
                            h->d_f, h->cur_s0);
         hipError_t e = hipGetLastError();

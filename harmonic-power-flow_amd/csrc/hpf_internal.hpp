@@ -33,6 +33,7 @@ struct Tree {
     std::vector<int> lin;             // [n] 1: the whole subtree of the bus is linear -> harmonic-diagonal 2x2 algebra
     std::vector<int> lin_ptr;         // [n_lin_roots+1] into lin_post
     std::vector<int> lin_post;        // post-order node lists of the maximal linear subtrees
+    std::vector<int> all_ptr, all_post;   // the whole tree as one post-order list (fundamental power flow)
     int n_lin_roots = 0;
     int n_dense = 0;
     int* d_parent = nullptr;
@@ -46,6 +47,8 @@ struct Tree {
     int* d_lin = nullptr;
     int* d_lin_ptr = nullptr;
     int* d_lin_post = nullptr;
+    int* d_all_ptr = nullptr;
+    int* d_all_post = nullptr;
     double flops_per_solve = 0.0;     // factor sweep + back sweep
     double flops_factor = 0.0;        // factor sweep only (k_tree_factor, all levels)
 };
@@ -133,6 +136,7 @@ struct ScopedTimer {
 int tree_build(hpf_handle* h, const hpf_desc* d);
 void tree_free(hpf_handle* h);
 int tree_alloc_scenarios(hpf_handle* h);
+int tree_fund_step(hpf_handle* h, bool only_active);     // fundamental pf Newton step on the tree (2x2 blocks)
 int tree_newton_step(hpf_handle* h, bool only_active);   // assembles, eliminates, back-substitutes -> d_f holds the step
 
 }  // namespace hpf

@@ -427,7 +427,7 @@ int launch_update(hpf_handle* h, const int* active) {
 template <bool FUND>
 int newton_step(hpf_handle* h, const int* active) {
     int r;
-    if (!FUND && h->solver == HPF_SOLVER_BLOCK_TREE) return tree_newton_step(h, active != nullptr);
+    if (h->solver == HPF_SOLVER_BLOCK_TREE) return FUND ? tree_fund_step(h, active != nullptr) : tree_newton_step(h, active != nullptr);
     const int Nsys = FUND ? h->Nf : h->N;
     if ((r = ensure_dense(h, Nsys))) return r;
     if ((r = launch_jacobian_dense<FUND>(h, active))) return r;
@@ -503,7 +503,7 @@ int nr_loop(hpf_handle* h, double thresh, int max_iter, int* n_iter, double* err
         HIPCHK(hipMemcpyAsync(act.data(), h->d_active, sizeof(int) * S, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         nactive = count_active();
-        if (FUND || h->solver == HPF_SOLVER_DENSE)
+        if (h->solver == HPF_SOLVER_DENSE)
             if ((r = check_info(h, was))) return r;
         ++it;
     }

@@ -266,8 +266,13 @@ def test_block_tree_step_equals_dense_step(tmp_path, coupled, hmax):
         try:
             dm.set_loads(buses["P"].to_numpy(float), buses["Q"].to_numpy(float))
             dm.set_state(None, None, n_scen=1)
-            dm.fund_pf(1e-6, 30)
+            dm.fund_pf(1e-6, 30)                       # dense: rocSOLVER; block_tree: 2x2 elimination along the tree
             v0 = dm.get_state()
+            if "dense" in out:                         # same start for the step comparison (the pf seeds agree to round-off)
+                np.testing.assert_allclose(v0[0], out["dense"][0][0], rtol=0, atol=1e-13)
+                np.testing.assert_allclose(v0[1], out["dense"][0][1], rtol=0, atol=1e-13)
+                v0 = out["dense"][0]
+                dm.set_state(v0[0], v0[1])
             dm.mismatch()
             dm.iterate(1)
             dm.sync()
@@ -279,7 +284,6 @@ def test_block_tree_step_equals_dense_step(tmp_path, coupled, hmax):
         finally:
             dm.close()
     (v0d, v1d, ed, v3d), (v0b, v1b, eb, v3b) = out["dense"], out["block_tree"]
-    assert np.array_equal(v0d[0], v0b[0])
     step = np.abs(v1d[0] - v0d[0]).max()
     assert step > 1e-3
     assert np.abs(v1d[0] - v1b[0]).max() <= 1e-10 * max(1.0, step)
