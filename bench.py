@@ -151,11 +151,16 @@ def main():
     sweep = None
     if not args.no_finish:
         dm.set_state(seed[0], seed[1])
+        torch.cuda.synchronize()
+        t_sw = time.perf_counter()
         n_iter, err, _ = dm.solve(inp["st"].thresh_h, inp["st"].max_iter_h)
+        t_sw = time.perf_counter() - t_sw
         rec = torch.empty((S, 24), dtype=torch.uint8, device="cuda")
         dm.stats_to_device(rec.data_ptr())
         allrec = gather_stats(rec if backend == "nccl" else rec.cpu(), world)
         sweep = summarize(allrec.cpu().numpy())
+        sweep["solve_wall_s_rank0"] = t_sw        # hpf_solve of this rank's scenarios with the reference's stop rule (untimed leg)
+        sweep["iters_per_s_rank0"] = float(n_iter.sum()) / t_sw
 
     if rank != 0:
         if world > 1:

@@ -170,9 +170,10 @@ __global__ void k_update(int n, int c, int count, int stride, int N, int Nc, con
 __global__ void k_finalize(int S, int first, double thresh, int max_iter, int hist_cap, int hist_off,
                            const unsigned long long* __restrict__ errbits, double* __restrict__ err,
                            int* __restrict__ niter, int* __restrict__ active, int* __restrict__ nactive,
-                           double* __restrict__ hist) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= S) return;
+                           double* __restrict__ hist, int s0) {
+    const int sl = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sl >= S) return;
+    const int s = sl + s0;
     if (first) {
         const double e = __longlong_as_double((long long)errbits[s]);
         err[s] = e;
@@ -470,7 +471,7 @@ int nr_loop(hpf_handle* h, double thresh, int max_iter, int* n_iter, double* err
     if ((r = launch_mismatch<FUND>(h, nullptr))) return r;
     HIPCHK(hipMemsetAsync(h->d_nactive, 0, sizeof(int), h->stream));
     hipLaunchKernelGGL(k_finalize, dim3((S + 63) / 64), dim3(64), 0, h->stream, S, 1, thresh, max_iter, h->hist_cap,
-                       hist_off, h->d_errbits, h->d_err, h->d_niter, h->d_active, h->d_nactive, h->d_hist);
+                       hist_off, h->d_errbits, h->d_err, h->d_niter, h->d_active, h->d_nactive, h->d_hist, 0);
     std::vector<int> act(S), was(S);
     auto count_active = [&]() {
         int c = 0;
@@ -481,13 +482,24 @@ int nr_loop(hpf_handle* h, double thresh, int max_iter, int* n_iter, double* err
     HIPCHK(hipStreamSynchronize(h->stream));
     int nactive = count_active();
     int it = 0;
+    // The per-scenario stop rule lives on the device (k_finalize after every iteration, in the scenario group's own pipeline), so
+    // the host only has to notice when NO scenario is active any more: it looks every `chunk` iterations.  Frozen scenarios are
+    // skipped by every kernel, so looking late changes nothing in the results.
+    const int chunk = (!FUND && h->solver == HPF_SOLVER_BLOCK_TREE) ? 4 : 1;
     while (nactive > 0 && it < max_iter) {
         was = act;
+        const int todo = (max_iter - it) < chunk ? (max_iter - it) : chunk;
         auto body = [&]() -> int {
             int rr;
-            if ((rr = newton_step<FUND>(h, h->d_active))) return rr;
-            if ((rr = launch_update<FUND>(h, h->d_active))) return rr;
-            return launch_mismatch<FUND>(h, h->d_active);
+            for (int j = 0; j < todo; ++j) {
+                if ((rr = newton_step<FUND>(h, h->d_active))) return rr;
+                if ((rr = launch_update<FUND>(h, h->d_active))) return rr;
+                if ((rr = launch_mismatch<FUND>(h, h->d_active))) return rr;
+                hipLaunchKernelGGL(k_finalize, dim3((h->cur_S + 63) / 64), dim3(64), 0, h->cur_stream, h->cur_S, 0, thresh,
+                                   max_iter, h->hist_cap, hist_off, h->d_errbits, h->d_err, h->d_niter, h->d_active,
+                                   h->d_nactive, h->d_hist, h->cur_s0);
+            }
+            return HPF_OK;
         };
         if (FUND) {
             full_ctx(h);
@@ -496,16 +508,12 @@ int nr_loop(hpf_handle* h, double thresh, int max_iter, int* n_iter, double* err
             r = for_groups(h, body);
         }
         if (r) return r;
-        HIPCHK(hipMemsetAsync(h->d_nactive, 0, sizeof(int), h->stream));
-        hipLaunchKernelGGL(k_finalize, dim3((S + 63) / 64), dim3(64), 0, h->stream, S, 0, thresh, max_iter,
-                           h->hist_cap, hist_off, h->d_errbits, h->d_err, h->d_niter, h->d_active, h->d_nactive,
-                           h->d_hist);
         HIPCHK(hipMemcpyAsync(act.data(), h->d_active, sizeof(int) * S, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         nactive = count_active();
         if (h->solver == HPF_SOLVER_DENSE)
             if ((r = check_info(h, was))) return r;
-        ++it;
+        it += todo;
     }
     h->mismatch_valid = false;   // frozen scenarios leave stale rows in d_f: hpf_mismatch before hpf_iterate
     if (n_iter) HIPCHK(hipMemcpy(n_iter, h->d_niter, sizeof(int) * S, hipMemcpyDeviceToHost));
