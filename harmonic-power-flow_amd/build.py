@@ -5,7 +5,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["hpf_lib.hip", "hpf_block.hip"]
-HEADERS = ["hpf_assembly.hpp", "hpf_internal.hpp", "hpf_gj.hpp", "hpf_gj_mfma.hpp", os.path.join("..", "..", "include", "hpf.h")]
+HEADERS = ["hpf_assembly.hpp", "hpf_internal.hpp", "hpf_gj.hpp", "hpf_gj_mfma.hpp", "hpf_quad.hpp", os.path.join("..", "..", "include", "hpf.h")]
 OUT = os.path.join(HERE, "libhpf.so")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 
@@ -23,8 +23,10 @@ def build_lib(force=False, verbose=False, stamps=False):
     out = os.path.join(HERE, "libhpf_stamps.so") if stamps else OUT
     if not stamps and not force and not needs_build():
         return OUT
+    extra = os.environ.get("HPF_CFLAGS", "").split()          # experiments: e.g. HPF_CFLAGS=-DHPF_Q_OCC=5 HPF_BUILD_OUT=tools/bin/x.so
+    out = os.environ.get("HPF_BUILD_OUT", out)
     cmd = [os.path.join(ROCM, "bin", "hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
-           "-Wno-unused-value", "-fPIC", "-shared"] + (["-DHPF_FACTOR_STAMPS"] if stamps else []) + \
+           "-Wno-unused-value", "-fPIC", "-shared"] + (["-DHPF_FACTOR_STAMPS"] if stamps else []) + extra + \
           [os.path.join(CSRC, f) for f in SOURCES] + \
           ["-o", out, "-L" + os.path.join(ROCM, "lib"), "-lrocsolver", "-lrocblas",
            "-Wl,-rpath," + os.path.join(ROCM, "lib")]

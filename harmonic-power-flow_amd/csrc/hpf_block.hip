@@ -625,7 +625,7 @@ __global__ __launch_bounds__(64, MODE == 1 ? 2 : 1) void k_factor_w(Model M, Tre
             }
         }
         HPF_STAMP(st3);
-        gauss_jordan_mfma<NT>(ct, (b + 3) / 4, panel);
+        gauss_jordan_mfma<NT, B / 4>(ct, panel);
         HPF_STAMP(st4);
         tiles_to_global<B, NT>(ct, lane, tbuf, As + (size_t)k * BB, ws + (size_t)k * B);
         HPF_STAMP(st5);
@@ -912,6 +912,8 @@ int launch_back_w(hpf_handle* h, const TreeDev& T, const int* nodes, int count, 
     return HPF_OK;
 }
 
+#include "hpf_quad.hpp"
+
 // padded block size of the wave-per-bus path (0: use the 256-thread generic kernels)
 int wave_block_size(int b) { return b <= 12 ? 12 : (b <= 28 ? 28 : (b <= 52 ? 52 : 0)); }
 
@@ -1128,7 +1130,8 @@ int tree_alloc_scenarios(hpf_handle* h) {
     const int bw = wave_block_size(2 * h->Hn);
     const size_t b = bw ? (size_t)bw : 2 * (size_t)h->Hn, S = h->S_max, n = h->n;
     hipError_t e;
-    if ((e = hipMalloc((void**)&h->d_Z, sizeof(double) * S * n * b * b)) != hipSuccess ||
+    const size_t ct = bw ? (size_t)(((bw + 16) / 16) * ((bw + 16) / 16) * 256) : 0;     // accumulator-tile image of a block
+    if ((e = hipMalloc((void**)&h->d_Z, sizeof(double) * S * n * (b * b > ct ? b * b : ct))) != hipSuccess ||
         (e = hipMalloc((void**)&h->d_w, sizeof(double) * S * n * b)) != hipSuccess ||
         (e = hipMalloc((void**)&h->d_x, sizeof(double) * S * n * b)) != hipSuccess ||
         (e = hipMalloc((void**)&h->d_linA, sizeof(double) * S * n * (size_t)h->Hn * 4)) != hipSuccess ||
@@ -1208,9 +1211,16 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
             int r;
             ScopedTimer t(h, T_SOLVE);          // one span per k_factor_w launch (what rocprofv3 --stats averages)
             switch (BW) {
-                case 12: r = h->gj_mode ? launch_factor_w<12, 1>(h, td, nodes, cnt, active) : launch_factor_w<12, 0>(h, td, nodes, cnt, active); break;
-                case 28: r = h->gj_mode ? launch_factor_w<28, 1>(h, td, nodes, cnt, active) : launch_factor_w<28, 0>(h, td, nodes, cnt, active); break;
-                case 52: r = h->gj_mode ? launch_factor_w<52, 1>(h, td, nodes, cnt, active) : launch_factor_w<52, 0>(h, td, nodes, cnt, active); break;
+#define HPF_FACTOR_CASE(BB_)                                                                                  \
+    case BB_:                                                                                                 \
+        r = h->gj_mode == 1 ? launch_factor_q<BB_>(h, td, nodes, cnt, active)                                 \
+            : (h->gj_mode == 2 ? launch_factor_w<BB_, 1>(h, td, nodes, cnt, active)                           \
+                               : launch_factor_w<BB_, 0>(h, td, nodes, cnt, active));                         \
+        break
+                HPF_FACTOR_CASE(12);
+                HPF_FACTOR_CASE(28);
+                HPF_FACTOR_CASE(52);
+#undef HPF_FACTOR_CASE
                 default:
                     switch (R) {
                         case 4: r = launch_factor<4>(h, td, nodes, cnt, active); break;
@@ -1230,9 +1240,9 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
         const int* nodes = T.d_dep_nodes + T.dep_ptr[dl];
         int r = HPF_OK;
         switch (BW) {
-            case 12: r = launch_back_w<12>(h, td, nodes, cnt, active); break;
-            case 28: r = launch_back_w<28>(h, td, nodes, cnt, active); break;
-            case 52: r = launch_back_w<52>(h, td, nodes, cnt, active); break;
+            case 12: r = h->gj_mode == 1 ? launch_back_q<12>(h, td, nodes, cnt, active) : launch_back_w<12>(h, td, nodes, cnt, active); break;
+            case 28: r = h->gj_mode == 1 ? launch_back_q<28>(h, td, nodes, cnt, active) : launch_back_w<28>(h, td, nodes, cnt, active); break;
+            case 52: r = h->gj_mode == 1 ? launch_back_q<52>(h, td, nodes, cnt, active) : launch_back_w<52>(h, td, nodes, cnt, active); break;
             default: {
                 hipLaunchKernelGGL(k_tree_back, dim3((unsigned)cnt, (unsigned)h->cur_S), dim3(256), 0, h->cur_stream, h->n, h->c,
                                    h->Hn, td, nodes, b, h->N, h->Nc, active, h->d_Z, h->d_w, h->d_x, h->d_f, h->cur_s0);

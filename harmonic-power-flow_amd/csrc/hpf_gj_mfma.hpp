@@ -24,9 +24,19 @@ __device__ __forceinline__ double rl_f64(double v, int lane_uniform) {
     return __hiloint2double(hi, lo);
 }
 
+// reciprocal on the pivot critical path: v_rcp_f64 (~2^-23 relative) + two Newton steps -> within 1 ulp of 1/x, a third of
+// the latency of the IEEE division sequence
+__device__ __forceinline__ double rcp_nr(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-x, r, 1.0);
+    return fma(r, e, r);
+}
+
 // inverse of a 2x2 [a b; c d]
 __device__ __forceinline__ void inv2(double a, double b, double c, double d, double& ia, double& ib, double& ic, double& id) {
-    const double r = 1.0 / fma(a, d, -(b * c));
+    const double r = rcp_nr(fma(a, d, -(b * c)));
     ia = d * r;
     ib = -b * r;
     ic = -c * r;
@@ -61,14 +71,45 @@ __device__ __forceinline__ void inv4(const double (&m)[4][4], double (&w)[4][4])
     w[1][0] = p10 - fma(u10, y00, u11 * y10); w[1][1] = p11 - fma(u10, y01, u11 * y11);
 }
 
-// c: NT x NT accumulator tiles; nbs: number of 4x4 block steps to perform (ceil(b/4)); panel: LDS, NT*64 + 16 doubles.
-template <int NT>
-__device__ __forceinline__ void gauss_jordan_mfma(d4_t (&c)[NT][NT], int nbs, double* panel) {
+// Lane-parallel inverse of a 4x4 block held in LDS (pv[r*4+c], row-major): lane l computes ONE cofactor, (i, j) = ((l>>2)&3,
+// l&3), from nine lane-addressed LDS reads; the determinant is the Laplace expansion along row i, summed over the lane quad
+// with two DPP steps; returns W[j][i] = C_ij / det (the lane's element of the inverse, transposed position).  ~20 dependent
+// FP64 operations instead of the ~80 of the uniform Schur-complement form (inv4), no v_readlane.  Every lane of the wave
+// takes part (lanes >= 16 repeat the pattern).
+__device__ __forceinline__ double inv4_cofactor_lane(const double* pv, int lane) {
+    const int i = (lane >> 2) & 3, j = lane & 3;
+    const int r0 = i == 0 ? 1 : 0, r1 = i <= 1 ? 2 : 1, r2 = i == 3 ? 2 : 3;
+    const int c0 = j == 0 ? 1 : 0, c1 = j <= 1 ? 2 : 1, c2 = j == 3 ? 2 : 3;
+    const double a00 = pv[r0 * 4 + c0], a01 = pv[r0 * 4 + c1], a02 = pv[r0 * 4 + c2];
+    const double a10 = pv[r1 * 4 + c0], a11 = pv[r1 * 4 + c1], a12 = pv[r1 * 4 + c2];
+    const double a20 = pv[r2 * 4 + c0], a21 = pv[r2 * 4 + c1], a22 = pv[r2 * 4 + c2];
+    const double aij = pv[i * 4 + j];
+    const double m0 = fma(a11, a22, -(a12 * a21));
+    const double m1 = fma(a10, a22, -(a12 * a20));
+    const double m2 = fma(a10, a21, -(a11 * a20));
+    double cof = fma(a02, m2, fma(a00, m0, -(a01 * m1)));
+    cof = ((i + j) & 1) ? -cof : cof;
+    double det = aij * cof;
+    {
+        int lo = __double2loint(det), hi = __double2hiint(det);
+        det += __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xf, 0xf, false),
+                                __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xf, 0xf, false));       // quad_perm [1,0,3,2]
+        lo = __double2loint(det), hi = __double2hiint(det);
+        det += __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xf, 0xf, false),
+                                __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xf, 0xf, false));       // quad_perm [2,3,0,1]
+    }
+    return cof * rcp_nr(det);
+}
+
+// c: NT x NT accumulator tiles; NBS: number of 4x4 block steps (compile time: identity-padded rows / columns are no-ops,
+// and a fixed step count keeps the accumulators in place between steps); panel: LDS, NT*64 + 16 doubles.
+template <int NT, int NBS>
+__device__ __forceinline__ void gauss_jordan_mfma(d4_t (&c)[NT][NT], double* panel) {
     const int lane = threadIdx.x, lg = lane >> 4, jj = lane & 15;
     double* wl = panel + NT * 64;
 #pragma unroll
-    for (int s = 0; s < NT * 4; ++s) {
-        if (s < nbs) {
+    for (int s = 0; s < NBS; ++s) {
+        {
             constexpr int dummy = 0;
             (void)dummy;
             const int tP = s >> 2, rg = s & 3, j0 = 4 * (s & 3);

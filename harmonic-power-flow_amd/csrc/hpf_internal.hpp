@@ -62,7 +62,7 @@ struct hpf_handle {
     int N = 0, Nc = 0, Nf = 0;
     bool loads_set = false, state_set = false, mismatch_valid = false;
     int last_detail = 0;
-    int gj_mode = 1;                  // BLOCK_TREE block inversion: 0 pivoted wave Gauss-Jordan (VALU), 1 MFMA static 4x4 blocks
+    int gj_mode = 1;                  // BLOCK_TREE block inversion: 0 pivoted wave Gauss-Jordan (VALU), 1 MFMA static 4x4 blocks, NT waves per bus (hpf_quad.hpp), 2 same, one wave per bus
     int debug_ablate = 0;             // HPF_DEBUG_ABLATE: timing-only ablation of factor-kernel phases (results invalid)
 
     // model (device)

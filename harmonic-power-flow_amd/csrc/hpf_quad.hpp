@@ -1,0 +1,479 @@
+// BLOCK_TREE factor / back-substitution kernels with ONE WORKGROUP OF NT WAVEFRONTS per (bus, scenario) pair.
+//
+// The bus block (b x b, padded to 16*NT with the right-hand side in column B) lives in FP64 MFMA accumulator tiles, as in
+// hpf_gj_mfma.hpp, but wave `wv` of the workgroup owns tile COLUMN wv only (NT tiles = 8*NT VGPRs instead of 8*NT*NT), so 5-6
+// waves fit on a SIMD instead of 2 and the latency-bound phases of one block (assembly loads, child Schur complements, stores)
+// run NT-wide while other blocks keep the matrix cores busy.  Column ownership makes the blocked Gauss-Jordan step local:
+//   - new pivot rows  W * A_P,:  of the own column tile: the old rows sit in the own accumulators in B-operand layout;
+//   - the pivot columns (A operand of every wave) and W = A_PP^-1 come from the wave that owns tile column s>>2, through a
+//     double-buffered LDS panel -> one workgroup barrier per block step, 1 + NT MFMAs per wave and step;
+//   - the child -> parent Schur complement G A^-1 H (schur_tiles) needs lane^1 / lane^16 partners only: no cross-wave traffic.
+// The un-eliminated block is assembled directly in tile layout: lane (lg, jj) of wave wv holds column 16*wv+jj = (harmonic
+// p, component t') and rows 16*tr + lg + 4*reg, so its Norton cross terms (HG:425-435) are 4*NT independent Y_N loads times
+// two per-lane constants.  The harmonic-diagonal part (network entry, linear children) is computed per row by wave 0 and
+// patched in through LDS.
+//
+// HBM layout of the inverse for the back sweep: accumulator tiles [tile tr*NT+tc][reg][lane] (512-byte coalesced rows), the
+// same layout as the Schur-complement slots; w = A^-1 y additionally goes to the [bus][B] array shared with the linear-subtree
+// kernels.
+#pragma once
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// sum over the 16 lanes of a DPP row (all lanes receive it)
+__device__ __forceinline__ double row_sum16(double v) {
+    v += dpp_f64<0xB1>(v);     // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E>(v);     // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141>(v);    // row_half_mirror
+    v += dpp_f64<0x140>(v);    // row_mirror
+    return v;
+}
+
+#ifndef HPF_Q_OCC
+#define HPF_Q_OCC 4        // waves per SIMD the B = 52 factor kernel is compiled for (register budget 512 / HPF_Q_OCC)
+#endif
+
+template <int B>
+__global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? HPF_Q_OCC : 5)) void k_factor_q(
+    Model M, TreeDev T, const int* __restrict__ nodes, int b, int N, int Nc, const int* __restrict__ active,
+    const cplx* __restrict__ Uall, const cplx* __restrict__ Eall, const double* __restrict__ fall, double* __restrict__ Zall,
+    double* __restrict__ wall, const double* __restrict__ linAall, double* __restrict__ Call, double* __restrict__ Hall,
+    long long* __restrict__ dbg, int ablate, int s0) {
+    constexpr int NT = (B + 16) / 16;
+    constexpr size_t CT = (size_t)NT * NT * 256;
+    constexpr int tcB = B >> 4, jjB = B & 15;
+    HPF_STAMP_DECL;      // cycle stamps of wave 0: -DHPF_FACTOR_STAMPS build only
+#ifdef HPF_FACTOR_STAMPS
+    long long sa = 0, sc = 0, gown = 0, gwait = 0, gmf = 0;
+#endif
+    HPF_STAMP(st0);
+    const int s = blockIdx.y + s0;
+    if (active && !active[s]) return;
+    const int k = nodes[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, lg = lane >> 4, jj = lane & 15;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = M.n, c = M.c, Hn = M.Hn;
+    const size_t so = (size_t)s * n * Hn;
+    const cplx* U = Uall + so;
+    const cplx* E = Eall + so;
+
+    __shared__ double tab[(B / 2) * 8];
+    __shared__ double dgb[64 * 3];          // per row: harmonic-diagonal 2x2 part (d0, d1) and right-hand side y
+    __shared__ double cc[NT][64 * 3];       // the linear children's contributions to (d0, d1, y), one slot per wave
+    __shared__ double panel[2][NT * 64];
+    __shared__ double wl[2][16], pv[2][16];
+    __shared__ double gl[NT * 32], hl[NT * 32];
+
+    const int par = T.parent[k];
+    const int lin_beg = T.child_ptr[k], lin_end = T.child_mid[k], den_end = T.child_ptr[k + 1];
+    const bool nl = k >= M.m && M.coupled;
+    const int col = 16 * wv + jj, p = col >> 1, t1 = col & 1;      // own column = (harmonic position p, component t1)
+    const int t = lg & 1;                                          // component of every row this lane holds
+
+    // ---- B0. Schur complement of the FIRST dense child (accumulator layout, own tile column): the loads are issued here and
+    //      first touched after the assembly, so their HBM latency hides behind it ----------------------------------------------
+    const double* Cs = Call + (size_t)s * n * CT;
+    double sumc[NT * 4];
+#pragma unroll
+    for (int e = 0; e < NT * 4; ++e) sumc[e] = 0.0;
+    if (lin_end < den_end) {
+        const double* Cc = Cs + (size_t)T.child[lin_end] * CT + lane;
+#pragma unroll
+        for (int e = 0; e < NT * 4; ++e)
+            if (16 * (e >> 2) + 4 * (e & 3) < B) sumc[e] = Cc[(size_t)(((e >> 2) * NT + wv) * 4 + (e & 3)) * 64];
+    }
+
+    // ---- A1. roles before the first barrier.  Last wave: bus voltages of the Norton cross terms -> LDS --------------------
+    if (nl && wv == NT - 1 && lane < Hn) {
+        const cplx u = U[(size_t)lane * n + k], e = E[(size_t)lane * n + k];
+        double* t0 = tab + lane * 4;
+        double* t1p = tab + (B / 2) * 4 + lane * 4;
+        t0[0] = u.re;   t0[1] = u.im;    t0[2] = e.im;    t0[3] = -e.re;
+        t1p[0] = u.im;  t1p[1] = -u.re;  t1p[2] = -e.re;  t1p[3] = -e.im;
+    }
+    // wave 1: coupling blocks with the parent, G = A(parent, k) and H = A(k, parent), for the push (E) and the back sweep
+    if (par >= 0 && wv == (NT > 1 ? 1 : 0) && lane < NT * 8) {
+        double g4[4] = {0.0, 0.0, 0.0, 0.0}, h4[4] = {0.0, 0.0, 0.0, 0.0};
+        if (lane < Hn) {
+            coupling_block(M, U, E, lane, par, k, T.e_dn[k], g4);
+            coupling_block(M, U, E, lane, k, par, T.e_up[k], h4);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            gl[lane * 4 + e] = g4[e];
+            hl[lane * 4 + e] = h4[e];
+        }
+        if (lane < Hn) {
+            double* Hk = Hall + ((size_t)s * n + k) * Hn * 4 + lane * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Hk[e] = h4[e];
+        }
+    }
+    {
+        // lane = row 2q+tr_: wave 0 forms the network part of the harmonic-diagonal 2x2 and the right-hand side; the children
+        // whose whole subtree is linear (harmonic-diagonal Schur complements, k_lin_factor) are dealt round-robin to the waves
+        const int q = lane >> 1, tr_ = lane & 1;
+        const bool rowvalid = lane < b && loc_valid(n, c, k, lane);
+        if (wv == 0) {
+            double y = 0.0, d0 = 0.0, d1 = 0.0;
+            if (rowvalid) {
+                const double* f = fall + (size_t)s * N;
+                const int kst = q * n + k;
+                y = tr_ ? f[Nc + kst - c] : f[kst - 1];
+                const int diag_e = M.diag[k];
+                const Blk2 blk = (q == 0 && k < M.m) ? jac_power_entry<false>(M, U, E, k, k, diag_e)
+                                                      : jac_current_entry(M, U, E, q, k, k, diag_e);
+                d0 = pick(blk, tr_, 0);
+                d1 = pick(blk, tr_, 1);
+            }
+            dgb[lane * 3 + 0] = d0;
+            dgb[lane * 3 + 1] = d1;
+            dgb[lane * 3 + 2] = y;
+        }
+        if (lin_beg + wv < lin_end) {
+            double e0 = 0.0, e1 = 0.0, ey = 0.0;
+            if (rowvalid) {
+                const double* ws = wall + (size_t)s * n * B;
+                const double* linA = linAall + so * 4;
+                for (int cp = lin_beg + wv; cp < lin_end; cp += NT) {
+                    const int ch = T.child[cp];
+                    const Blk2 g = offdiag_block(M, U, E, q, k, ch, T.e_dn[ch]);     // A(parent, child), my harmonic
+                    const double g0 = pick(g, tr_, 0);
+                    const double g1 = loc_valid(n, c, ch, 2 * q + 1) ? pick(g, tr_, 1) : 0.0;
+                    double h4[4];
+                    coupling_block(M, U, E, q, ch, k, T.e_up[ch], h4);               // A(child, parent)
+                    const double* ic = linA + ((size_t)ch * Hn + q) * 4;
+                    const double v0 = fma(g1, ic[2], g0 * ic[0]), v1 = fma(g1, ic[3], g0 * ic[1]);
+                    e0 += fma(v1, h4[2], v0 * h4[0]);
+                    e1 += fma(v1, h4[3], v0 * h4[1]);
+                    const double* wc = ws + (size_t)ch * B;
+                    ey = fma(g0, wc[2 * q], ey);
+                    ey = fma(g1, wc[2 * q + 1], ey);
+                }
+            }
+            cc[wv][lane * 3 + 0] = e0;
+            cc[wv][lane * 3 + 1] = e1;
+            cc[wv][lane * 3 + 2] = ey;
+        }
+    }
+    __syncthreads();
+    HPF_STAMP(sa);
+    {
+        const int nw = (lin_end - lin_beg) < NT ? (lin_end - lin_beg) : NT;
+        for (int idx = tid; idx < 64 * 3; idx += 64 * NT) {
+            double v = dgb[idx];
+            for (int w2 = 0; w2 < nw; ++w2) v -= cc[w2][idx];       // fixed order
+            dgb[idx] = v;
+        }
+    }
+
+    // ---- A3. own tile column: Norton cross terms -Y_N[q,p] * (jU | E)_{p,k} picked Re/Im (assemble_row's component form:
+    //      v = yi*P + yr*Q, (P,Q) depend on (t, t', p) only -> two per-lane constants) ----------------------------------------
+    d4_t ct[NT];
+#pragma unroll
+    for (int tr = 0; tr < NT; ++tr) ct[tr] = d4_t{0.0, 0.0, 0.0, 0.0};
+    if (nl) {
+        const int pp = p < B / 2 ? p : 0;
+        const double P = tab[t * (B / 2) * 4 + pp * 4 + 2 * t1];
+        const double Q = tab[t * (B / 2) * 4 + pp * 4 + 2 * t1 + 1];
+        const cplx* yn = M.YN + (size_t)M.dev[k] * Hn * Hn + (p < Hn ? p : 0);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            cplx ynb[NT * 2];
+#pragma unroll
+            for (int e = 0; e < NT * 2; ++e) {
+                const int tr = (half * NT * 2 + e) >> 2, reg = (half * NT * 2 + e) & 3;
+                const int q = 8 * tr + 2 * reg + (lg >> 1);
+                ynb[e] = yn[(size_t)(q < Hn ? q : 0) * Hn];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < NT * 2; ++e) {
+                const int tr = (half * NT * 2 + e) >> 2, reg = (half * NT * 2 + e) & 3;
+                ct[tr][reg] = ynb[e].im * P + ynb[e].re * Q;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    HPF_STAMP(sc);
+    __syncthreads();
+    // ---- A4. patch (selects only): harmonic-diagonal 2x2, right-hand side in column B, identity padding for missing
+    //      unknowns / equations (slack and PV buses at harmonic position 0; rows / columns beyond b) ---------------------------
+    {
+        const bool cvalid = col < b && (col >= 2 || (col == 0 ? k >= 1 : k >= c));
+        const bool colB = col == B, colgt = col > B;
+        const int dsel = colB ? 2 : t1;
+#pragma unroll
+        for (int tr = 0; tr < NT; ++tr)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int row = 16 * tr + 4 * reg + lg;
+                const double ident = (row == col) ? 1.0 : 0.0;
+                if (16 * tr + 4 * reg >= B) {                        // compile-time: identity rows beyond the block
+                    ct[tr][reg] = ident;
+                } else {
+                    bool rv = row < b;
+                    if (tr == 0 && reg == 0) rv = rv && (lg >= 2 || (lg == 0 ? k >= 1 : k >= c));
+                    const double dv = dgb[row * 3 + dsel];
+                    double v = ct[tr][reg];
+                    v = ((row >> 1) == p) ? dv : v;
+                    v = (rv && cvalid) ? v : ident;
+                    v = colB ? dv : v;
+                    v = colgt ? 0.0 : v;
+                    ct[tr][reg] = v;
+                }
+            }
+    }
+    HPF_STAMP(st1);
+
+    // ---- B. remaining dense children (fixed order), then subtract the sum -----------------------------------------------------
+    for (int cp = lin_end + 1; cp < den_end; ++cp) {
+        const double* Cc = Cs + (size_t)T.child[cp] * CT + lane;
+        double tmp[NT * 4];
+#pragma unroll
+        for (int e = 0; e < NT * 4; ++e)
+            if (16 * (e >> 2) + 4 * (e & 3) < B) tmp[e] = Cc[(size_t)(((e >> 2) * NT + wv) * 4 + (e & 3)) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < NT * 4; ++e)
+            if (16 * (e >> 2) + 4 * (e & 3) < B) sumc[e] += tmp[e];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int e = 0; e < NT * 4; ++e)
+        if (16 * (e >> 2) + 4 * (e & 3) < B) ct[e >> 2][e & 3] -= sumc[e];
+
+    HPF_STAMP(st3);
+    // ---- C. blocked Gauss-Jordan, static 4x4 pivot blocks (hpf_gj_mfma.hpp), tile columns spread over the waves ------------
+    // (all B/4 block steps are always performed: rows / columns beyond b are identity-padded, their steps are no-ops in
+    //  exact arithmetic, and a step count known at compile time keeps the accumulators in place -- no copies between steps)
+#pragma unroll
+    for (int st = 0; st < B / 4; ++st) {
+        {
+            const int tP = st >> 2, rg = st & 3, j0 = 4 * (st & 3), buf = st & 1;
+            const bool incol = jj >= j0 && jj < j0 + 4;
+#ifdef HPF_Q_PRIO
+            // the wave that owns the NEXT pivot block is the critical path of the block (its update MFMAs gate the pivot
+            // inverse): let it issue first on its SIMD
+            if (((st + 1) >> 2) == wv || tP == wv) __builtin_amdgcn_s_setprio(HPF_Q_PRIO); else __builtin_amdgcn_s_setprio(0);
+#endif
+#ifdef HPF_FACTOR_STAMPS
+            const long long g0_ = __builtin_amdgcn_s_memtime();
+#endif
+            if (wv == tP) {
+                // pivot block -> LDS scratch (the 16 lanes that hold it), lane-parallel cofactor inverse, W -> LDS; the pivot
+                // columns (64 x 4 panel) follow while the inverse's LDS reads are in flight
+                if (incol) pv[buf][lg * 4 + (jj - j0)] = ct[tP][rg];
+                const double wji = inv4_cofactor_lane(pv[buf], lane);
+                if (incol) {
+#pragma unroll
+                    for (int tr = 0; tr < NT; ++tr)
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) panel[buf][(16 * tr + lg + 4 * reg) * 4 + (jj - j0)] = ct[tr][reg];
+                }
+                if (lane < 16) wl[buf][(lane & 3) * 4 + (lane >> 2)] = wji;        // lane (i, j) holds W[j][i]
+            }
+#ifdef HPF_FACTOR_STAMPS
+            const long long g1_ = __builtin_amdgcn_s_memtime();
+#endif
+            __syncthreads();
+#ifdef HPF_FACTOR_STAMPS
+            const long long g2_ = __builtin_amdgcn_s_memtime();
+#endif
+            double aop[NT];
+#pragma unroll
+            for (int tr = 0; tr < NT; ++tr) {
+                const double v = panel[buf][(16 * tr + jj) * 4 + lg];
+                aop[tr] = (tr == tP && incol) ? 0.0 : -v;            // pivot rows are not updated by the rank-4 MFMA
+            }
+            const double aw = jj < 4 ? wl[buf][jj * 4 + lg] : 0.0;    // W padded to 16 x 4
+            const d4_t z = {0.0, 0.0, 0.0, 0.0};
+            const d4_t d = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, ct[tP][rg], z, 0, 0, 0);
+            double rfin = d[0];
+            if (wv == tP && incol) {
+                rfin = wl[buf][lg * 4 + (jj - j0)];                   // W itself in the pivot block; zeroed pivot columns
+#pragma unroll                                                        // make the update produce -A_iP W
+                for (int tr = 0; tr < NT; ++tr) ct[tr] = d4_t{0.0, 0.0, 0.0, 0.0};
+            }
+#pragma unroll
+            for (int tr = 0; tr < NT; ++tr) ct[tr] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[tr], rfin, ct[tr], 0, 0, 0);
+            ct[tP][rg] = rfin;
+#ifdef HPF_FACTOR_STAMPS
+            {
+                // wave 0: owner work (steps it owns), barrier wait and post-barrier section (read panel, MFMAs; the next stamp
+                // waits for the accumulators only where the next step's owner reads them)
+                const long long g3_ = __builtin_amdgcn_s_memtime();
+                if (tP == 0) gown += g1_ - g0_;
+                gwait += g2_ - g1_;
+                gmf += g3_ - g2_;
+            }
+#endif
+        }
+    }
+
+#ifdef HPF_Q_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    HPF_STAMP(st4);
+    // ---- D. inverse (tile layout) and w = A^-1 y ------------------------------------------------------------------------
+    {
+        double* Zk = Zall + ((size_t)s * n + k) * CT + lane;
+#pragma unroll
+        for (int tr = 0; tr < NT; ++tr)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+                if (16 * tr + 4 * reg < B) Zk[(size_t)((tr * NT + wv) * 4 + reg) * 64] = ct[tr][reg];
+        if (wv == tcB && jj == jjB) {
+            double* wk = wall + ((size_t)s * n + k) * B;
+#pragma unroll
+            for (int tr = 0; tr < NT; ++tr)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int row = 16 * tr + lg + 4 * reg;
+                    if (row < B) wk[row] = ct[tr][reg];
+                }
+        }
+    }
+
+    HPF_STAMP(st5);
+    // ---- E. push: Schur complement of this bus for its parent, C = G A^-1 H and G w in column B (schur_tiles on the own
+    //      tile column; gl / hl were staged in A1) ---------------------------------------------------------------------------
+    if (par >= 0) {
+        const int ti = lg & 1, tcn = jj & 1;
+        double ha = hl[p * 4 + 2 * tcn + tcn];              // H[tcn][tcn]
+        double hb = hl[p * 4 + 2 * (tcn ^ 1) + tcn];        // H[tcn^1][tcn]
+        if (col == B) {                                     // right-hand-side column: G w
+            ha = 1.0;
+            hb = 0.0;
+        }
+        if (col > B) {
+            ha = 0.0;
+            hb = 0.0;
+        }
+        double* Ck = Call + ((size_t)s * n + k) * CT + lane;
+#pragma unroll
+        for (int tr = 0; tr < NT; ++tr)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int q = 8 * tr + 2 * reg + (lg >> 1);
+                const double ga = gl[q * 4 + 2 * ti + ti];          // G[ti][ti]
+                const double gb = gl[q * 4 + 2 * ti + (ti ^ 1)];    // G[ti][ti^1]
+                const double own = ct[tr][reg];
+                const double rowp = xor16_f64(own);
+                const double colp = xor1_f64(own);
+                const double both = xor1_f64(rowp);
+                const double v = fma(gb, fma(both, hb, rowp * ha), ga * fma(colp, hb, own * ha));
+                if (16 * tr + 4 * reg < B) Ck[(size_t)((tr * NT + wv) * 4 + reg) * 64] = v;
+            }
+    }
+#ifdef HPF_FACTOR_STAMPS
+    if ((ablate & 16) && tid == 0 && dbg) {
+        st6 = __builtin_amdgcn_s_memtime();
+        long long* o = dbg + ((size_t)s * n + k) * 8;
+        o[0] = st1 - st0;   // assembly (+ linear children)
+        // packed sub-phases of the assembly (16 bits each, units of 16 cycles): roles up to barrier 1 | reduction + Y_N
+        o[1] = (((sa - st0) >> 4) & 0xffff) | ((((sc - sa) >> 4) & 0xffff) << 16) | (1ll << 62);
+        o[2] = ((gown >> 4) & 0xfffff) | (((gwait >> 4) & 0xfffff) << 20) | (((gmf >> 4) & 0xfffff) << 40);   // GJ split
+        o[3] = st4 - st3;   // MFMA Gauss-Jordan
+        o[4] = st5 - st4;   // inverse tiles, w
+        o[5] = st6 - st5;   // Schur push
+        o[6] = T.child_ptr[k + 1] - T.child_mid[k];
+        o[7] = (k >= M.m) | ((T.child_mid[k] - T.child_ptr[k]) << 1);
+    }
+#endif
+}
+
+// root -> leaves: x_k = w_k - D_k^{-1} (A(k,parent) x_parent), inverse in tile layout; wave wv multiplies its tile column,
+// the partial row sums meet in LDS.
+template <int B>
+__global__ __launch_bounds__(64 * ((B + 16) / 16)) void k_back_q(
+    Model M, TreeDev T, const int* __restrict__ nodes, int b, int N, int Nc, const int* __restrict__ active,
+    const double* __restrict__ Zall, const double* __restrict__ wall, double* __restrict__ xall, double* __restrict__ step,
+    const double* __restrict__ Hall, int s0) {
+    constexpr int NT = (B + 16) / 16;
+    constexpr size_t CT = (size_t)NT * NT * 256;
+    const int s = blockIdx.y + s0;
+    if (active && !active[s]) return;
+    const int k = nodes[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, lg = lane >> 4, jj = lane & 15;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = M.n, c = M.c, Hn = M.Hn;
+    double* xs = xall + (size_t)s * n * B;
+    __shared__ double part[NT][64];
+    const int par = T.parent[k];
+    double x = 0.0;
+    if (tid < B) x = wall[((size_t)s * n + k) * B + tid];
+    if (par >= 0) {
+        const double* Zk = Zall + ((size_t)s * n + k) * CT + lane;
+        double zr[NT * 4];
+#pragma unroll
+        for (int e = 0; e < NT * 4; ++e)
+            if (16 * (e >> 2) + 4 * (e & 3) < B) zr[e] = Zk[(size_t)(((e >> 2) * NT + wv) * 4 + (e & 3)) * 64];
+        const int col = 16 * wv + jj, p = col >> 1, t1 = col & 1;
+        double tv = 0.0;
+        if (col < b) {
+            const double* hk = Hall + ((size_t)s * n + k) * Hn * 4 + p * 4 + t1 * 2;
+            const double* xp = xs + (size_t)par * B;
+            tv = fma(hk[1], xp[2 * p + 1], hk[0] * xp[2 * p]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < NT * 4; ++e)
+            if (16 * (e >> 2) + 4 * (e & 3) < B) {
+                const double r = row_sum16(zr[e] * tv);
+                if (jj == 0) part[wv][16 * (e >> 2) + lg + 4 * (e & 3)] = r;
+            }
+        __syncthreads();
+        if (tid < B) {
+            double acc = part[0][tid];
+#pragma unroll
+            for (int w2 = 1; w2 < NT; ++w2) acc += part[w2][tid];
+            x -= acc;
+        }
+    }
+    if (tid < B) {
+        xs[(size_t)k * B + tid] = x;
+        if (tid < b) {
+            const int kst = (tid >> 1) * n + k;
+            double* st = step + (size_t)s * N;
+            if (tid & 1) {
+                if (kst >= c) st[Nc + kst - c] = x;
+            } else {
+                if (kst >= 1) st[kst - 1] = x;
+            }
+        }
+    }
+}
+
+template <int B>
+int launch_factor_q(hpf_handle* h, const TreeDev& T, const int* nodes, int count, const int* active) {
+    constexpr int NT = (B + 16) / 16;
+    hipLaunchKernelGGL((k_factor_q<B>), dim3((unsigned)count, (unsigned)h->cur_S), dim3(64 * NT), 0, h->cur_stream, h->M, T, nodes,
+                       2 * h->Hn, h->N, h->Nc, active, h->d_U, h->d_E, h->d_f, h->d_Z, h->d_w, h->d_linA, h->d_C, h->d_H,
+                       h->d_dbg, h->debug_ablate, h->cur_s0);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        h->last_detail = (int)e;
+        return HPF_E_HIP;
+    }
+    return HPF_OK;
+}
+
+template <int B>
+int launch_back_q(hpf_handle* h, const TreeDev& T, const int* nodes, int count, const int* active) {
+    constexpr int NT = (B + 16) / 16;
+    hipLaunchKernelGGL((k_back_q<B>), dim3((unsigned)count, (unsigned)h->cur_S), dim3(64 * NT), 0, h->cur_stream, h->M, T, nodes,
+                       2 * h->Hn, h->N, h->Nc, active, h->d_Z, h->d_w, h->d_x, h->d_f, h->d_H, h->cur_s0);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        h->last_detail = (int)e;
+        return HPF_E_HIP;
+    }
+    return HPF_OK;
+}

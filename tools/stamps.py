@@ -47,4 +47,18 @@ for label, sel in (("nonlinear leaf (0 dense children)", dense & (d[0, :, 6] == 
         continue
     x = d[:, sel, :6].reshape(-1, 6)
     med = np.median(x, axis=0)
+    sub = d[:, sel, 1].reshape(-1)
+    packed = sub.max() > (1 << 20)      # multi-wave kernel: slot 1 holds packed sub-phases (units of 16 cycles)
+    gsp = d[:, sel, 2].reshape(-1)
+    osp = d[:, sel, 4].reshape(-1)
+    if packed:
+        med[1] = 0
+        med[2] = 0
+
     print("%-38s n=%4d  " % (label, sel.sum()) + "  ".join("%s %7.0f" % (nm, v) for nm, v in zip(names, med)) + "   total %8.0f" % med.sum())
+    if packed:
+        print("      assembly split: roles up to barrier 1 %6.0f   reduction + Y_N %6.0f"
+              % tuple(np.median((sub >> sh) & 0xffff) * 16 for sh in (0, 16)))
+        print("      GJ split (wave 0, sums over the block steps): owner work of its 4 steps %6.0f   barrier waits %6.0f   post-barrier sections %6.0f"
+              % tuple(np.median((gsp >> sh) & 0xfffff) * 16 for sh in (0, 20, 40)))
+

@@ -1,18 +1,28 @@
 #!/usr/bin/env python3
-"""Print the per-launch timeline of the last NR step from a rocprofv3 --kernel-trace CSV (gpurun_out/<dir>)."""
+"""Per-launch timeline of the last NR step of ONE scenario group (run with HPF_GROUPS=1) from a rocprofv3 --kernel-trace CSV
+(gpurun_out/<dir>), plus per-kernel totals of that step."""
 import csv, glob, sys
 d = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof"
 f = sorted(glob.glob(d + "/*/*_kernel_trace.csv"))[-1]
 rows = list(csv.DictReader(open(f)))
-keys = ("k_factor_w", "k_assemble_w", "k_back_w", "k_lin", "k_mismatch", "k_update", "k_tree")
-mine = [r for r in rows if any(k in r["Kernel_Name"] for k in keys)]
+keys = ("k_factor_q", "k_factor_w", "k_back_q", "k_back_w", "k_lin_factor", "k_lin_back", "k_mismatch", "k_update", "k_tree", "k_finalize")
+mine = sorted([r for r in rows if any(k in r["Kernel_Name"] for k in keys)], key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(mine) if "k_lin_factor" in r["Kernel_Name"]][-1]
 step = mine[idx:]
 t0 = int(step[0]["Start_Timestamp"])
+tot = {}
+prev_end = t0
 for r in step:
     nm = [k for k in keys if k in r["Kernel_Name"]][0]
-    if nm == "k_lin":
-        nm = "k_lin_factor" if "k_lin_factor" in r["Kernel_Name"] else "k_lin_back"
     s = (int(r["Start_Timestamp"]) - t0) / 1e3
     dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-    print("%-14s grid.x %7s  start %8.1f us  dur %7.1f us" % (nm, r["Grid_Size_X"], s, dur))
+    gap = (int(r["Start_Timestamp"]) - prev_end) / 1e3
+    prev_end = int(r["End_Timestamp"])
+    a = tot.setdefault(nm, [0, 0.0, 0.0])
+    a[0] += 1; a[1] += dur; a[2] += max(gap, 0.0)
+    print("%-14s grid %6d x %4d  start %8.1f us  dur %7.1f us  gap before %5.1f us"
+          % (nm, int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), int(r["Grid_Size_Y"]), s, dur, gap))
+print()
+for nm, (cnt, dur, gap) in tot.items():
+    print("%-14s launches %3d  busy %8.1f us  gaps before %7.1f us" % (nm, cnt, dur, gap))
+print("step wall %.1f us" % ((prev_end - t0) / 1e3))
