@@ -157,12 +157,15 @@ HPF_HD cplx norton_injection(const Model& M, const cplx* U, int q, int i) {
 
 // Complex mismatch of stacked index k >= 1 (HG:360-390): power balance for linear buses at the fundamental,
 // current balance otherwise.  FUND: fundamental power flow (HG:195-202), every bus is a power row.
+// Iout (optional): receives the network current I of a power row -- the Jacobian's diagonal power entries (HG:451-459) need
+// the same sum again, and the block-tree kernels read it back instead of re-walking the admittance row.
 template <bool FUND>
-HPF_HD cplx mismatch_row(const Model& M, const cplx* U, const double* P, const double* Q, int k) {
+HPF_HD cplx mismatch_row(const Model& M, const cplx* U, const double* P, const double* Q, int k, cplx* Iout = nullptr) {
     const int q = FUND ? 0 : k / M.n;
     const int i = FUND ? k : k - q * M.n;
     const cplx I = FUND ? row_current_fund(M, U, i) : row_current(M, U, q, i);
     if (FUND || (q == 0 && i < M.m)) {
+        if (Iout) Iout[i] = I;
         // V_i * conj(Y_ij @ V_j): NumPy array multiply (HG:198,379), then + S
         const cplx sl = cmul_npy(U[i], cconj(I));
         return {P[i] + sl.re, Q[i] + sl.im};
@@ -209,6 +212,18 @@ HPF_HD Blk2 jac_norton_cross(const Model& M, const cplx* U, const cplx* E, int q
 
 // Power rows at the fundamental (HG:451-459 for the harmonic NR, HG:207-214 for pf): entry (i, j) of
 //   dSdA = 1j*diag(U) @ conj(diag(I) - Y1 @ diag(U)),   dSdV = diag(E) @ conj(diag(I)) + diag(U) @ conj(Y1 @ diag(E)).
+// (jac_power_diag: the diagonal entry with the row current I supplied by the caller)
+HPF_HD Blk2 jac_power_diag(const Model& M, const cplx* U, const cplx* E, int i, int e, cplx I) {
+    const cplx y = M.Y[e];
+    const cplx yu = cmul_unf(y, U[i]);
+    const cplx ye = cmul_unf(y, E[i]);
+    Blk2 b;
+    const cplx t = csub(I, yu);
+    b.dV = cadd(cmul_unf(E[i], cconj(I)), cmul_unf(U[i], cconj(ye)));
+    b.dA = cmul_unf(cmulj(U[i]), cconj(t));
+    return b;
+}
+
 template <bool FUND>
 HPF_HD Blk2 jac_power_entry(const Model& M, const cplx* U, const cplx* E, int i, int j, int e) {
     const cplx y = M.Y[e];

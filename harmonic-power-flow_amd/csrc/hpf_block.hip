@@ -773,9 +773,10 @@ __global__ __launch_bounds__(64) void k_back_w(Model M, TreeDev T, const int* __
 // (maximal linear subtree, harmonic, scenario) walks the subtree in post-order (factor) / reverse post-order (back).
 // =============================================================================================================
 template <bool FUND>
-__device__ __forceinline__ void diag2x2(const Model& M, const cplx* U, const cplx* E, int q, int k, double m2[4]) {
+__device__ __forceinline__ void diag2x2(const Model& M, const cplx* U, const cplx* E, const cplx* I0, int q, int k, double m2[4]) {
+    // harmonic NR power rows: row current kept by the mismatch kernel of the same state (I0)
     const Blk2 blk = FUND ? jac_power_entry<true>(M, U, E, k, k, M.diag[k])
-                          : ((q == 0 && k < M.m) ? jac_power_entry<false>(M, U, E, k, k, M.diag[k])
+                          : ((q == 0 && k < M.m) ? jac_power_diag(M, U, E, k, M.diag[k], I0[k])
                                                   : jac_current_entry(M, U, E, q, k, k, M.diag[k]));
     const bool v0 = loc_valid(M.n, M.c, k, 2 * q), v1 = loc_valid(M.n, M.c, k, 2 * q + 1);
     m2[0] = v0 ? blk.dA.re : 1.0;
@@ -788,7 +789,8 @@ template <bool FUND>
 __global__ __launch_bounds__(128) void k_lin_factor(Model M, TreeDev T, int nroots, int N, int Nc, int Bst,
                                                     const int* __restrict__ active, const cplx* __restrict__ Uall,
                                                     const cplx* __restrict__ Eall, const double* __restrict__ fall,
-                                                    double* __restrict__ linAall, double* __restrict__ wall, int s0) {
+                                                    double* __restrict__ linAall, double* __restrict__ wall,
+                                                    const cplx* __restrict__ I0all, int s0) {
     const int s = blockIdx.y + s0;
     if (active && !active[s]) return;
     const int tix = blockIdx.x * 128 + threadIdx.x;
@@ -805,7 +807,7 @@ __global__ __launch_bounds__(128) void k_lin_factor(Model M, TreeDev T, int nroo
     for (int idx = T.lin_ptr[r]; idx < T.lin_ptr[r + 1]; ++idx) {
         const int k = T.lin_post[idx];
         double m2[4];
-        diag2x2<FUND>(M, U, E, q, k, m2);
+        diag2x2<FUND>(M, U, E, FUND ? nullptr : I0all + (size_t)s * n, q, k, m2);
         const int kst = q * n + k;
         double y0 = kst >= 1 ? f[kst - 1] : 0.0;
         double y1 = kst >= c ? f[Nc + kst - c] : 0.0;
@@ -1157,7 +1159,7 @@ int tree_fund_step(hpf_handle* h, bool only_active) {
     const int Bst = BW ? BW : b;
     ScopedTimer t(h, T_SOLVE);
     hipLaunchKernelGGL((k_lin_factor<true>), dim3(1, (unsigned)h->cur_S), dim3(128), 0, h->cur_stream, h->M, td, 1, h->Nf,
-                       h->n - 1, Bst, active, h->d_U, h->d_E, h->d_f, h->d_linA, h->d_w, h->cur_s0);
+                       h->n - 1, Bst, active, h->d_U, h->d_E, h->d_f, h->d_linA, h->d_w, nullptr, h->cur_s0);
     hipLaunchKernelGGL((k_lin_back<true>), dim3(1, (unsigned)h->cur_S), dim3(128), 0, h->cur_stream, h->M, td, 1, h->Nf,
                        h->n - 1, Bst, active, h->d_U, h->d_E, h->d_linA, h->d_w, h->d_x, h->d_f, h->cur_s0);
     hipError_t e = hipGetLastError();
@@ -1181,7 +1183,7 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
         if (lin_threads > 0) {
             hipLaunchKernelGGL((k_lin_factor<false>), dim3((unsigned)((lin_threads + 127) / 128), (unsigned)h->cur_S), dim3(128), 0,
                                h->cur_stream, h->M, td, T.n_lin_roots, h->N, h->Nc, Bst, active, h->d_U, h->d_E, h->d_f,
-                               h->d_linA, h->d_w, h->cur_s0);
+                               h->d_linA, h->d_w, h->d_I0, h->cur_s0);
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) {
                 h->last_detail = (int)e;

@@ -72,6 +72,7 @@ struct hpf_handle {
     double *d_P = nullptr, *d_Q = nullptr, *d_Vm = nullptr, *d_Va = nullptr;
     hpf::cplx *d_U = nullptr, *d_E = nullptr;
     double* d_f = nullptr;            // [S][N]  mismatch, overwritten by the Newton step during a solve
+    hpf::cplx* d_I0 = nullptr;            // [S][n]  network current of the power rows, kept by the harmonic mismatch kernel
     unsigned long long* d_errbits = nullptr;   // [S]
     double* d_err = nullptr;          // [S]
     int* d_niter = nullptr;           // [S]

@@ -80,13 +80,14 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
 template <bool FUND>
 __global__ void k_mismatch(Model M, int count, int N, int Nc, const int* __restrict__ active, const cplx* __restrict__ U,
                            const double* __restrict__ P, const double* __restrict__ Q, double* __restrict__ f,
-                           unsigned long long* __restrict__ errbits, int s0) {
+                           unsigned long long* __restrict__ errbits, cplx* __restrict__ I0, int s0) {
     const int s = blockIdx.y + s0;
     if (active && !active[s]) return;
     const int k = blockIdx.x * TPB + threadIdx.x + 1;
     unsigned long long b = 0;
     if (k < count) {
-        const cplx v = mismatch_row<FUND>(M, U + (size_t)s * M.n * M.Hn, P + (size_t)s * M.n, Q + (size_t)s * M.n, k);
+        const cplx v = mismatch_row<FUND>(M, U + (size_t)s * M.n * M.Hn, P + (size_t)s * M.n, Q + (size_t)s * M.n, k,
+                                          (!FUND && I0) ? I0 + (size_t)s * M.n : nullptr);
         store_mismatch(f + (size_t)s * N, Nc, M.c, k, v);
         b = abs_bits(v.re);
         if (k >= M.c) {
@@ -368,7 +369,7 @@ int launch_mismatch(hpf_handle* h, const int* active) {
     const int Nc = FUND ? h->n - 1 : h->Nc;
     if (count > 1) {
         hipLaunchKernelGGL((k_mismatch<FUND>), grid2(count - 1, h->cur_S), dim3(TPB), 0, h->cur_stream, h->M, count, N, Nc,
-                           active, h->d_U, h->d_P, h->d_Q, h->d_f, h->d_errbits, h->cur_s0);
+                           active, h->d_U, h->d_P, h->d_Q, h->d_f, h->d_errbits, h->d_I0, h->cur_s0);
         HIPCHK(hipGetLastError());
     }
     return HPF_OK;
@@ -533,7 +534,7 @@ int nr_loop(hpf_handle* h, double thresh, int max_iter, int* n_iter, double* err
 
 void free_all(hpf_handle* h) {
     void* ptrs[] = {h->d_rowptr, h->d_col, h->d_diag, h->d_erow, h->d_dev, h->d_Y, h->d_YN, h->d_IN, h->d_P, h->d_Q,
-                    h->d_Vm, h->d_Va, h->d_U, h->d_E, h->d_f, h->d_errbits, h->d_err, h->d_niter, h->d_active,
+                    h->d_Vm, h->d_Va, h->d_U, h->d_E, h->d_I0, h->d_f, h->d_errbits, h->d_err, h->d_niter, h->d_active,
                     h->d_nactive, h->d_hist, h->d_stats, h->d_J, h->d_ipiv, h->d_info, h->d_Z, h->d_w, h->d_x, h->d_linA, h->d_C, h->d_dbg, h->d_H};
     for (void* p : ptrs)
         if (p) hipFree(p);
@@ -642,6 +643,7 @@ int hpf_create(hpf_handle** out, const hpf_desc* d) {
     if ((r = dev_alloc(h, &h->d_Va, S * HnN))) return fail(r);
     if ((r = dev_alloc(h, &h->d_U, S * HnN))) return fail(r);
     if ((r = dev_alloc(h, &h->d_E, S * HnN))) return fail(r);
+    if ((r = dev_alloc(h, &h->d_I0, S * (size_t)h->n))) return fail(r);
     if ((r = dev_alloc(h, &h->d_f, S * (size_t)(h->N > h->Nf ? h->N : h->Nf)))) return fail(r);
     if ((r = dev_alloc(h, &h->d_errbits, S))) return fail(r);
     if ((r = dev_alloc(h, &h->d_err, S))) return fail(r);

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? HPF_Q_OCC : 5)) voi
     Model M, TreeDev T, const int* __restrict__ nodes, int b, int N, int Nc, const int* __restrict__ active,
     const cplx* __restrict__ Uall, const cplx* __restrict__ Eall, const double* __restrict__ fall, double* __restrict__ Zall,
     double* __restrict__ wall, const double* __restrict__ linAall, double* __restrict__ Call, double* __restrict__ Hall,
-    long long* __restrict__ dbg, int ablate, int s0) {
+    const cplx* __restrict__ I0all, long long* __restrict__ dbg, int ablate, int s0) {
     constexpr int NT = (B + 16) / 16;
     constexpr size_t CT = (size_t)NT * NT * 256;
     constexpr int tcB = B >> 4, jjB = B & 15;
@@ -127,7 +127,8 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? HPF_Q_OCC : 5)) voi
                 const int kst = q * n + k;
                 y = tr_ ? f[Nc + kst - c] : f[kst - 1];
                 const int diag_e = M.diag[k];
-                const Blk2 blk = (q == 0 && k < M.m) ? jac_power_entry<false>(M, U, E, k, k, diag_e)
+                // power rows (HG:451-459): the row current was kept by the mismatch kernel of this very state (I0)
+                const Blk2 blk = (q == 0 && k < M.m) ? jac_power_diag(M, U, E, k, diag_e, I0all[(size_t)s * n + k])
                                                       : jac_current_entry(M, U, E, q, k, k, diag_e);
                 d0 = pick(blk, tr_, 0);
                 d1 = pick(blk, tr_, 1);
@@ -456,7 +457,7 @@ int launch_factor_q(hpf_handle* h, const TreeDev& T, const int* nodes, int count
     constexpr int NT = (B + 16) / 16;
     hipLaunchKernelGGL((k_factor_q<B>), dim3((unsigned)count, (unsigned)h->cur_S), dim3(64 * NT), 0, h->cur_stream, h->M, T, nodes,
                        2 * h->Hn, h->N, h->Nc, active, h->d_U, h->d_E, h->d_f, h->d_Z, h->d_w, h->d_linA, h->d_C, h->d_H,
-                       h->d_dbg, h->debug_ablate, h->cur_s0);
+                       h->d_I0, h->d_dbg, h->debug_ablate, h->cur_s0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         h->last_detail = (int)e;
