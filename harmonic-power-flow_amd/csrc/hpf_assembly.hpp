@@ -199,6 +199,21 @@ HPF_HD Blk2 jac_current_entry(const Model& M, const cplx* U, const cplx* E, int 
     return b;
 }
 
+// Diagonal current-balance entry (i == j) with the device type of the bus supplied by the caller (-1: linear bus).
+HPF_HD Blk2 jac_current_diag(const Model& M, const cplx* U, const cplx* E, int q, int i, int e, int d) {
+    const cplx y = M.Y[(size_t)q * M.nnz + e];
+    const size_t kc = (size_t)q * M.n + i;
+    Blk2 b;
+    b.dV = cmul_unf(y, E[kc]);
+    b.dA = cmul_unf(cmulj(y), U[kc]);
+    if (i >= M.m) {
+        const cplx yn = M.coupled ? M.YN[((size_t)d * M.Hn + q) * M.Hn + q] : M.YN[(size_t)d * M.Hn + q];
+        b.dV = csub(b.dV, cmul_unf(yn, E[kc]));
+        b.dA = csub(b.dA, cmul_unf(cmulj(yn), U[kc]));
+    }
+    return b;
+}
+
 // Coupled Norton cross terms q != p at nonlinear bus i (HG:425-435): entry [q*n+i, p*n+i] = 0 - Y_N[q,p]*...
 HPF_HD Blk2 jac_norton_cross(const Model& M, const cplx* U, const cplx* E, int q, int p, int i) {
     const int d = M.dev[i];

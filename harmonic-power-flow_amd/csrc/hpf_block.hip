@@ -42,6 +42,7 @@ struct TreeDev {
     const int* child_mid;   // children [child_ptr, child_mid) have all-linear subtrees, [child_mid, child_ptr+1) are dense
     const int* lin_ptr;
     const int* lin_post;
+    const int* child3;      // [child-list position][4]: child, e_dn[child], e_up[child], 0
 };
 
 // validity of local index l = 2q+t of bus i as an unknown / equation (same rule for both, see hpf_assembly.hpp)
@@ -1087,6 +1088,36 @@ int tree_build(hpf_handle* h, const hpf_desc* d) {
             }
         }
     }
+    // node records of the multi-wave kernels (hpf_quad.hpp)
+    std::vector<int> fdesc((size_t)T.n_dense * 16, 0), child3((size_t)(n > 1 ? n - 1 : 0) * 4, 0), bdesc((size_t)T.n_dense * 2, 0);
+    for (size_t cp = 0; cp < T.child.size(); ++cp) {
+        const int ch = T.child[cp];
+        child3[cp * 4 + 0] = ch;
+        child3[cp * 4 + 1] = e_dn[ch];
+        child3[cp * 4 + 2] = e_up[ch];
+    }
+    for (int pos = 0; pos < T.n_dense; ++pos) {
+        const int k = T.lvl_nodes[pos];
+        int* r = &fdesc[(size_t)pos * 16];
+        int diag_e = -1;
+        for (int e = d->rowptr[k]; e < d->rowptr[k + 1]; ++e)
+            if (d->col[e] == k) diag_e = e;
+        if (diag_e < 0) return HPF_E_ARG;
+        r[0] = k;
+        r[1] = T.parent[k];
+        r[2] = diag_e;
+        r[3] = d->dev_of_bus[k];
+        r[4] = e_dn[k];
+        r[5] = e_up[k];
+        r[6] = T.child_ptr[k];
+        r[7] = T.child_mid[k] - T.child_ptr[k];
+        r[8] = T.child_mid[k];
+        r[9] = T.child_ptr[k + 1] - T.child_mid[k];
+        for (int i = 0; i < 4 && i < r[9]; ++i) r[10 + i] = T.child[T.child_mid[k] + i];
+        const int kb = T.dep_nodes[pos];
+        bdesc[(size_t)pos * 2 + 0] = kb;
+        bdesc[(size_t)pos * 2 + 1] = T.parent[kb];
+    }
     const double bd = b;
     // exact FP64 flop count of the dense part of the elimination: per dense bus 2 b^3 (block inversion), (4 b^2 + 4 b)
     // per dense child pulled, 2 b^2 (w = D^-1 y); per non-root dense bus 4 b^2 (D^-1 A(k,parent)) in the parent's pull
@@ -1117,13 +1148,17 @@ int tree_build(hpf_handle* h, const hpf_desc* d) {
     if ((r = upload(h, &T.d_lin_post, T.lin_post))) return r;
     if ((r = upload(h, &T.d_all_ptr, T.all_ptr))) return r;
     if ((r = upload(h, &T.d_all_post, T.all_post))) return r;
+    if ((r = upload(h, &T.d_fdesc, fdesc))) return r;
+    if ((r = upload(h, &T.d_child3, child3))) return r;
+    if ((r = upload(h, &T.d_bdesc, bdesc))) return r;
     return HPF_OK;
 }
 
 void tree_free(hpf_handle* h) {
     Tree& T = h->tree;
     void* ptrs[] = {T.d_parent, T.d_lvl_nodes, T.d_dep_nodes, T.d_child_ptr, T.d_child, T.d_e_up, T.d_e_dn,
-                    T.d_child_mid, T.d_lin, T.d_lin_ptr, T.d_lin_post, T.d_all_ptr, T.d_all_post};
+                    T.d_child_mid, T.d_lin, T.d_lin_ptr, T.d_lin_post, T.d_all_ptr, T.d_all_post, T.d_fdesc, T.d_child3,
+                    T.d_bdesc};
     for (void* p : ptrs)
         if (p) hipFree(p);
 }
@@ -1153,7 +1188,7 @@ int tree_alloc_scenarios(hpf_handle* h) {
 int tree_fund_step(hpf_handle* h, bool only_active) {
     Tree& T = h->tree;
     const int* active = only_active ? h->d_active : nullptr;
-    const TreeDev td{T.d_parent, T.d_child_ptr, T.d_child, T.d_e_up, T.d_e_dn, T.d_child_mid, T.d_all_ptr, T.d_all_post};
+    const TreeDev td{T.d_parent, T.d_child_ptr, T.d_child, T.d_e_up, T.d_e_dn, T.d_child_mid, T.d_all_ptr, T.d_all_post, T.d_child3};
     const int b = 2 * h->Hn;
     const int BW = wave_block_size(b);
     const int Bst = BW ? BW : b;
@@ -1173,7 +1208,7 @@ int tree_fund_step(hpf_handle* h, bool only_active) {
 int tree_newton_step(hpf_handle* h, bool only_active) {
     Tree& T = h->tree;
     const int* active = only_active ? h->d_active : nullptr;
-    const TreeDev td{T.d_parent, T.d_child_ptr, T.d_child, T.d_e_up, T.d_e_dn, T.d_child_mid, T.d_lin_ptr, T.d_lin_post};
+    const TreeDev td{T.d_parent, T.d_child_ptr, T.d_child, T.d_e_up, T.d_e_dn, T.d_child_mid, T.d_lin_ptr, T.d_lin_post, T.d_child3};
     const int b = 2 * h->Hn;
     const int R = (b + 15) / 16;
     const int BW = wave_block_size(b);
@@ -1215,7 +1250,7 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
             switch (BW) {
 #define HPF_FACTOR_CASE(BB_)                                                                                  \
     case BB_:                                                                                                 \
-        r = h->gj_mode == 1 ? launch_factor_q<BB_>(h, td, nodes, cnt, active)                                 \
+        r = h->gj_mode == 1 ? launch_factor_q<BB_>(h, td, T.d_fdesc + 16 * (size_t)T.lvl_ptr[l], cnt, active) \
             : (h->gj_mode == 2 ? launch_factor_w<BB_, 1>(h, td, nodes, cnt, active)                           \
                                : launch_factor_w<BB_, 0>(h, td, nodes, cnt, active));                         \
         break
@@ -1242,9 +1277,9 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
         const int* nodes = T.d_dep_nodes + T.dep_ptr[dl];
         int r = HPF_OK;
         switch (BW) {
-            case 12: r = h->gj_mode == 1 ? launch_back_q<12>(h, td, nodes, cnt, active) : launch_back_w<12>(h, td, nodes, cnt, active); break;
-            case 28: r = h->gj_mode == 1 ? launch_back_q<28>(h, td, nodes, cnt, active) : launch_back_w<28>(h, td, nodes, cnt, active); break;
-            case 52: r = h->gj_mode == 1 ? launch_back_q<52>(h, td, nodes, cnt, active) : launch_back_w<52>(h, td, nodes, cnt, active); break;
+            case 12: r = h->gj_mode == 1 ? launch_back_q<12>(h, td, T.d_bdesc + 2 * (size_t)T.dep_ptr[dl], cnt, active) : launch_back_w<12>(h, td, nodes, cnt, active); break;
+            case 28: r = h->gj_mode == 1 ? launch_back_q<28>(h, td, T.d_bdesc + 2 * (size_t)T.dep_ptr[dl], cnt, active) : launch_back_w<28>(h, td, nodes, cnt, active); break;
+            case 52: r = h->gj_mode == 1 ? launch_back_q<52>(h, td, T.d_bdesc + 2 * (size_t)T.dep_ptr[dl], cnt, active) : launch_back_w<52>(h, td, nodes, cnt, active); break;
             default: {
                 hipLaunchKernelGGL(k_tree_back, dim3((unsigned)cnt, (unsigned)h->cur_S), dim3(256), 0, h->cur_stream, h->n, h->c,
                                    h->Hn, td, nodes, b, h->N, h->Nc, active, h->d_Z, h->d_w, h->d_x, h->d_f, h->cur_s0);

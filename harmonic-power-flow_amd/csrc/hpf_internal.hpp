@@ -49,6 +49,11 @@ struct Tree {
     int* d_lin_post = nullptr;
     int* d_all_ptr = nullptr;
     int* d_all_post = nullptr;
+    int* d_fdesc = nullptr;           // [n_dense][16] node records of the multi-wave factor kernel, elimination-level order:
+                                      //   k, parent, diag entry, device, e_dn, e_up, lin child begin, count, dense child begin,
+                                      //   count, first four dense children (everything a block needs behind ONE scalar load)
+    int* d_child3 = nullptr;          // [n-1][4] per child-list position: child, e_dn[child], e_up[child], 0
+    int* d_bdesc = nullptr;           // [n_dense][2] (k, parent) in back-substitution (depth) order
     double flops_per_solve = 0.0;     // factor sweep + back sweep
     double flops_factor = 0.0;        // factor sweep only (k_tree_factor, all levels)
 };

@@ -55,7 +55,20 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? HPF_Q_OCC : 5)) voi
     HPF_STAMP(st0);
     const int s = blockIdx.y + s0;
     if (active && !active[s]) return;
-    const int k = nodes[blockIdx.x];
+    // node record: everything the block needs to form its addresses, behind one scalar load (Tree::d_fdesc)
+    const int4* nd = reinterpret_cast<const int4*>(nodes) + 4 * (size_t)blockIdx.x;
+    const int4 nd0 = nd[0], nd1 = nd[1], nd2 = nd[2], nd3 = nd[3];
+    const int k = nd0.x, par = nd0.y, diag_e = nd0.z, devk = nd0.w;
+    const int e_dn_k = nd1.x, e_up_k = nd1.y, lin_beg = nd1.z, lin_end = nd1.z + nd1.w;
+    const int den_beg = nd2.x, n_den = nd2.y;
+#ifdef HPF_FACTOR_STAMPS
+    long long sd1 = 0, sd2 = 0, sd3 = 0;
+    {
+        int kk = k;
+        asm volatile("" : "+s"(kk));
+        sd1 = __builtin_amdgcn_s_memtime();
+    }
+#endif
     const int tid = threadIdx.x, lane = tid & 63, lg = lane >> 4, jj = lane & 15;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = M.n, c = M.c, Hn = M.Hn;
@@ -70,8 +83,6 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? HPF_Q_OCC : 5)) voi
     __shared__ double wl[2][16], pv[2][16];
     __shared__ double gl[NT * 32], hl[NT * 32];
 
-    const int par = T.parent[k];
-    const int lin_beg = T.child_ptr[k], lin_end = T.child_mid[k], den_end = T.child_ptr[k + 1];
     const bool nl = k >= M.m && M.coupled;
     const int col = 16 * wv + jj, p = col >> 1, t1 = col & 1;      // own column = (harmonic position p, component t1)
     const int t = lg & 1;                                          // component of every row this lane holds
@@ -82,8 +93,8 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? HPF_Q_OCC : 5)) voi
     double sumc[NT * 4];
 #pragma unroll
     for (int e = 0; e < NT * 4; ++e) sumc[e] = 0.0;
-    if (lin_end < den_end) {
-        const double* Cc = Cs + (size_t)T.child[lin_end] * CT + lane;
+    if (n_den > 0) {
+        const double* Cc = Cs + (size_t)nd2.z * CT + lane;
 #pragma unroll
         for (int e = 0; e < NT * 4; ++e)
             if (16 * (e >> 2) + 4 * (e & 3) < B) sumc[e] = Cc[(size_t)(((e >> 2) * NT + wv) * 4 + (e & 3)) * 64];
@@ -101,8 +112,8 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? HPF_Q_OCC : 5)) voi
     if (par >= 0 && wv == (NT > 1 ? 1 : 0) && lane < NT * 8) {
         double g4[4] = {0.0, 0.0, 0.0, 0.0}, h4[4] = {0.0, 0.0, 0.0, 0.0};
         if (lane < Hn) {
-            coupling_block(M, U, E, lane, par, k, T.e_dn[k], g4);
-            coupling_block(M, U, E, lane, k, par, T.e_up[k], h4);
+            coupling_block(M, U, E, lane, par, k, e_dn_k, g4);
+            coupling_block(M, U, E, lane, k, par, e_up_k, h4);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -126,13 +137,16 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? HPF_Q_OCC : 5)) voi
                 const double* f = fall + (size_t)s * N;
                 const int kst = q * n + k;
                 y = tr_ ? f[Nc + kst - c] : f[kst - 1];
-                const int diag_e = M.diag[k];
                 // power rows (HG:451-459): the row current was kept by the mismatch kernel of this very state (I0)
                 const Blk2 blk = (q == 0 && k < M.m) ? jac_power_diag(M, U, E, k, diag_e, I0all[(size_t)s * n + k])
-                                                      : jac_current_entry(M, U, E, q, k, k, diag_e);
+                                                      : jac_current_diag(M, U, E, q, k, diag_e, devk);
                 d0 = pick(blk, tr_, 0);
                 d1 = pick(blk, tr_, 1);
             }
+#ifdef HPF_FACTOR_STAMPS
+            asm volatile("" : "+v"(d0), "+v"(d1), "+v"(y));
+            sd2 = __builtin_amdgcn_s_memtime();
+#endif
             dgb[lane * 3 + 0] = d0;
             dgb[lane * 3 + 1] = d1;
             dgb[lane * 3 + 2] = y;
@@ -142,13 +156,15 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? HPF_Q_OCC : 5)) voi
             if (rowvalid) {
                 const double* ws = wall + (size_t)s * n * B;
                 const double* linA = linAall + so * 4;
+                const int4* c3 = reinterpret_cast<const int4*>(T.child3);
                 for (int cp = lin_beg + wv; cp < lin_end; cp += NT) {
-                    const int ch = T.child[cp];
-                    const Blk2 g = offdiag_block(M, U, E, q, k, ch, T.e_dn[ch]);     // A(parent, child), my harmonic
+                    const int4 cr = c3[cp];
+                    const int ch = cr.x;
+                    const Blk2 g = offdiag_block(M, U, E, q, k, ch, cr.y);           // A(parent, child), my harmonic
                     const double g0 = pick(g, tr_, 0);
                     const double g1 = loc_valid(n, c, ch, 2 * q + 1) ? pick(g, tr_, 1) : 0.0;
                     double h4[4];
-                    coupling_block(M, U, E, q, ch, k, T.e_up[ch], h4);               // A(child, parent)
+                    coupling_block(M, U, E, q, ch, k, cr.z, h4);                     // A(child, parent)
                     const double* ic = linA + ((size_t)ch * Hn + q) * 4;
                     const double v0 = fma(g1, ic[2], g0 * ic[0]), v1 = fma(g1, ic[3], g0 * ic[1]);
                     e0 += fma(v1, h4[2], v0 * h4[0]);
@@ -163,6 +179,7 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? HPF_Q_OCC : 5)) voi
             cc[wv][lane * 3 + 2] = ey;
         }
     }
+    HPF_STAMP(sd3);
     __syncthreads();
     HPF_STAMP(sa);
     {
@@ -183,7 +200,7 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? HPF_Q_OCC : 5)) voi
         const int pp = p < B / 2 ? p : 0;
         const double P = tab[t * (B / 2) * 4 + pp * 4 + 2 * t1];
         const double Q = tab[t * (B / 2) * 4 + pp * 4 + 2 * t1 + 1];
-        const cplx* yn = M.YN + (size_t)M.dev[k] * Hn * Hn + (p < Hn ? p : 0);
+        const cplx* yn = M.YN + (size_t)devk * Hn * Hn + (p < Hn ? p : 0);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             cplx ynb[NT * 2];
@@ -234,8 +251,9 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? HPF_Q_OCC : 5)) voi
     HPF_STAMP(st1);
 
     // ---- B. remaining dense children (fixed order), then subtract the sum -----------------------------------------------------
-    for (int cp = lin_end + 1; cp < den_end; ++cp) {
-        const double* Cc = Cs + (size_t)T.child[cp] * CT + lane;
+    for (int i = 1; i < n_den; ++i) {
+        const int ch = i == 1 ? nd2.w : (i == 2 ? nd3.x : (i == 3 ? nd3.y : T.child[den_beg + i]));
+        const double* Cc = Cs + (size_t)ch * CT + lane;
         double tmp[NT * 4];
 #pragma unroll
         for (int e = 0; e < NT * 4; ++e)
@@ -380,12 +398,14 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? HPF_Q_OCC : 5)) voi
         o[0] = st1 - st0;   // assembly (+ linear children)
         // packed sub-phases of the assembly (16 bits each, units of 16 cycles): roles up to barrier 1 | reduction + Y_N
         o[1] = (((sa - st0) >> 4) & 0xffff) | ((((sc - sa) >> 4) & 0xffff) << 16) | (1ll << 62);
+        // wave 0 before barrier 1: node record | base diagonal | linear children of wave 0 | wait at the barrier
+        o[4] = (((sd1 - st0) >> 4) & 0xffff) | ((((sd2 - sd1) >> 4) & 0xffff) << 16) | ((((sd3 - sd2) >> 4) & 0xffff) << 32) |
+               ((((sa - sd3) >> 4) & 0xffff) << 48);
         o[2] = ((gown >> 4) & 0xfffff) | (((gwait >> 4) & 0xfffff) << 20) | (((gmf >> 4) & 0xfffff) << 40);   // GJ split
         o[3] = st4 - st3;   // MFMA Gauss-Jordan
-        o[4] = st5 - st4;   // inverse tiles, w
         o[5] = st6 - st5;   // Schur push
-        o[6] = T.child_ptr[k + 1] - T.child_mid[k];
-        o[7] = (k >= M.m) | ((T.child_mid[k] - T.child_ptr[k]) << 1);
+        o[6] = n_den;
+        o[7] = (k >= M.m) | ((lin_end - lin_beg) << 1);
     }
 #endif
 }
@@ -401,13 +421,13 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16)) void k_back_q(
     constexpr size_t CT = (size_t)NT * NT * 256;
     const int s = blockIdx.y + s0;
     if (active && !active[s]) return;
-    const int k = nodes[blockIdx.x];
+    const int2 kp = reinterpret_cast<const int2*>(nodes)[blockIdx.x];          // Tree::d_bdesc: (bus, parent)
+    const int k = kp.x, par = kp.y;
     const int tid = threadIdx.x, lane = tid & 63, lg = lane >> 4, jj = lane & 15;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = M.n, c = M.c, Hn = M.Hn;
     double* xs = xall + (size_t)s * n * B;
     __shared__ double part[NT][64];
-    const int par = T.parent[k];
     double x = 0.0;
     if (tid < B) x = wall[((size_t)s * n + k) * B + tid];
     if (par >= 0) {

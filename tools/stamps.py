@@ -54,11 +54,14 @@ for label, sel in (("nonlinear leaf (0 dense children)", dense & (d[0, :, 6] == 
     if packed:
         med[1] = 0
         med[2] = 0
+        med[4] = 0
 
     print("%-38s n=%4d  " % (label, sel.sum()) + "  ".join("%s %7.0f" % (nm, v) for nm, v in zip(names, med)) + "   total %8.0f" % med.sum())
     if packed:
         print("      assembly split: roles up to barrier 1 %6.0f   reduction + Y_N %6.0f"
               % tuple(np.median((sub >> sh) & 0xffff) * 16 for sh in (0, 16)))
+        print("      wave 0 up to barrier 1: node record %6.0f   base diagonal %6.0f   its linear children %6.0f   wait at barrier %6.0f"
+              % tuple(np.median((osp >> sh) & 0xffff) * 16 for sh in (0, 16, 32, 48)))
         print("      GJ split (wave 0, sums over the block steps): owner work of its 4 steps %6.0f   barrier waits %6.0f   post-barrier sections %6.0f"
               % tuple(np.median((gsp >> sh) & 0xfffff) * 16 for sh in (0, 20, 40)))
 
