@@ -43,6 +43,10 @@ struct TreeDev {
     const int* lin_ptr;
     const int* lin_post;
     const int* child3;      // [child-list position][4]: child, e_dn[child], e_up[child], 0
+    const int* dchild;      // dense children (through contracted chains) of the dense buses, see the node records
+    const int* chain_ptr;   // contracted chains of pass-through buses, bottom-up
+    const int* chain_nodes;
+    const int* chain_ch;    // the dense bus below the chain
 };
 
 // validity of local index l = 2q+t of bus i as an unknown / equation (same rule for both, see hpf_assembly.hpp)
@@ -890,6 +894,160 @@ __global__ __launch_bounds__(128) void k_lin_back(Model M, TreeDev T, int nroots
     }
 }
 
+// =============================================================================================================
+// Contracted chains of pass-through buses (Tree::chain_*; linear bus, exactly one dense child): every block involved is
+// harmonic-diagonal, so a chain is eliminated bottom-up in 2x2-per-harmonic algebra BEFORE the dense levels.  Eliminating
+// bus k between the dense bus ch below it and its parent `up` leaves
+//     D_ch += -A(ch,k) D_k^-1 A(k,ch),   y_ch += -A(ch,k) D_k^-1 y_k,
+//     A'(ch,up) = -A(ch,k) D_k^-1 A(k,up),   A'(up,ch) = -A(up,k) D_k^-1 A(k,ch),
+//     D_up += -A(up,k) D_k^-1 A(k,up),   y_up += -A(up,k) D_k^-1 y_k     (carried if `up` is the next chain bus; the dense bus
+//                                                                          on top of the chain folds them like a linear child)
+// One thread per (chain, harmonic, scenario).
+// =============================================================================================================
+__device__ __forceinline__ void mul22(const double a[4], const double b[4], double o[4]) {
+    o[0] = fma(a[1], b[2], a[0] * b[0]);
+    o[1] = fma(a[1], b[3], a[0] * b[1]);
+    o[2] = fma(a[3], b[2], a[2] * b[0]);
+    o[3] = fma(a[3], b[3], a[2] * b[1]);
+}
+
+__global__ __launch_bounds__(128) void k_chain_factor(Model M, TreeDev T, int nchains, int N, int Nc, int Bst,
+                                                      const int* __restrict__ active, const cplx* __restrict__ Uall,
+                                                      const cplx* __restrict__ Eall, const double* __restrict__ fall,
+                                                      double* __restrict__ linAall, double* __restrict__ wall,
+                                                      const cplx* __restrict__ I0all, double* __restrict__ chG,
+                                                      double* __restrict__ chH, double* __restrict__ chD, double* __restrict__ chy,
+                                                      double* __restrict__ chZ, int s0) {
+    const int s = blockIdx.y + s0;
+    if (active && !active[s]) return;
+    const int tix = blockIdx.x * 128 + threadIdx.x;
+    if (tix >= nchains * M.Hn) return;
+    const int q = tix % M.Hn, r = tix / M.Hn;
+    const int n = M.n, c = M.c, Hn = M.Hn;
+    const size_t so = (size_t)s * n * Hn;
+    const cplx* U = Uall + so;
+    const cplx* E = Eall + so;
+    const double* f = fall + (size_t)s * N;
+    double* linA = linAall + so * 4;
+    double* ws = wall + (size_t)s * n * Bst;
+    const int ch = T.chain_ch[r];
+    const int beg = T.chain_ptr[r], end = T.chain_ptr[r + 1];
+    double a_kc[4], a_ck[4];                       // A(k, ch), A(ch, k) for the current chain bus k (fill after the first)
+    {
+        const int k1 = T.chain_nodes[beg];
+        coupling_block(M, U, E, q, k1, ch, T.e_dn[ch], a_kc);
+        coupling_block(M, U, E, q, ch, k1, T.e_up[ch], a_ck);
+    }
+    double dD[4] = {0.0, 0.0, 0.0, 0.0}, dy[2] = {0.0, 0.0}, cD[4] = {0.0, 0.0, 0.0, 0.0}, cy[2] = {0.0, 0.0};
+    for (int idx = beg; idx < end; ++idx) {
+        const int k = T.chain_nodes[idx];
+        const int up = T.parent[k];
+        double m2[4];
+        diag2x2<false>(M, U, E, I0all + (size_t)s * n, q, k, m2);
+        const int kst = q * n + k;
+        double y0 = (kst >= 1 ? f[kst - 1] : 0.0) + cy[0];
+        double y1 = (kst >= c ? f[Nc + kst - c] : 0.0) + cy[1];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m2[e] += cD[e];
+        for (int cp = T.child_ptr[k]; cp < T.child_mid[k]; ++cp) {          // the linear subtrees hanging off k
+            const int lc = T.child[cp];
+            double g4[4], h4[4], gi[4], gh[4];
+            coupling_block(M, U, E, q, k, lc, T.e_dn[lc], g4);
+            coupling_block(M, U, E, q, lc, k, T.e_up[lc], h4);
+            mul22(g4, linA + ((size_t)lc * Hn + q) * 4, gi);
+            mul22(gi, h4, gh);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m2[e] -= gh[e];
+            const double* wc = ws + (size_t)lc * Bst + 2 * q;
+            y0 -= fma(g4[1], wc[1], g4[0] * wc[0]);
+            y1 -= fma(g4[3], wc[1], g4[2] * wc[0]);
+        }
+        double di[4];
+        inv2(m2[0], m2[1], m2[2], m2[3], di[0], di[1], di[2], di[3]);
+        double* ik = linA + ((size_t)k * Hn + q) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ik[e] = di[e];
+        const double w0 = fma(di[1], y1, di[0] * y0), w1 = fma(di[3], y1, di[2] * y0);
+        double* wk = ws + (size_t)k * Bst + 2 * q;
+        wk[0] = w0;
+        wk[1] = w1;
+        double a_ku[4], a_uk[4], zc[4], zu[4], t4[4];
+        coupling_block(M, U, E, q, k, up, T.e_up[k], a_ku);              // A(k, up)
+        coupling_block(M, U, E, q, up, k, T.e_dn[k], a_uk);              // A(up, k)
+        mul22(di, a_kc, zc);                                             // D_k^-1 A(k, ch): kept for the back substitution
+        mul22(di, a_ku, zu);
+        double* zk = chZ + (so + (size_t)k * Hn + q) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) zk[e] = zc[e];
+        mul22(a_ck, zc, t4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dD[e] -= t4[e];
+        dy[0] -= fma(a_ck[1], w1, a_ck[0] * w0);
+        dy[1] -= fma(a_ck[3], w1, a_ck[2] * w0);
+        double n_ck[4], n_kc[4];
+        mul22(a_ck, zu, n_ck);                                           // -A'(ch, up)
+        mul22(a_uk, zc, n_kc);                                           // -A'(up, ch)
+        mul22(a_uk, zu, t4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            cD[e] = -t4[e];
+            a_ck[e] = -n_ck[e];
+            a_kc[e] = -n_kc[e];
+        }
+        cy[0] = -fma(a_uk[1], w1, a_uk[0] * w0);
+        cy[1] = -fma(a_uk[3], w1, a_uk[2] * w0);
+    }
+    const size_t o = (so + (size_t)ch * Hn + q);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        chG[o * 4 + e] = a_kc[e];                  // A'(top parent, ch)
+        chH[o * 4 + e] = a_ck[e];                  // A'(ch, top parent)
+        chD[o * 4 + e] = dD[e];
+    }
+    chy[o * 2 + 0] = dy[0];
+    chy[o * 2 + 1] = dy[1];
+}
+
+// after the dense back sweep (x of the dense buses known): x_k = w_k - D_k^-1 A(k,up) x_up - D_k^-1 A'(k,ch) x_ch, top-down
+__global__ __launch_bounds__(128) void k_chain_back(Model M, TreeDev T, int nchains, int N, int Nc, int Bst,
+                                                    const int* __restrict__ active, const cplx* __restrict__ Uall,
+                                                    const cplx* __restrict__ Eall, const double* __restrict__ linAall,
+                                                    const double* __restrict__ wall, double* __restrict__ xall,
+                                                    double* __restrict__ step, const double* __restrict__ chZ, int s0) {
+    const int s = blockIdx.y + s0;
+    if (active && !active[s]) return;
+    const int tix = blockIdx.x * 128 + threadIdx.x;
+    if (tix >= nchains * M.Hn) return;
+    const int q = tix % M.Hn, r = tix / M.Hn;
+    const int n = M.n, c = M.c, Hn = M.Hn;
+    const size_t so = (size_t)s * n * Hn;
+    const double* linA = linAall + so * 4;
+    const double* ws = wall + (size_t)s * n * Bst;
+    double* xs = xall + (size_t)s * n * Bst;
+    double* st = step + (size_t)s * N;
+    const int ch = T.chain_ch[r];
+    const double xc0 = xs[(size_t)ch * Bst + 2 * q], xc1 = xs[(size_t)ch * Bst + 2 * q + 1];
+    for (int idx = T.chain_ptr[r + 1] - 1; idx >= T.chain_ptr[r]; --idx) {
+        const int k = T.chain_nodes[idx];
+        const int up = T.parent[k];
+        double h4[4];
+        coupling_block(M, Uall + so, Eall + so, q, k, up, T.e_up[k], h4);        // A(k, up)
+        const double* xp = xs + (size_t)up * Bst + 2 * q;
+        const double t0 = fma(h4[1], xp[1], h4[0] * xp[0]), t1 = fma(h4[3], xp[1], h4[2] * xp[0]);
+        const double* ik = linA + ((size_t)k * Hn + q) * 4;
+        const double* zk = chZ + (so + (size_t)k * Hn + q) * 4;
+        const double* wk = ws + (size_t)k * Bst + 2 * q;
+        const double x0 = wk[0] - fma(ik[1], t1, ik[0] * t0) - fma(zk[1], xc1, zk[0] * xc0);
+        const double x1 = wk[1] - fma(ik[3], t1, ik[2] * t0) - fma(zk[3], xc1, zk[2] * xc0);
+        double* xk = xs + (size_t)k * Bst + 2 * q;
+        xk[0] = x0;
+        xk[1] = x1;
+        const int kst = q * n + k;
+        if (kst >= 1) st[kst - 1] = x0;
+        if (kst >= c) st[Nc + kst - c] = x1;
+    }
+}
+
 template <int B, int MODE>
 int launch_factor_w(hpf_handle* h, const TreeDev& T, const int* nodes, int count, const int* active) {
     hipLaunchKernelGGL((k_factor_w<B, MODE>), dim3((unsigned)count, (unsigned)h->cur_S), dim3(64), 0, h->cur_stream, h->M, T, nodes,
@@ -967,12 +1125,11 @@ int launch_factor(hpf_handle* h, const TreeDev& T, const int* nodes, int count, 
 
 namespace hpf {
 
-int tree_build(hpf_handle* h, const hpf_desc* d) {
+static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contract) {
     const int n = d->n;
     const int b = 2 * d->Hn;
     if (b > 16 * 7) return HPF_E_ARG;                          // register tile limit (K <= 55)
     if (d->nnz != n + 2 * (n - 1)) return HPF_E_TOPOLOGY;
-    Tree& T = h->tree;
     T.parent.assign(n, -2);
     std::vector<int> order, depth(n, 0), height(n, 0), e_up(n, -1), e_dn(n, -1);
     order.reserve(n);
@@ -985,7 +1142,6 @@ int tree_build(hpf_handle* h, const hpf_desc* d) {
             if (j == i) continue;
             if (T.parent[j] == -2) {
                 T.parent[j] = i;
-                depth[j] = depth[i] + 1;
                 e_dn[j] = e;                                   // entry (parent, child)
                 order.push_back(j);
             }
@@ -1008,16 +1164,37 @@ int tree_build(hpf_handle* h, const hpf_desc* d) {
             if (!T.lin[i]) T.lin[T.parent[i]] = 0;
         }
     }
-    // heights over the DENSE buses only (linear subtrees are finished before the first dense level)
+    // pass-through buses (contract): linear bus, not the root, exactly one child with nonlinear buses below it -> its block is
+    // harmonic-diagonal and eliminating it FIRST only re-links that child to the grandparent (2x2-per-harmonic fill)
+    std::vector<int> pass(n, 0), ndc(n, 0);
+    for (int i = 1; i < n; ++i)
+        if (!T.lin[i]) ndc[T.parent[i]]++;
+    if (contract)
+        for (int i = 1; i < n; ++i) pass[i] = (!T.lin[i] && i < d->m && ndc[i] == 1) ? 1 : 0;
+    auto kept = [&](int i) { return !T.lin[i] && !pass[i]; };
+    std::vector<int> pard(n, -1);                              // parent in the dense tree (through chains)
+    for (size_t oi = 1; oi < order.size(); ++oi) {
+        const int i = order[oi];
+        if (!kept(i)) continue;
+        int p = T.parent[i];
+        while (p >= 0 && pass[p]) p = T.parent[p];
+        pard[i] = p;
+    }
+    // heights / depths over the dense tree (linear subtrees and chains are finished before the first dense level)
+    for (size_t oi = 1; oi < order.size(); ++oi) {              // BFS order: parents before children
+        const int i = order[oi];
+        if (kept(i)) depth[i] = depth[pard[i]] + 1;
+    }
     for (int oi = n - 1; oi > 0; --oi) {
-        const int i = order[oi], p = T.parent[i];
-        if (T.lin[i]) continue;
+        const int i = order[oi];
+        if (!kept(i)) continue;
+        const int p = pard[i];
         if (height[i] + 1 > height[p]) height[p] = height[i] + 1;
     }
     int maxh = 0, maxd = 0;
     T.n_dense = 0;
     for (int i = 0; i < n; ++i) {
-        if (T.lin[i]) continue;
+        if (!kept(i)) continue;
         ++T.n_dense;
         maxh = height[i] > maxh ? height[i] : maxh;
         maxd = depth[i] > maxd ? depth[i] : maxd;
@@ -1027,16 +1204,18 @@ int tree_build(hpf_handle* h, const hpf_desc* d) {
     auto bucket = [&](const std::vector<int>& key, int nb, std::vector<int>& ptr, std::vector<int>& items) {
         ptr.assign(nb + 1, 0);
         for (int i = 0; i < n; ++i)
-            if (!T.lin[i]) ptr[key[i] + 1]++;
+            if (kept(i)) ptr[key[i] + 1]++;
         for (int l = 0; l < nb; ++l) ptr[l + 1] += ptr[l];
         items.assign(T.n_dense, 0);
         std::vector<int> pos(ptr.begin(), ptr.end() - 1);
         for (int i = 0; i < n; ++i)
-            if (!T.lin[i]) items[pos[key[i]]++] = i;             // ascending bus index inside a level
+            if (kept(i)) items[pos[key[i]]++] = i;               // ascending bus index inside a level
     };
     bucket(height, T.n_levels, T.lvl_ptr, T.lvl_nodes);
     bucket(depth, T.n_depths, T.dep_ptr, T.dep_nodes);
-    // children lists: linear-subtree children first, then dense children, ascending bus index inside each group
+    // network children lists: linear-subtree children first, then pass-through children, then dense children, ascending bus
+    // index inside each group.  child_mid: end of the part the bus folds in 2x2-per-harmonic algebra -- the linear subtrees
+    // and, at a dense bus, the tops of contracted chains; a pass-through bus folds its linear subtrees only.
     T.child_ptr.assign(n + 1, 0);
     for (int i = 1; i < n; ++i) T.child_ptr[T.parent[i] + 1]++;
     for (int i = 0; i < n; ++i) T.child_ptr[i + 1] += T.child_ptr[i];
@@ -1046,10 +1225,36 @@ int tree_build(hpf_handle* h, const hpf_desc* d) {
         std::vector<int> pos(T.child_ptr.begin(), T.child_ptr.end() - 1);
         for (int i = 1; i < n; ++i)
             if (T.lin[i]) T.child[pos[T.parent[i]]++] = i;
-        for (int i = 0; i < n; ++i) T.child_mid[i] = pos[i];
+        for (int i = 0; i < n; ++i)
+            if (pass[i]) T.child_mid[i] = pos[i];
         for (int i = 1; i < n; ++i)
-            if (!T.lin[i]) T.child[pos[T.parent[i]]++] = i;
+            if (pass[i]) T.child[pos[T.parent[i]]++] = i;
+        for (int i = 0; i < n; ++i)
+            if (!pass[i]) T.child_mid[i] = pos[i];
+        for (int i = 1; i < n; ++i)
+            if (kept(i)) T.child[pos[T.parent[i]]++] = i;
     }
+    // dense children of the dense buses (through chains), ascending bus index
+    std::vector<int> dchild_ptr(n + 1, 0), dchild(T.n_dense > 0 ? T.n_dense - 1 : 0, 0);
+    for (int i = 1; i < n; ++i)
+        if (kept(i)) dchild_ptr[pard[i] + 1]++;
+    for (int i = 0; i < n; ++i) dchild_ptr[i + 1] += dchild_ptr[i];
+    {
+        std::vector<int> pos(dchild_ptr.begin(), dchild_ptr.end() - 1);
+        for (int i = 1; i < n; ++i)
+            if (kept(i)) dchild[pos[pard[i]]++] = i;
+    }
+    // contracted chains, bottom-up: ch (dense) -> k1 = parent(ch) -> ... -> kt, parent(kt) dense
+    T.chain_ptr.assign(1, 0);
+    T.chain_nodes.clear();
+    T.chain_ch.clear();
+    for (int i = 1; i < n; ++i) {
+        if (!kept(i) || !pass[T.parent[i]]) continue;
+        for (int k = T.parent[i]; pass[k]; k = T.parent[k]) T.chain_nodes.push_back(k);
+        T.chain_ptr.push_back((int)T.chain_nodes.size());
+        T.chain_ch.push_back(i);
+    }
+    T.n_chains = (int)T.chain_ch.size();
     // maximal linear subtrees, post-order (children before parents; iterative DFS)
     T.lin_ptr.assign(1, 0);
     T.lin_post.clear();
@@ -1104,29 +1309,30 @@ int tree_build(hpf_handle* h, const hpf_desc* d) {
             if (d->col[e] == k) diag_e = e;
         if (diag_e < 0) return HPF_E_ARG;
         r[0] = k;
-        r[1] = T.parent[k];
+        r[1] = pard[k];
         r[2] = diag_e;
         r[3] = d->dev_of_bus[k];
         r[4] = e_dn[k];
         r[5] = e_up[k];
         r[6] = T.child_ptr[k];
         r[7] = T.child_mid[k] - T.child_ptr[k];
-        r[8] = T.child_mid[k];
-        r[9] = T.child_ptr[k + 1] - T.child_mid[k];
-        for (int i = 0; i < 4 && i < r[9]; ++i) r[10 + i] = T.child[T.child_mid[k] + i];
+        r[8] = dchild_ptr[k];
+        r[9] = dchild_ptr[k + 1] - dchild_ptr[k];
+        for (int i = 0; i < 4 && i < r[9]; ++i) r[10 + i] = dchild[dchild_ptr[k] + i];
+        r[14] = (k > 0 && pass[T.parent[k]]) ? 1 : 0;              // linked to its dense parent through a contracted chain
         const int kb = T.dep_nodes[pos];
         bdesc[(size_t)pos * 2 + 0] = kb;
-        bdesc[(size_t)pos * 2 + 1] = T.parent[kb];
+        bdesc[(size_t)pos * 2 + 1] = pard[kb];
     }
     const double bd = b;
     // exact FP64 flop count of the dense part of the elimination: per dense bus 2 b^3 (block inversion), (4 b^2 + 4 b)
     // per dense child pulled, 2 b^2 (w = D^-1 y); per non-root dense bus 4 b^2 (D^-1 A(k,parent)) in the parent's pull
-    // and 2 b^2 in the back sweep.  The 2x2 work of the linear subtrees (~60 flop per bus and harmonic) is not counted.
+    // and 2 b^2 in the back sweep.  The 2x2 work of the linear subtrees and chains (~60 flop per bus and harmonic) is not counted.
     T.flops_factor = 0.0;
     int n_dense_nonroot = 0;
     for (int i = 0; i < n; ++i) {
-        if (T.lin[i]) continue;
-        const int nch = T.child_ptr[i + 1] - T.child_mid[i];
+        if (!kept(i)) continue;
+        const int nch = dchild_ptr[i + 1] - dchild_ptr[i];
         T.flops_factor += 2.0 * bd * bd * bd + (4.0 * bd * bd + 4.0 * bd) * nch + 2.0 * bd * bd;
         if (i > 0) {
             T.flops_factor += 4.0 * bd * bd;
@@ -1151,16 +1357,35 @@ int tree_build(hpf_handle* h, const hpf_desc* d) {
     if ((r = upload(h, &T.d_fdesc, fdesc))) return r;
     if ((r = upload(h, &T.d_child3, child3))) return r;
     if ((r = upload(h, &T.d_bdesc, bdesc))) return r;
+    if ((r = upload(h, &T.d_dchild, dchild))) return r;
+    if ((r = upload(h, &T.d_chain_ptr, T.chain_ptr))) return r;
+    if ((r = upload(h, &T.d_chain_nodes, T.chain_nodes))) return r;
+    if ((r = upload(h, &T.d_chain_ch, T.chain_ch))) return r;
     return HPF_OK;
 }
 
-void tree_free(hpf_handle* h) {
-    Tree& T = h->tree;
+int tree_build(hpf_handle* h, const hpf_desc* d) {
+    int r = tree_build_into(h, d, h->tree, false);
+    if (r) return r;
+    h->has_ctree = wave_block_size(2 * d->Hn) != 0;
+    if (h->has_ctree) r = tree_build_into(h, d, h->ctree, true);
+    return r;
+}
+
+// the tree the Newton step of the current mode runs on
+Tree& active_tree(hpf_handle* h) { return (h->has_ctree && h->gj_mode == 1) ? h->ctree : h->tree; }
+
+static void tree_free_one(Tree& T) {
     void* ptrs[] = {T.d_parent, T.d_lvl_nodes, T.d_dep_nodes, T.d_child_ptr, T.d_child, T.d_e_up, T.d_e_dn,
                     T.d_child_mid, T.d_lin, T.d_lin_ptr, T.d_lin_post, T.d_all_ptr, T.d_all_post, T.d_fdesc, T.d_child3,
-                    T.d_bdesc};
+                    T.d_bdesc, T.d_dchild, T.d_chain_ptr, T.d_chain_nodes, T.d_chain_ch};
     for (void* p : ptrs)
         if (p) hipFree(p);
+}
+
+void tree_free(hpf_handle* h) {
+    tree_free_one(h->tree);
+    tree_free_one(h->ctree);
 }
 
 int tree_alloc_scenarios(hpf_handle* h) {
@@ -1173,6 +1398,11 @@ int tree_alloc_scenarios(hpf_handle* h) {
         (e = hipMalloc((void**)&h->d_x, sizeof(double) * S * n * b)) != hipSuccess ||
         (e = hipMalloc((void**)&h->d_linA, sizeof(double) * S * n * (size_t)h->Hn * 4)) != hipSuccess ||
         (e = hipMalloc((void**)&h->d_H, sizeof(double) * S * n * (size_t)h->Hn * 4)) != hipSuccess ||
+        (h->has_ctree && ((e = hipMalloc((void**)&h->d_chG, sizeof(double) * S * n * (size_t)h->Hn * 4)) != hipSuccess ||
+                          (e = hipMalloc((void**)&h->d_chH, sizeof(double) * S * n * (size_t)h->Hn * 4)) != hipSuccess ||
+                          (e = hipMalloc((void**)&h->d_chD, sizeof(double) * S * n * (size_t)h->Hn * 4)) != hipSuccess ||
+                          (e = hipMalloc((void**)&h->d_chy, sizeof(double) * S * n * (size_t)h->Hn * 2)) != hipSuccess ||
+                          (e = hipMalloc((void**)&h->d_chZ, sizeof(double) * S * n * (size_t)h->Hn * 4)) != hipSuccess)) ||
         ((h->debug_ablate & 16) && (e = hipMalloc((void**)&h->d_dbg, sizeof(long long) * S * n * 8)) != hipSuccess) ||
         (bw && (e = hipMalloc((void**)&h->d_C, sizeof(double) * S * n * (size_t)(((bw + 16) / 16) * ((bw + 16) / 16) * 256))) != hipSuccess)) {
         h->last_detail = (int)e;
@@ -1188,7 +1418,7 @@ int tree_alloc_scenarios(hpf_handle* h) {
 int tree_fund_step(hpf_handle* h, bool only_active) {
     Tree& T = h->tree;
     const int* active = only_active ? h->d_active : nullptr;
-    const TreeDev td{T.d_parent, T.d_child_ptr, T.d_child, T.d_e_up, T.d_e_dn, T.d_child_mid, T.d_all_ptr, T.d_all_post, T.d_child3};
+    const TreeDev td{T.d_parent, T.d_child_ptr, T.d_child, T.d_e_up, T.d_e_dn, T.d_child_mid, T.d_all_ptr, T.d_all_post, T.d_child3, T.d_dchild, T.d_chain_ptr, T.d_chain_nodes, T.d_chain_ch};
     const int b = 2 * h->Hn;
     const int BW = wave_block_size(b);
     const int Bst = BW ? BW : b;
@@ -1206,9 +1436,9 @@ int tree_fund_step(hpf_handle* h, bool only_active) {
 }
 
 int tree_newton_step(hpf_handle* h, bool only_active) {
-    Tree& T = h->tree;
+    Tree& T = active_tree(h);
     const int* active = only_active ? h->d_active : nullptr;
-    const TreeDev td{T.d_parent, T.d_child_ptr, T.d_child, T.d_e_up, T.d_e_dn, T.d_child_mid, T.d_lin_ptr, T.d_lin_post, T.d_child3};
+    const TreeDev td{T.d_parent, T.d_child_ptr, T.d_child, T.d_e_up, T.d_e_dn, T.d_child_mid, T.d_lin_ptr, T.d_lin_post, T.d_child3, T.d_dchild, T.d_chain_ptr, T.d_chain_nodes, T.d_chain_ch};
     const int b = 2 * h->Hn;
     const int R = (b + 15) / 16;
     const int BW = wave_block_size(b);
@@ -1219,6 +1449,16 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
             hipLaunchKernelGGL((k_lin_factor<false>), dim3((unsigned)((lin_threads + 127) / 128), (unsigned)h->cur_S), dim3(128), 0,
                                h->cur_stream, h->M, td, T.n_lin_roots, h->N, h->Nc, Bst, active, h->d_U, h->d_E, h->d_f,
                                h->d_linA, h->d_w, h->d_I0, h->cur_s0);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) {
+                h->last_detail = (int)e;
+                return HPF_E_HIP;
+            }
+        }
+        if (T.n_chains > 0) {
+            hipLaunchKernelGGL(k_chain_factor, dim3((unsigned)((T.n_chains * h->Hn + 127) / 128), (unsigned)h->cur_S), dim3(128), 0,
+                               h->cur_stream, h->M, td, T.n_chains, h->N, h->Nc, Bst, active, h->d_U, h->d_E, h->d_f, h->d_linA,
+                               h->d_w, h->d_I0, h->d_chG, h->d_chH, h->d_chD, h->d_chy, h->d_chZ, h->cur_s0);
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) {
                 h->last_detail = (int)e;
@@ -1291,6 +1531,16 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
             }
         }
         if (r) return r;
+    }
+    if (T.n_chains > 0) {
+        hipLaunchKernelGGL(k_chain_back, dim3((unsigned)((T.n_chains * h->Hn + 127) / 128), (unsigned)h->cur_S), dim3(128), 0,
+                           h->cur_stream, h->M, td, T.n_chains, h->N, h->Nc, Bst, active, h->d_U, h->d_E, h->d_linA, h->d_w, h->d_x,
+                           h->d_f, h->d_chZ, h->cur_s0);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) {
+            h->last_detail = (int)e;
+            return HPF_E_HIP;
+        }
     }
     if (lin_threads > 0) {
         hipLaunchKernelGGL((k_lin_back<false>), dim3((unsigned)((lin_threads + 127) / 128), (unsigned)h->cur_S), dim3(128), 0, h->cur_stream,

@@ -54,6 +54,14 @@ struct Tree {
                                       //   count, first four dense children (everything a block needs behind ONE scalar load)
     int* d_child3 = nullptr;          // [n-1][4] per child-list position: child, e_dn[child], e_up[child], 0
     int* d_bdesc = nullptr;           // [n_dense][2] (k, parent) in back-substitution (depth) order
+    // contraction of pass-through buses (linear bus, exactly one dense child): eliminated in 2x2-per-harmonic algebra before
+    // the dense levels; `parent` stays the network parent, the dense tree links a chain's bottom bus to the chain's top parent
+    int n_chains = 0;
+    std::vector<int> chain_ptr, chain_nodes, chain_ch;   // chains bottom-up: nodes k1..kt, ch = the dense bus below k1
+    int* d_dchild = nullptr;          // dense children lists of the dense buses (through chains), indexed by the node records
+    int* d_chain_ptr = nullptr;
+    int* d_chain_nodes = nullptr;
+    int* d_chain_ch = nullptr;
     double flops_per_solve = 0.0;     // factor sweep + back sweep
     double flops_factor = 0.0;        // factor sweep only (k_tree_factor, all levels)
 };
@@ -93,13 +101,20 @@ struct hpf_handle {
     int* d_ipiv = nullptr;
     int* d_info = nullptr;
     // block-tree solver
-    hpf::Tree tree;
+    hpf::Tree tree;                   // elimination tree as the network gives it (single-wave / generic kernels, pf)
+    hpf::Tree ctree;                  // the same with pass-through buses contracted (multi-wave kernels, gj_mode 1)
+    bool has_ctree = false;
     double* d_Z = nullptr;            // [S][n][b*b]
     double* d_w = nullptr;            // [S][n][b]
     double* d_x = nullptr;            // [S][n][b]  Newton step, bus-major
     long long* d_dbg = nullptr;       // [S][n][8] diagnostic phase stamps of the factor kernel (HPF_DEBUG_ABLATE & 16)
     double* d_C = nullptr;            // [S][n][(B+1)*B] Schur complements pushed by dense children (MFMA mode)
     double* d_H = nullptr;            // [S][n][Hn][4] A(k,parent) blocks of the dense buses, kept for the back sweep
+    double* d_chG = nullptr;          // [S][n][Hn][4] contracted tree: A'(top parent, ch) of a chain's bottom dense bus ch
+    double* d_chH = nullptr;          // [S][n][Hn][4]                  A'(ch, top parent)
+    double* d_chD = nullptr;          // [S][n][Hn][4] harmonic-diagonal addend to the diagonal block of ch
+    double* d_chy = nullptr;          // [S][n][Hn][2] addend to the right-hand side of ch
+    double* d_chZ = nullptr;          // [S][n][Hn][4] D_k^-1 A'(k, ch) of the chain buses k (back substitution)
     double* d_linA = nullptr;         // [S][n][Hn][4] inverse 2x2 blocks of the all-linear-subtree buses
 
     hipStream_t own_stream = nullptr, stream = nullptr;
@@ -140,6 +155,7 @@ struct ScopedTimer {
 
 // block-tree solver (hpf_block.hip)
 int tree_build(hpf_handle* h, const hpf_desc* d);
+hpf::Tree& active_tree(hpf_handle* h);
 void tree_free(hpf_handle* h);
 int tree_alloc_scenarios(hpf_handle* h);
 int tree_fund_step(hpf_handle* h, bool only_active);     // fundamental pf Newton step on the tree (2x2 blocks)

@@ -535,7 +535,7 @@ int nr_loop(hpf_handle* h, double thresh, int max_iter, int* n_iter, double* err
 void free_all(hpf_handle* h) {
     void* ptrs[] = {h->d_rowptr, h->d_col, h->d_diag, h->d_erow, h->d_dev, h->d_Y, h->d_YN, h->d_IN, h->d_P, h->d_Q,
                     h->d_Vm, h->d_Va, h->d_U, h->d_E, h->d_I0, h->d_f, h->d_errbits, h->d_err, h->d_niter, h->d_active,
-                    h->d_nactive, h->d_hist, h->d_stats, h->d_J, h->d_ipiv, h->d_info, h->d_Z, h->d_w, h->d_x, h->d_linA, h->d_C, h->d_dbg, h->d_H};
+                    h->d_nactive, h->d_hist, h->d_stats, h->d_J, h->d_ipiv, h->d_info, h->d_Z, h->d_w, h->d_x, h->d_linA, h->d_C, h->d_dbg, h->d_H, h->d_chG, h->d_chH, h->d_chD, h->d_chy, h->d_chZ};
     for (void* p : ptrs)
         if (p) hipFree(p);
     tree_free(h);
@@ -674,8 +674,8 @@ int hpf_destroy(hpf_handle* h) {
 
 int hpf_num_unknowns(const hpf_handle* h) { return h ? h->N : HPF_E_ARG; }
 int hpf_num_unknowns_fund(const hpf_handle* h) { return h ? h->Nf : HPF_E_ARG; }
-int hpf_tree_levels(const hpf_handle* h) { return h ? h->tree.n_levels : HPF_E_ARG; }
-int hpf_tree_depths(const hpf_handle* h) { return h ? h->tree.n_depths : HPF_E_ARG; }
+int hpf_tree_levels(const hpf_handle* h) { return h ? active_tree(const_cast<hpf_handle*>(h)).n_levels : HPF_E_ARG; }
+int hpf_tree_depths(const hpf_handle* h) { return h ? active_tree(const_cast<hpf_handle*>(h)).n_depths : HPF_E_ARG; }
 
 int hpf_set_loads(hpf_handle* h, int n_scen, const double* P, const double* Q) {
     if (!h || !P || !Q || n_scen < 1 || n_scen > h->S_max) return HPF_E_ARG;
@@ -871,7 +871,7 @@ int hpf_timing_reset(hpf_handle* h) {
 
 double hpf_solve_flops(const hpf_handle* h) {
     if (!h) return 0.0;
-    if (h->solver == HPF_SOLVER_BLOCK_TREE) return h->tree.flops_factor;
+    if (h->solver == HPF_SOLVER_BLOCK_TREE) return active_tree(const_cast<hpf_handle*>(h)).flops_factor;
     const double N = h->N;
     return (2.0 / 3.0) * N * N * N + 2.0 * N * N;
 }

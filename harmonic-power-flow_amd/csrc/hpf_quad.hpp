@@ -44,7 +44,8 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? HPF_Q_OCC : 5)) voi
     Model M, TreeDev T, const int* __restrict__ nodes, int b, int N, int Nc, const int* __restrict__ active,
     const cplx* __restrict__ Uall, const cplx* __restrict__ Eall, const double* __restrict__ fall, double* __restrict__ Zall,
     double* __restrict__ wall, const double* __restrict__ linAall, double* __restrict__ Call, double* __restrict__ Hall,
-    const cplx* __restrict__ I0all, long long* __restrict__ dbg, int ablate, int s0) {
+    const cplx* __restrict__ I0all, const double* __restrict__ chG, const double* __restrict__ chH,
+    const double* __restrict__ chD, const double* __restrict__ chy, long long* __restrict__ dbg, int ablate, int s0) {
     constexpr int NT = (B + 16) / 16;
     constexpr size_t CT = (size_t)NT * NT * 256;
     constexpr int tcB = B >> 4, jjB = B & 15;
@@ -61,6 +62,7 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? HPF_Q_OCC : 5)) voi
     const int k = nd0.x, par = nd0.y, diag_e = nd0.z, devk = nd0.w;
     const int e_dn_k = nd1.x, e_up_k = nd1.y, lin_beg = nd1.z, lin_end = nd1.z + nd1.w;
     const int den_beg = nd2.x, n_den = nd2.y;
+    const bool via_chain = nd3.z != 0;       // linked to the dense parent through a contracted chain (k_chain_factor)
 #ifdef HPF_FACTOR_STAMPS
     long long sd1 = 0, sd2 = 0, sd3 = 0;
     {
@@ -112,8 +114,17 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? HPF_Q_OCC : 5)) voi
     if (par >= 0 && wv == (NT > 1 ? 1 : 0) && lane < NT * 8) {
         double g4[4] = {0.0, 0.0, 0.0, 0.0}, h4[4] = {0.0, 0.0, 0.0, 0.0};
         if (lane < Hn) {
-            coupling_block(M, U, E, lane, par, k, e_dn_k, g4);
-            coupling_block(M, U, E, lane, k, par, e_up_k, h4);
+            if (via_chain) {
+                const size_t o = (so + (size_t)k * Hn + lane) * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    g4[e] = chG[o + e];
+                    h4[e] = chH[o + e];
+                }
+            } else {
+                coupling_block(M, U, E, lane, par, k, e_dn_k, g4);
+                coupling_block(M, U, E, lane, k, par, e_up_k, h4);
+            }
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -142,6 +153,12 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? HPF_Q_OCC : 5)) voi
                                                       : jac_current_diag(M, U, E, q, k, diag_e, devk);
                 d0 = pick(blk, tr_, 0);
                 d1 = pick(blk, tr_, 1);
+                if (via_chain) {                 // what the elimination of the chain above left on this bus
+                    const size_t o = so + (size_t)k * Hn + q;
+                    d0 += chD[o * 4 + 2 * tr_];
+                    d1 += chD[o * 4 + 2 * tr_ + 1];
+                    y += chy[o * 2 + tr_];
+                }
             }
 #ifdef HPF_FACTOR_STAMPS
             asm volatile("" : "+v"(d0), "+v"(d1), "+v"(y));
@@ -252,7 +269,7 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? HPF_Q_OCC : 5)) voi
 
     // ---- B. remaining dense children (fixed order), then subtract the sum -----------------------------------------------------
     for (int i = 1; i < n_den; ++i) {
-        const int ch = i == 1 ? nd2.w : (i == 2 ? nd3.x : (i == 3 ? nd3.y : T.child[den_beg + i]));
+        const int ch = i == 1 ? nd2.w : (i == 2 ? nd3.x : (i == 3 ? nd3.y : T.dchild[den_beg + i]));
         const double* Cc = Cs + (size_t)ch * CT + lane;
         double tmp[NT * 4];
 #pragma unroll
@@ -477,7 +494,7 @@ int launch_factor_q(hpf_handle* h, const TreeDev& T, const int* nodes, int count
     constexpr int NT = (B + 16) / 16;
     hipLaunchKernelGGL((k_factor_q<B>), dim3((unsigned)count, (unsigned)h->cur_S), dim3(64 * NT), 0, h->cur_stream, h->M, T, nodes,
                        2 * h->Hn, h->N, h->Nc, active, h->d_U, h->d_E, h->d_f, h->d_Z, h->d_w, h->d_linA, h->d_C, h->d_H,
-                       h->d_I0, h->d_dbg, h->debug_ablate, h->cur_s0);
+                       h->d_I0, h->d_chG, h->d_chH, h->d_chD, h->d_chy, h->d_dbg, h->debug_ablate, h->cur_s0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         h->last_detail = (int)e;
