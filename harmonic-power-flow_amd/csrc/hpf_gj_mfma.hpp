@@ -101,6 +101,32 @@ __device__ __forceinline__ double inv4_cofactor_lane(const double* pv, int lane)
     return cof * rcp_nr(det);
 }
 
+// The same with the cofactor position (i, j) chosen by the caller: returns C_ij / det = W[j][i].  The four lanes of a DPP quad
+// must hold either the four j of one i (row expansion of the determinant) or the four i of one j (column expansion).
+__device__ __forceinline__ double inv4_cofactor_ij(const double* pv, int i, int j) {
+    const int r0 = i == 0 ? 1 : 0, r1 = i <= 1 ? 2 : 1, r2 = i == 3 ? 2 : 3;
+    const int c0 = j == 0 ? 1 : 0, c1 = j <= 1 ? 2 : 1, c2 = j == 3 ? 2 : 3;
+    const double a00 = pv[r0 * 4 + c0], a01 = pv[r0 * 4 + c1], a02 = pv[r0 * 4 + c2];
+    const double a10 = pv[r1 * 4 + c0], a11 = pv[r1 * 4 + c1], a12 = pv[r1 * 4 + c2];
+    const double a20 = pv[r2 * 4 + c0], a21 = pv[r2 * 4 + c1], a22 = pv[r2 * 4 + c2];
+    const double aij = pv[i * 4 + j];
+    const double m0 = fma(a11, a22, -(a12 * a21));
+    const double m1 = fma(a10, a22, -(a12 * a20));
+    const double m2 = fma(a10, a21, -(a11 * a20));
+    double cof = fma(a02, m2, fma(a00, m0, -(a01 * m1)));
+    cof = ((i + j) & 1) ? -cof : cof;
+    double det = aij * cof;
+    {
+        int lo = __double2loint(det), hi = __double2hiint(det);
+        det += __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xf, 0xf, false),
+                                __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xf, 0xf, false));       // quad_perm [1,0,3,2]
+        lo = __double2loint(det), hi = __double2hiint(det);
+        det += __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xf, 0xf, false),
+                                __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xf, 0xf, false));       // quad_perm [2,3,0,1]
+    }
+    return cof * rcp_nr(det);
+}
+
 // c: NT x NT accumulator tiles; NBS: number of 4x4 block steps (compile time: identity-padded rows / columns are no-ops,
 // and a fixed step count keeps the accumulators in place between steps); panel: LDS, NT*64 + 16 doubles.
 template <int NT, int NBS>

@@ -35,6 +35,50 @@ __device__ __forceinline__ double row_sum16(double v) {
     return v;
 }
 
+// Value forms of the per-entry Jacobian formulas of hpf_assembly.hpp (same operations, operands already in registers).
+// blk_current: current-balance row, network entry y, column-bus voltages (HG:403-411).
+__device__ __forceinline__ Blk2 blk_current(cplx y, cplx Uj, cplx Ej) {
+    Blk2 b;
+    b.dV = cmul_unf(y, Ej);
+    b.dA = cmul_unf(cmulj(y), Uj);
+    return b;
+}
+// diagonal current-balance entry incl. the p == h Norton term of a nonlinear bus (HG:432-435)
+__device__ __forceinline__ Blk2 blk_current_diag(cplx y, cplx U, cplx E, cplx yn, bool nonlinear) {
+    Blk2 b = blk_current(y, U, E);
+    if (nonlinear) {
+        b.dV = csub(b.dV, cmul_unf(yn, E));
+        b.dA = csub(b.dA, cmul_unf(cmulj(yn), U));
+    }
+    return b;
+}
+// power row i, off-diagonal column j (HG:451-459, jac_power_entry with i != j)
+__device__ __forceinline__ Blk2 blk_power_off(cplx y, cplx Ui, cplx Uj, cplx Ej) {
+    const cplx yu = cmul_unf(y, Uj);
+    const cplx ye = cmul_unf(y, Ej);
+    Blk2 b;
+    b.dV = cmul_unf(Ui, cconj(ye));
+    b.dA = cmul_unf(cmulj(Ui), cconj(cneg(yu)));
+    return b;
+}
+// power row, diagonal entry, row current I supplied (jac_power_diag)
+__device__ __forceinline__ Blk2 blk_power_diag(cplx y, cplx U, cplx E, cplx I) {
+    const cplx yu = cmul_unf(y, U);
+    const cplx ye = cmul_unf(y, E);
+    Blk2 b;
+    b.dV = cadd(cmul_unf(E, cconj(I)), cmul_unf(U, cconj(ye)));
+    b.dA = cmul_unf(cmulj(U), cconj(csub(I, yu)));
+    return b;
+}
+// 2x2 real block of (row bus i, column bus j) at harmonic position q, masked to existing equations / unknowns (coupling_block)
+__device__ __forceinline__ void mask_block(int n, int c, int q, int i, int j, const Blk2& blk, double out[4]) {
+#pragma unroll
+    for (int tr = 0; tr < 2; ++tr)
+#pragma unroll
+        for (int tc = 0; tc < 2; ++tc)
+            out[tr * 2 + tc] = (loc_valid(n, c, i, 2 * q + tr) && loc_valid(n, c, j, 2 * q + tc)) ? pick(blk, tr, tc) : 0.0;
+}
+
 #ifndef HPF_Q_OCC
 #define HPF_Q_OCC 4        // waves per SIMD the B = 52 factor kernel is compiled for (register budget 512 / HPF_Q_OCC)
 #endif
@@ -84,27 +128,31 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? HPF_Q_OCC : 5)) voi
     __shared__ double panel[2][NT * 64];
     __shared__ double wl[2][16], pv[2][16];
     __shared__ double gl[NT * 32], hl[NT * 32];
+    __shared__ cplx ynl[(B / 2) * (B / 2)];
 
     const bool nl = k >= M.m && M.coupled;
     const int col = 16 * wv + jj, p = col >> 1, t1 = col & 1;      // own column = (harmonic position p, component t1)
     const int t = lg & 1;                                          // component of every row this lane holds
 
-    // ---- B0. Schur complement of the FIRST dense child (accumulator layout, own tile column): the loads are issued here and
-    //      first touched after the assembly, so their HBM latency hides behind it ----------------------------------------------
-    const double* Cs = Call + (size_t)s * n * CT;
-    double sumc[NT * 4];
+    // ---- A0. the device type's Y_N (Hn x Hn complex, shared by every scenario: L2) is fetched once per block, all loads in
+    //      flight behind the node record; it reaches LDS just before the first barrier ---------------------------------------
+    constexpr int YNL = ((B / 2) * (B / 2) + 64 * NT - 1) / (64 * NT);
+    cplx ynr[YNL];
+    if (nl) {
+        const cplx* ynd = M.YN + (size_t)devk * Hn * Hn;
 #pragma unroll
-    for (int e = 0; e < NT * 4; ++e) sumc[e] = 0.0;
-    if (n_den > 0) {
-        const double* Cc = Cs + (size_t)nd2.z * CT + lane;
-#pragma unroll
-        for (int e = 0; e < NT * 4; ++e)
-            if (16 * (e >> 2) + 4 * (e & 3) < B) sumc[e] = Cc[(size_t)(((e >> 2) * NT + wv) * 4 + (e & 3)) * 64];
+        for (int j = 0; j < YNL; ++j) {
+            const int idx = tid + 64 * NT * j;
+            ynr[j] = ynd[idx < Hn * Hn ? idx : 0];
+        }
     }
-
-    // ---- A1. roles before the first barrier.  Last wave: bus voltages of the Norton cross terms -> LDS --------------------
+    // ---- A1. roles before the first barrier.  Every role FIRST issues all its loads (addresses come from the node record
+    //      alone), then computes from registers with the value forms of the per-entry formulas (blk_current / blk_power_off /
+    //      blk_power_diag): one memory round trip per role instead of one per operand group.
+    //      Last wave: bus voltages of the Norton cross terms -> LDS --------------------------------------------------------------
     if (nl && wv == NT - 1 && lane < Hn) {
         const cplx u = U[(size_t)lane * n + k], e = E[(size_t)lane * n + k];
+        __builtin_amdgcn_sched_barrier(0);
         double* t0 = tab + lane * 4;
         double* t1p = tab + (B / 2) * 4 + lane * 4;
         t0[0] = u.re;   t0[1] = u.im;    t0[2] = e.im;    t0[3] = -e.re;
@@ -114,16 +162,22 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? HPF_Q_OCC : 5)) voi
     if (par >= 0 && wv == (NT > 1 ? 1 : 0) && lane < NT * 8) {
         double g4[4] = {0.0, 0.0, 0.0, 0.0}, h4[4] = {0.0, 0.0, 0.0, 0.0};
         if (lane < Hn) {
+            const int q = lane;
             if (via_chain) {
-                const size_t o = (so + (size_t)k * Hn + lane) * 4;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    g4[e] = chG[o + e];
-                    h4[e] = chH[o + e];
-                }
+                const double2* pg = reinterpret_cast<const double2*>(chG + (so + (size_t)k * Hn + q) * 4);
+                const double2* ph = reinterpret_cast<const double2*>(chH + (so + (size_t)k * Hn + q) * 4);
+                const double2 ga = pg[0], gb = pg[1], ha = ph[0], hb = ph[1];
+                g4[0] = ga.x; g4[1] = ga.y; g4[2] = gb.x; g4[3] = gb.y;
+                h4[0] = ha.x; h4[1] = ha.y; h4[2] = hb.x; h4[3] = hb.y;
             } else {
-                coupling_block(M, U, E, lane, par, k, e_dn_k, g4);
-                coupling_block(M, U, E, lane, k, par, e_up_k, h4);
+                const cplx ydn = M.Y[(size_t)q * M.nnz + e_dn_k], yup = M.Y[(size_t)q * M.nnz + e_up_k];
+                const cplx uk = U[(size_t)q * n + k], ek = E[(size_t)q * n + k];
+                const cplx up = U[(size_t)q * n + par], ep = E[(size_t)q * n + par];
+                __builtin_amdgcn_sched_barrier(0);
+                const Blk2 g = (q == 0 && par < M.m) ? blk_power_off(ydn, up, uk, ek) : blk_current(ydn, uk, ek);   // row par, col k
+                const Blk2 hh = (q == 0 && k < M.m) ? blk_power_off(yup, uk, up, ep) : blk_current(yup, up, ep);     // row k, col par
+                mask_block(n, c, q, par, k, g, g4);
+                mask_block(n, c, q, k, par, hh, h4);
             }
         }
 #pragma unroll
@@ -139,26 +193,34 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? HPF_Q_OCC : 5)) voi
     }
     {
         // lane = row 2q+tr_: wave 0 forms the network part of the harmonic-diagonal 2x2 and the right-hand side; the children
-        // whose whole subtree is linear (harmonic-diagonal Schur complements, k_lin_factor) are dealt round-robin to the waves
+        // folded in 2x2-per-harmonic algebra (linear subtrees, contracted chains) are dealt to the waves, lightest roles first
         const int q = lane >> 1, tr_ = lane & 1;
         const bool rowvalid = lane < b && loc_valid(n, c, k, lane);
+        const size_t kq = (size_t)(q < Hn ? q : 0) * n + k;
         if (wv == 0) {
             double y = 0.0, d0 = 0.0, d1 = 0.0;
             if (rowvalid) {
                 const double* f = fall + (size_t)s * N;
                 const int kst = q * n + k;
-                y = tr_ ? f[Nc + kst - c] : f[kst - 1];
-                // power rows (HG:451-459): the row current was kept by the mismatch kernel of this very state (I0)
-                const Blk2 blk = (q == 0 && k < M.m) ? jac_power_diag(M, U, E, k, diag_e, I0all[(size_t)s * n + k])
-                                                      : jac_current_diag(M, U, E, q, k, diag_e, devk);
-                d0 = pick(blk, tr_, 0);
-                d1 = pick(blk, tr_, 1);
-                if (via_chain) {                 // what the elimination of the chain above left on this bus
+                const bool prow = q == 0 && k < M.m;                     // power row (HG:451-459)
+                const double fy = tr_ ? f[Nc + kst - c] : f[kst - 1];
+                const cplx yd = M.Y[(size_t)q * M.nnz + diag_e];
+                const cplx uk = U[kq], ek = E[kq];
+                cplx yn = {0.0, 0.0}, I0v = {0.0, 0.0};
+                if (k >= M.m) yn = M.coupled ? M.YN[((size_t)devk * Hn + q) * Hn + q] : M.YN[(size_t)devk * Hn + q];
+                if (prow) I0v = I0all[(size_t)s * n + k];                // kept by the mismatch kernel of this very state
+                double a0 = 0.0, a1 = 0.0, ay = 0.0;
+                if (via_chain) {                                         // what the elimination of the chain above left here
                     const size_t o = so + (size_t)k * Hn + q;
-                    d0 += chD[o * 4 + 2 * tr_];
-                    d1 += chD[o * 4 + 2 * tr_ + 1];
-                    y += chy[o * 2 + tr_];
+                    a0 = chD[o * 4 + 2 * tr_];
+                    a1 = chD[o * 4 + 2 * tr_ + 1];
+                    ay = chy[o * 2 + tr_];
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                const Blk2 blk = prow ? blk_power_diag(yd, uk, ek, I0v) : blk_current_diag(yd, uk, ek, yn, k >= M.m);
+                d0 = pick(blk, tr_, 0) + a0;
+                d1 = pick(blk, tr_, 1) + a1;
+                y = fy + ay;
             }
 #ifdef HPF_FACTOR_STAMPS
             asm volatile("" : "+v"(d0), "+v"(d1), "+v"(y));
@@ -168,34 +230,61 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? HPF_Q_OCC : 5)) voi
             dgb[lane * 3 + 1] = d1;
             dgb[lane * 3 + 2] = y;
         }
-        if (lin_beg + wv < lin_end) {
+        const int slot = (wv + NT - (2 % NT)) % NT;          // waves 2, 3 have the lightest roles: they take the first children
+        if (lin_beg + slot < lin_end) {
             double e0 = 0.0, e1 = 0.0, ey = 0.0;
             if (rowvalid) {
                 const double* ws = wall + (size_t)s * n * B;
                 const double* linA = linAall + so * 4;
                 const int4* c3 = reinterpret_cast<const int4*>(T.child3);
-                for (int cp = lin_beg + wv; cp < lin_end; cp += NT) {
+                const cplx uk = U[kq], ek = E[kq];
+                for (int cp = lin_beg + slot; cp < lin_end; cp += NT) {
                     const int4 cr = c3[cp];
                     const int ch = cr.x;
-                    const Blk2 g = offdiag_block(M, U, E, q, k, ch, cr.y);           // A(parent, child), my harmonic
+                    const cplx ydn = M.Y[(size_t)q * M.nnz + cr.y], yup = M.Y[(size_t)q * M.nnz + cr.z];
+                    const cplx uc = U[(size_t)q * n + ch], ec = E[(size_t)q * n + ch];
+                    const double2* pic = reinterpret_cast<const double2*>(linA + ((size_t)ch * Hn + q) * 4);
+                    const double2 ic01 = pic[0], ic23 = pic[1];
+                    const double2 wc = *reinterpret_cast<const double2*>(ws + (size_t)ch * B + 2 * q);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const Blk2 g = (q == 0 && k < M.m) ? blk_power_off(ydn, uk, uc, ec) : blk_current(ydn, uc, ec);   // A(k, child)
+                    const Blk2 hb = (q == 0 && ch < M.m) ? blk_power_off(yup, uc, uk, ek) : blk_current(yup, uk, ek);  // A(child, k)
                     const double g0 = pick(g, tr_, 0);
                     const double g1 = loc_valid(n, c, ch, 2 * q + 1) ? pick(g, tr_, 1) : 0.0;
                     double h4[4];
-                    coupling_block(M, U, E, q, ch, k, cr.z, h4);                     // A(child, parent)
-                    const double* ic = linA + ((size_t)ch * Hn + q) * 4;
-                    const double v0 = fma(g1, ic[2], g0 * ic[0]), v1 = fma(g1, ic[3], g0 * ic[1]);
+                    mask_block(n, c, q, ch, k, hb, h4);
+                    const double v0 = fma(g1, ic23.x, g0 * ic01.x), v1 = fma(g1, ic23.y, g0 * ic01.y);
                     e0 += fma(v1, h4[2], v0 * h4[0]);
                     e1 += fma(v1, h4[3], v0 * h4[1]);
-                    const double* wc = ws + (size_t)ch * B;
-                    ey = fma(g0, wc[2 * q], ey);
-                    ey = fma(g1, wc[2 * q + 1], ey);
+                    ey = fma(g0, wc.x, ey);
+                    ey = fma(g1, wc.y, ey);
                 }
             }
-            cc[wv][lane * 3 + 0] = e0;
-            cc[wv][lane * 3 + 1] = e1;
-            cc[wv][lane * 3 + 2] = ey;
+            cc[slot][lane * 3 + 0] = e0;
+            cc[slot][lane * 3 + 1] = e1;
+            cc[slot][lane * 3 + 2] = ey;
         }
     }
+    if (nl) {            // Y_N of the device type -> LDS (loads issued at the top of the kernel); before the prefetch
+                         // below, whose loads nothing may wait for yet
+#pragma unroll
+        for (int j = 0; j < YNL; ++j)
+            if (tid + 64 * NT * j < Hn * Hn) ynl[tid + 64 * NT * j] = ynr[j];
+    }
+    // ---- B0. Schur complement of the FIRST dense child (accumulator layout, own tile column): the loads are issued here, after
+    //      the role loads (loads return in order: a role must not wait behind them), and first touched after the assembly ----------
+    const double* Cs = Call + (size_t)s * n * CT;
+    double sumc[NT * 4];
+#pragma unroll
+    for (int e = 0; e < NT * 4; ++e) sumc[e] = 0.0;
+#ifndef HPF_Q_NOPREFETCH
+    if (n_den > 0) {
+        const double* Cc = Cs + (size_t)nd2.z * CT + lane;
+#pragma unroll
+        for (int e = 0; e < NT * 4; ++e)
+            if (16 * (e >> 2) + 4 * (e & 3) < B) sumc[e] = Cc[(size_t)(((e >> 2) * NT + wv) * 4 + (e & 3)) * 64];
+    }
+#endif
     HPF_STAMP(sd3);
     __syncthreads();
     HPF_STAMP(sa);
@@ -217,24 +306,15 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? HPF_Q_OCC : 5)) voi
         const int pp = p < B / 2 ? p : 0;
         const double P = tab[t * (B / 2) * 4 + pp * 4 + 2 * t1];
         const double Q = tab[t * (B / 2) * 4 + pp * 4 + 2 * t1 + 1];
-        const cplx* yn = M.YN + (size_t)devk * Hn * Hn + (p < Hn ? p : 0);
+        const cplx* yn = ynl + (p < Hn ? p : 0);
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            cplx ynb[NT * 2];
+        for (int tr = 0; tr < NT; ++tr)
 #pragma unroll
-            for (int e = 0; e < NT * 2; ++e) {
-                const int tr = (half * NT * 2 + e) >> 2, reg = (half * NT * 2 + e) & 3;
+            for (int reg = 0; reg < 4; ++reg) {
                 const int q = 8 * tr + 2 * reg + (lg >> 1);
-                ynb[e] = yn[(size_t)(q < Hn ? q : 0) * Hn];
+                const cplx y = yn[(q < Hn ? q : 0) * Hn];
+                ct[tr][reg] = y.im * P + y.re * Q;
             }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int e = 0; e < NT * 2; ++e) {
-                const int tr = (half * NT * 2 + e) >> 2, reg = (half * NT * 2 + e) & 3;
-                ct[tr][reg] = ynb[e].im * P + ynb[e].re * Q;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
     }
     HPF_STAMP(sc);
     __syncthreads();
@@ -268,8 +348,13 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? HPF_Q_OCC : 5)) voi
     HPF_STAMP(st1);
 
     // ---- B. remaining dense children (fixed order), then subtract the sum -----------------------------------------------------
+#ifdef HPF_Q_NOPREFETCH
+    for (int i = 0; i < n_den; ++i) {
+        const int ch = i == 0 ? nd2.z : i == 1 ? nd2.w : (i == 2 ? nd3.x : (i == 3 ? nd3.y : T.dchild[den_beg + i]));
+#else
     for (int i = 1; i < n_den; ++i) {
         const int ch = i == 1 ? nd2.w : (i == 2 ? nd3.x : (i == 3 ? nd3.y : T.dchild[den_beg + i]));
+#endif
         const double* Cc = Cs + (size_t)ch * CT + lane;
         double tmp[NT * 4];
 #pragma unroll
