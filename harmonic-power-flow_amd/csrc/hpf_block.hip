@@ -16,6 +16,7 @@
 // pulled from HBM; D_k is inverted in place by Gauss-Jordan with partial (row) pivoting, rows/columns of each step
 // broadcast through LDS (2 barriers per step); Z_k (b x b) and w_k (b) are the only HBM writes.
 // Bound: FP64 FMA rate (2 b^3 flop per bus) against 24 b^2 bytes of Z traffic per bus -> ~4.3 flop/B at b = 52.
+#include <complex>
 #include "hpf_internal.hpp"
 #include "hpf_gj.hpp"
 #include "hpf_gj_mfma.hpp"
@@ -1301,6 +1302,123 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
         child3[cp * 4 + 1] = e_dn[ch];
         child3[cp * 4 + 2] = e_up[ch];
     }
+    // ---- constant-inverse leaves (see Tree::d_Minv) -----------------------------------------------------------------------
+    std::vector<int> cleaf_of(n, -1);
+    std::vector<double> minv;
+    T.n_cleaf = 0;
+    const int BWc = wave_block_size(b);
+    if (contract && d->coupled && BWc) {
+        typedef std::complex<double> cd;
+        const int Hn = d->Hn, nnz = d->nnz;
+        auto yv = [&](int q, int e) { return cd(d->Yval[((size_t)q * nnz + e) * 2], d->Yval[((size_t)q * nnz + e) * 2 + 1]); };
+        std::vector<int> diag(n, -1);
+        for (int i = 0; i < n; ++i)
+            for (int e = d->rowptr[i]; e < d->rowptr[i + 1]; ++e)
+                if (d->col[e] == i) diag[i] = e;
+        // series elimination of the all-linear subtrees at the harmonics q >= 1 (current rows: complex-linear, constant):
+        // dl[q][i] = y_ii - sum_children y_ic y_ci / dl[q][c]
+        std::vector<cd> dl((size_t)Hn * n, cd(0.0, 0.0));
+        for (int q = 1; q < Hn; ++q)
+            for (size_t idx = 0; idx < T.lin_post.size(); ++idx) {          // children before parents
+                const int i = T.lin_post[idx];
+                cd v = yv(q, diag[i]);
+                for (int cp = T.child_ptr[i]; cp < T.child_ptr[i + 1]; ++cp) {
+                    const int g = T.child[cp];
+                    v -= yv(q, e_dn[g]) * yv(q, e_up[g]) / dl[(size_t)q * n + g];
+                }
+                dl[(size_t)q * n + i] = v;
+            }
+        std::vector<int> chain_of(n, -1);
+        for (int r2 = 0; r2 < T.n_chains; ++r2) chain_of[T.chain_ch[r2]] = r2;
+        const int NTc = (BWc + 16) / 16;
+        const size_t CTc = (size_t)NTc * NTc * 256;
+        for (int pos = 0; pos < T.n_dense; ++pos) {
+            const int k = T.lvl_nodes[pos];
+            if (k < d->m || dchild_ptr[k + 1] != dchild_ptr[k] || d->dev_of_bus[k] < 0) continue;
+            std::vector<cd> Yc((size_t)Hn * Hn);
+            const double* yn = d->Y_N + (size_t)d->dev_of_bus[k] * Hn * Hn * 2;
+            for (int q = 0; q < Hn; ++q)
+                for (int p2 = 0; p2 < Hn; ++p2) Yc[(size_t)q * Hn + p2] = -cd(yn[((size_t)q * Hn + p2) * 2], yn[((size_t)q * Hn + p2) * 2 + 1]);
+            for (int q = 0; q < Hn; ++q) {
+                cd v = yv(q, diag[k]);
+                if (q >= 1) {
+                    for (int cp = T.child_ptr[k]; cp < T.child_mid[k]; ++cp) {         // linear subtrees below k
+                        const int g = T.child[cp];
+                        v -= yv(q, e_dn[g]) * yv(q, e_up[g]) / dl[(size_t)q * n + g];
+                    }
+                    if (chain_of[k] >= 0) {                                              // contracted chain above k (k_chain_factor)
+                        const int r2 = chain_of[k];
+                        cd a_kc = yv(q, e_dn[k]), a_ck = yv(q, e_up[k]), carry(0.0, 0.0), dD(0.0, 0.0);
+                        for (int idx = T.chain_ptr[r2]; idx < T.chain_ptr[r2 + 1]; ++idx) {
+                            const int kk = T.chain_nodes[idx];
+                            cd dk = yv(q, diag[kk]) + carry;
+                            for (int cp = T.child_ptr[kk]; cp < T.child_mid[kk]; ++cp) {
+                                const int g = T.child[cp];
+                                dk -= yv(q, e_dn[g]) * yv(q, e_up[g]) / dl[(size_t)q * n + g];
+                            }
+                            const cd a_ku = yv(q, e_up[kk]), a_uk = yv(q, e_dn[kk]);
+                            dD -= a_ck * a_kc / dk;
+                            const cd n_ck = -a_ck * a_ku / dk, n_kc = -a_uk * a_kc / dk;
+                            carry = -a_uk * a_ku / dk;
+                            a_ck = n_ck;
+                            a_kc = n_kc;
+                        }
+                        v += dD;
+                    }
+                }
+                Yc[(size_t)q * Hn + q] += v;
+            }
+            // complex Gauss-Jordan with partial pivoting
+            std::vector<cd> Mi((size_t)Hn * Hn, cd(0.0, 0.0));
+            for (int q = 0; q < Hn; ++q) Mi[(size_t)q * Hn + q] = cd(1.0, 0.0);
+            bool ok = true;
+            for (int col = 0; col < Hn && ok; ++col) {
+                int piv = col;
+                for (int r2 = col + 1; r2 < Hn; ++r2)
+                    if (std::abs(Yc[(size_t)r2 * Hn + col]) > std::abs(Yc[(size_t)piv * Hn + col])) piv = r2;
+                if (std::abs(Yc[(size_t)piv * Hn + col]) == 0.0) {
+                    ok = false;
+                    break;
+                }
+                if (piv != col)
+                    for (int c2 = 0; c2 < Hn; ++c2) {
+                        std::swap(Yc[(size_t)piv * Hn + c2], Yc[(size_t)col * Hn + c2]);
+                        std::swap(Mi[(size_t)piv * Hn + c2], Mi[(size_t)col * Hn + c2]);
+                    }
+                const cd ip = cd(1.0, 0.0) / Yc[(size_t)col * Hn + col];
+                for (int c2 = 0; c2 < Hn; ++c2) {
+                    Yc[(size_t)col * Hn + c2] *= ip;
+                    Mi[(size_t)col * Hn + c2] *= ip;
+                }
+                for (int r2 = 0; r2 < Hn; ++r2) {
+                    if (r2 == col) continue;
+                    const cd fct = Yc[(size_t)r2 * Hn + col];
+                    if (fct == cd(0.0, 0.0)) continue;
+                    for (int c2 = 0; c2 < Hn; ++c2) {
+                        Yc[(size_t)r2 * Hn + c2] -= fct * Yc[(size_t)col * Hn + c2];
+                        Mi[(size_t)r2 * Hn + c2] -= fct * Mi[(size_t)col * Hn + c2];
+                    }
+                }
+            }
+            if (!ok) continue;                                       // singular constant part: leave the bus on the general path
+            cleaf_of[k] = T.n_cleaf++;
+            minv.resize((size_t)T.n_cleaf * CTc, 0.0);
+            double* Mt = &minv[(size_t)cleaf_of[k] * CTc];
+            for (int row = 0; row < 16 * NTc; ++row)
+                for (int col = 0; col < 16 * NTc; ++col) {
+                    double v = (row == col) ? 1.0 : 0.0;              // identity padding beyond b
+                    if (row < b && col < b) {
+                        const cd z = Mi[(size_t)(row >> 1) * Hn + (col >> 1)];
+                        const int t = row & 1, t2 = col & 1;          // R(z) = [re -im; im re]
+                        v = (t == t2) ? z.real() : (t ? z.imag() : -z.imag());
+                    } else if (row < b || col < b) {
+                        v = 0.0;
+                    }
+                    const int tr = row >> 4, tc = col >> 4, lg = row & 3, reg = (row & 15) >> 2, jj = col & 15;
+                    Mt[(size_t)((tr * NTc + tc) * 4 + reg) * 64 + lg * 16 + jj] = v;
+                }
+        }
+    }
     for (int pos = 0; pos < T.n_dense; ++pos) {
         const int k = T.lvl_nodes[pos];
         int* r = &fdesc[(size_t)pos * 16];
@@ -1320,6 +1438,7 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
         r[9] = dchild_ptr[k + 1] - dchild_ptr[k];
         for (int i = 0; i < 4 && i < r[9]; ++i) r[10 + i] = dchild[dchild_ptr[k] + i];
         r[14] = (k > 0 && pass[T.parent[k]]) ? 1 : 0;              // linked to its dense parent through a contracted chain
+        r[15] = cleaf_of[k] + 1;                                   // constant-inverse leaf: 1 + slot in Tree::d_Minv
         const int kb = T.dep_nodes[pos];
         bdesc[(size_t)pos * 2 + 0] = kb;
         bdesc[(size_t)pos * 2 + 1] = pard[kb];
@@ -1361,6 +1480,7 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
     if ((r = upload(h, &T.d_chain_ptr, T.chain_ptr))) return r;
     if ((r = upload(h, &T.d_chain_nodes, T.chain_nodes))) return r;
     if ((r = upload(h, &T.d_chain_ch, T.chain_ch))) return r;
+    if ((r = upload(h, &T.d_Minv, minv))) return r;
     return HPF_OK;
 }
 
@@ -1378,7 +1498,7 @@ Tree& active_tree(hpf_handle* h) { return (h->has_ctree && h->gj_mode == 1) ? h-
 static void tree_free_one(Tree& T) {
     void* ptrs[] = {T.d_parent, T.d_lvl_nodes, T.d_dep_nodes, T.d_child_ptr, T.d_child, T.d_e_up, T.d_e_dn,
                     T.d_child_mid, T.d_lin, T.d_lin_ptr, T.d_lin_post, T.d_all_ptr, T.d_all_post, T.d_fdesc, T.d_child3,
-                    T.d_bdesc, T.d_dchild, T.d_chain_ptr, T.d_chain_nodes, T.d_chain_ch};
+                    T.d_bdesc, T.d_dchild, T.d_chain_ptr, T.d_chain_nodes, T.d_chain_ch, T.d_Minv};
     for (void* p : ptrs)
         if (p) hipFree(p);
 }

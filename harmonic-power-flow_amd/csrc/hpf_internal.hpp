@@ -62,6 +62,11 @@ struct Tree {
     int* d_chain_ptr = nullptr;
     int* d_chain_nodes = nullptr;
     int* d_chain_ch = nullptr;
+    // constant-inverse leaves (contracted tree only): nonlinear buses without dense children.  In rectangular coordinates their
+    // block is  R(y_kk I - Y_N - series terms of the linear neighbourhood)  + a 2x2 state-dependent term at the fundamental, so
+    // the complex Hn x Hn inverse is computed ONCE per model (host) and kept in accumulator-tile layout
+    int n_cleaf = 0;
+    double* d_Minv = nullptr;         // [n_cleaf][NT*NT*256]
     double flops_per_solve = 0.0;     // factor sweep + back sweep
     double flops_factor = 0.0;        // factor sweep only (k_tree_factor, all levels)
 };

@@ -89,7 +89,8 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? HPF_Q_OCC : 5)) voi
     const cplx* __restrict__ Uall, const cplx* __restrict__ Eall, const double* __restrict__ fall, double* __restrict__ Zall,
     double* __restrict__ wall, const double* __restrict__ linAall, double* __restrict__ Call, double* __restrict__ Hall,
     const cplx* __restrict__ I0all, const double* __restrict__ chG, const double* __restrict__ chH,
-    const double* __restrict__ chD, const double* __restrict__ chy, long long* __restrict__ dbg, int ablate, int s0) {
+    const double* __restrict__ chD, const double* __restrict__ chy, const double* __restrict__ Minv,
+    long long* __restrict__ dbg, int ablate, int s0) {
     constexpr int NT = (B + 16) / 16;
     constexpr size_t CT = (size_t)NT * NT * 256;
     constexpr int tcB = B >> 4, jjB = B & 15;
@@ -107,6 +108,7 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? HPF_Q_OCC : 5)) voi
     const int e_dn_k = nd1.x, e_up_k = nd1.y, lin_beg = nd1.z, lin_end = nd1.z + nd1.w;
     const int den_beg = nd2.x, n_den = nd2.y;
     const bool via_chain = nd3.z != 0;       // linked to the dense parent through a contracted chain (k_chain_factor)
+    const int cleaf = nd3.w;                 // constant-inverse leaf: 1 + slot in Minv (0: general path)
 #ifdef HPF_FACTOR_STAMPS
     long long sd1 = 0, sd2 = 0, sd3 = 0;
     {
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? HPF_Q_OCC : 5)) voi
     //      flight behind the node record; it reaches LDS just before the first barrier ---------------------------------------
     constexpr int YNL = ((B / 2) * (B / 2) + 64 * NT - 1) / (64 * NT);
     cplx ynr[YNL];
-    if (nl) {
+    if (nl && !cleaf) {
         const cplx* ynd = M.YN + (size_t)devk * Hn * Hn;
 #pragma unroll
         for (int j = 0; j < YNL; ++j) {
@@ -150,13 +152,24 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? HPF_Q_OCC : 5)) voi
     //      alone), then computes from registers with the value forms of the per-entry formulas (blk_current / blk_power_off /
     //      blk_power_diag): one memory round trip per role instead of one per operand group.
     //      Last wave: bus voltages of the Norton cross terms -> LDS --------------------------------------------------------------
-    if (nl && wv == NT - 1 && lane < Hn) {
-        const cplx u = U[(size_t)lane * n + k], e = E[(size_t)lane * n + k];
+    if (nl && wv == NT - 1 && lane < B / 2) {
+        cplx u = {0.0, -1.0}, e = {0.0, 1.0};               // padding harmonics: S = [-ui er; ur ei] = identity
+        if (lane < Hn) {
+            u = U[(size_t)lane * n + k];
+            e = E[(size_t)lane * n + k];
+        }
         __builtin_amdgcn_sched_barrier(0);
         double* t0 = tab + lane * 4;
-        double* t1p = tab + (B / 2) * 4 + lane * 4;
-        t0[0] = u.re;   t0[1] = u.im;    t0[2] = e.im;    t0[3] = -e.re;
-        t1p[0] = u.im;  t1p[1] = -u.re;  t1p[2] = -e.re;  t1p[3] = -e.im;
+        if (cleaf) {
+            // polar -> rectangular map of harmonic q: S = [dU/dtheta | dU/dV] = [-ui er; ur ei]; keep S^-1 (row-major)
+            const double idet = 1.0 / (-(u.im * e.im) - e.re * u.re);
+            t0[0] = e.im * idet;   t0[1] = -e.re * idet;
+            t0[2] = -u.re * idet;  t0[3] = -u.im * idet;
+        } else if (lane < Hn) {
+            double* t1p = tab + (B / 2) * 4 + lane * 4;
+            t0[0] = u.re;   t0[1] = u.im;    t0[2] = e.im;    t0[3] = -e.re;
+            t1p[0] = u.im;  t1p[1] = -u.re;  t1p[2] = -e.re;  t1p[3] = -e.im;
+        }
     }
     // wave 1: coupling blocks with the parent, G = A(parent, k) and H = A(k, parent), for the push (E) and the back sweep
     if (par >= 0 && wv == (NT > 1 ? 1 : 0) && lane < NT * 8) {
@@ -218,8 +231,10 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? HPF_Q_OCC : 5)) voi
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 const Blk2 blk = prow ? blk_power_diag(yd, uk, ek, I0v) : blk_current_diag(yd, uk, ek, yn, k >= M.m);
-                d0 = pick(blk, tr_, 0) + a0;
-                d1 = pick(blk, tr_, 1) + a1;
+                // (constant-inverse leaf: the network part lives in the precomputed inverse; rows 0/1 carry the state-dependent
+                //  2x2 term of the fundamental, i.e. what the 2x2-algebra neighbours left there)
+                d0 = (cleaf ? 0.0 : pick(blk, tr_, 0)) + a0;
+                d1 = (cleaf ? 0.0 : pick(blk, tr_, 1)) + a1;
                 y = fy + ay;
             }
 #ifdef HPF_FACTOR_STAMPS
@@ -265,7 +280,7 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? HPF_Q_OCC : 5)) voi
             cc[slot][lane * 3 + 2] = ey;
         }
     }
-    if (nl) {            // Y_N of the device type -> LDS (loads issued at the top of the kernel); before the prefetch
+    if (nl && !cleaf) {  // Y_N of the device type -> LDS (loads issued at the top of the kernel); before the prefetch
                          // below, whose loads nothing may wait for yet
 #pragma unroll
         for (int j = 0; j < YNL; ++j)
@@ -297,11 +312,80 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? HPF_Q_OCC : 5)) voi
         }
     }
 
-    // ---- A3. own tile column: Norton cross terms -Y_N[q,p] * (jU | E)_{p,k} picked Re/Im (assemble_row's component form:
-    //      v = yi*P + yr*Q, (P,Q) depend on (t, t', p) only -> two per-lane constants) ----------------------------------------
     d4_t ct[NT];
 #pragma unroll
     for (int tr = 0; tr < NT; ++tr) ct[tr] = d4_t{0.0, 0.0, 0.0, 0.0};
+    if (cleaf) {
+        // ================= constant-inverse leaf (Tree::d_Minv) =====================================================
+        // In rectangular coordinates the block is  R(Yc) + E0 D E0^T : Yc constant (precomputed inverse M = R(Yc^-1), tile
+        // layout), D = Delta_polar S_0^-1 the 2x2 term of the fundamental.  Woodbury:  Drect^-1 = M - M E0 K E0^T M  with
+        // K = (I + D M00)^-1 D;  polar inverse = S^-1 Drect^-1 (row pairs scaled by the 2x2 S_q^-1);  w = A^-1 y by row sums.
+        const double* Mk = Minv + (size_t)(cleaf - 1) * CT + lane;
+#pragma unroll
+        for (int e = 0; e < NT * 4; ++e)
+            if (16 * (e >> 2) + 4 * (e & 3) < B) ct[e >> 2][e & 3] = Mk[(size_t)(((e >> 2) * NT + wv) * 4 + (e & 3)) * 64];
+        double* mc = &panel[0][0];          // M[:, 0:2]  as mc[row*2 + a]
+        double* mr = &panel[1][0];          // M[0:2, :]  as mr[a*64 + col]
+        if (wv == 0 && jj < 2) {
+#pragma unroll
+            for (int tr = 0; tr < NT; ++tr)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) mc[(16 * tr + 4 * reg + lg) * 2 + jj] = ct[tr][reg];
+        }
+        if (lg < 2) mr[lg * 64 + col] = ct[0][0];
+        __syncthreads();
+        double kv0, kv1;                    // (K Mr)[a][col]
+        {
+            const double si0 = tab[0], si1 = tab[1], si2 = tab[2], si3 = tab[3];           // S_0^-1
+            const double p00 = dgb[0], p01 = dgb[1], p10 = dgb[3], p11 = dgb[4];           // Delta_polar
+            const double d00 = fma(p01, si2, p00 * si0), d01 = fma(p01, si3, p00 * si1);   // Delta_rect = Delta_polar S_0^-1
+            const double d10 = fma(p11, si2, p10 * si0), d11 = fma(p11, si3, p10 * si1);
+            const double m00 = mr[0], m01 = mr[1], m10 = mr[64], m11 = mr[65];
+            const double t00 = 1.0 + fma(d01, m10, d00 * m00), t01 = fma(d01, m11, d00 * m01);
+            const double t10 = fma(d11, m10, d10 * m00), t11 = 1.0 + fma(d11, m11, d10 * m01);
+            double i00, i01, i10, i11;
+            inv2(t00, t01, t10, t11, i00, i01, i10, i11);
+            const double k00 = fma(i01, d10, i00 * d00), k01 = fma(i01, d11, i00 * d01);
+            const double k10 = fma(i11, d10, i10 * d00), k11 = fma(i11, d11, i10 * d01);
+            const double r0 = mr[col], r1 = mr[64 + col];
+            kv0 = fma(k01, r1, k00 * r0);
+            kv1 = fma(k11, r1, k10 * r0);
+        }
+        const double yc = col < B ? dgb[col * 3 + 2] : 0.0;
+#pragma unroll
+        for (int tr = 0; tr < NT; ++tr)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                if (16 * tr + 4 * reg >= B) continue;
+                const int row = 16 * tr + 4 * reg + lg;
+                double v = ct[tr][reg];
+                v = fma(-mc[row * 2 + 1], kv1, fma(-mc[row * 2], kv0, v));                // Woodbury
+                const double pr = xor16_f64(v);                                             // the other row of the harmonic
+                const double* si = tab + (row >> 1) * 4 + 2 * t;
+                v = t ? fma(si[1], v, si[0] * pr) : fma(si[1], pr, si[0] * v);              // S_q^-1 from the left
+                ct[tr][reg] = v;
+                const double sm = row_sum16(v * yc);
+                if (jj == 0) cc[wv][row] = sm;
+            }
+        __syncthreads();
+        if (wv == tcB && jj == jjB) {                                                       // w = A^-1 y into column B
+#pragma unroll
+            for (int tr = 0; tr < NT; ++tr)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    if (16 * tr + 4 * reg >= B) continue;
+                    const int row = 16 * tr + 4 * reg + lg;
+                    double acc = cc[0][row];
+#pragma unroll
+                    for (int w2 = 1; w2 < NT; ++w2) acc += cc[w2][row];
+                    ct[tr][reg] = acc;
+                }
+        }
+        HPF_STAMP(st1);
+        HPF_STAMP(st3);
+    } else {
+    // ---- A3. own tile column: Norton cross terms -Y_N[q,p] * (jU | E)_{p,k} picked Re/Im (assemble_row's component form:
+    //      v = yi*P + yr*Q, (P,Q) depend on (t, t', p) only -> two per-lane constants) ----------------------------------------
     if (nl) {
         const int pp = p < B / 2 ? p : 0;
         const double P = tab[t * (B / 2) * 4 + pp * 4 + 2 * t1];
@@ -438,6 +522,7 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? HPF_Q_OCC : 5)) voi
         }
     }
 
+    }
 #ifdef HPF_Q_PRIO
     __builtin_amdgcn_s_setprio(0);
 #endif
@@ -579,7 +664,7 @@ int launch_factor_q(hpf_handle* h, const TreeDev& T, const int* nodes, int count
     constexpr int NT = (B + 16) / 16;
     hipLaunchKernelGGL((k_factor_q<B>), dim3((unsigned)count, (unsigned)h->cur_S), dim3(64 * NT), 0, h->cur_stream, h->M, T, nodes,
                        2 * h->Hn, h->N, h->Nc, active, h->d_U, h->d_E, h->d_f, h->d_Z, h->d_w, h->d_linA, h->d_C, h->d_H,
-                       h->d_I0, h->d_chG, h->d_chH, h->d_chD, h->d_chy, h->d_dbg, h->debug_ablate, h->cur_s0);
+                       h->d_I0, h->d_chG, h->d_chH, h->d_chD, h->d_chy, active_tree(h).d_Minv, h->d_dbg, h->debug_ablate, h->cur_s0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         h->last_detail = (int)e;
