@@ -1295,7 +1295,7 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
         }
     }
     // node records of the multi-wave kernels (hpf_quad.hpp)
-    std::vector<int> fdesc((size_t)T.n_dense * 16, 0), child3((size_t)(n > 1 ? n - 1 : 0) * 4, 0), bdesc((size_t)T.n_dense * 2, 0);
+    std::vector<int> fdesc((size_t)T.n_dense * 16, 0), child3((size_t)(n > 1 ? n - 1 : 0) * 4, 0), bdesc((size_t)T.n_dense * 4, 0);
     for (size_t cp = 0; cp < T.child.size(); ++cp) {
         const int ch = T.child[cp];
         child3[cp * 4 + 0] = ch;
@@ -1368,39 +1368,60 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
                 }
                 Yc[(size_t)q * Hn + q] += v;
             }
-            // complex Gauss-Jordan with partial pivoting
-            std::vector<cd> Mi((size_t)Hn * Hn, cd(0.0, 0.0));
-            for (int q = 0; q < Hn; ++q) Mi[(size_t)q * Hn + q] = cd(1.0, 0.0);
+            // Bordered form around the fundamental (index 0), the only place where a state-dependent 2x2 term D enters:
+            //     [a00 + D  A0h]^-1        [0   0    ]   [  I   ]                     [        ]
+            //     [Ah0      Ahh]      =    [0  Ahh^-1] + [ Lc_h ] (c0 + D)^-1  [ I  Lr_h ],   Lc_h = -Ahh^-1 Ah0,  Lr_h = -A0h Ahh^-1,
+            // c0 = a00 - A0h Ahh^-1 Ah0.  Everything but D is constant: keep R(Ahh^-1), R(Lc_h), R(Lr_h), R(c0) as ONE b x b image
+            // (additive rank-2 update on the device: no cancellation, unlike a Woodbury correction of the full inverse).
+            const int Hh = Hn - 1;
+            std::vector<cd> Ah((size_t)Hh * Hh), Bh((size_t)Hh * Hh, cd(0.0, 0.0));
+            for (int q = 0; q < Hh; ++q)
+                for (int p2 = 0; p2 < Hh; ++p2) Ah[(size_t)q * Hh + p2] = Yc[(size_t)(q + 1) * Hn + p2 + 1];
+            for (int q = 0; q < Hh; ++q) Bh[(size_t)q * Hh + q] = cd(1.0, 0.0);
             bool ok = true;
-            for (int col = 0; col < Hn && ok; ++col) {
+            for (int col = 0; col < Hh && ok; ++col) {                // complex Gauss-Jordan with partial pivoting
                 int piv = col;
-                for (int r2 = col + 1; r2 < Hn; ++r2)
-                    if (std::abs(Yc[(size_t)r2 * Hn + col]) > std::abs(Yc[(size_t)piv * Hn + col])) piv = r2;
-                if (std::abs(Yc[(size_t)piv * Hn + col]) == 0.0) {
+                for (int r2 = col + 1; r2 < Hh; ++r2)
+                    if (std::abs(Ah[(size_t)r2 * Hh + col]) > std::abs(Ah[(size_t)piv * Hh + col])) piv = r2;
+                if (std::abs(Ah[(size_t)piv * Hh + col]) == 0.0) {
                     ok = false;
                     break;
                 }
                 if (piv != col)
-                    for (int c2 = 0; c2 < Hn; ++c2) {
-                        std::swap(Yc[(size_t)piv * Hn + c2], Yc[(size_t)col * Hn + c2]);
-                        std::swap(Mi[(size_t)piv * Hn + c2], Mi[(size_t)col * Hn + c2]);
+                    for (int c2 = 0; c2 < Hh; ++c2) {
+                        std::swap(Ah[(size_t)piv * Hh + c2], Ah[(size_t)col * Hh + c2]);
+                        std::swap(Bh[(size_t)piv * Hh + c2], Bh[(size_t)col * Hh + c2]);
                     }
-                const cd ip = cd(1.0, 0.0) / Yc[(size_t)col * Hn + col];
-                for (int c2 = 0; c2 < Hn; ++c2) {
-                    Yc[(size_t)col * Hn + c2] *= ip;
-                    Mi[(size_t)col * Hn + c2] *= ip;
+                const cd ip = cd(1.0, 0.0) / Ah[(size_t)col * Hh + col];
+                for (int c2 = 0; c2 < Hh; ++c2) {
+                    Ah[(size_t)col * Hh + c2] *= ip;
+                    Bh[(size_t)col * Hh + c2] *= ip;
                 }
-                for (int r2 = 0; r2 < Hn; ++r2) {
+                for (int r2 = 0; r2 < Hh; ++r2) {
                     if (r2 == col) continue;
-                    const cd fct = Yc[(size_t)r2 * Hn + col];
+                    const cd fct = Ah[(size_t)r2 * Hh + col];
                     if (fct == cd(0.0, 0.0)) continue;
-                    for (int c2 = 0; c2 < Hn; ++c2) {
-                        Yc[(size_t)r2 * Hn + c2] -= fct * Yc[(size_t)col * Hn + c2];
-                        Mi[(size_t)r2 * Hn + c2] -= fct * Mi[(size_t)col * Hn + c2];
+                    for (int c2 = 0; c2 < Hh; ++c2) {
+                        Ah[(size_t)r2 * Hh + c2] -= fct * Ah[(size_t)col * Hh + c2];
+                        Bh[(size_t)r2 * Hh + c2] -= fct * Bh[(size_t)col * Hh + c2];
                     }
                 }
             }
             if (!ok) continue;                                       // singular constant part: leave the bus on the general path
+            std::vector<cd> img((size_t)Hn * Hn, cd(0.0, 0.0));      // complex image: [c0 Lr_h; Lc_h Ahh^-1]
+            cd c0 = Yc[0];
+            for (int q = 0; q < Hh; ++q) {
+                cd lc(0.0, 0.0), lr(0.0, 0.0);
+                for (int p2 = 0; p2 < Hh; ++p2) {
+                    lc -= Bh[(size_t)q * Hh + p2] * Yc[(size_t)(p2 + 1) * Hn];          // -(Ahh^-1 Ah0)[q]
+                    lr -= Yc[p2 + 1] * Bh[(size_t)p2 * Hh + q];                          // -(A0h Ahh^-1)[q]
+                }
+                img[(size_t)(q + 1) * Hn] = lc;
+                img[q + 1] = lr;
+                for (int p2 = 0; p2 < Hh; ++p2) img[(size_t)(q + 1) * Hn + p2 + 1] = Bh[(size_t)q * Hh + p2];
+            }
+            for (int p2 = 0; p2 < Hh; ++p2) c0 += Yc[p2 + 1] * img[(size_t)(p2 + 1) * Hn];   // a00 + A0h Lc_h
+            img[0] = c0;
             cleaf_of[k] = T.n_cleaf++;
             minv.resize((size_t)T.n_cleaf * CTc, 0.0);
             double* Mt = &minv[(size_t)cleaf_of[k] * CTc];
@@ -1408,7 +1429,7 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
                 for (int col = 0; col < 16 * NTc; ++col) {
                     double v = (row == col) ? 1.0 : 0.0;              // identity padding beyond b
                     if (row < b && col < b) {
-                        const cd z = Mi[(size_t)(row >> 1) * Hn + (col >> 1)];
+                        const cd z = img[(size_t)(row >> 1) * Hn + (col >> 1)];
                         const int t = row & 1, t2 = col & 1;          // R(z) = [re -im; im re]
                         v = (t == t2) ? z.real() : (t ? z.imag() : -z.imag());
                     } else if (row < b || col < b) {
@@ -1440,8 +1461,9 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
         r[14] = (k > 0 && pass[T.parent[k]]) ? 1 : 0;              // linked to its dense parent through a contracted chain
         r[15] = cleaf_of[k] + 1;                                   // constant-inverse leaf: 1 + slot in Tree::d_Minv
         const int kb = T.dep_nodes[pos];
-        bdesc[(size_t)pos * 2 + 0] = kb;
-        bdesc[(size_t)pos * 2 + 1] = pard[kb];
+        bdesc[(size_t)pos * 4 + 0] = kb;
+        bdesc[(size_t)pos * 4 + 1] = pard[kb];
+        bdesc[(size_t)pos * 4 + 2] = cleaf_of[kb] + 1;
     }
     const double bd = b;
     // exact FP64 flop count of the dense part of the elimination: per dense bus 2 b^3 (block inversion), (4 b^2 + 4 b)
@@ -1522,7 +1544,9 @@ int tree_alloc_scenarios(hpf_handle* h) {
                           (e = hipMalloc((void**)&h->d_chH, sizeof(double) * S * n * (size_t)h->Hn * 4)) != hipSuccess ||
                           (e = hipMalloc((void**)&h->d_chD, sizeof(double) * S * n * (size_t)h->Hn * 4)) != hipSuccess ||
                           (e = hipMalloc((void**)&h->d_chy, sizeof(double) * S * n * (size_t)h->Hn * 2)) != hipSuccess ||
-                          (e = hipMalloc((void**)&h->d_chZ, sizeof(double) * S * n * (size_t)h->Hn * 4)) != hipSuccess)) ||
+                          (e = hipMalloc((void**)&h->d_chZ, sizeof(double) * S * n * (size_t)h->Hn * 4)) != hipSuccess ||
+                          (e = hipMalloc((void**)&h->d_lfK, sizeof(double) * S * n * 4)) != hipSuccess ||
+                          (e = hipMalloc((void**)&h->d_lfS, sizeof(double) * S * n * (size_t)h->Hn * 4)) != hipSuccess)) ||
         ((h->debug_ablate & 16) && (e = hipMalloc((void**)&h->d_dbg, sizeof(long long) * S * n * 8)) != hipSuccess) ||
         (bw && (e = hipMalloc((void**)&h->d_C, sizeof(double) * S * n * (size_t)(((bw + 16) / 16) * ((bw + 16) / 16) * 256))) != hipSuccess)) {
         h->last_detail = (int)e;
@@ -1637,9 +1661,9 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
         const int* nodes = T.d_dep_nodes + T.dep_ptr[dl];
         int r = HPF_OK;
         switch (BW) {
-            case 12: r = h->gj_mode == 1 ? launch_back_q<12>(h, td, T.d_bdesc + 2 * (size_t)T.dep_ptr[dl], cnt, active) : launch_back_w<12>(h, td, nodes, cnt, active); break;
-            case 28: r = h->gj_mode == 1 ? launch_back_q<28>(h, td, T.d_bdesc + 2 * (size_t)T.dep_ptr[dl], cnt, active) : launch_back_w<28>(h, td, nodes, cnt, active); break;
-            case 52: r = h->gj_mode == 1 ? launch_back_q<52>(h, td, T.d_bdesc + 2 * (size_t)T.dep_ptr[dl], cnt, active) : launch_back_w<52>(h, td, nodes, cnt, active); break;
+            case 12: r = h->gj_mode == 1 ? launch_back_q<12>(h, td, T.d_bdesc + 4 * (size_t)T.dep_ptr[dl], cnt, active) : launch_back_w<12>(h, td, nodes, cnt, active); break;
+            case 28: r = h->gj_mode == 1 ? launch_back_q<28>(h, td, T.d_bdesc + 4 * (size_t)T.dep_ptr[dl], cnt, active) : launch_back_w<28>(h, td, nodes, cnt, active); break;
+            case 52: r = h->gj_mode == 1 ? launch_back_q<52>(h, td, T.d_bdesc + 4 * (size_t)T.dep_ptr[dl], cnt, active) : launch_back_w<52>(h, td, nodes, cnt, active); break;
             default: {
                 hipLaunchKernelGGL(k_tree_back, dim3((unsigned)cnt, (unsigned)h->cur_S), dim3(256), 0, h->cur_stream, h->n, h->c,
                                    h->Hn, td, nodes, b, h->N, h->Nc, active, h->d_Z, h->d_w, h->d_x, h->d_f, h->cur_s0);

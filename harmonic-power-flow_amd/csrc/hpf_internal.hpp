@@ -53,7 +53,7 @@ struct Tree {
                                       //   k, parent, diag entry, device, e_dn, e_up, lin child begin, count, dense child begin,
                                       //   count, first four dense children (everything a block needs behind ONE scalar load)
     int* d_child3 = nullptr;          // [n-1][4] per child-list position: child, e_dn[child], e_up[child], 0
-    int* d_bdesc = nullptr;           // [n_dense][2] (k, parent) in back-substitution (depth) order
+    int* d_bdesc = nullptr;           // [n_dense][4] (k, dense parent, constant-inverse slot + 1, 0) in back-substitution (depth) order
     // contraction of pass-through buses (linear bus, exactly one dense child): eliminated in 2x2-per-harmonic algebra before
     // the dense levels; `parent` stays the network parent, the dense tree links a chain's bottom bus to the chain's top parent
     int n_chains = 0;
@@ -64,7 +64,8 @@ struct Tree {
     int* d_chain_ch = nullptr;
     // constant-inverse leaves (contracted tree only): nonlinear buses without dense children.  In rectangular coordinates their
     // block is  R(y_kk I - Y_N - series terms of the linear neighbourhood)  + a 2x2 state-dependent term at the fundamental, so
-    // the complex Hn x Hn inverse is computed ONCE per model (host) and kept in accumulator-tile layout
+    // the inverse of the harmonic part and its borders are computed ONCE per model (host, complex) and kept as a b x b image
+    // [c0 Lr; Lc Ahh^-1] in accumulator-tile layout; the device adds the rank-2 term  [I; Lc] (c0 + D)^-1 [I Lr]
     int n_cleaf = 0;
     double* d_Minv = nullptr;         // [n_cleaf][NT*NT*256]
     double flops_per_solve = 0.0;     // factor sweep + back sweep
@@ -119,6 +120,8 @@ struct hpf_handle {
     double* d_chH = nullptr;          // [S][n][Hn][4]                  A'(ch, top parent)
     double* d_chD = nullptr;          // [S][n][Hn][4] harmonic-diagonal addend to the diagonal block of ch
     double* d_chy = nullptr;          // [S][n][Hn][2] addend to the right-hand side of ch
+    double* d_lfK = nullptr;          // [S][n][4]     constant-inverse leaves: (c0 + D)^-1 of the bus (back sweep)
+    double* d_lfS = nullptr;          // [S][n][Hn][4] constant-inverse leaves: S_q^-1 (polar <- rectangular), row-major
     double* d_chZ = nullptr;          // [S][n][Hn][4] D_k^-1 A'(k, ch) of the chain buses k (back substitution)
     double* d_linA = nullptr;         // [S][n][Hn][4] inverse 2x2 blocks of the all-linear-subtree buses
 

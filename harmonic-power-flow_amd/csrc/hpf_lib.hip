@@ -535,7 +535,7 @@ int nr_loop(hpf_handle* h, double thresh, int max_iter, int* n_iter, double* err
 void free_all(hpf_handle* h) {
     void* ptrs[] = {h->d_rowptr, h->d_col, h->d_diag, h->d_erow, h->d_dev, h->d_Y, h->d_YN, h->d_IN, h->d_P, h->d_Q,
                     h->d_Vm, h->d_Va, h->d_U, h->d_E, h->d_I0, h->d_f, h->d_errbits, h->d_err, h->d_niter, h->d_active,
-                    h->d_nactive, h->d_hist, h->d_stats, h->d_J, h->d_ipiv, h->d_info, h->d_Z, h->d_w, h->d_x, h->d_linA, h->d_C, h->d_dbg, h->d_H, h->d_chG, h->d_chH, h->d_chD, h->d_chy, h->d_chZ};
+                    h->d_nactive, h->d_hist, h->d_stats, h->d_J, h->d_ipiv, h->d_info, h->d_Z, h->d_w, h->d_x, h->d_linA, h->d_C, h->d_dbg, h->d_H, h->d_chG, h->d_chH, h->d_chD, h->d_chy, h->d_chZ, h->d_lfK, h->d_lfS};
     for (void* p : ptrs)
         if (p) hipFree(p);
     tree_free(h);

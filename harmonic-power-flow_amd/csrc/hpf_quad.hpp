@@ -90,7 +90,7 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? HPF_Q_OCC : 5)) voi
     double* __restrict__ wall, const double* __restrict__ linAall, double* __restrict__ Call, double* __restrict__ Hall,
     const cplx* __restrict__ I0all, const double* __restrict__ chG, const double* __restrict__ chH,
     const double* __restrict__ chD, const double* __restrict__ chy, const double* __restrict__ Minv,
-    long long* __restrict__ dbg, int ablate, int s0) {
+    double* __restrict__ lfK, double* __restrict__ lfS, long long* __restrict__ dbg, int ablate, int s0) {
     constexpr int NT = (B + 16) / 16;
     constexpr size_t CT = (size_t)NT * NT * 256;
     constexpr int tcB = B >> 4, jjB = B & 15;
@@ -317,15 +317,16 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? HPF_Q_OCC : 5)) voi
     for (int tr = 0; tr < NT; ++tr) ct[tr] = d4_t{0.0, 0.0, 0.0, 0.0};
     if (cleaf) {
         // ================= constant-inverse leaf (Tree::d_Minv) =====================================================
-        // In rectangular coordinates the block is  R(Yc) + E0 D E0^T : Yc constant (precomputed inverse M = R(Yc^-1), tile
-        // layout), D = Delta_polar S_0^-1 the 2x2 term of the fundamental.  Woodbury:  Drect^-1 = M - M E0 K E0^T M  with
-        // K = (I + D M00)^-1 D;  polar inverse = S^-1 Drect^-1 (row pairs scaled by the 2x2 S_q^-1);  w = A^-1 y by row sums.
+        // In rectangular coordinates the block is  R(Yc) + E0 D E0^T : Yc constant, D = Delta_polar S_0^-1 the 2x2 term of the
+        // fundamental.  With the per-model image  [c0 Lr; Lc Ahh^-1]  (tile layout):
+        //     Drect^-1 = [0 0; 0 Ahh^-1] + [I; Lc] (c0 + D)^-1 [I Lr];
+        // polar inverse = S^-1 Drect^-1 (row pairs scaled by the 2x2 S_q^-1);  w = A^-1 y by row sums.
         const double* Mk = Minv + (size_t)(cleaf - 1) * CT + lane;
 #pragma unroll
         for (int e = 0; e < NT * 4; ++e)
             if (16 * (e >> 2) + 4 * (e & 3) < B) ct[e >> 2][e & 3] = Mk[(size_t)(((e >> 2) * NT + wv) * 4 + (e & 3)) * 64];
-        double* mc = &panel[0][0];          // M[:, 0:2]  as mc[row*2 + a]
-        double* mr = &panel[1][0];          // M[0:2, :]  as mr[a*64 + col]
+        double* mc = &panel[0][0];          // [I; Lc]  as mc[row*2 + a]
+        double* mr = &panel[1][0];          // [I  Lr]  as mr[a*64 + col]  (positions (a, 0..1) hold c0)
         if (wv == 0 && jj < 2) {
 #pragma unroll
             for (int tr = 0; tr < NT; ++tr)
@@ -334,22 +335,23 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? HPF_Q_OCC : 5)) voi
         }
         if (lg < 2) mr[lg * 64 + col] = ct[0][0];
         __syncthreads();
-        double kv0, kv1;                    // (K Mr)[a][col]
+        double kv0, kv1;                    // ((c0 + D)^-1 [I Lr])[a][col]
         {
             const double si0 = tab[0], si1 = tab[1], si2 = tab[2], si3 = tab[3];           // S_0^-1
             const double p00 = dgb[0], p01 = dgb[1], p10 = dgb[3], p11 = dgb[4];           // Delta_polar
-            const double d00 = fma(p01, si2, p00 * si0), d01 = fma(p01, si3, p00 * si1);   // Delta_rect = Delta_polar S_0^-1
-            const double d10 = fma(p11, si2, p10 * si0), d11 = fma(p11, si3, p10 * si1);
-            const double m00 = mr[0], m01 = mr[1], m10 = mr[64], m11 = mr[65];
-            const double t00 = 1.0 + fma(d01, m10, d00 * m00), t01 = fma(d01, m11, d00 * m01);
-            const double t10 = fma(d11, m10, d10 * m00), t11 = 1.0 + fma(d11, m11, d10 * m01);
-            double i00, i01, i10, i11;
-            inv2(t00, t01, t10, t11, i00, i01, i10, i11);
-            const double k00 = fma(i01, d10, i00 * d00), k01 = fma(i01, d11, i00 * d01);
-            const double k10 = fma(i11, d10, i10 * d00), k11 = fma(i11, d11, i10 * d01);
-            const double r0 = mr[col], r1 = mr[64 + col];
+            const double q00 = mr[0] + fma(p01, si2, p00 * si0), q01 = mr[1] + fma(p01, si3, p00 * si1);      // c0 + Delta_polar S_0^-1
+            const double q10 = mr[64] + fma(p11, si2, p10 * si0), q11 = mr[65] + fma(p11, si3, p10 * si1);
+            double k00, k01, k10, k11;
+            inv2(q00, q01, q10, q11, k00, k01, k10, k11);
+            const double r0 = col < 2 ? (col == 0 ? 1.0 : 0.0) : mr[col];
+            const double r1 = col < 2 ? (col == 1 ? 1.0 : 0.0) : mr[64 + col];
             kv0 = fma(k01, r1, k00 * r0);
             kv1 = fma(k11, r1, k10 * r0);
+            if (tid == 0) {                 // the back sweep rebuilds  A^-1 t  from the image, this 2x2 and S^-1: no inverse goes to HBM
+                double* kk = lfK + ((size_t)s * n + k) * 4;
+                kk[0] = k00; kk[1] = k01; kk[2] = k10; kk[3] = k11;
+            }
+            if (tid < Hn * 4) lfS[(so + (size_t)k * Hn) * 4 + tid] = tab[tid];
         }
         const double yc = col < B ? dgb[col * 3 + 2] : 0.0;
 #pragma unroll
@@ -358,8 +360,10 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? HPF_Q_OCC : 5)) voi
             for (int reg = 0; reg < 4; ++reg) {
                 if (16 * tr + 4 * reg >= B) continue;
                 const int row = 16 * tr + 4 * reg + lg;
-                double v = ct[tr][reg];
-                v = fma(-mc[row * 2 + 1], kv1, fma(-mc[row * 2], kv0, v));                // Woodbury
+                double v = (row < 2 || col < 2) ? 0.0 : ct[tr][reg];
+                const double c0r = row < 2 ? (row == 0 ? 1.0 : 0.0) : mc[row * 2];
+                const double c1r = row < 2 ? (row == 1 ? 1.0 : 0.0) : mc[row * 2 + 1];
+                v = fma(c1r, kv1, fma(c0r, kv0, v));                                        // + [I; Lc] (c0 + D)^-1 [I Lr]
                 const double pr = xor16_f64(v);                                             // the other row of the harmonic
                 const double* si = tab + (row >> 1) * 4 + 2 * t;
                 v = t ? fma(si[1], v, si[0] * pr) : fma(si[1], pr, si[0] * v);              // S_q^-1 from the left
@@ -530,11 +534,13 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? HPF_Q_OCC : 5)) voi
     // ---- D. inverse (tile layout) and w = A^-1 y ------------------------------------------------------------------------
     {
         double* Zk = Zall + ((size_t)s * n + k) * CT + lane;
+        if (!cleaf) {
 #pragma unroll
-        for (int tr = 0; tr < NT; ++tr)
+            for (int tr = 0; tr < NT; ++tr)
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg)
-                if (16 * tr + 4 * reg < B) Zk[(size_t)((tr * NT + wv) * 4 + reg) * 64] = ct[tr][reg];
+                for (int reg = 0; reg < 4; ++reg)
+                    if (16 * tr + 4 * reg < B) Zk[(size_t)((tr * NT + wv) * 4 + reg) * 64] = ct[tr][reg];
+        }
         if (wv == tcB && jj == jjB) {
             double* wk = wall + ((size_t)s * n + k) * B;
 #pragma unroll
@@ -598,27 +604,30 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? HPF_Q_OCC : 5)) voi
 }
 
 // root -> leaves: x_k = w_k - D_k^{-1} (A(k,parent) x_parent), inverse in tile layout; wave wv multiplies its tile column,
-// the partial row sums meet in LDS.
+// the partial row sums meet in LDS.  Constant-inverse leaves keep no inverse in HBM:  D^-1 t = S^-1 (M t - Mc K (Mr t))  with
+// the per-model M (tile layout, L2 / Infinity Cache), the Woodbury core K and S^-1 left by the factor kernel.
 template <int B>
 __global__ __launch_bounds__(64 * ((B + 16) / 16)) void k_back_q(
     Model M, TreeDev T, const int* __restrict__ nodes, int b, int N, int Nc, const int* __restrict__ active,
     const double* __restrict__ Zall, const double* __restrict__ wall, double* __restrict__ xall, double* __restrict__ step,
-    const double* __restrict__ Hall, int s0) {
+    const double* __restrict__ Hall, const double* __restrict__ Minv, const double* __restrict__ lfK,
+    const double* __restrict__ lfS, int s0) {
     constexpr int NT = (B + 16) / 16;
     constexpr size_t CT = (size_t)NT * NT * 256;
     const int s = blockIdx.y + s0;
     if (active && !active[s]) return;
-    const int2 kp = reinterpret_cast<const int2*>(nodes)[blockIdx.x];          // Tree::d_bdesc: (bus, parent)
-    const int k = kp.x, par = kp.y;
+    const int4 kp = reinterpret_cast<const int4*>(nodes)[blockIdx.x];          // Tree::d_bdesc: (bus, parent, leaf slot + 1, 0)
+    const int k = kp.x, par = kp.y, cleaf = kp.z;
     const int tid = threadIdx.x, lane = tid & 63, lg = lane >> 4, jj = lane & 15;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = M.n, c = M.c, Hn = M.Hn;
     double* xs = xall + (size_t)s * n * B;
     __shared__ double part[NT][64];
+    __shared__ double mcl[64 * 2], zl[64];
     double x = 0.0;
     if (tid < B) x = wall[((size_t)s * n + k) * B + tid];
     if (par >= 0) {
-        const double* Zk = Zall + ((size_t)s * n + k) * CT + lane;
+        const double* Zk = (cleaf ? Minv + (size_t)(cleaf - 1) * CT : Zall + ((size_t)s * n + k) * CT) + lane;
         double zr[NT * 4];
 #pragma unroll
         for (int e = 0; e < NT * 4; ++e)
@@ -630,20 +639,49 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16)) void k_back_q(
             const double* xp = xs + (size_t)par * B;
             tv = fma(hk[1], xp[2 * p + 1], hk[0] * xp[2 * p]);
         }
+        if (cleaf && tid < 2) zl[tid] = tv;                        // t[0], t[1]
+        const double tvs = (cleaf && col < 2) ? 0.0 : tv;          // leaf image: columns 0, 1 hold the border, not the inverse
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int e = 0; e < NT * 4; ++e)
             if (16 * (e >> 2) + 4 * (e & 3) < B) {
-                const double r = row_sum16(zr[e] * tv);
+                const double r = row_sum16(zr[e] * tvs);
                 if (jj == 0) part[wv][16 * (e >> 2) + lg + 4 * (e & 3)] = r;
+                if (cleaf && wv == 0 && jj < 2) mcl[(16 * (e >> 2) + lg + 4 * (e & 3)) * 2 + jj] = zr[e];      // M[:, 0:2]
             }
         __syncthreads();
+        double acc = 0.0;
         if (tid < B) {
-            double acc = part[0][tid];
+            acc = part[0][tid];
 #pragma unroll
             for (int w2 = 1; w2 < NT; ++w2) acc += part[w2][tid];
-            x -= acc;
         }
+        if (cleaf) {                                              // block-uniform
+            // acc = S[row] = sum over columns >= 2 of image[row][col] t[col]:  rows 0, 1 -> (Lr t_h), rows >= 2 -> (Ahh^-1 t_h)
+            double t0 = 0.0, t1v = 0.0;
+            if (tid < B) {
+                t0 = zl[0];
+                t1v = zl[1];
+            }
+            __syncthreads();
+            if (tid < 2) zl[tid] = acc + (tid == 0 ? t0 : t1v);   // [I Lr] t
+            __syncthreads();
+            if (tid < B) {
+                const double* kk = lfK + ((size_t)s * n + k) * 4;
+                const double u0 = fma(kk[1], zl[1], kk[0] * zl[0]), u1 = fma(kk[3], zl[1], kk[2] * zl[0]);     // (c0 + D)^-1 [I Lr] t
+                const double c0r = tid < 2 ? (tid == 0 ? 1.0 : 0.0) : mcl[tid * 2];
+                const double c1r = tid < 2 ? (tid == 1 ? 1.0 : 0.0) : mcl[tid * 2 + 1];
+                acc = fma(c1r, u1, fma(c0r, u0, tid < 2 ? 0.0 : acc));
+            }
+            __syncthreads();
+            if (tid < B) zl[tid] = acc;                           // Drect^-1 t
+            __syncthreads();
+            if (tid < B) {
+                const double* si = lfS + (((size_t)s * n + k) * Hn + (tid >> 1)) * 4 + 2 * (tid & 1);
+                acc = (tid >> 1) < Hn ? fma(si[1], zl[tid | 1], si[0] * zl[tid & ~1]) : acc;                    // S_q^-1 from the left
+            }
+        }
+        if (tid < B) x -= acc;
     }
     if (tid < B) {
         xs[(size_t)k * B + tid] = x;
@@ -664,7 +702,7 @@ int launch_factor_q(hpf_handle* h, const TreeDev& T, const int* nodes, int count
     constexpr int NT = (B + 16) / 16;
     hipLaunchKernelGGL((k_factor_q<B>), dim3((unsigned)count, (unsigned)h->cur_S), dim3(64 * NT), 0, h->cur_stream, h->M, T, nodes,
                        2 * h->Hn, h->N, h->Nc, active, h->d_U, h->d_E, h->d_f, h->d_Z, h->d_w, h->d_linA, h->d_C, h->d_H,
-                       h->d_I0, h->d_chG, h->d_chH, h->d_chD, h->d_chy, active_tree(h).d_Minv, h->d_dbg, h->debug_ablate, h->cur_s0);
+                       h->d_I0, h->d_chG, h->d_chH, h->d_chD, h->d_chy, active_tree(h).d_Minv, h->d_lfK, h->d_lfS, h->d_dbg, h->debug_ablate, h->cur_s0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         h->last_detail = (int)e;
@@ -677,7 +715,8 @@ template <int B>
 int launch_back_q(hpf_handle* h, const TreeDev& T, const int* nodes, int count, const int* active) {
     constexpr int NT = (B + 16) / 16;
     hipLaunchKernelGGL((k_back_q<B>), dim3((unsigned)count, (unsigned)h->cur_S), dim3(64 * NT), 0, h->cur_stream, h->M, T, nodes,
-                       2 * h->Hn, h->N, h->Nc, active, h->d_Z, h->d_w, h->d_x, h->d_f, h->d_H, h->cur_s0);
+                       2 * h->Hn, h->N, h->Nc, active, h->d_Z, h->d_w, h->d_x, h->d_f, h->d_H, active_tree(h).d_Minv, h->d_lfK,
+                       h->d_lfS, h->cur_s0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         h->last_detail = (int)e;
