@@ -1294,6 +1294,43 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
             }
         }
     }
+    // records of the level-parallel 2x2 kernels
+    std::vector<int> lrec, crec, cnode;
+    {
+        std::vector<int> diag0(n, -1), hl(n, 0);
+        for (int i = 0; i < n; ++i)
+            for (int e = d->rowptr[i]; e < d->rowptr[i + 1]; ++e)
+                if (d->col[e] == i) diag0[i] = e;
+        int maxhl = -1;
+        for (int oi = n - 1; oi >= 0; --oi) {
+            const int i = order[oi];
+            if (!T.lin[i]) continue;
+            maxhl = hl[i] > maxhl ? hl[i] : maxhl;
+            const int pp = T.parent[i];
+            if (pp >= 0 && T.lin[pp] && hl[i] + 1 > hl[pp]) hl[pp] = hl[i] + 1;
+        }
+        T.n_lin_heights = maxhl + 1;
+        T.lh_ptr.assign(T.n_lin_heights + 1, 0);
+        auto put = [&](std::vector<int>& v, int k2) {
+            const int a[8] = {k2, diag0[k2], T.parent[k2], k2 > 0 ? e_up[k2] : 0, k2 > 0 ? e_dn[k2] : 0, T.child_ptr[k2],
+                              T.child_mid[k2] - T.child_ptr[k2], d->dev_of_bus[k2]};
+            v.insert(v.end(), a, a + 8);
+        };
+        for (int hh = 0; hh < T.n_lin_heights; ++hh) {
+            for (int i = 0; i < n; ++i)
+                if (T.lin[i] && hl[i] == hh) {
+                    put(lrec, i);
+                    lrec[lrec.size() - 2] = T.child_ptr[i + 1] - T.child_ptr[i];      // every child of such a bus is linear
+                }
+            T.lh_ptr[hh + 1] = (int)lrec.size() / 8;
+        }
+        for (int r2 = 0; r2 < T.n_chains; ++r2) {
+            const int ch = T.chain_ch[r2];
+            const int a[8] = {ch, e_dn[ch], e_up[ch], T.chain_ptr[r2], T.chain_ptr[r2 + 1] - T.chain_ptr[r2], 0, 0, 0};
+            crec.insert(crec.end(), a, a + 8);
+        }
+        for (size_t idx = 0; idx < T.chain_nodes.size(); ++idx) put(cnode, T.chain_nodes[idx]);   // folds its linear subtrees only
+    }
     // node records of the multi-wave kernels (hpf_quad.hpp)
     std::vector<int> fdesc((size_t)T.n_dense * 16, 0), child3((size_t)(n > 1 ? n - 1 : 0) * 4, 0), bdesc((size_t)T.n_dense * 4, 0);
     for (size_t cp = 0; cp < T.child.size(); ++cp) {
@@ -1503,6 +1540,9 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
     if ((r = upload(h, &T.d_chain_nodes, T.chain_nodes))) return r;
     if ((r = upload(h, &T.d_chain_ch, T.chain_ch))) return r;
     if ((r = upload(h, &T.d_Minv, minv))) return r;
+    if ((r = upload(h, &T.d_lrec, lrec))) return r;
+    if ((r = upload(h, &T.d_crec, crec))) return r;
+    if ((r = upload(h, &T.d_cnode, cnode))) return r;
     return HPF_OK;
 }
 
@@ -1520,7 +1560,7 @@ Tree& active_tree(hpf_handle* h) { return (h->has_ctree && h->gj_mode == 1) ? h-
 static void tree_free_one(Tree& T) {
     void* ptrs[] = {T.d_parent, T.d_lvl_nodes, T.d_dep_nodes, T.d_child_ptr, T.d_child, T.d_e_up, T.d_e_dn,
                     T.d_child_mid, T.d_lin, T.d_lin_ptr, T.d_lin_post, T.d_all_ptr, T.d_all_post, T.d_fdesc, T.d_child3,
-                    T.d_bdesc, T.d_dchild, T.d_chain_ptr, T.d_chain_nodes, T.d_chain_ch, T.d_Minv};
+                    T.d_bdesc, T.d_dchild, T.d_chain_ptr, T.d_chain_nodes, T.d_chain_ch, T.d_Minv, T.d_lrec, T.d_crec, T.d_cnode};
     for (void* p : ptrs)
         if (p) hipFree(p);
 }
@@ -1589,7 +1629,27 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
     const int lin_threads = T.n_lin_roots * h->Hn;
     const int Bst = BW ? BW : b;
     {
-        if (lin_threads > 0) {
+        const bool lvl2x2 = h->has_ctree && h->gj_mode == 1;         // level-parallel 2x2 kernels (records of the contracted tree)
+        if (lvl2x2) {
+            for (int hh = 0; hh < T.n_lin_heights; ++hh) {
+                const int cnt = T.lh_ptr[hh + 1] - T.lh_ptr[hh];
+                if (cnt == 0) continue;
+                hipLaunchKernelGGL(k_lin_level_factor, dim3((unsigned)((cnt * h->Hn + 127) / 128), (unsigned)h->cur_S), dim3(128), 0,
+                                   h->cur_stream, h->M, td, T.d_lrec + 8 * (size_t)T.lh_ptr[hh], cnt, h->N, h->Nc, Bst, active,
+                                   h->d_U, h->d_E, h->d_f, h->d_linA, h->d_w, h->d_I0, h->cur_s0);
+            }
+            if (T.n_chains > 0)
+                hipLaunchKernelGGL(k_chain_factor2, dim3((unsigned)((T.n_chains * h->Hn + 127) / 128), (unsigned)h->cur_S), dim3(128),
+                                   0, h->cur_stream, h->M, td, T.d_crec, T.d_cnode, T.n_chains, h->N, h->Nc, Bst, active, h->d_U,
+                                   h->d_E, h->d_f, h->d_linA, h->d_w, h->d_I0, h->d_chG, h->d_chH, h->d_chD, h->d_chy, h->d_chZ,
+                                   h->cur_s0);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) {
+                h->last_detail = (int)e;
+                return HPF_E_HIP;
+            }
+        }
+        if (!lvl2x2 && lin_threads > 0) {
             hipLaunchKernelGGL((k_lin_factor<false>), dim3((unsigned)((lin_threads + 127) / 128), (unsigned)h->cur_S), dim3(128), 0,
                                h->cur_stream, h->M, td, T.n_lin_roots, h->N, h->Nc, Bst, active, h->d_U, h->d_E, h->d_f,
                                h->d_linA, h->d_w, h->d_I0, h->cur_s0);
@@ -1599,7 +1659,7 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
                 return HPF_E_HIP;
             }
         }
-        if (T.n_chains > 0) {
+        if (!lvl2x2 && T.n_chains > 0) {
             hipLaunchKernelGGL(k_chain_factor, dim3((unsigned)((T.n_chains * h->Hn + 127) / 128), (unsigned)h->cur_S), dim3(128), 0,
                                h->cur_stream, h->M, td, T.n_chains, h->N, h->Nc, Bst, active, h->d_U, h->d_E, h->d_f, h->d_linA,
                                h->d_w, h->d_I0, h->d_chG, h->d_chH, h->d_chD, h->d_chy, h->d_chZ, h->cur_s0);
@@ -1675,6 +1735,26 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
             }
         }
         if (r) return r;
+    }
+    const bool lvl2x2b = h->has_ctree && h->gj_mode == 1;
+    if (lvl2x2b) {
+        if (T.n_chains > 0)
+            hipLaunchKernelGGL(k_chain_back2, dim3((unsigned)((T.n_chains * h->Hn + 127) / 128), (unsigned)h->cur_S), dim3(128), 0,
+                               h->cur_stream, h->M, td, T.d_crec, T.d_cnode, T.n_chains, h->N, h->Nc, Bst, active, h->d_U, h->d_E,
+                               h->d_linA, h->d_w, h->d_x, h->d_f, h->d_chZ, h->cur_s0);
+        for (int hh = T.n_lin_heights - 1; hh >= 0; --hh) {
+            const int cnt = T.lh_ptr[hh + 1] - T.lh_ptr[hh];
+            if (cnt == 0) continue;
+            hipLaunchKernelGGL(k_lin_level_back, dim3((unsigned)((cnt * h->Hn + 127) / 128), (unsigned)h->cur_S), dim3(128), 0,
+                               h->cur_stream, h->M, td, T.d_lrec + 8 * (size_t)T.lh_ptr[hh], cnt, h->N, h->Nc, Bst, active, h->d_U,
+                               h->d_E, h->d_linA, h->d_w, h->d_x, h->d_f, h->cur_s0);
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) {
+            h->last_detail = (int)e;
+            return HPF_E_HIP;
+        }
+        return HPF_OK;
     }
     if (T.n_chains > 0) {
         hipLaunchKernelGGL(k_chain_back, dim3((unsigned)((T.n_chains * h->Hn + 127) / 128), (unsigned)h->cur_S), dim3(128), 0,

@@ -66,6 +66,14 @@ struct Tree {
     // block is  R(y_kk I - Y_N - series terms of the linear neighbourhood)  + a 2x2 state-dependent term at the fundamental, so
     // the inverse of the harmonic part and its borders are computed ONCE per model (host, complex) and kept as a b x b image
     // [c0 Lr; Lc Ahh^-1] in accumulator-tile layout; the device adds the rank-2 term  [I; Lc] (c0 + D)^-1 [I Lr]
+    // level-parallel kernels of the 2x2 algebra (contracted tree): all-linear-subtree buses grouped by their height inside the
+    // subtree, one record of 8 ints per bus (k, diagonal entry, parent, e_up, e_dn, first child position, children, 0); chains:
+    // 8 ints per chain (ch, e_dn[ch], e_up[ch], first node record, nodes, 0, 0, 0) and the same node records, bottom-up
+    int n_lin_heights = 0;
+    std::vector<int> lh_ptr;          // [n_lin_heights+1] into the records
+    int* d_lrec = nullptr;
+    int* d_crec = nullptr;            // chain headers
+    int* d_cnode = nullptr;           // chain node records
     int n_cleaf = 0;
     double* d_Minv = nullptr;         // [n_cleaf][NT*NT*256]
     double flops_per_solve = 0.0;     // factor sweep + back sweep

@@ -724,3 +724,288 @@ int launch_back_q(hpf_handle* h, const TreeDev& T, const int* nodes, int count, 
     }
     return HPF_OK;
 }
+
+// =============================================================================================================
+// Level-parallel kernels of the 2x2-per-harmonic algebra (contracted tree).  The all-linear subtrees are at most a few buses
+// deep: instead of one thread walking a whole subtree (k_lin_factor: every bus costs a chain of dependent loads), the buses
+// are grouped by their height inside the subtree and one launch handles one height, one thread per (bus, harmonic,
+// scenario), with every operand address coming from an 8-int record and all loads of a thread issued before the arithmetic.
+// =============================================================================================================
+struct Rec8 {
+    int k, diag_e, parent, e_up, e_dn, cbeg, nch, pad;
+};
+
+// un-eliminated 2x2 diagonal block of a bus k of the 2x2 algebra at harmonic position q with identity padding (diag2x2), value form
+__device__ __forceinline__ void diag2x2_val(int n, int c, int m, int q, int k, cplx yd, cplx uk, cplx ek, cplx I0v, cplx yn,
+                                            double m2[4]) {
+    // (k >= m only with uncoupled Norton data, where nonlinear buses stay in the 2x2 algebra: diagonal Norton term HG:442-443)
+    const Blk2 blk = (q == 0 && k < m) ? blk_power_diag(yd, uk, ek, I0v) : blk_current_diag(yd, uk, ek, yn, k >= m);
+    const bool v0 = loc_valid(n, c, k, 2 * q), v1 = loc_valid(n, c, k, 2 * q + 1);
+    m2[0] = v0 ? blk.dA.re : 1.0;
+    m2[1] = (v0 && v1) ? blk.dV.re : 0.0;
+    m2[2] = (v0 && v1) ? blk.dA.im : 0.0;
+    m2[3] = v1 ? blk.dV.im : 1.0;
+}
+
+// masked coupling block A(row bus i, column bus j) at q from values: y = Y_q[i,j], Ui (row bus, used by power rows), Uj / Ej
+__device__ __forceinline__ void coupling_val(int n, int c, int m, int q, int i, int j, cplx y, cplx Ui, cplx Uj, cplx Ej, double out[4]) {
+    const Blk2 blk = (q == 0 && i < m) ? blk_power_off(y, Ui, Uj, Ej) : blk_current(y, Uj, Ej);
+    mask_block(n, c, q, i, j, blk, out);
+}
+
+// fold the 2x2-algebra children [cbeg, cbeg+nch) of bus k into (m2, y0, y1): m2 -= A(k,ch) D_ch^-1 A(ch,k), y -= A(k,ch) w_ch
+__device__ __forceinline__ void fold_children(const Model& M, const TreeDev& T, const cplx* U, const cplx* E, const double* linA,
+                                              const double* ws, int Bst, int q, int k, cplx uk, cplx ek, int cbeg, int nch,
+                                              double m2[4], double& y0, double& y1) {
+    const int n = M.n, c = M.c, Hn = M.Hn;
+    const int4* c3 = reinterpret_cast<const int4*>(T.child3);
+    for (int j = 0; j < nch; ++j) {
+        const int4 cr = c3[cbeg + j];
+        const int ch = cr.x;
+        const cplx ydn = M.Y[(size_t)q * M.nnz + cr.y], yup = M.Y[(size_t)q * M.nnz + cr.z];
+        const cplx uc = U[(size_t)q * n + ch], ec = E[(size_t)q * n + ch];
+        const double2* pic = reinterpret_cast<const double2*>(linA + ((size_t)ch * Hn + q) * 4);
+        const double2 ic01 = pic[0], ic23 = pic[1];
+        const double2 wc = *reinterpret_cast<const double2*>(ws + (size_t)ch * Bst + 2 * q);
+        __builtin_amdgcn_sched_barrier(0);
+        double g4[4], h4[4], gi[4], gh[4];
+        coupling_val(n, c, M.m, q, k, ch, ydn, uk, uc, ec, g4);              // A(k, child)
+        coupling_val(n, c, M.m, q, ch, k, yup, uc, uk, ek, h4);              // A(child, k)
+        const double ic[4] = {ic01.x, ic01.y, ic23.x, ic23.y};
+        mul22(g4, ic, gi);
+        mul22(gi, h4, gh);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m2[e] -= gh[e];
+        y0 -= fma(g4[1], wc.y, g4[0] * wc.x);
+        y1 -= fma(g4[3], wc.y, g4[2] * wc.x);
+    }
+}
+
+__global__ __launch_bounds__(128) void k_lin_level_factor(Model M, TreeDev T, const int* __restrict__ rec, int count, int N, int Nc,
+                                                          int Bst, const int* __restrict__ active, const cplx* __restrict__ Uall,
+                                                          const cplx* __restrict__ Eall, const double* __restrict__ fall,
+                                                          double* __restrict__ linAall, double* __restrict__ wall,
+                                                          const cplx* __restrict__ I0all, int s0) {
+    const int s = blockIdx.y + s0;
+    if (active && !active[s]) return;
+    const int tix = blockIdx.x * 128 + threadIdx.x;
+    if (tix >= count * M.Hn) return;
+    const int q = tix % M.Hn, pos = tix / M.Hn;
+    const int n = M.n, c = M.c, Hn = M.Hn;
+    const size_t so = (size_t)s * n * Hn;
+    const cplx* U = Uall + so;
+    const cplx* E = Eall + so;
+    const double* f = fall + (size_t)s * N;
+    double* linA = linAall + so * 4;
+    double* ws = wall + (size_t)s * n * Bst;
+    const int4 r0 = reinterpret_cast<const int4*>(rec)[2 * pos], r1 = reinterpret_cast<const int4*>(rec)[2 * pos + 1];
+    const int k = r0.x;
+    const int kst = q * n + k;
+    const cplx yd = M.Y[(size_t)q * M.nnz + r0.y];
+    const cplx uk = U[kst], ek = E[kst];
+    cplx I0v = {0.0, 0.0}, yn = {0.0, 0.0};
+    if (q == 0 && k < M.m) I0v = I0all[(size_t)s * n + k];
+    if (k >= M.m) yn = M.coupled ? M.YN[((size_t)r1.w * Hn + q) * Hn + q] : M.YN[(size_t)r1.w * Hn + q];
+    double y0 = kst >= 1 ? f[kst - 1] : 0.0;
+    double y1 = kst >= c ? f[Nc + kst - c] : 0.0;
+    __builtin_amdgcn_sched_barrier(0);
+    double m2[4];
+    diag2x2_val(n, c, M.m, q, k, yd, uk, ek, I0v, yn, m2);
+    fold_children(M, T, U, E, linA, ws, Bst, q, k, uk, ek, r1.y, r1.z, m2, y0, y1);
+    double di[4];
+    inv2(m2[0], m2[1], m2[2], m2[3], di[0], di[1], di[2], di[3]);
+    double* ik = linA + ((size_t)k * Hn + q) * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ik[e] = di[e];
+    double* wk = ws + (size_t)k * Bst + 2 * q;
+    wk[0] = fma(di[1], y1, di[0] * y0);
+    wk[1] = fma(di[3], y1, di[2] * y0);
+}
+
+__global__ __launch_bounds__(128) void k_lin_level_back(Model M, TreeDev T, const int* __restrict__ rec, int count, int N, int Nc,
+                                                        int Bst, const int* __restrict__ active, const cplx* __restrict__ Uall,
+                                                        const cplx* __restrict__ Eall, const double* __restrict__ linAall,
+                                                        const double* __restrict__ wall, double* __restrict__ xall,
+                                                        double* __restrict__ step, int s0) {
+    const int s = blockIdx.y + s0;
+    if (active && !active[s]) return;
+    const int tix = blockIdx.x * 128 + threadIdx.x;
+    if (tix >= count * M.Hn) return;
+    const int q = tix % M.Hn, pos = tix / M.Hn;
+    const int n = M.n, c = M.c, Hn = M.Hn;
+    const size_t so = (size_t)s * n * Hn;
+    const cplx* U = Uall + so;
+    const cplx* E = Eall + so;
+    const double* linA = linAall + so * 4;
+    const double* ws = wall + (size_t)s * n * Bst;
+    double* xs = xall + (size_t)s * n * Bst;
+    double* st = step + (size_t)s * N;
+    const int4 r0 = reinterpret_cast<const int4*>(rec)[2 * pos], r1 = reinterpret_cast<const int4*>(rec)[2 * pos + 1];
+    const int k = r0.x, par = r0.z;
+    const double2 wk = *reinterpret_cast<const double2*>(ws + (size_t)k * Bst + 2 * q);
+    double x0 = wk.x, x1 = wk.y;
+    if (par >= 0) {
+        const cplx yup = M.Y[(size_t)q * M.nnz + r0.w];
+        const cplx uk = U[(size_t)q * n + k];
+        const cplx up = U[(size_t)q * n + par], ep = E[(size_t)q * n + par];
+        const double2 xp = *reinterpret_cast<const double2*>(xs + (size_t)par * Bst + 2 * q);
+        const double2* pik = reinterpret_cast<const double2*>(linA + ((size_t)k * Hn + q) * 4);
+        const double2 i01 = pik[0], i23 = pik[1];
+        __builtin_amdgcn_sched_barrier(0);
+        double h4[4];
+        coupling_val(n, c, M.m, q, k, par, yup, uk, up, ep, h4);             // A(k, parent)
+        const double t0 = fma(h4[1], xp.y, h4[0] * xp.x), t1 = fma(h4[3], xp.y, h4[2] * xp.x);
+        x0 -= fma(i01.y, t1, i01.x * t0);
+        x1 -= fma(i23.y, t1, i23.x * t0);
+    }
+    (void)r1;
+    double* xk = xs + (size_t)k * Bst + 2 * q;
+    xk[0] = x0;
+    xk[1] = x1;
+    const int kst = q * n + k;
+    if (kst >= 1) st[kst - 1] = x0;
+    if (kst >= c) st[Nc + kst - c] = x1;
+}
+
+// Contracted chains (see k_chain_factor for the algebra): same elimination, operands of a chain bus loaded in one batch.
+__global__ __launch_bounds__(128) void k_chain_factor2(Model M, TreeDev T, const int* __restrict__ crec, const int* __restrict__ cnode,
+                                                       int nchains, int N, int Nc, int Bst, const int* __restrict__ active,
+                                                       const cplx* __restrict__ Uall, const cplx* __restrict__ Eall,
+                                                       const double* __restrict__ fall, double* __restrict__ linAall,
+                                                       double* __restrict__ wall, const cplx* __restrict__ I0all,
+                                                       double* __restrict__ chG, double* __restrict__ chH, double* __restrict__ chD,
+                                                       double* __restrict__ chy, double* __restrict__ chZ, int s0) {
+    const int s = blockIdx.y + s0;
+    if (active && !active[s]) return;
+    const int tix = blockIdx.x * 128 + threadIdx.x;
+    if (tix >= nchains * M.Hn) return;
+    const int q = tix % M.Hn, r = tix / M.Hn;
+    const int n = M.n, c = M.c, Hn = M.Hn;
+    const size_t so = (size_t)s * n * Hn;
+    const cplx* U = Uall + so;
+    const cplx* E = Eall + so;
+    const double* f = fall + (size_t)s * N;
+    double* linA = linAall + so * 4;
+    double* ws = wall + (size_t)s * n * Bst;
+    const int4 h0 = reinterpret_cast<const int4*>(crec)[2 * r], h1 = reinterpret_cast<const int4*>(crec)[2 * r + 1];
+    const int ch = h0.x, beg = h0.w, len = h1.x;
+    const cplx uch = U[(size_t)q * n + ch], ech = E[(size_t)q * n + ch];
+    const cplx y_kc = M.Y[(size_t)q * M.nnz + h0.y], y_ck = M.Y[(size_t)q * M.nnz + h0.z];
+    double a_kc[4], a_ck[4];
+    double dD[4] = {0.0, 0.0, 0.0, 0.0}, dy[2] = {0.0, 0.0}, cD[4] = {0.0, 0.0, 0.0, 0.0}, cy[2] = {0.0, 0.0};
+    for (int idx = 0; idx < len; ++idx) {
+        const int4 r0 = reinterpret_cast<const int4*>(cnode)[2 * (beg + idx)], r1 = reinterpret_cast<const int4*>(cnode)[2 * (beg + idx) + 1];
+        const int k = r0.x, up = r0.z;
+        const int kst = q * n + k;
+        const cplx yd = M.Y[(size_t)q * M.nnz + r0.y];
+        const cplx uk = U[kst], ek = E[kst];
+        const cplx uu = U[(size_t)q * n + up], eu = E[(size_t)q * n + up];
+        const cplx y_ku = M.Y[(size_t)q * M.nnz + r0.w], y_uk = M.Y[(size_t)q * M.nnz + r1.x];
+        cplx I0v = {0.0, 0.0};
+        if (q == 0 && k < M.m) I0v = I0all[(size_t)s * n + k];
+        double y0 = (kst >= 1 ? f[kst - 1] : 0.0) + cy[0];
+        double y1 = (kst >= c ? f[Nc + kst - c] : 0.0) + cy[1];
+        __builtin_amdgcn_sched_barrier(0);
+        if (idx == 0) {
+            coupling_val(n, c, M.m, q, k, ch, y_kc, uk, uch, ech, a_kc);     // A(k1, ch)
+            coupling_val(n, c, M.m, q, ch, k, y_ck, uch, uk, ek, a_ck);      // A(ch, k1)
+        }
+        double m2[4];
+        diag2x2_val(n, c, M.m, q, k, yd, uk, ek, I0v, cplx{0.0, 0.0}, m2);      // chain buses are linear buses
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m2[e] += cD[e];
+        fold_children(M, T, U, E, linA, ws, Bst, q, k, uk, ek, r1.y, r1.z, m2, y0, y1);
+        double di[4];
+        inv2(m2[0], m2[1], m2[2], m2[3], di[0], di[1], di[2], di[3]);
+        double* ik = linA + ((size_t)k * Hn + q) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ik[e] = di[e];
+        const double w0 = fma(di[1], y1, di[0] * y0), w1 = fma(di[3], y1, di[2] * y0);
+        double* wk = ws + (size_t)k * Bst + 2 * q;
+        wk[0] = w0;
+        wk[1] = w1;
+        double a_ku[4], a_uk[4], zc[4], zu[4], t4[4];
+        coupling_val(n, c, M.m, q, k, up, y_ku, uk, uu, eu, a_ku);           // A(k, up)
+        coupling_val(n, c, M.m, q, up, k, y_uk, uu, uk, ek, a_uk);           // A(up, k)
+        mul22(di, a_kc, zc);
+        mul22(di, a_ku, zu);
+        double* zk = chZ + (so + (size_t)k * Hn + q) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) zk[e] = zc[e];
+        mul22(a_ck, zc, t4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dD[e] -= t4[e];
+        dy[0] -= fma(a_ck[1], w1, a_ck[0] * w0);
+        dy[1] -= fma(a_ck[3], w1, a_ck[2] * w0);
+        double n_ck[4], n_kc[4];
+        mul22(a_ck, zu, n_ck);
+        mul22(a_uk, zc, n_kc);
+        mul22(a_uk, zu, t4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            cD[e] = -t4[e];
+            a_ck[e] = -n_ck[e];
+            a_kc[e] = -n_kc[e];
+        }
+        cy[0] = -fma(a_uk[1], w1, a_uk[0] * w0);
+        cy[1] = -fma(a_uk[3], w1, a_uk[2] * w0);
+    }
+    const size_t o = (so + (size_t)ch * Hn + q);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        chG[o * 4 + e] = a_kc[e];
+        chH[o * 4 + e] = a_ck[e];
+        chD[o * 4 + e] = dD[e];
+    }
+    chy[o * 2 + 0] = dy[0];
+    chy[o * 2 + 1] = dy[1];
+}
+
+__global__ __launch_bounds__(128) void k_chain_back2(Model M, TreeDev T, const int* __restrict__ crec, const int* __restrict__ cnode,
+                                                     int nchains, int N, int Nc, int Bst, const int* __restrict__ active,
+                                                     const cplx* __restrict__ Uall, const cplx* __restrict__ Eall,
+                                                     const double* __restrict__ linAall, const double* __restrict__ wall,
+                                                     double* __restrict__ xall, double* __restrict__ step,
+                                                     const double* __restrict__ chZ, int s0) {
+    const int s = blockIdx.y + s0;
+    if (active && !active[s]) return;
+    const int tix = blockIdx.x * 128 + threadIdx.x;
+    if (tix >= nchains * M.Hn) return;
+    const int q = tix % M.Hn, r = tix / M.Hn;
+    const int n = M.n, c = M.c, Hn = M.Hn;
+    const size_t so = (size_t)s * n * Hn;
+    const cplx* U = Uall + so;
+    const cplx* E = Eall + so;
+    const double* linA = linAall + so * 4;
+    const double* ws = wall + (size_t)s * n * Bst;
+    double* xs = xall + (size_t)s * n * Bst;
+    double* st = step + (size_t)s * N;
+    const int4 h0 = reinterpret_cast<const int4*>(crec)[2 * r], h1 = reinterpret_cast<const int4*>(crec)[2 * r + 1];
+    const int ch = h0.x, beg = h0.w, len = h1.x;
+    const double2 xc = *reinterpret_cast<const double2*>(xs + (size_t)ch * Bst + 2 * q);
+    for (int idx = len - 1; idx >= 0; --idx) {
+        const int4 r0 = reinterpret_cast<const int4*>(cnode)[2 * (beg + idx)];
+        const int k = r0.x, up = r0.z;
+        const cplx y_ku = M.Y[(size_t)q * M.nnz + r0.w];
+        const cplx uk = U[(size_t)q * n + k];
+        const cplx uu = U[(size_t)q * n + up], eu = E[(size_t)q * n + up];
+        const double2 xp = *reinterpret_cast<const double2*>(xs + (size_t)up * Bst + 2 * q);
+        const double2* pik = reinterpret_cast<const double2*>(linA + ((size_t)k * Hn + q) * 4);
+        const double2 i01 = pik[0], i23 = pik[1];
+        const double2* pzk = reinterpret_cast<const double2*>(chZ + (so + (size_t)k * Hn + q) * 4);
+        const double2 z01 = pzk[0], z23 = pzk[1];
+        const double2 wk = *reinterpret_cast<const double2*>(ws + (size_t)k * Bst + 2 * q);
+        __builtin_amdgcn_sched_barrier(0);
+        double h4[4];
+        coupling_val(n, c, M.m, q, k, up, y_ku, uk, uu, eu, h4);             // A(k, up)
+        const double t0 = fma(h4[1], xp.y, h4[0] * xp.x), t1 = fma(h4[3], xp.y, h4[2] * xp.x);
+        const double x0 = wk.x - fma(i01.y, t1, i01.x * t0) - fma(z01.y, xc.y, z01.x * xc.x);
+        const double x1 = wk.y - fma(i23.y, t1, i23.x * t0) - fma(z23.y, xc.y, z23.x * xc.x);
+        double* xk = xs + (size_t)k * Bst + 2 * q;
+        xk[0] = x0;
+        xk[1] = x1;
+        const int kst = q * n + k;
+        if (kst >= 1) st[kst - 1] = x0;
+        if (kst >= c) st[Nc + kst - c] = x1;
+    }
+}
