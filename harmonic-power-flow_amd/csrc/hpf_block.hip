@@ -1741,13 +1741,13 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
         if (T.n_chains > 0)
             hipLaunchKernelGGL(k_chain_back2, dim3((unsigned)((T.n_chains * h->Hn + 127) / 128), (unsigned)h->cur_S), dim3(128), 0,
                                h->cur_stream, h->M, td, T.d_crec, T.d_cnode, T.n_chains, h->N, h->Nc, Bst, active, h->d_U, h->d_E,
-                               h->d_linA, h->d_w, h->d_x, h->d_f, h->d_chZ, h->cur_s0);
+                               h->d_linA, h->d_w, h->d_x, (double*)nullptr, h->d_chZ, h->cur_s0);
         for (int hh = T.n_lin_heights - 1; hh >= 0; --hh) {
             const int cnt = T.lh_ptr[hh + 1] - T.lh_ptr[hh];
             if (cnt == 0) continue;
             hipLaunchKernelGGL(k_lin_level_back, dim3((unsigned)((cnt * h->Hn + 127) / 128), (unsigned)h->cur_S), dim3(128), 0,
                                h->cur_stream, h->M, td, T.d_lrec + 8 * (size_t)T.lh_ptr[hh], cnt, h->N, h->Nc, Bst, active, h->d_U,
-                               h->d_E, h->d_linA, h->d_w, h->d_x, h->d_f, h->cur_s0);
+                               h->d_E, h->d_linA, h->d_w, h->d_x, (double*)nullptr, h->cur_s0);
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) {

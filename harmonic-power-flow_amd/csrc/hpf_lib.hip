@@ -148,16 +148,26 @@ __global__ void k_jac_cross_dense(Model M, int total, int N, int Nc, size_t J_st
 template <bool FUND>
 __global__ void k_update(int n, int c, int count, int stride, int N, int Nc, const int* __restrict__ active,
                          const double* __restrict__ step, double* __restrict__ Vm, double* __restrict__ Va,
-                         cplx* __restrict__ U, cplx* __restrict__ E, unsigned long long* __restrict__ errbits, int s0) {
+                         cplx* __restrict__ U, cplx* __restrict__ E, unsigned long long* __restrict__ errbits,
+                         const double* __restrict__ xbus, int Bst, int s0) {
     const int s = blockIdx.y + s0;
     if (active && !active[s]) return;
     const int k = blockIdx.x * TPB + threadIdx.x;
     if (k >= count) return;
     const size_t o = (size_t)s * stride + k;
-    const double* d = step + (size_t)s * N;
     double va = Va[o], vm = Vm[o];
-    if (k >= 1) va = va - d[k - 1];
-    if (k >= c) vm = vm - d[Nc + k - c];
+    if (xbus) {
+        // multi-wave block-tree sweep: the Newton step stays in its bus-major image [bus][2q+t] (no scattered copy into the
+        // reference's stacked order by the back-substitution kernels)
+        const int q = k / n, i = k - q * n;
+        const double2 dx = *reinterpret_cast<const double2*>(xbus + ((size_t)s * n + i) * Bst + 2 * q);
+        if (k >= 1) va = va - dx.x;
+        if (k >= c) vm = vm - dx.y;
+    } else {
+        const double* d = step + (size_t)s * N;
+        if (k >= 1) va = va - d[k - 1];
+        if (k >= c) vm = vm - d[Nc + k - c];
+    }
     Va[o] = va;
     Vm[o] = vm;
     cplx u, e;
@@ -419,8 +429,11 @@ int launch_update(hpf_handle* h, const int* active) {
     const int count = FUND ? h->n : h->n * h->Hn;
     const int N = FUND ? h->Nf : h->N;
     const int Nc = FUND ? h->n - 1 : h->Nc;
+    const bool busx = !FUND && h->solver == HPF_SOLVER_BLOCK_TREE && h->has_ctree && h->gj_mode == 1;
+    const int bw = 2 * h->Hn <= 12 ? 12 : (2 * h->Hn <= 28 ? 28 : 52);
     hipLaunchKernelGGL((k_update<FUND>), grid2(count, h->cur_S), dim3(TPB), 0, h->cur_stream, h->n, h->c, count,
-                       h->n * h->Hn, N, Nc, active, h->d_f, h->d_Vm, h->d_Va, h->d_U, h->d_E, h->d_errbits, h->cur_s0);
+                       h->n * h->Hn, N, Nc, active, h->d_f, h->d_Vm, h->d_Va, h->d_U, h->d_E, h->d_errbits,
+                       busx ? h->d_x : nullptr, bw, h->cur_s0);
     HIPCHK(hipGetLastError());
     return HPF_OK;
 }

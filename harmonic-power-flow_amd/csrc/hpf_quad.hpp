@@ -685,7 +685,7 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16)) void k_back_q(
     }
     if (tid < B) {
         xs[(size_t)k * B + tid] = x;
-        if (tid < b) {
+        if (step && tid < b) {                 // (nullptr: the update kernel reads the bus-major image xs instead)
             const int kst = (tid >> 1) * n + k;
             double* st = step + (size_t)s * N;
             if (tid & 1) {
@@ -715,7 +715,7 @@ template <int B>
 int launch_back_q(hpf_handle* h, const TreeDev& T, const int* nodes, int count, const int* active) {
     constexpr int NT = (B + 16) / 16;
     hipLaunchKernelGGL((k_back_q<B>), dim3((unsigned)count, (unsigned)h->cur_S), dim3(64 * NT), 0, h->cur_stream, h->M, T, nodes,
-                       2 * h->Hn, h->N, h->Nc, active, h->d_Z, h->d_w, h->d_x, h->d_f, h->d_H, active_tree(h).d_Minv, h->d_lfK,
+                       2 * h->Hn, h->N, h->Nc, active, h->d_Z, h->d_w, h->d_x, (double*)nullptr, h->d_H, active_tree(h).d_Minv, h->d_lfK,
                        h->d_lfS, h->cur_s0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -862,9 +862,11 @@ __global__ __launch_bounds__(128) void k_lin_level_back(Model M, TreeDev T, cons
     double* xk = xs + (size_t)k * Bst + 2 * q;
     xk[0] = x0;
     xk[1] = x1;
-    const int kst = q * n + k;
-    if (kst >= 1) st[kst - 1] = x0;
-    if (kst >= c) st[Nc + kst - c] = x1;
+    if (step) {
+        const int kst = q * n + k;
+        if (kst >= 1) st[kst - 1] = x0;
+        if (kst >= c) st[Nc + kst - c] = x1;
+    }
 }
 
 // Contracted chains (see k_chain_factor for the algebra): same elimination, operands of a chain bus loaded in one batch.
@@ -1004,8 +1006,10 @@ __global__ __launch_bounds__(128) void k_chain_back2(Model M, TreeDev T, const i
         double* xk = xs + (size_t)k * Bst + 2 * q;
         xk[0] = x0;
         xk[1] = x1;
-        const int kst = q * n + k;
-        if (kst >= 1) st[kst - 1] = x0;
-        if (kst >= c) st[Nc + kst - c] = x1;
+        if (step) {
+            const int kst = q * n + k;
+            if (kst >= 1) st[kst - 1] = x0;
+            if (kst >= c) st[Nc + kst - c] = x1;
+        }
     }
 }
