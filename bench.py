@@ -178,21 +178,22 @@ def main():
     # averages the launch durations as if they were alone.  achieved = algorithmic flops of all launches / sum of their
     # durations = (flops per launch) / (average launch duration).
     flops_step = dm.solve_flops() * S                  # all factor launches of one NR step on this GPU
+    bytes_sweep = dm.solve_bytes() * S                 # algorithmic HBM bytes of the same launches (hpf_solve_bytes)
     launches_per_step = solve_n / max(K, 1)
-    achieved = flops_step * K / (solve_ms * 1e-3) / 1e12 if solve_ms > 0 else None
-    flops = flops_step / max(launches_per_step, 1)
+    achieved_tf = flops_step * K / (solve_ms * 1e-3) / 1e12 if solve_ms > 0 else None
+    achieved_gbs = bytes_sweep * K / (solve_ms * 1e-3) / 1e9 if solve_ms > 0 else None
     G = max(1, round(launches_per_step / max(dm.n_levels, 1)))
     b = 2 * Hn
     nnz = len(inp["Y"].col)
-    n_nl = n - inp["m"]
-    # algorithmic HBM bytes of one step and one scenario (SURVEY.md §8(d) adapted to the fused block path):
-    #   mismatch: Y + U + pattern + P,Q + f;   factor: Z written once, read by the parent;  back sweep: Z read, step written
-    bytes_mismatch = 16 * Hn * n + 16 * (inp["m"] - 1) + 8 * dm.N
-    bytes_factor = 8 * (2 * b * b + 2 * b) * (n - 1) + 8 * dm.N + 32 * Hn * n
-    bytes_back = 8 * (b * b + 3 * b) * (n - 1) + 8 * dm.N
-    bytes_update = 8 * dm.N + 2 * 16 * Hn * n + 4 * 8 * Hn * n
-    shared_bytes = 16 * Hn * nnz + 4 * (nnz + n + 1) + 16 * (Hn * Hn + Hn) + 4 * n
-    step_bytes = S * (bytes_mismatch + bytes_factor + bytes_back + bytes_update) + 4 * shared_bytes
+    # algorithmic HBM bytes of the other kernels of a step, one scenario (per-scenario arrays only; Y, Y_N, the tree records and
+    # the leaf images are shared by all scenarios and served by L2 / Infinity Cache):
+    #   mismatch: U in, f out;  back sweep: the inverses of the Gauss-Jordan buses in, w and A(k,parent) in, x out;
+    #   2x2 kernels: per bus and harmonic 2x2 inverse + w out and in, voltages in;  update: x, Vm, Va in, Vm, Va, U, E out
+    bytes_mismatch = 16 * Hn * n + 8 * dm.N
+    bytes_back = dm.back_bytes()
+    bytes_2x2 = (32 + 16) * 2 * Hn * n + 2 * 16 * Hn * n
+    bytes_update = 16 * Hn * n + 2 * 8 * Hn * n + 2 * 8 * Hn * n + 2 * 16 * Hn * n
+    step_bytes = S * (dm.solve_bytes() + bytes_mismatch + bytes_back + bytes_2x2 + bytes_update)
     traffic, traffic_note = pmc_traffic(args, S)
     out = {
         "metric": "NR iterations/sec + ms/iter, 1 000-bus x 25-harmonic feeder; |dV| vs reference",
@@ -207,18 +208,30 @@ def main():
                    "solver": dm.solver, "step": "one NR iteration of every scenario (HG:537-540)",
                    "pf_iterations": int(nf.max())},
         "ms_per_iter_per_scenario": ms_step / S,
-        "roofline": {"bound": "mfma", "kernel": "k_factor_w<52> (one sweep = %d launches, one per tree level)"
-                                                % dm_levels(dm) if args.solver == "block_tree" else "rocsolver getrf+getrs",
-                     "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": (achieved / FP64_PEAK_TFLOPS) if achieved else None, "traffic": traffic,
-                     "traffic_note": traffic_note,
-                     "flop_per_launch": flops, "avg_ms": solve_ms / max(solve_n, 1), "launches_per_step": launches_per_step,
+        "roofline": {"bound": "hbm",
+                     "kernel": "k_factor_q<%d> (multi-wave block-tree factor kernel; one sweep = %d launches per scenario "
+                               "group, one per tree level)" % (52 if b > 28 else (28 if b > 12 else 12), dm.n_levels),
+                     "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved_gbs / HBM_PEAK_GBS if achieved_gbs else None,
+                     "traffic": traffic / max(launches_per_step, 1) if traffic else None, "traffic_note": traffic_note,
+                     "bytes_per_launch": bytes_sweep / max(launches_per_step, 1),
+                     "avg_ms": solve_ms / max(solve_n, 1), "launches_per_step": launches_per_step,
                      "concurrent_groups": G,
-                     "aggregate_tflops_over_step_wall": flops_step / (ms_step * 1e-3) / 1e12},
+                     "aggregate_over_step_wall": bytes_sweep / (ms_step * 1e-3) / 1e9,
+                     "note": "launches of the %d scenario groups overlap on separate streams, so a launch's duration includes the "
+                             "share of the GPU the other groups take; aggregate_over_step_wall = algorithmic bytes of all factor "
+                             "launches of a step / step wall time (GB/s). " % G +
+                             "arithmetic intensity of the sweep %.2f flop/B < ridge %.1f: HBM-bound by the roofline; achieved = "
+                             "algorithmic bytes per launch / average launch duration (HIP events on the launch streams)"
+                             % (flops_step / bytes_sweep, FP64_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS)},
+        "roofline_mfma": {"bound": "mfma", "kernel": "same launches", "achieved": achieved_tf, "peak": FP64_PEAK_TFLOPS,
+                          "unit": "TFLOP/s", "frac": achieved_tf / FP64_PEAK_TFLOPS if achieved_tf else None,
+                          "flop_per_launch": flops_step / max(launches_per_step, 1)},
         "roofline_hbm_step": {"bound": "hbm", "achieved": step_bytes / (ms_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                               "unit": "GB/s", "frac": step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                               "bytes_per_step": step_bytes,
-                              "note": "algorithmic bytes of a whole NR step (mismatch + factor + back sweep + update)"},
+                              "note": "algorithmic bytes of a whole NR step (factor sweep + back sweep + 2x2 kernels + mismatch "
+                                      "+ update) over the step wall time"},
         "phase_ms_per_step": {k: (v[0] / max(v[1], 1)) for k, v in tim.items() if v[1]},
         "phase_note": "solve: per k_factor_w launch; others: per scenario group and step (%d groups overlap on separate "
                       "streams)" % G,
@@ -243,12 +256,13 @@ def pmc_traffic(args, S):
     path = os.path.join(REPO, "profiles", "pmc_traffic_latest.json")
     if not os.path.exists(path) or (args.buses, args.hmax, S, args.solver) != (1000, 51, 128, "block_tree"):
         return None, "no PMC pass for this workload"
-    d = json.load(open(path))["per_step_bytes"].get("k_factor_w")
+    d = json.load(open(path))["per_step_bytes"].get("k_factor_q")
     if not d:
         return None, "no PMC pass for this kernel"
-    return d["fetch_raw"] + d["write"], ("bytes per factor sweep = FETCH_SIZE*1024 (raw; %.3g B if the gfx950 x2 wide-stream "
-                                         "correction applied) + WRITE_SIZE*1024, separate rocprofv3 --pmc passes, see "
-                                         "profiles/pmc_traffic_latest.json" % d["fetch_x2_gfx950_wide_stream_correction"])
+    return d["fetch_raw"] + d.get("write_calibrated", d["write"]), ("per launch: (FETCH_SIZE*1024 raw + WRITE_SIZE*1024 x store calibration) of a factor sweep / launches; "
+                                         "8 B/lane streams: loads calibrate at 1.0 (k_back_q), stores at ~0.5 (k_update, known "
+                                         "bytes); includes the shared leaf images served by the Infinity Cache; separate "
+                                         "rocprofv3 --pmc passes, see profiles/pmc_traffic_latest.json")
 
 
 def K_steps(args):

@@ -57,6 +57,8 @@ SYMBOLS = {
     "hpf_timing_get": (C.c_int, [_H, C.c_int, c_dbl_p, C.POINTER(C.c_int64)]),
     "hpf_timing_reset": (C.c_int, [_H]),
     "hpf_solve_flops": (C.c_double, [_H]),
+    "hpf_solve_bytes": (C.c_double, [_H]),
+    "hpf_back_bytes": (C.c_double, [_H]),
 }
 
 _lib = None

@@ -1503,17 +1503,32 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
         bdesc[(size_t)pos * 4 + 2] = cleaf_of[kb] + 1;
     }
     const double bd = b;
-    // exact FP64 flop count of the dense part of the elimination: per dense bus 2 b^3 (block inversion), (4 b^2 + 4 b)
-    // per dense child pulled, 2 b^2 (w = D^-1 y); per non-root dense bus 4 b^2 (D^-1 A(k,parent)) in the parent's pull
-    // and 2 b^2 in the back sweep.  The 2x2 work of the linear subtrees and chains (~60 flop per bus and harmonic) is not counted.
+    // FP64 flop count of the dense part of the elimination (one scenario, one Newton step).  Gauss-Jordan bus: 2 b^3 (block
+    // inversion) + 2 b^2 (w = D^-1 y) + b^2 per dense child (Schur complement subtracted) + 8 b^2 (push G D^-1 H) if not the
+    // root.  Constant-inverse leaf: 4 b^2 (rank-2 update) + 4 b^2 (S^-1 row scaling) + 2 b^2 (w) + 8 b^2 (push).  Back sweep:
+    // 2 b^2 per non-root dense bus.  The 2x2 work of the linear subtrees and chains (~60 flop per bus and harmonic) is not counted.
+    // Algorithmic HBM bytes of the factor sweep: every Schur complement once out and once in, the inverse of a Gauss-Jordan bus
+    // once out (tile image, padded rows skipped: TB bytes), plus the per-scenario operands of a bus (voltages, mismatch rows,
+    // w, A(k,parent), 2x2 results of the folded children); model data shared by all scenarios (Y, Y_N, leaf images) is not counted.
     T.flops_factor = 0.0;
+    T.bytes_factor = 0.0;
+    T.bytes_back = 0.0;
     int n_dense_nonroot = 0;
+    const int BWf = wave_block_size(b);
+    const double TB = BWf ? (double)((BWf + 3) / 4) * ((BWf + 16) / 16) * 512.0 : 8.0 * bd * bd;
     for (int i = 0; i < n; ++i) {
         if (!kept(i)) continue;
         const int nch = dchild_ptr[i + 1] - dchild_ptr[i];
-        T.flops_factor += 2.0 * bd * bd * bd + (4.0 * bd * bd + 4.0 * bd) * nch + 2.0 * bd * bd;
+        const bool leaf = cleaf_of[i] >= 0;
+        T.flops_factor += leaf ? 10.0 * bd * bd : 2.0 * bd * bd * bd + 2.0 * bd * bd + bd * bd * nch;
+        T.bytes_factor += TB * nch + (leaf ? 0.0 : TB) + 8.0 * (4.0 * bd + bd + bd + 2.0 * bd) +
+                          48.0 * d->Hn * (T.child_mid[i] - T.child_ptr[i]);
         if (i > 0) {
-            T.flops_factor += 4.0 * bd * bd;
+            T.flops_factor += 8.0 * bd * bd;
+            T.bytes_factor += TB;
+            // back sweep: inverse of a Gauss-Jordan bus in (leaves rebuild it from the shared image), w, A(k,parent), x of the
+            // parent in, x out; leaves also their 2x2 core and S^-1
+            T.bytes_back += (leaf ? 32.0 + 32.0 * d->Hn : TB) + 8.0 * (bd + 2.0 * bd + bd + bd);
             ++n_dense_nonroot;
         }
     }

@@ -78,6 +78,8 @@ struct Tree {
     double* d_Minv = nullptr;         // [n_cleaf][NT*NT*256]
     double flops_per_solve = 0.0;     // factor sweep + back sweep
     double flops_factor = 0.0;        // factor sweep only (k_tree_factor, all levels)
+    double bytes_back = 0.0;          // algorithmic HBM bytes of the dense back sweep, one scenario and step
+    double bytes_factor = 0.0;        // algorithmic HBM bytes of the factor sweep, one scenario and step (see hpf_solve_bytes)
 };
 
 }  // namespace hpf

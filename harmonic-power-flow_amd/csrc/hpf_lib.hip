@@ -889,4 +889,16 @@ double hpf_solve_flops(const hpf_handle* h) {
     return (2.0 / 3.0) * N * N * N + 2.0 * N * N;
 }
 
+double hpf_solve_bytes(const hpf_handle* h) {
+    if (!h) return 0.0;
+    if (h->solver == HPF_SOLVER_BLOCK_TREE) return active_tree(const_cast<hpf_handle*>(h)).bytes_factor;
+    const double N = h->N;
+    return 8.0 * (2.0 * N * N + 2.0 * N);           // Jacobian written by the assembly, read and written back by getrf
+}
+
+double hpf_back_bytes(const hpf_handle* h) {
+    if (!h || h->solver != HPF_SOLVER_BLOCK_TREE) return 0.0;
+    return active_tree(const_cast<hpf_handle*>(h)).bytes_back;
+}
+
 }  // extern "C"

@@ -99,10 +99,14 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? HPF_Q_OCC : 5)) voi
     long long sa = 0, sc = 0, gown = 0, gwait = 0, gmf = 0;
 #endif
     HPF_STAMP(st0);
-    const int s = blockIdx.y + s0;
+    // grid (buses, scenarios), or (scenarios, buses) when gridDim.z == 2: consecutive workgroups then share the bus and with it
+    // the constant image of a leaf (26 KB from L2 instead of the Infinity Cache)
+    const bool sfast = gridDim.z == 2;
+    if (sfast && blockIdx.z) return;
+    const int s = (sfast ? blockIdx.x : blockIdx.y) + s0;
     if (active && !active[s]) return;
     // node record: everything the block needs to form its addresses, behind one scalar load (Tree::d_fdesc)
-    const int4* nd = reinterpret_cast<const int4*>(nodes) + 4 * (size_t)blockIdx.x;
+    const int4* nd = reinterpret_cast<const int4*>(nodes) + 4 * (size_t)(sfast ? blockIdx.y : blockIdx.x);
     const int4 nd0 = nd[0], nd1 = nd[1], nd2 = nd[2], nd3 = nd[3];
     const int k = nd0.x, par = nd0.y, diag_e = nd0.z, devk = nd0.w;
     const int e_dn_k = nd1.x, e_up_k = nd1.y, lin_beg = nd1.z, lin_end = nd1.z + nd1.w;
@@ -700,7 +704,9 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16)) void k_back_q(
 template <int B>
 int launch_factor_q(hpf_handle* h, const TreeDev& T, const int* nodes, int count, const int* active) {
     constexpr int NT = (B + 16) / 16;
-    hipLaunchKernelGGL((k_factor_q<B>), dim3((unsigned)count, (unsigned)h->cur_S), dim3(64 * NT), 0, h->cur_stream, h->M, T, nodes,
+    static const int sfast = getenv("HPF_SFAST") ? atoi(getenv("HPF_SFAST")) : 0;
+    const dim3 grid = sfast ? dim3((unsigned)h->cur_S, (unsigned)count, 2) : dim3((unsigned)count, (unsigned)h->cur_S);
+    hipLaunchKernelGGL((k_factor_q<B>), grid, dim3(64 * NT), 0, h->cur_stream, h->M, T, nodes,
                        2 * h->Hn, h->N, h->Nc, active, h->d_U, h->d_E, h->d_f, h->d_Z, h->d_w, h->d_linA, h->d_C, h->d_H,
                        h->d_I0, h->d_chG, h->d_chH, h->d_chD, h->d_chy, active_tree(h).d_Minv, h->d_lfK, h->d_lfS, h->d_dbg, h->debug_ablate, h->cur_s0);
     hipError_t e = hipGetLastError();

@@ -188,3 +188,10 @@ class DeviceModel:
 
     def solve_flops(self):
         return float(self.lib.hpf_solve_flops(self._h))
+
+    def solve_bytes(self):
+        """Algorithmic HBM bytes of the linear-solve span of one scenario and one Newton step (hpf_solve_bytes)."""
+        return float(self.lib.hpf_solve_bytes(self._h))
+
+    def back_bytes(self):
+        return float(self.lib.hpf_back_bytes(self._h))

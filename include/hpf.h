@@ -149,9 +149,15 @@ int  hpf_sync(hpf_handle* h);
 int  hpf_timing_enable(hpf_handle* h, int on);
 int  hpf_timing_get(hpf_handle* h, int which, double* ms, int64_t* launches);
 int  hpf_timing_reset(hpf_handle* h);
-/* Exact FP64 flop count of the span `which == 2` for ONE scenario and ONE Newton step (roofline numerator):
- * DENSE 2/3 N^3 + 2 N^2; BLOCK_TREE sum over buses of 2 b^3 + (4 b^2 + 4 b) per child + 2 b^2 (+ 4 b^2 non-root). */
+/* FP64 flop count of the span `which == 2` for ONE scenario and ONE Newton step (roofline numerator):
+ * DENSE 2/3 N^3 + 2 N^2; BLOCK_TREE (b = 2 Hn) per Gauss-Jordan bus 2 b^3 + 2 b^2 + b^2 per dense child (+ 8 b^2 non-root),
+ * per constant-inverse leaf 18 b^2. */
 double hpf_solve_flops(const hpf_handle* h);
+/* Algorithmic HBM bytes of the same span (one scenario, one Newton step): BLOCK_TREE every Schur complement once out and once
+ * in, every Gauss-Jordan inverse once out, per-scenario bus operands; DENSE the Jacobian out and through getrf. */
+double hpf_solve_bytes(const hpf_handle* h);
+/* ... and of the span `which == 4` (BLOCK_TREE back sweep: Gauss-Jordan inverses in, w, A(k,parent), x in / out); 0 for DENSE. */
+double hpf_back_bytes(const hpf_handle* h);
 
 #ifdef __cplusplus
 }

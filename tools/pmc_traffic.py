@@ -15,7 +15,8 @@ import os
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KEYS = ("k_factor_w", "k_back_w", "k_mismatch", "k_update", "k_tree_factor", "k_tree_back")
+KEYS = ("k_factor_q", "k_back_q", "k_lin_level", "k_chain", "k_mismatch", "k_update", "k_factor_w", "k_back_w", "k_tree_factor",
+        "k_tree_back")
 
 
 def main():
@@ -23,7 +24,7 @@ def main():
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
     res = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
-        f = sorted(glob.glob(os.path.join(REPO, "gpurun_out", f"pmc_{c}", "*", "*counter_collection.csv")))[-1]
+        f = max(glob.glob(os.path.join(REPO, "gpurun_out", f"pmc_{c}", "*", "*counter_collection.csv")), key=os.path.getmtime)
         agg = collections.defaultdict(lambda: [0, 0.0])
         for r in csv.DictReader(open(f)):
             for key in KEYS:
@@ -38,9 +39,21 @@ def main():
         fe = res["FETCH_SIZE"][k]["sum_counter_KB"] / steps * 1024
         wr = res["WRITE_SIZE"].get(k, {"sum_counter_KB": 0.0})["sum_counter_KB"] / steps * 1024
         out["per_step_bytes"][k] = {"fetch_raw": fe, "fetch_x2_gfx950_wide_stream_correction": 2 * fe, "write": wr}
+    # calibration of the store counter on THIS access pattern (MI355X_MICROARCH.md: widths other than 16 B/lane are
+    # uncalibrated): k_update writes exactly Vm, Va (8 B/lane) and U, E (16 B/lane) of every (bus, harmonic, scenario)
+    n_b, n_h, n_s = (int(a) for a in (sys.argv[3:6] if len(sys.argv) >= 6 else (1000, 26, 128)))
+    known = 48.0 * n_b * n_h * n_s
+    upd = out["per_step_bytes"].get("k_update")
+    if upd and upd["write"] > 0:
+        cal = known / upd["write"]
+        out["write_calibration"] = {"kernel": "k_update", "known_bytes": known, "counter_bytes": upd["write"], "factor": cal,
+                                    "note": "WRITE_SIZE over-counts the 8 B/lane stores of these kernels; the 8 B/lane LOADS "
+                                            "calibrate at 1.0 on k_back_q (raw FETCH_SIZE = inverse tiles + operands)"}
+        for k in out["per_step_bytes"]:
+            out["per_step_bytes"][k]["write_calibrated"] = out["per_step_bytes"][k]["write"] * cal
     out["note"] = ("FETCH_SIZE/WRITE_SIZE are KB. MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reads exactly 1/2 of the bytes of a "
-                   "wide coalesced 16 B/lane stream and other widths are uncalibrated; the factor kernel reads 16-byte pairs "
-                   "shared by two lanes, the back sweep 8 B/lane, so raw and doubled values are both given.")
+                   "wide coalesced 16 B/lane stream and other widths are uncalibrated; the factor / back kernels stream 8 B/lane "
+                   "(512-byte tile rows), so raw and doubled values are both given.")
     json.dump(out, open(out_path, "w"), indent=1)
     print(json.dumps(out["per_step_bytes"], indent=1))
 
