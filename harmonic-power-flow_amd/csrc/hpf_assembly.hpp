@@ -40,6 +40,10 @@ HPF_HD cplx cmulj(cplx a) { return {-a.im, a.re}; }   // 1j*a, exact
 // Read-only model shared by all scenarios (device pointers inside kernels).
 struct Model {
     int n, m, c, Hn, nnz, n_dev, coupled;
+    int bus_major = 0;    // layout of the per-scenario voltage arrays U, E (and Vm, Va): 0 stacked index q*n + i (the reference's
+                          // order, HG:139-143; host emulation), 1 bus-major i*Hn + q (device: every kernel that walks a bus or a
+                          // tree reads the Hn harmonics of a bus as one contiguous run)
+    HPF_HD size_t vi(int q, int i) const { return bus_major ? (size_t)i * Hn + q : (size_t)q * n + i; }
     const int* rowptr;    // [n+1]
     const int* col;       // [nnz]
     const int* diag;      // [n] position of the diagonal entry of each row
@@ -72,8 +76,7 @@ HPF_HD void polar(double vm, double va, cplx& U, cplx& E) {
 HPF_HD cplx row_current(const Model& M, const cplx* U, int q, int i) {
     cplx acc = {0.0, 0.0};
     const cplx* Yq = M.Y + (size_t)q * M.nnz;
-    const cplx* Uq = U + (size_t)q * M.n;
-    for (int e = M.rowptr[i]; e < M.rowptr[i + 1]; ++e) acc = cadd(acc, cmul_unf(Yq[e], Uq[M.col[e]]));
+    for (int e = M.rowptr[i]; e < M.rowptr[i + 1]; ++e) acc = cadd(acc, cmul_unf(Yq[e], U[M.vi(q, M.col[e])]));
     return acc;
 }
 
@@ -90,7 +93,7 @@ HPF_HD cplx row_current_fund(const Model& M, const cplx* U, int i) {
     cplx t = {0.0, 0.0};
     for (int e = M.rowptr[i]; e < M.rowptr[i + 1]; ++e) {
         const int j = M.col[e];
-        const cplx y = M.Y[e], u = U[j];
+        const cplx y = M.Y[e], u = U[M.vi(0, j)];
         if (j < n1) {
             const int l = j & 1;
             a[l][0] = fma(y.re, u.re, a[l][0]);
@@ -130,7 +133,7 @@ HPF_HD cplx norton_injection(const Model& M, const cplx* U, int q, int i) {
                 double rr = 0, ii = 0, ri = 0, ir = 0;
                 const int p1 = p0 + 4 < M.Hn ? p0 + 4 : M.Hn;
                 for (int p = p0; p < p1; ++p) {
-                    const cplx u = U[(size_t)p * M.n + i];
+                    const cplx u = U[M.vi(p, i)];
                     rr = fma(yn[p].re, u.re, rr);
                     ri = fma(yn[p].re, u.im, ri);
                     ii = fma(yn[p].im, u.im, ii);
@@ -141,7 +144,7 @@ HPF_HD cplx norton_injection(const Model& M, const cplx* U, int q, int i) {
             }
         } else {
             for (int p = 0; p < M.Hn; ++p) {
-                const cplx u = U[(size_t)p * M.n + i];
+                const cplx u = U[M.vi(p, i)];
                 acc.re += fma(yn[p].re, u.re, -(yn[p].im * u.im));
                 acc.im += fma(yn[p].re, u.im, yn[p].im * u.re);
             }
@@ -149,7 +152,7 @@ HPF_HD cplx norton_injection(const Model& M, const cplx* U, int q, int i) {
     } else {
         // np.diag(Y_N).dot(U_bus): the same zgemv_n kernel on a diagonal matrix -> one product per row, rounded
         // like the kernel's row class (unfused partials in the 4-row body, fused in the Hn % 4 tail rows)
-        const cplx y = M.YN[(size_t)d * M.Hn + q], u = U[(size_t)q * M.n + i];
+        const cplx y = M.YN[(size_t)d * M.Hn + q], u = U[M.vi(q, i)];
         acc = q < (M.Hn & ~3) ? cmul_unf(y, u) : cmul_npy(y, u);
     }
     return csub(in, acc);
@@ -167,7 +170,7 @@ HPF_HD cplx mismatch_row(const Model& M, const cplx* U, const double* P, const d
     if (FUND || (q == 0 && i < M.m)) {
         if (Iout) Iout[i] = I;
         // V_i * conj(Y_ij @ V_j): NumPy array multiply (HG:198,379), then + S
-        const cplx sl = cmul_npy(U[i], cconj(I));
+        const cplx sl = cmul_npy(U[M.vi(0, i)], cconj(I));
         return {P[i] + sl.re, Q[i] + sl.im};
     }
     if (i >= M.m) return cadd(I, norton_injection(M, U, q, i));   // HG:351,354
@@ -186,7 +189,7 @@ struct Blk2 {
 // Current-balance rows (k >= m), HG:403-411 and the p == h Norton terms of HG:432-435 / HG:442-443.
 HPF_HD Blk2 jac_current_entry(const Model& M, const cplx* U, const cplx* E, int q, int i, int j, int e) {
     const cplx y = M.Y[(size_t)q * M.nnz + e];
-    const size_t kc = (size_t)q * M.n + j;
+    const size_t kc = M.vi(q, j);
     Blk2 b;
     b.dV = cmul_unf(y, E[kc]);               // Y_diag @ V_norm_diag
     b.dA = cmul_unf(cmulj(y), U[kc]);        // (1j*Y_diag) @ V_diag
@@ -202,7 +205,7 @@ HPF_HD Blk2 jac_current_entry(const Model& M, const cplx* U, const cplx* E, int 
 // Diagonal current-balance entry (i == j) with the device type of the bus supplied by the caller (-1: linear bus).
 HPF_HD Blk2 jac_current_diag(const Model& M, const cplx* U, const cplx* E, int q, int i, int e, int d) {
     const cplx y = M.Y[(size_t)q * M.nnz + e];
-    const size_t kc = (size_t)q * M.n + i;
+    const size_t kc = M.vi(q, i);
     Blk2 b;
     b.dV = cmul_unf(y, E[kc]);
     b.dA = cmul_unf(cmulj(y), U[kc]);
@@ -218,7 +221,7 @@ HPF_HD Blk2 jac_current_diag(const Model& M, const cplx* U, const cplx* E, int q
 HPF_HD Blk2 jac_norton_cross(const Model& M, const cplx* U, const cplx* E, int q, int p, int i) {
     const int d = M.dev[i];
     const cplx yn = M.YN[((size_t)d * M.Hn + q) * M.Hn + p];
-    const size_t kc = (size_t)p * M.n + i;
+    const size_t kc = M.vi(p, i);
     Blk2 b;
     b.dV = cneg(cmul_unf(yn, E[kc]));
     b.dA = cneg(cmul_unf(cmulj(yn), U[kc]));
@@ -230,31 +233,33 @@ HPF_HD Blk2 jac_norton_cross(const Model& M, const cplx* U, const cplx* E, int q
 // (jac_power_diag: the diagonal entry with the row current I supplied by the caller)
 HPF_HD Blk2 jac_power_diag(const Model& M, const cplx* U, const cplx* E, int i, int e, cplx I) {
     const cplx y = M.Y[e];
-    const cplx yu = cmul_unf(y, U[i]);
-    const cplx ye = cmul_unf(y, E[i]);
+    const cplx ui = U[M.vi(0, i)], ei = E[M.vi(0, i)];
+    const cplx yu = cmul_unf(y, ui);
+    const cplx ye = cmul_unf(y, ei);
     Blk2 b;
     const cplx t = csub(I, yu);
-    b.dV = cadd(cmul_unf(E[i], cconj(I)), cmul_unf(U[i], cconj(ye)));
-    b.dA = cmul_unf(cmulj(U[i]), cconj(t));
+    b.dV = cadd(cmul_unf(ei, cconj(I)), cmul_unf(ui, cconj(ye)));
+    b.dA = cmul_unf(cmulj(ui), cconj(t));
     return b;
 }
 
 template <bool FUND>
 HPF_HD Blk2 jac_power_entry(const Model& M, const cplx* U, const cplx* E, int i, int j, int e) {
     const cplx y = M.Y[e];
-    const cplx yu = cmul_unf(y, U[j]);
-    const cplx ye = cmul_unf(y, E[j]);
+    const cplx ui = U[M.vi(0, i)];
+    const cplx yu = cmul_unf(y, U[M.vi(0, j)]);
+    const cplx ye = cmul_unf(y, E[M.vi(0, j)]);
     Blk2 b;
     cplx t;
     if (i == j) {
         const cplx I = FUND ? row_current_fund(M, U, i) : row_current(M, U, 0, i);
         t = csub(I, yu);
-        b.dV = cadd(cmul_unf(E[i], cconj(I)), cmul_unf(U[i], cconj(ye)));
+        b.dV = cadd(cmul_unf(E[M.vi(0, i)], cconj(I)), cmul_unf(ui, cconj(ye)));
     } else {
         t = cneg(yu);
-        b.dV = cmul_unf(U[i], cconj(ye));
+        b.dV = cmul_unf(ui, cconj(ye));
     }
-    b.dA = cmul_unf(cmulj(U[i]), cconj(t));
+    b.dA = cmul_unf(cmulj(ui), cconj(t));
     return b;
 }
 

@@ -436,7 +436,7 @@ __device__ __forceinline__ void assemble_row(const Model& M, const TreeDev& T, c
     if (nl) {
         __syncthreads();
         if (lane < Hn) {
-            const cplx u = U[(size_t)lane * n + k], e = E[(size_t)lane * n + k];
+            const cplx u = U[M.vi(lane, k)], e = E[M.vi(lane, k)];
             double* t0 = ue + lane * 4;
             double* t1 = ue + (B / 2) * 4 + lane * 4;
             t0[0] = u.re;  t0[1] = u.im;   t0[2] = e.im;   t0[3] = -e.re;
@@ -1595,6 +1595,7 @@ int tree_alloc_scenarios(hpf_handle* h) {
         (e = hipMalloc((void**)&h->d_x, sizeof(double) * S * n * b)) != hipSuccess ||
         (e = hipMalloc((void**)&h->d_linA, sizeof(double) * S * n * (size_t)h->Hn * 4)) != hipSuccess ||
         (e = hipMalloc((void**)&h->d_H, sizeof(double) * S * n * (size_t)h->Hn * 4)) != hipSuccess ||
+        (e = hipMalloc((void**)&h->d_fb, sizeof(double) * S * n * b)) != hipSuccess ||
         (h->has_ctree && ((e = hipMalloc((void**)&h->d_chG, sizeof(double) * S * n * (size_t)h->Hn * 4)) != hipSuccess ||
                           (e = hipMalloc((void**)&h->d_chH, sizeof(double) * S * n * (size_t)h->Hn * 4)) != hipSuccess ||
                           (e = hipMalloc((void**)&h->d_chD, sizeof(double) * S * n * (size_t)h->Hn * 4)) != hipSuccess ||
@@ -1651,12 +1652,12 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
                 if (cnt == 0) continue;
                 hipLaunchKernelGGL(k_lin_level_factor, dim3((unsigned)((cnt * h->Hn + 127) / 128), (unsigned)h->cur_S), dim3(128), 0,
                                    h->cur_stream, h->M, td, T.d_lrec + 8 * (size_t)T.lh_ptr[hh], cnt, h->N, h->Nc, Bst, active,
-                                   h->d_U, h->d_E, h->d_f, h->d_linA, h->d_w, h->d_I0, h->cur_s0);
+                                   h->d_U, h->d_E, h->d_fb, h->d_linA, h->d_w, h->d_I0, h->cur_s0);
             }
             if (T.n_chains > 0)
                 hipLaunchKernelGGL(k_chain_factor2, dim3((unsigned)((T.n_chains * h->Hn + 127) / 128), (unsigned)h->cur_S), dim3(128),
                                    0, h->cur_stream, h->M, td, T.d_crec, T.d_cnode, T.n_chains, h->N, h->Nc, Bst, active, h->d_U,
-                                   h->d_E, h->d_f, h->d_linA, h->d_w, h->d_I0, h->d_chG, h->d_chH, h->d_chD, h->d_chy, h->d_chZ,
+                                   h->d_E, h->d_fb, h->d_linA, h->d_w, h->d_I0, h->d_chG, h->d_chH, h->d_chD, h->d_chy, h->d_chZ,
                                    h->cur_s0);
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) {

@@ -48,12 +48,14 @@ namespace {
 constexpr int TPB = 256;
 
 // polar -> rectangular for `count` stacked entries of every scenario (count = Hn*n, or n for the fundamental pf)
+// Device layout of Vm, Va, U, E: bus-major, entry (bus i, harmonic position q) at i*Hn + q (Model::vi); the C ABI keeps the
+// reference's stacked order and hpf_set_state / hpf_get_state transpose.  FUND: the n entries of harmonic position 0.
 template <bool FUND>
-__global__ void k_polar(int count, int stride, const double* __restrict__ Vm, const double* __restrict__ Va,
+__global__ void k_polar(int count, int stride, int Hn, const double* __restrict__ Vm, const double* __restrict__ Va,
                         cplx* __restrict__ U, cplx* __restrict__ E) {
     const int k = blockIdx.x * TPB + threadIdx.x;
     if (k >= count) return;
-    const size_t o = (size_t)blockIdx.y * stride + k;
+    const size_t o = (size_t)blockIdx.y * stride + (FUND ? (size_t)k * Hn : (size_t)k);
     cplx u, e;
     polar<FUND>(Vm[o], Va[o], u, e);
     U[o] = u;
@@ -76,23 +78,36 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
     return v;
 }
 
-// One thread per complex mismatch row (k = 1 .. count-1) of one scenario (blockIdx.y).
+// One thread per complex mismatch row of one scenario (blockIdx.y): thread t = i*Hn + q (bus-major, coalesced voltage
+// reads), stacked index k = q*n + i, k >= 1.  f: the reference's stacked real layout (HG:388; dense solver, C ABI) or nullptr;
+// fb: bus-major image [bus][2q + (Re|Im)] with stride Bst and zeros where there is no equation (tree kernels) or nullptr.
 template <bool FUND>
 __global__ void k_mismatch(Model M, int count, int N, int Nc, const int* __restrict__ active, const cplx* __restrict__ U,
                            const double* __restrict__ P, const double* __restrict__ Q, double* __restrict__ f,
-                           unsigned long long* __restrict__ errbits, cplx* __restrict__ I0, int s0) {
+                           unsigned long long* __restrict__ errbits, cplx* __restrict__ I0, double* __restrict__ fb, int Bst,
+                           int s0) {
     const int s = blockIdx.y + s0;
     if (active && !active[s]) return;
-    const int k = blockIdx.x * TPB + threadIdx.x + 1;
+    const int t = blockIdx.x * TPB + threadIdx.x;
     unsigned long long b = 0;
-    if (k < count) {
-        const cplx v = mismatch_row<FUND>(M, U + (size_t)s * M.n * M.Hn, P + (size_t)s * M.n, Q + (size_t)s * M.n, k,
-                                          (!FUND && I0) ? I0 + (size_t)s * M.n : nullptr);
-        store_mismatch(f + (size_t)s * N, Nc, M.c, k, v);
-        b = abs_bits(v.re);
-        if (k >= M.c) {
-            const unsigned long long bi = abs_bits(v.im);
-            b = bi > b ? bi : b;
+    if (t < count) {
+        const int i = FUND ? t : t / M.Hn, q = FUND ? 0 : t - i * M.Hn;
+        const int k = q * M.n + i;
+        cplx v = {0.0, 0.0};
+        if (k >= 1) {
+            v = mismatch_row<FUND>(M, U + (size_t)s * M.n * M.Hn, P + (size_t)s * M.n, Q + (size_t)s * M.n, k,
+                                   (!FUND && I0) ? I0 + (size_t)s * M.n : nullptr);
+            if (f) store_mismatch(f + (size_t)s * N, Nc, M.c, k, v);
+            b = abs_bits(v.re);
+            if (k >= M.c) {
+                const unsigned long long bi = abs_bits(v.im);
+                b = bi > b ? bi : b;
+            }
+        }
+        if (!FUND && fb) {
+            double* o = fb + ((size_t)s * M.n + i) * Bst + 2 * q;
+            o[0] = k >= 1 ? v.re : 0.0;
+            o[1] = k >= M.c ? v.im : 0.0;
         }
     }
     b = wave_max_u64(b);
@@ -146,20 +161,21 @@ __global__ void k_jac_cross_dense(Model M, int total, int N, int Nc, size_t J_st
 
 // x <- x - step, scattered back into (Va, Vm) (HG:478,484-485 / HG:229,234-235), then refresh U, E of the entry.
 template <bool FUND>
-__global__ void k_update(int n, int c, int count, int stride, int N, int Nc, const int* __restrict__ active,
+__global__ void k_update(int n, int Hn, int c, int count, int stride, int N, int Nc, const int* __restrict__ active,
                          const double* __restrict__ step, double* __restrict__ Vm, double* __restrict__ Va,
                          cplx* __restrict__ U, cplx* __restrict__ E, unsigned long long* __restrict__ errbits,
                          const double* __restrict__ xbus, int Bst, int s0) {
     const int s = blockIdx.y + s0;
     if (active && !active[s]) return;
-    const int k = blockIdx.x * TPB + threadIdx.x;
-    if (k >= count) return;
-    const size_t o = (size_t)s * stride + k;
+    const int t = blockIdx.x * TPB + threadIdx.x;
+    if (t >= count) return;
+    const int i = FUND ? t : t / Hn, q = FUND ? 0 : t - i * Hn;          // thread t = i*Hn + q: bus-major state arrays
+    const int k = q * n + i;                                             // stacked index (HG:139-143)
+    const size_t o = (size_t)s * stride + (size_t)i * Hn + q;
     double va = Va[o], vm = Vm[o];
     if (xbus) {
         // multi-wave block-tree sweep: the Newton step stays in its bus-major image [bus][2q+t] (no scattered copy into the
         // reference's stacked order by the back-substitution kernels)
-        const int q = k / n, i = k - q * n;
         const double2 dx = *reinterpret_cast<const double2*>(xbus + ((size_t)s * n + i) * Bst + 2 * q);
         if (k >= 1) va = va - dx.x;
         if (k >= c) vm = vm - dx.y;
@@ -216,11 +232,11 @@ __global__ void k_set_int(int* p, int count, int v) {
     if (i < count) p[i] = v;
 }
 
-__global__ void k_init_voltages(int n, int count, double* Vm, double* Va) {
+__global__ void k_init_voltages(int Hn, int count, double* Vm, double* Va) {
     const int k = blockIdx.x * TPB + threadIdx.x;
     if (k >= count) return;
     const size_t o = (size_t)blockIdx.y * count + k;
-    Vm[o] = k < n ? 1.0 : 0.1;     // HG:181-183
+    Vm[o] = (k % Hn) == 0 ? 1.0 : 0.1;     // HG:181-183 (bus-major: harmonic position k % Hn)
     Va[o] = 0.0;
 }
 
@@ -233,8 +249,8 @@ __global__ void k_stats(int n, int Hn, double thresh, int max_iter, const double
     bool nan = false;
     for (int b = threadIdx.x; b < n; b += TPB) {
         double hs = 0.0;
-        for (int q = 1; q < Hn; ++q) hs = hs + V[(size_t)q * n + b] * V[(size_t)q * n + b];
-        const double t = sqrt(hs) / fabs(V[b]);
+        for (int q = 1; q < Hn; ++q) hs = hs + V[(size_t)b * Hn + q] * V[(size_t)b * Hn + q];
+        const double t = sqrt(hs) / fabs(V[(size_t)b * Hn]);
         if (t != t) nan = true;
         best = t > best ? t : best;
     }
@@ -365,21 +381,28 @@ template <bool FUND>
 int launch_polar(hpf_handle* h) {
     full_ctx(h);
     const int count = FUND ? h->n : h->n * h->Hn;
-    hipLaunchKernelGGL((k_polar<FUND>), grid2(count, h->S), dim3(TPB), 0, h->stream, count, h->n * h->Hn, h->d_Vm,
+    hipLaunchKernelGGL((k_polar<FUND>), grid2(count, h->S), dim3(TPB), 0, h->stream, count, h->n * h->Hn, h->Hn, h->d_Vm,
                        h->d_Va, h->d_U, h->d_E);
     HIPCHK(hipGetLastError());
     return HPF_OK;
 }
 
+// the Newton step of the multi-wave block-tree sweep works on bus-major images of the mismatch and of the step
+static bool bus_images(const hpf_handle* h) { return h->solver == HPF_SOLVER_BLOCK_TREE && h->has_ctree && h->gj_mode == 1; }
+static int tree_bst(const hpf_handle* h) { return 2 * h->Hn <= 12 ? 12 : (2 * h->Hn <= 28 ? 28 : (2 * h->Hn <= 52 ? 52 : 2 * h->Hn)); }
+
+// stacked: also write the mismatch in the reference's stacked order (C ABI, dense solver, single-wave / generic tree kernels)
 template <bool FUND>
-int launch_mismatch(hpf_handle* h, const int* active) {
+int launch_mismatch(hpf_handle* h, const int* active, bool stacked = true) {
     ScopedTimer t(h, T_MISMATCH);
     const int count = FUND ? h->n : h->n * h->Hn;
     const int N = FUND ? h->Nf : h->N;
     const int Nc = FUND ? h->n - 1 : h->Nc;
+    const bool img = !FUND && h->d_fb && bus_images(h);
     if (count > 1) {
-        hipLaunchKernelGGL((k_mismatch<FUND>), grid2(count - 1, h->cur_S), dim3(TPB), 0, h->cur_stream, h->M, count, N, Nc,
-                           active, h->d_U, h->d_P, h->d_Q, h->d_f, h->d_errbits, h->d_I0, h->cur_s0);
+        hipLaunchKernelGGL((k_mismatch<FUND>), grid2(count, h->cur_S), dim3(TPB), 0, h->cur_stream, h->M, count, N, Nc,
+                           active, h->d_U, h->d_P, h->d_Q, (stacked || !img) ? h->d_f : nullptr, h->d_errbits, h->d_I0,
+                           img ? h->d_fb : nullptr, tree_bst(h), h->cur_s0);
         HIPCHK(hipGetLastError());
     }
     return HPF_OK;
@@ -429,9 +452,9 @@ int launch_update(hpf_handle* h, const int* active) {
     const int count = FUND ? h->n : h->n * h->Hn;
     const int N = FUND ? h->Nf : h->N;
     const int Nc = FUND ? h->n - 1 : h->Nc;
-    const bool busx = !FUND && h->solver == HPF_SOLVER_BLOCK_TREE && h->has_ctree && h->gj_mode == 1;
-    const int bw = 2 * h->Hn <= 12 ? 12 : (2 * h->Hn <= 28 ? 28 : 52);
-    hipLaunchKernelGGL((k_update<FUND>), grid2(count, h->cur_S), dim3(TPB), 0, h->cur_stream, h->n, h->c, count,
+    const bool busx = !FUND && bus_images(h);
+    const int bw = tree_bst(h);
+    hipLaunchKernelGGL((k_update<FUND>), grid2(count, h->cur_S), dim3(TPB), 0, h->cur_stream, h->n, h->Hn, h->c, count,
                        h->n * h->Hn, N, Nc, active, h->d_f, h->d_Vm, h->d_Va, h->d_U, h->d_E, h->d_errbits,
                        busx ? h->d_x : nullptr, bw, h->cur_s0);
     HIPCHK(hipGetLastError());
@@ -482,7 +505,7 @@ int nr_loop(hpf_handle* h, double thresh, int max_iter, int* n_iter, double* err
     }
     if ((r = launch_polar<FUND>(h))) return r;
     HIPCHK(hipMemsetAsync(h->d_errbits, 0, sizeof(unsigned long long) * S, h->stream));
-    if ((r = launch_mismatch<FUND>(h, nullptr))) return r;
+    if ((r = launch_mismatch<FUND>(h, nullptr, false))) return r;
     HIPCHK(hipMemsetAsync(h->d_nactive, 0, sizeof(int), h->stream));
     hipLaunchKernelGGL(k_finalize, dim3((S + 63) / 64), dim3(64), 0, h->stream, S, 1, thresh, max_iter, h->hist_cap,
                        hist_off, h->d_errbits, h->d_err, h->d_niter, h->d_active, h->d_nactive, h->d_hist, 0);
@@ -508,7 +531,7 @@ int nr_loop(hpf_handle* h, double thresh, int max_iter, int* n_iter, double* err
             for (int j = 0; j < todo; ++j) {
                 if ((rr = newton_step<FUND>(h, h->d_active))) return rr;
                 if ((rr = launch_update<FUND>(h, h->d_active))) return rr;
-                if ((rr = launch_mismatch<FUND>(h, h->d_active))) return rr;
+                if ((rr = launch_mismatch<FUND>(h, h->d_active, false))) return rr;
                 hipLaunchKernelGGL(k_finalize, dim3((h->cur_S + 63) / 64), dim3(64), 0, h->cur_stream, h->cur_S, 0, thresh,
                                    max_iter, h->hist_cap, hist_off, h->d_errbits, h->d_err, h->d_niter, h->d_active,
                                    h->d_nactive, h->d_hist, h->cur_s0);
@@ -548,7 +571,7 @@ int nr_loop(hpf_handle* h, double thresh, int max_iter, int* n_iter, double* err
 void free_all(hpf_handle* h) {
     void* ptrs[] = {h->d_rowptr, h->d_col, h->d_diag, h->d_erow, h->d_dev, h->d_Y, h->d_YN, h->d_IN, h->d_P, h->d_Q,
                     h->d_Vm, h->d_Va, h->d_U, h->d_E, h->d_I0, h->d_f, h->d_errbits, h->d_err, h->d_niter, h->d_active,
-                    h->d_nactive, h->d_hist, h->d_stats, h->d_J, h->d_ipiv, h->d_info, h->d_Z, h->d_w, h->d_x, h->d_linA, h->d_C, h->d_dbg, h->d_H, h->d_chG, h->d_chH, h->d_chD, h->d_chy, h->d_chZ, h->d_lfK, h->d_lfS};
+                    h->d_nactive, h->d_hist, h->d_stats, h->d_J, h->d_ipiv, h->d_info, h->d_Z, h->d_w, h->d_x, h->d_linA, h->d_C, h->d_dbg, h->d_H, h->d_chG, h->d_chH, h->d_chD, h->d_chy, h->d_chZ, h->d_lfK, h->d_lfS, h->d_fb};
     for (void* p : ptrs)
         if (p) hipFree(p);
     tree_free(h);
@@ -665,7 +688,7 @@ int hpf_create(hpf_handle** out, const hpf_desc* d) {
     if ((r = dev_alloc(h, &h->d_nactive, (size_t)1))) return fail(r);
     if ((r = dev_alloc(h, &h->d_stats, S))) return fail(r);
     Model& M = h->M;
-    M.n = d->n; M.m = d->m; M.c = d->c; M.Hn = d->Hn; M.nnz = d->nnz; M.n_dev = d->n_dev; M.coupled = h->coupled;
+    M.n = d->n; M.m = d->m; M.c = d->c; M.Hn = d->Hn; M.nnz = d->nnz; M.n_dev = d->n_dev; M.coupled = h->coupled; M.bus_major = 1;
     M.rowptr = h->d_rowptr; M.col = h->d_col; M.diag = h->d_diag; M.Y = h->d_Y; M.dev = h->d_dev;
     M.YN = h->d_YN; M.IN = h->d_IN;
     if (d->solver == HPF_SOLVER_BLOCK_TREE) {
@@ -708,10 +731,18 @@ int hpf_set_state(hpf_handle* h, int n_scen, const double* Vm, const double* Va)
     h->S = n_scen;
     const int count = h->n * h->Hn;
     if (Vm) {
-        HIPCHK(hipMemcpyAsync(h->d_Vm, Vm, sizeof(double) * (size_t)n_scen * count, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(h->d_Va, Va, sizeof(double) * (size_t)n_scen * count, hipMemcpyHostToDevice, h->stream));
+        // ABI: stacked order q*n + i per scenario (HG:174-184); device: bus-major i*Hn + q
+        std::vector<double> tm((size_t)n_scen * count), ta((size_t)n_scen * count);
+        for (int sc = 0; sc < n_scen; ++sc)
+            for (int q = 0; q < h->Hn; ++q)
+                for (int i = 0; i < h->n; ++i) {
+                    tm[(size_t)sc * count + (size_t)i * h->Hn + q] = Vm[(size_t)sc * count + (size_t)q * h->n + i];
+                    ta[(size_t)sc * count + (size_t)i * h->Hn + q] = Va[(size_t)sc * count + (size_t)q * h->n + i];
+                }
+        HIPCHK(hipMemcpy(h->d_Vm, tm.data(), sizeof(double) * tm.size(), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_Va, ta.data(), sizeof(double) * ta.size(), hipMemcpyHostToDevice));
     } else {
-        hipLaunchKernelGGL(k_init_voltages, grid2(count, n_scen), dim3(TPB), 0, h->stream, h->n, count, h->d_Vm, h->d_Va);
+        hipLaunchKernelGGL(k_init_voltages, grid2(count, n_scen), dim3(TPB), 0, h->stream, h->Hn, count, h->d_Vm, h->d_Va);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -723,10 +754,17 @@ int hpf_set_state(hpf_handle* h, int n_scen, const double* Vm, const double* Va)
 int hpf_get_state(hpf_handle* h, double* Vm, double* Va) {
     if (!h || !Vm || !Va) return HPF_E_ARG;
     if (!h->state_set) return HPF_E_STATE;
-    const size_t cnt = (size_t)h->S * h->n * h->Hn;
+    const size_t count = (size_t)h->n * h->Hn, cnt = (size_t)h->S * count;
     HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipMemcpy(Vm, h->d_Vm, sizeof(double) * cnt, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(Va, h->d_Va, sizeof(double) * cnt, hipMemcpyDeviceToHost));
+    std::vector<double> tm(cnt), ta(cnt);
+    HIPCHK(hipMemcpy(tm.data(), h->d_Vm, sizeof(double) * cnt, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ta.data(), h->d_Va, sizeof(double) * cnt, hipMemcpyDeviceToHost));
+    for (int sc = 0; sc < h->S; ++sc)                                   // device bus-major -> ABI stacked order
+        for (int q = 0; q < h->Hn; ++q)
+            for (int i = 0; i < h->n; ++i) {
+                Vm[(size_t)sc * count + (size_t)q * h->n + i] = tm[(size_t)sc * count + (size_t)i * h->Hn + q];
+                Va[(size_t)sc * count + (size_t)q * h->n + i] = ta[(size_t)sc * count + (size_t)i * h->Hn + q];
+            }
     return HPF_OK;
 }
 
@@ -794,7 +832,7 @@ int hpf_iterate(hpf_handle* h, int iters) {
                 full_ctx(h);
             if ((r = newton_step<false>(h, nullptr))) break;
             if ((r = launch_update<false>(h, nullptr))) break;
-            r = launch_mismatch<false>(h, nullptr);
+            r = launch_mismatch<false>(h, nullptr, false);
         }
     }
     if (G > 1) {

@@ -159,8 +159,8 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? HPF_Q_OCC : 5)) voi
     if (nl && wv == NT - 1 && lane < B / 2) {
         cplx u = {0.0, -1.0}, e = {0.0, 1.0};               // padding harmonics: S = [-ui er; ur ei] = identity
         if (lane < Hn) {
-            u = U[(size_t)lane * n + k];
-            e = E[(size_t)lane * n + k];
+            u = U[(size_t)k * Hn + lane];
+            e = E[(size_t)k * Hn + lane];
         }
         __builtin_amdgcn_sched_barrier(0);
         double* t0 = tab + lane * 4;
@@ -188,8 +188,8 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? HPF_Q_OCC : 5)) voi
                 h4[0] = ha.x; h4[1] = ha.y; h4[2] = hb.x; h4[3] = hb.y;
             } else {
                 const cplx ydn = M.Y[(size_t)q * M.nnz + e_dn_k], yup = M.Y[(size_t)q * M.nnz + e_up_k];
-                const cplx uk = U[(size_t)q * n + k], ek = E[(size_t)q * n + k];
-                const cplx up = U[(size_t)q * n + par], ep = E[(size_t)q * n + par];
+                const cplx uk = U[(size_t)k * Hn + q], ek = E[(size_t)k * Hn + q];
+                const cplx up = U[(size_t)par * Hn + q], ep = E[(size_t)par * Hn + q];
                 __builtin_amdgcn_sched_barrier(0);
                 const Blk2 g = (q == 0 && par < M.m) ? blk_power_off(ydn, up, uk, ek) : blk_current(ydn, uk, ek);   // row par, col k
                 const Blk2 hh = (q == 0 && k < M.m) ? blk_power_off(yup, uk, up, ep) : blk_current(yup, up, ep);     // row k, col par
@@ -213,14 +213,12 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? HPF_Q_OCC : 5)) voi
         // folded in 2x2-per-harmonic algebra (linear subtrees, contracted chains) are dealt to the waves, lightest roles first
         const int q = lane >> 1, tr_ = lane & 1;
         const bool rowvalid = lane < b && loc_valid(n, c, k, lane);
-        const size_t kq = (size_t)(q < Hn ? q : 0) * n + k;
+        const size_t kq = (size_t)k * Hn + (q < Hn ? q : 0);
         if (wv == 0) {
             double y = 0.0, d0 = 0.0, d1 = 0.0;
             if (rowvalid) {
-                const double* f = fall + (size_t)s * N;
-                const int kst = q * n + k;
                 const bool prow = q == 0 && k < M.m;                     // power row (HG:451-459)
-                const double fy = tr_ ? f[Nc + kst - c] : f[kst - 1];
+                const double fy = fall[((size_t)s * n + k) * B + lane];  // bus-major mismatch image (k_mismatch)
                 const cplx yd = M.Y[(size_t)q * M.nnz + diag_e];
                 const cplx uk = U[kq], ek = E[kq];
                 cplx yn = {0.0, 0.0}, I0v = {0.0, 0.0};
@@ -261,7 +259,7 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? HPF_Q_OCC : 5)) voi
                     const int4 cr = c3[cp];
                     const int ch = cr.x;
                     const cplx ydn = M.Y[(size_t)q * M.nnz + cr.y], yup = M.Y[(size_t)q * M.nnz + cr.z];
-                    const cplx uc = U[(size_t)q * n + ch], ec = E[(size_t)q * n + ch];
+                    const cplx uc = U[(size_t)ch * Hn + q], ec = E[(size_t)ch * Hn + q];
                     const double2* pic = reinterpret_cast<const double2*>(linA + ((size_t)ch * Hn + q) * 4);
                     const double2 ic01 = pic[0], ic23 = pic[1];
                     const double2 wc = *reinterpret_cast<const double2*>(ws + (size_t)ch * B + 2 * q);
@@ -707,7 +705,7 @@ int launch_factor_q(hpf_handle* h, const TreeDev& T, const int* nodes, int count
     static const int sfast = getenv("HPF_SFAST") ? atoi(getenv("HPF_SFAST")) : 0;
     const dim3 grid = sfast ? dim3((unsigned)h->cur_S, (unsigned)count, 2) : dim3((unsigned)count, (unsigned)h->cur_S);
     hipLaunchKernelGGL((k_factor_q<B>), grid, dim3(64 * NT), 0, h->cur_stream, h->M, T, nodes,
-                       2 * h->Hn, h->N, h->Nc, active, h->d_U, h->d_E, h->d_f, h->d_Z, h->d_w, h->d_linA, h->d_C, h->d_H,
+                       2 * h->Hn, h->N, h->Nc, active, h->d_U, h->d_E, h->d_fb, h->d_Z, h->d_w, h->d_linA, h->d_C, h->d_H,
                        h->d_I0, h->d_chG, h->d_chH, h->d_chD, h->d_chy, active_tree(h).d_Minv, h->d_lfK, h->d_lfS, h->d_dbg, h->debug_ablate, h->cur_s0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -769,7 +767,7 @@ __device__ __forceinline__ void fold_children(const Model& M, const TreeDev& T, 
         const int4 cr = c3[cbeg + j];
         const int ch = cr.x;
         const cplx ydn = M.Y[(size_t)q * M.nnz + cr.y], yup = M.Y[(size_t)q * M.nnz + cr.z];
-        const cplx uc = U[(size_t)q * n + ch], ec = E[(size_t)q * n + ch];
+        const cplx uc = U[(size_t)ch * Hn + q], ec = E[(size_t)ch * Hn + q];
         const double2* pic = reinterpret_cast<const double2*>(linA + ((size_t)ch * Hn + q) * 4);
         const double2 ic01 = pic[0], ic23 = pic[1];
         const double2 wc = *reinterpret_cast<const double2*>(ws + (size_t)ch * Bst + 2 * q);
@@ -801,19 +799,17 @@ __global__ __launch_bounds__(128) void k_lin_level_factor(Model M, TreeDev T, co
     const size_t so = (size_t)s * n * Hn;
     const cplx* U = Uall + so;
     const cplx* E = Eall + so;
-    const double* f = fall + (size_t)s * N;
     double* linA = linAall + so * 4;
     double* ws = wall + (size_t)s * n * Bst;
     const int4 r0 = reinterpret_cast<const int4*>(rec)[2 * pos], r1 = reinterpret_cast<const int4*>(rec)[2 * pos + 1];
     const int k = r0.x;
-    const int kst = q * n + k;
     const cplx yd = M.Y[(size_t)q * M.nnz + r0.y];
-    const cplx uk = U[kst], ek = E[kst];
+    const cplx uk = U[(size_t)k * Hn + q], ek = E[(size_t)k * Hn + q];
     cplx I0v = {0.0, 0.0}, yn = {0.0, 0.0};
     if (q == 0 && k < M.m) I0v = I0all[(size_t)s * n + k];
     if (k >= M.m) yn = M.coupled ? M.YN[((size_t)r1.w * Hn + q) * Hn + q] : M.YN[(size_t)r1.w * Hn + q];
-    double y0 = kst >= 1 ? f[kst - 1] : 0.0;
-    double y1 = kst >= c ? f[Nc + kst - c] : 0.0;
+    const double2 fy = *reinterpret_cast<const double2*>(fall + ((size_t)s * n + k) * Bst + 2 * q);   // bus-major mismatch image
+    double y0 = fy.x, y1 = fy.y;
     __builtin_amdgcn_sched_barrier(0);
     double m2[4];
     diag2x2_val(n, c, M.m, q, k, yd, uk, ek, I0v, yn, m2);
@@ -852,8 +848,8 @@ __global__ __launch_bounds__(128) void k_lin_level_back(Model M, TreeDev T, cons
     double x0 = wk.x, x1 = wk.y;
     if (par >= 0) {
         const cplx yup = M.Y[(size_t)q * M.nnz + r0.w];
-        const cplx uk = U[(size_t)q * n + k];
-        const cplx up = U[(size_t)q * n + par], ep = E[(size_t)q * n + par];
+        const cplx uk = U[(size_t)k * Hn + q];
+        const cplx up = U[(size_t)par * Hn + q], ep = E[(size_t)par * Hn + q];
         const double2 xp = *reinterpret_cast<const double2*>(xs + (size_t)par * Bst + 2 * q);
         const double2* pik = reinterpret_cast<const double2*>(linA + ((size_t)k * Hn + q) * 4);
         const double2 i01 = pik[0], i23 = pik[1];
@@ -892,27 +888,26 @@ __global__ __launch_bounds__(128) void k_chain_factor2(Model M, TreeDev T, const
     const size_t so = (size_t)s * n * Hn;
     const cplx* U = Uall + so;
     const cplx* E = Eall + so;
-    const double* f = fall + (size_t)s * N;
     double* linA = linAall + so * 4;
     double* ws = wall + (size_t)s * n * Bst;
     const int4 h0 = reinterpret_cast<const int4*>(crec)[2 * r], h1 = reinterpret_cast<const int4*>(crec)[2 * r + 1];
     const int ch = h0.x, beg = h0.w, len = h1.x;
-    const cplx uch = U[(size_t)q * n + ch], ech = E[(size_t)q * n + ch];
+    const cplx uch = U[(size_t)ch * Hn + q], ech = E[(size_t)ch * Hn + q];
     const cplx y_kc = M.Y[(size_t)q * M.nnz + h0.y], y_ck = M.Y[(size_t)q * M.nnz + h0.z];
     double a_kc[4], a_ck[4];
     double dD[4] = {0.0, 0.0, 0.0, 0.0}, dy[2] = {0.0, 0.0}, cD[4] = {0.0, 0.0, 0.0, 0.0}, cy[2] = {0.0, 0.0};
     for (int idx = 0; idx < len; ++idx) {
         const int4 r0 = reinterpret_cast<const int4*>(cnode)[2 * (beg + idx)], r1 = reinterpret_cast<const int4*>(cnode)[2 * (beg + idx) + 1];
         const int k = r0.x, up = r0.z;
-        const int kst = q * n + k;
         const cplx yd = M.Y[(size_t)q * M.nnz + r0.y];
-        const cplx uk = U[kst], ek = E[kst];
-        const cplx uu = U[(size_t)q * n + up], eu = E[(size_t)q * n + up];
+        const cplx uk = U[(size_t)k * Hn + q], ek = E[(size_t)k * Hn + q];
+        const cplx uu = U[(size_t)up * Hn + q], eu = E[(size_t)up * Hn + q];
         const cplx y_ku = M.Y[(size_t)q * M.nnz + r0.w], y_uk = M.Y[(size_t)q * M.nnz + r1.x];
         cplx I0v = {0.0, 0.0};
         if (q == 0 && k < M.m) I0v = I0all[(size_t)s * n + k];
-        double y0 = (kst >= 1 ? f[kst - 1] : 0.0) + cy[0];
-        double y1 = (kst >= c ? f[Nc + kst - c] : 0.0) + cy[1];
+        const double2 fy = *reinterpret_cast<const double2*>(fall + ((size_t)s * n + k) * Bst + 2 * q);
+        double y0 = fy.x + cy[0];
+        double y1 = fy.y + cy[1];
         __builtin_amdgcn_sched_barrier(0);
         if (idx == 0) {
             coupling_val(n, c, M.m, q, k, ch, y_kc, uk, uch, ech, a_kc);     // A(k1, ch)
@@ -995,8 +990,8 @@ __global__ __launch_bounds__(128) void k_chain_back2(Model M, TreeDev T, const i
         const int4 r0 = reinterpret_cast<const int4*>(cnode)[2 * (beg + idx)];
         const int k = r0.x, up = r0.z;
         const cplx y_ku = M.Y[(size_t)q * M.nnz + r0.w];
-        const cplx uk = U[(size_t)q * n + k];
-        const cplx uu = U[(size_t)q * n + up], eu = E[(size_t)q * n + up];
+        const cplx uk = U[(size_t)k * Hn + q];
+        const cplx uu = U[(size_t)up * Hn + q], eu = E[(size_t)up * Hn + q];
         const double2 xp = *reinterpret_cast<const double2*>(xs + (size_t)up * Bst + 2 * q);
         const double2* pik = reinterpret_cast<const double2*>(linA + ((size_t)k * Hn + q) * 4);
         const double2 i01 = pik[0], i23 = pik[1];
