@@ -1477,6 +1477,7 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
                 }
         }
     }
+    T.lvl_all_leaf.assign(T.n_levels > 0 ? T.n_levels : 1, 1);
     for (int pos = 0; pos < T.n_dense; ++pos) {
         const int k = T.lvl_nodes[pos];
         int* r = &fdesc[(size_t)pos * 16];
@@ -1497,6 +1498,7 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
         for (int i = 0; i < 4 && i < r[9]; ++i) r[10 + i] = dchild[dchild_ptr[k] + i];
         r[14] = (k > 0 && pass[T.parent[k]]) ? 1 : 0;              // linked to its dense parent through a contracted chain
         r[15] = cleaf_of[k] + 1;                                   // constant-inverse leaf: 1 + slot in Tree::d_Minv
+        if (cleaf_of[k] < 0) T.lvl_all_leaf[height[k]] = 0;
         const int kb = T.dep_nodes[pos];
         bdesc[(size_t)pos * 4 + 0] = kb;
         bdesc[(size_t)pos * 4 + 1] = pard[kb];
@@ -1710,7 +1712,8 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
             switch (BW) {
 #define HPF_FACTOR_CASE(BB_)                                                                                  \
     case BB_:                                                                                                 \
-        r = h->gj_mode == 1 ? launch_factor_q<BB_>(h, td, T.d_fdesc + 16 * (size_t)T.lvl_ptr[l], cnt, active) \
+        r = h->gj_mode == 1 ? launch_factor_q<BB_>(h, td, T.d_fdesc + 16 * (size_t)T.lvl_ptr[l], cnt, active, \
+                                                  T.lvl_all_leaf[l] != 0)                                       \
             : (h->gj_mode == 2 ? launch_factor_w<BB_, 1>(h, td, nodes, cnt, active)                           \
                                : launch_factor_w<BB_, 0>(h, td, nodes, cnt, active));                         \
         break

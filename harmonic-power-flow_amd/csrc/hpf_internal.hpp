@@ -74,6 +74,7 @@ struct Tree {
     int* d_lrec = nullptr;
     int* d_crec = nullptr;            // chain headers
     int* d_cnode = nullptr;           // chain node records
+    std::vector<int> lvl_all_leaf;    // [n_levels] 1: every bus of the elimination level is a constant-inverse leaf
     int n_cleaf = 0;
     double* d_Minv = nullptr;         // [n_cleaf][NT*NT*256]
     double flops_per_solve = 0.0;     // factor sweep + back sweep

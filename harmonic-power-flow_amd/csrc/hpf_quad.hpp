@@ -83,8 +83,10 @@ __device__ __forceinline__ void mask_block(int n, int c, int q, int i, int j, co
 #define HPF_Q_OCC 4        // waves per SIMD the B = 52 factor kernel is compiled for (register budget 512 / HPF_Q_OCC)
 #endif
 
-template <int B>
-__global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? HPF_Q_OCC : 5)) void k_factor_q(
+// LEAF: every bus of the launch is a constant-inverse leaf (elimination level 0 of the contracted tree): the general path
+// (assembly, child sums, Gauss-Jordan) is compiled out and with it most of the register budget -> more workgroups per CU.
+template <int B, bool LEAF>
+__global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_OCC) : 5)) void k_factor_q(
     Model M, TreeDev T, const int* __restrict__ nodes, int b, int N, int Nc, const int* __restrict__ active,
     const cplx* __restrict__ Uall, const cplx* __restrict__ Eall, const double* __restrict__ fall, double* __restrict__ Zall,
     double* __restrict__ wall, const double* __restrict__ linAall, double* __restrict__ Call, double* __restrict__ Hall,
@@ -112,7 +114,8 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? HPF_Q_OCC : 5)) voi
     const int e_dn_k = nd1.x, e_up_k = nd1.y, lin_beg = nd1.z, lin_end = nd1.z + nd1.w;
     const int den_beg = nd2.x, n_den = nd2.y;
     const bool via_chain = nd3.z != 0;       // linked to the dense parent through a contracted chain (k_chain_factor)
-    const int cleaf = nd3.w;                 // constant-inverse leaf: 1 + slot in Minv (0: general path)
+    const int cleafv = nd3.w;                // constant-inverse leaf: 1 + slot in Minv (0: general path)
+    const bool cleaf = LEAF || cleafv != 0;
 #ifdef HPF_FACTOR_STAMPS
     long long sd1 = 0, sd2 = 0, sd3 = 0;
     {
@@ -323,30 +326,31 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? HPF_Q_OCC : 5)) voi
         // fundamental.  With the per-model image  [c0 Lr; Lc Ahh^-1]  (tile layout):
         //     Drect^-1 = [0 0; 0 Ahh^-1] + [I; Lc] (c0 + D)^-1 [I Lr];
         // polar inverse = S^-1 Drect^-1 (row pairs scaled by the 2x2 S_q^-1);  w = A^-1 y by row sums.
-        const double* Mk = Minv + (size_t)(cleaf - 1) * CT + lane;
+        const double* Mk = Minv + (size_t)(cleafv - 1) * CT + lane;
 #pragma unroll
         for (int e = 0; e < NT * 4; ++e)
             if (16 * (e >> 2) + 4 * (e & 3) < B) ct[e >> 2][e & 3] = Mk[(size_t)(((e >> 2) * NT + wv) * 4 + (e & 3)) * 64];
         double* mc = &panel[0][0];          // [I; Lc]  as mc[row*2 + a]
-        double* mr = &panel[1][0];          // [I  Lr]  as mr[a*64 + col]  (positions (a, 0..1) hold c0)
+        double* mr = &panel[1][0];          // [I  Lr]  as mr[a*MRS + col]  (positions (a, 0..1) hold c0)
+        constexpr int MRS = 16 * NT;        // columns of the padded block (panel[1] holds NT*64 doubles)
         if (wv == 0 && jj < 2) {
 #pragma unroll
             for (int tr = 0; tr < NT; ++tr)
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) mc[(16 * tr + 4 * reg + lg) * 2 + jj] = ct[tr][reg];
         }
-        if (lg < 2) mr[lg * 64 + col] = ct[0][0];
+        if (lg < 2) mr[lg * MRS + col] = ct[0][0];
         __syncthreads();
         double kv0, kv1;                    // ((c0 + D)^-1 [I Lr])[a][col]
         {
             const double si0 = tab[0], si1 = tab[1], si2 = tab[2], si3 = tab[3];           // S_0^-1
             const double p00 = dgb[0], p01 = dgb[1], p10 = dgb[3], p11 = dgb[4];           // Delta_polar
             const double q00 = mr[0] + fma(p01, si2, p00 * si0), q01 = mr[1] + fma(p01, si3, p00 * si1);      // c0 + Delta_polar S_0^-1
-            const double q10 = mr[64] + fma(p11, si2, p10 * si0), q11 = mr[65] + fma(p11, si3, p10 * si1);
+            const double q10 = mr[MRS] + fma(p11, si2, p10 * si0), q11 = mr[MRS + 1] + fma(p11, si3, p10 * si1);
             double k00, k01, k10, k11;
             inv2(q00, q01, q10, q11, k00, k01, k10, k11);
             const double r0 = col < 2 ? (col == 0 ? 1.0 : 0.0) : mr[col];
-            const double r1 = col < 2 ? (col == 1 ? 1.0 : 0.0) : mr[64 + col];
+            const double r1 = col < 2 ? (col == 1 ? 1.0 : 0.0) : mr[MRS + col];
             kv0 = fma(k01, r1, k00 * r0);
             kv1 = fma(k11, r1, k10 * r0);
             if (tid == 0) {                 // the back sweep rebuilds  A^-1 t  from the image, this 2x2 and S^-1: no inverse goes to HBM
@@ -699,12 +703,12 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16)) void k_back_q(
     }
 }
 
-template <int B>
-int launch_factor_q(hpf_handle* h, const TreeDev& T, const int* nodes, int count, const int* active) {
+template <int B, bool LEAF>
+int launch_factor_q2(hpf_handle* h, const TreeDev& T, const int* nodes, int count, const int* active) {
     constexpr int NT = (B + 16) / 16;
     static const int sfast = getenv("HPF_SFAST") ? atoi(getenv("HPF_SFAST")) : 0;
     const dim3 grid = sfast ? dim3((unsigned)h->cur_S, (unsigned)count, 2) : dim3((unsigned)count, (unsigned)h->cur_S);
-    hipLaunchKernelGGL((k_factor_q<B>), grid, dim3(64 * NT), 0, h->cur_stream, h->M, T, nodes,
+    hipLaunchKernelGGL((k_factor_q<B, LEAF>), grid, dim3(64 * NT), 0, h->cur_stream, h->M, T, nodes,
                        2 * h->Hn, h->N, h->Nc, active, h->d_U, h->d_E, h->d_fb, h->d_Z, h->d_w, h->d_linA, h->d_C, h->d_H,
                        h->d_I0, h->d_chG, h->d_chH, h->d_chD, h->d_chy, active_tree(h).d_Minv, h->d_lfK, h->d_lfS, h->d_dbg, h->debug_ablate, h->cur_s0);
     hipError_t e = hipGetLastError();
@@ -713,6 +717,11 @@ int launch_factor_q(hpf_handle* h, const TreeDev& T, const int* nodes, int count
         return HPF_E_HIP;
     }
     return HPF_OK;
+}
+
+template <int B>
+int launch_factor_q(hpf_handle* h, const TreeDev& T, const int* nodes, int count, const int* active, bool all_leaves) {
+    return all_leaves ? launch_factor_q2<B, true>(h, T, nodes, count, active) : launch_factor_q2<B, false>(h, T, nodes, count, active);
 }
 
 template <int B>
