@@ -1295,7 +1295,7 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
         }
     }
     // records of the level-parallel 2x2 kernels
-    std::vector<int> lrec, crec, cnode;
+    std::vector<int> lrec, crec, cnode, arec;
     {
         std::vector<int> diag0(n, -1), hl(n, 0);
         for (int i = 0; i < n; ++i)
@@ -1330,6 +1330,24 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
             crec.insert(crec.end(), a, a + 8);
         }
         for (size_t idx = 0; idx < T.chain_nodes.size(); ++idx) put(cnode, T.chain_nodes[idx]);   // folds its linear subtrees only
+        // whole tree by height (fundamental power flow: every bus is a 2x2 bus at harmonic position 0)
+        std::vector<int> ha(n, 0);
+        int maxha = 0;
+        for (int oi = n - 1; oi > 0; --oi) {
+            const int i = order[oi], pp = T.parent[i];
+            if (ha[i] + 1 > ha[pp]) ha[pp] = ha[i] + 1;
+        }
+        for (int i = 0; i < n; ++i) maxha = ha[i] > maxha ? ha[i] : maxha;
+        T.n_all_heights = maxha + 1;
+        T.ah_ptr.assign(T.n_all_heights + 1, 0);
+        for (int hh = 0; hh < T.n_all_heights; ++hh) {
+            for (int i = 0; i < n; ++i)
+                if (ha[i] == hh) {
+                    put(arec, i);
+                    arec[arec.size() - 2] = T.child_ptr[i + 1] - T.child_ptr[i];
+                }
+            T.ah_ptr[hh + 1] = (int)arec.size() / 8;
+        }
     }
     // node records of the multi-wave kernels (hpf_quad.hpp)
     std::vector<int> fdesc((size_t)T.n_dense * 16, 0), child3((size_t)(n > 1 ? n - 1 : 0) * 4, 0), bdesc((size_t)T.n_dense * 4, 0);
@@ -1560,6 +1578,7 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
     if ((r = upload(h, &T.d_lrec, lrec))) return r;
     if ((r = upload(h, &T.d_crec, crec))) return r;
     if ((r = upload(h, &T.d_cnode, cnode))) return r;
+    if ((r = upload(h, &T.d_arec, arec))) return r;
     return HPF_OK;
 }
 
@@ -1577,7 +1596,7 @@ Tree& active_tree(hpf_handle* h) { return (h->has_ctree && h->gj_mode == 1) ? h-
 static void tree_free_one(Tree& T) {
     void* ptrs[] = {T.d_parent, T.d_lvl_nodes, T.d_dep_nodes, T.d_child_ptr, T.d_child, T.d_e_up, T.d_e_dn,
                     T.d_child_mid, T.d_lin, T.d_lin_ptr, T.d_lin_post, T.d_all_ptr, T.d_all_post, T.d_fdesc, T.d_child3,
-                    T.d_bdesc, T.d_dchild, T.d_chain_ptr, T.d_chain_nodes, T.d_chain_ch, T.d_Minv, T.d_lrec, T.d_crec, T.d_cnode};
+                    T.d_bdesc, T.d_dchild, T.d_chain_ptr, T.d_chain_nodes, T.d_chain_ch, T.d_Minv, T.d_lrec, T.d_crec, T.d_cnode, T.d_arec};
     for (void* p : ptrs)
         if (p) hipFree(p);
 }
@@ -1625,6 +1644,27 @@ int tree_fund_step(hpf_handle* h, bool only_active) {
     const int BW = wave_block_size(b);
     const int Bst = BW ? BW : b;
     ScopedTimer t(h, T_SOLVE);
+    if (BW) {
+        // level-parallel: one launch per height of the tree, one thread per (bus, scenario) (k_lin_level_*, fund = 1)
+        for (int hh = 0; hh < T.n_all_heights; ++hh) {
+            const int cnt = T.ah_ptr[hh + 1] - T.ah_ptr[hh];
+            hipLaunchKernelGGL(k_lin_level_factor, dim3((unsigned)((cnt + 127) / 128), (unsigned)h->cur_S), dim3(128), 0,
+                               h->cur_stream, h->M, td, T.d_arec + 8 * (size_t)T.ah_ptr[hh], cnt, h->Nf, h->n - 1, Bst, active, h->d_U,
+                               h->d_E, h->d_f, h->d_linA, h->d_w, h->d_I0, 1, h->cur_s0);
+        }
+        for (int hh = T.n_all_heights - 1; hh >= 0; --hh) {
+            const int cnt = T.ah_ptr[hh + 1] - T.ah_ptr[hh];
+            hipLaunchKernelGGL(k_lin_level_back, dim3((unsigned)((cnt + 127) / 128), (unsigned)h->cur_S), dim3(128), 0, h->cur_stream,
+                               h->M, td, T.d_arec + 8 * (size_t)T.ah_ptr[hh], cnt, h->Nf, h->n - 1, Bst, active, h->d_U, h->d_E,
+                               h->d_linA, h->d_w, h->d_x, h->d_f, 1, h->cur_s0);
+        }
+        hipError_t e2 = hipGetLastError();
+        if (e2 != hipSuccess) {
+            h->last_detail = (int)e2;
+            return HPF_E_HIP;
+        }
+        return HPF_OK;
+    }
     hipLaunchKernelGGL((k_lin_factor<true>), dim3(1, (unsigned)h->cur_S), dim3(128), 0, h->cur_stream, h->M, td, 1, h->Nf,
                        h->n - 1, Bst, active, h->d_U, h->d_E, h->d_f, h->d_linA, h->d_w, nullptr, h->cur_s0);
     hipLaunchKernelGGL((k_lin_back<true>), dim3(1, (unsigned)h->cur_S), dim3(128), 0, h->cur_stream, h->M, td, 1, h->Nf,
@@ -1654,7 +1694,7 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
                 if (cnt == 0) continue;
                 hipLaunchKernelGGL(k_lin_level_factor, dim3((unsigned)((cnt * h->Hn + 127) / 128), (unsigned)h->cur_S), dim3(128), 0,
                                    h->cur_stream, h->M, td, T.d_lrec + 8 * (size_t)T.lh_ptr[hh], cnt, h->N, h->Nc, Bst, active,
-                                   h->d_U, h->d_E, h->d_fb, h->d_linA, h->d_w, h->d_I0, h->cur_s0);
+                                   h->d_U, h->d_E, h->d_fb, h->d_linA, h->d_w, h->d_I0, 0, h->cur_s0);
             }
             if (T.n_chains > 0)
                 hipLaunchKernelGGL(k_chain_factor2, dim3((unsigned)((T.n_chains * h->Hn + 127) / 128), (unsigned)h->cur_S), dim3(128),
@@ -1766,7 +1806,7 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
             if (cnt == 0) continue;
             hipLaunchKernelGGL(k_lin_level_back, dim3((unsigned)((cnt * h->Hn + 127) / 128), (unsigned)h->cur_S), dim3(128), 0,
                                h->cur_stream, h->M, td, T.d_lrec + 8 * (size_t)T.lh_ptr[hh], cnt, h->N, h->Nc, Bst, active, h->d_U,
-                               h->d_E, h->d_linA, h->d_w, h->d_x, (double*)nullptr, h->cur_s0);
+                               h->d_E, h->d_linA, h->d_w, h->d_x, (double*)nullptr, 0, h->cur_s0);
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) {

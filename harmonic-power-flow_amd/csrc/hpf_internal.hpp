@@ -74,6 +74,9 @@ struct Tree {
     int* d_lrec = nullptr;
     int* d_crec = nullptr;            // chain headers
     int* d_cnode = nullptr;           // chain node records
+    int n_all_heights = 0;            // the whole tree by height (fundamental power flow)
+    std::vector<int> ah_ptr;
+    int* d_arec = nullptr;
     std::vector<int> lvl_all_leaf;    // [n_levels] 1: every bus of the elimination level is a constant-inverse leaf
     int n_cleaf = 0;
     double* d_Minv = nullptr;         // [n_cleaf][NT*NT*256]
@@ -121,6 +124,9 @@ struct hpf_handle {
     hpf::Tree tree;                   // elimination tree as the network gives it (single-wave / generic kernels, pf)
     hpf::Tree ctree;                  // the same with pass-through buses contracted (multi-wave kernels, gj_mode 1)
     bool has_ctree = false;
+    // one captured NR iteration per scenario group (hpf_iterate): replayed on the group's stream, no per-kernel launch cost
+    hipGraphExec_t step_graph[8] = {};
+    int graph_key = -1;               // (S, groups, mode) the graphs were captured for
     double* d_Z = nullptr;            // [S][n][b*b]
     double* d_w = nullptr;            // [S][n][b]
     double* d_x = nullptr;            // [S][n][b]  Newton step, bus-major

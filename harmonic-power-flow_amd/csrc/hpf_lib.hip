@@ -96,7 +96,7 @@ __global__ void k_mismatch(Model M, int count, int N, int Nc, const int* __restr
         cplx v = {0.0, 0.0};
         if (k >= 1) {
             v = mismatch_row<FUND>(M, U + (size_t)s * M.n * M.Hn, P + (size_t)s * M.n, Q + (size_t)s * M.n, k,
-                                   (!FUND && I0) ? I0 + (size_t)s * M.n : nullptr);
+                                   I0 ? I0 + (size_t)s * M.n : nullptr);
             if (f) store_mismatch(f + (size_t)s * N, Nc, M.c, k, v);
             b = abs_bits(v.re);
             if (k >= M.c) {
@@ -819,6 +819,53 @@ int hpf_iterate(hpf_handle* h, int iters) {
     // iteration-major enqueue order (all groups' step i before any group's step i+1) keeps the group pipelines in phase
     const int G = groups_for(h);
     int r = HPF_OK;
+    static const int use_graph = getenv("HPF_GRAPH") ? atoi(getenv("HPF_GRAPH")) : 0;
+    if (use_graph && !h->timing && G <= 8) {
+        const int key = h->S * 64 + G * 8 + h->gj_mode;
+        if (h->graph_key != key) {
+            for (int g = 0; g < 8; ++g)
+                if (h->step_graph[g]) {
+                    hipGraphExecDestroy(h->step_graph[g]);
+                    h->step_graph[g] = nullptr;
+                }
+            for (int g = 0; g < G; ++g) {
+                hipStream_t st = G > 1 ? h->gstream[g] : h->stream;
+                HIPCHK(hipStreamSynchronize(st));
+                HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+                if (G > 1)
+                    set_ctx(h, st, (int)((long long)h->S * g / G), (int)((long long)h->S * (g + 1) / G) - (int)((long long)h->S * g / G));
+                else
+                    full_ctx(h);
+                r = newton_step<false>(h, nullptr);
+                if (!r) r = launch_update<false>(h, nullptr);
+                if (!r) r = launch_mismatch<false>(h, nullptr, false);
+                hipGraph_t gr = nullptr;
+                const hipError_t ee = hipStreamEndCapture(st, &gr);
+                if (r || ee != hipSuccess) {
+                    full_ctx(h);
+                    h->last_detail = (int)ee;
+                    return r ? r : HPF_E_HIP;
+                }
+                HIPCHK(hipGraphInstantiate(&h->step_graph[g], gr, nullptr, nullptr, 0));
+                hipGraphDestroy(gr);
+            }
+            h->graph_key = key;
+        }
+        if (G > 1) {
+            HIPCHK(hipEventRecord(h->fork_ev, h->stream));
+            for (int g = 0; g < G; ++g) HIPCHK(hipStreamWaitEvent(h->gstream[g], h->fork_ev, 0));
+        }
+        for (int it = 0; it < iters; ++it)
+            for (int g = 0; g < G; ++g) HIPCHK(hipGraphLaunch(h->step_graph[g], G > 1 ? h->gstream[g] : h->stream));
+        if (G > 1) {
+            for (int g = 0; g < G; ++g) {
+                HIPCHK(hipEventRecord(h->join_ev[g], h->gstream[g]));
+                HIPCHK(hipStreamWaitEvent(h->stream, h->join_ev[g], 0));
+            }
+        }
+        full_ctx(h);
+        return HPF_OK;
+    }
     if (G > 1) {
         HIPCHK(hipEventRecord(h->fork_ev, h->stream));
         for (int g = 0; g < G; ++g) HIPCHK(hipStreamWaitEvent(h->gstream[g], h->fork_ev, 0));

@@ -769,7 +769,7 @@ __device__ __forceinline__ void coupling_val(int n, int c, int m, int q, int i, 
 // fold the 2x2-algebra children [cbeg, cbeg+nch) of bus k into (m2, y0, y1): m2 -= A(k,ch) D_ch^-1 A(ch,k), y -= A(k,ch) w_ch
 __device__ __forceinline__ void fold_children(const Model& M, const TreeDev& T, const cplx* U, const cplx* E, const double* linA,
                                               const double* ws, int Bst, int q, int k, cplx uk, cplx ek, int cbeg, int nch,
-                                              double m2[4], double& y0, double& y1) {
+                                              double m2[4], double& y0, double& y1, int m_eff) {
     const int n = M.n, c = M.c, Hn = M.Hn;
     const int4* c3 = reinterpret_cast<const int4*>(T.child3);
     for (int j = 0; j < nch; ++j) {
@@ -782,8 +782,8 @@ __device__ __forceinline__ void fold_children(const Model& M, const TreeDev& T, 
         const double2 wc = *reinterpret_cast<const double2*>(ws + (size_t)ch * Bst + 2 * q);
         __builtin_amdgcn_sched_barrier(0);
         double g4[4], h4[4], gi[4], gh[4];
-        coupling_val(n, c, M.m, q, k, ch, ydn, uk, uc, ec, g4);              // A(k, child)
-        coupling_val(n, c, M.m, q, ch, k, yup, uc, uk, ek, h4);              // A(child, k)
+        coupling_val(n, c, m_eff, q, k, ch, ydn, uk, uc, ec, g4);            // A(k, child)
+        coupling_val(n, c, m_eff, q, ch, k, yup, uc, uk, ek, h4);            // A(child, k)
         const double ic[4] = {ic01.x, ic01.y, ic23.x, ic23.y};
         mul22(g4, ic, gi);
         mul22(gi, h4, gh);
@@ -798,13 +798,17 @@ __global__ __launch_bounds__(128) void k_lin_level_factor(Model M, TreeDev T, co
                                                           int Bst, const int* __restrict__ active, const cplx* __restrict__ Uall,
                                                           const cplx* __restrict__ Eall, const double* __restrict__ fall,
                                                           double* __restrict__ linAall, double* __restrict__ wall,
-                                                          const cplx* __restrict__ I0all, int s0) {
+                                                          const cplx* __restrict__ I0all, int fund, int s0) {
+    // fund: fundamental power flow (HG:205-223) -- harmonic position 0 only, every bus a power row (m_eff = n), mismatch in
+    // the stacked order of `pf`; the records then cover the whole tree
     const int s = blockIdx.y + s0;
     if (active && !active[s]) return;
     const int tix = blockIdx.x * 128 + threadIdx.x;
-    if (tix >= count * M.Hn) return;
-    const int q = tix % M.Hn, pos = tix / M.Hn;
+    const int HnE = fund ? 1 : M.Hn;
+    if (tix >= count * HnE) return;
+    const int q = tix % HnE, pos = tix / HnE;
     const int n = M.n, c = M.c, Hn = M.Hn;
+    const int m_eff = fund ? n : M.m;
     const size_t so = (size_t)s * n * Hn;
     const cplx* U = Uall + so;
     const cplx* E = Eall + so;
@@ -815,14 +819,22 @@ __global__ __launch_bounds__(128) void k_lin_level_factor(Model M, TreeDev T, co
     const cplx yd = M.Y[(size_t)q * M.nnz + r0.y];
     const cplx uk = U[(size_t)k * Hn + q], ek = E[(size_t)k * Hn + q];
     cplx I0v = {0.0, 0.0}, yn = {0.0, 0.0};
-    if (q == 0 && k < M.m) I0v = I0all[(size_t)s * n + k];
-    if (k >= M.m) yn = M.coupled ? M.YN[((size_t)r1.w * Hn + q) * Hn + q] : M.YN[(size_t)r1.w * Hn + q];
-    const double2 fy = *reinterpret_cast<const double2*>(fall + ((size_t)s * n + k) * Bst + 2 * q);   // bus-major mismatch image
-    double y0 = fy.x, y1 = fy.y;
+    if (q == 0 && k < m_eff) I0v = I0all[(size_t)s * n + k];
+    if (k >= m_eff) yn = M.coupled ? M.YN[((size_t)r1.w * Hn + q) * Hn + q] : M.YN[(size_t)r1.w * Hn + q];
+    double y0, y1;
+    if (fund) {
+        const double* f = fall + (size_t)s * N;
+        y0 = k >= 1 ? f[k - 1] : 0.0;
+        y1 = k >= c ? f[Nc + k - c] : 0.0;
+    } else {
+        const double2 fy = *reinterpret_cast<const double2*>(fall + ((size_t)s * n + k) * Bst + 2 * q);   // bus-major mismatch image
+        y0 = fy.x;
+        y1 = fy.y;
+    }
     __builtin_amdgcn_sched_barrier(0);
     double m2[4];
-    diag2x2_val(n, c, M.m, q, k, yd, uk, ek, I0v, yn, m2);
-    fold_children(M, T, U, E, linA, ws, Bst, q, k, uk, ek, r1.y, r1.z, m2, y0, y1);
+    diag2x2_val(n, c, m_eff, q, k, yd, uk, ek, I0v, yn, m2);
+    fold_children(M, T, U, E, linA, ws, Bst, q, k, uk, ek, r1.y, r1.z, m2, y0, y1, m_eff);
     double di[4];
     inv2(m2[0], m2[1], m2[2], m2[3], di[0], di[1], di[2], di[3]);
     double* ik = linA + ((size_t)k * Hn + q) * 4;
@@ -837,13 +849,15 @@ __global__ __launch_bounds__(128) void k_lin_level_back(Model M, TreeDev T, cons
                                                         int Bst, const int* __restrict__ active, const cplx* __restrict__ Uall,
                                                         const cplx* __restrict__ Eall, const double* __restrict__ linAall,
                                                         const double* __restrict__ wall, double* __restrict__ xall,
-                                                        double* __restrict__ step, int s0) {
+                                                        double* __restrict__ step, int fund, int s0) {
     const int s = blockIdx.y + s0;
     if (active && !active[s]) return;
     const int tix = blockIdx.x * 128 + threadIdx.x;
-    if (tix >= count * M.Hn) return;
-    const int q = tix % M.Hn, pos = tix / M.Hn;
+    const int HnE = fund ? 1 : M.Hn;
+    if (tix >= count * HnE) return;
+    const int q = tix % HnE, pos = tix / HnE;
     const int n = M.n, c = M.c, Hn = M.Hn;
+    const int m_eff = fund ? n : M.m;
     const size_t so = (size_t)s * n * Hn;
     const cplx* U = Uall + so;
     const cplx* E = Eall + so;
@@ -864,7 +878,7 @@ __global__ __launch_bounds__(128) void k_lin_level_back(Model M, TreeDev T, cons
         const double2 i01 = pik[0], i23 = pik[1];
         __builtin_amdgcn_sched_barrier(0);
         double h4[4];
-        coupling_val(n, c, M.m, q, k, par, yup, uk, up, ep, h4);             // A(k, parent)
+        coupling_val(n, c, m_eff, q, k, par, yup, uk, up, ep, h4);           // A(k, parent)
         const double t0 = fma(h4[1], xp.y, h4[0] * xp.x), t1 = fma(h4[3], xp.y, h4[2] * xp.x);
         x0 -= fma(i01.y, t1, i01.x * t0);
         x1 -= fma(i23.y, t1, i23.x * t0);
@@ -926,7 +940,7 @@ __global__ __launch_bounds__(128) void k_chain_factor2(Model M, TreeDev T, const
         diag2x2_val(n, c, M.m, q, k, yd, uk, ek, I0v, cplx{0.0, 0.0}, m2);      // chain buses are linear buses
 #pragma unroll
         for (int e = 0; e < 4; ++e) m2[e] += cD[e];
-        fold_children(M, T, U, E, linA, ws, Bst, q, k, uk, ek, r1.y, r1.z, m2, y0, y1);
+        fold_children(M, T, U, E, linA, ws, Bst, q, k, uk, ek, r1.y, r1.z, m2, y0, y1, M.m);
         double di[4];
         inv2(m2[0], m2[1], m2[2], m2[3], di[0], di[1], di[2], di[3]);
         double* ik = linA + ((size_t)k * Hn + q) * 4;
