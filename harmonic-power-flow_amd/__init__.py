@@ -2,9 +2,10 @@
 hand-written HIP (gfx950) behind the reference's own Python call shapes.  See DESIGN.md / INTEGRATION.md."""
 from .settings import Settings
 from .api import (AdmittanceSet, build_admittance_matrices, build_harmonic_jacobian, get_THD, harmonic_mismatch,
-                  harmonic_state_vector, hpf, import_Norton_Equivalents, init_network, init_voltages, pf, solve)
+                  harmonic_state_vector, hpf, import_Norton_Equivalents, init_network, init_voltages, pf, solve,
+                  update_harmonic_state_vec)
 from .device import DeviceModel
 
 __all__ = ["Settings", "AdmittanceSet", "DeviceModel", "build_admittance_matrices", "build_harmonic_jacobian",
            "get_THD", "harmonic_mismatch", "harmonic_state_vector", "hpf", "import_Norton_Equivalents",
-           "init_network", "init_voltages", "pf", "solve"]
+           "init_network", "init_voltages", "pf", "solve", "update_harmonic_state_vec"]

@@ -56,6 +56,7 @@ SYMBOLS = {
     "hpf_timing_enable": (C.c_int, [_H, C.c_int]),
     "hpf_timing_get": (C.c_int, [_H, C.c_int, c_dbl_p, C.POINTER(C.c_int64)]),
     "hpf_timing_reset": (C.c_int, [_H]),
+    "hpf_dense_solve": (C.c_int, [C.c_int, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p]),
     "hpf_solve_flops": (C.c_double, [_H]),
     "hpf_solve_bytes": (C.c_double, [_H]),
     "hpf_back_bytes": (C.c_double, [_H]),

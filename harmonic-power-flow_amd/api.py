@@ -14,7 +14,9 @@ import numpy as np
 import pandas as pd
 import scipy.sparse as sp
 
-from . import admittance, ingest
+import ctypes as C
+
+from . import _lib, admittance, ingest
 from .device import DeviceModel
 from .settings import Settings
 
@@ -236,6 +238,23 @@ def harmonic_state_vector(V, c=None, buses=None):
         b = buses if buses is not None else _ctx["buses"]
         c = ingest.network_constants(b)[2]
     return np.append(V.V_a.to_numpy()[1:], V.V_m.to_numpy()[c:])
+
+
+def update_harmonic_state_vec(J, x, f, device=0):
+    """HG:476-479: x - spsolve(J, f).  The linear solve runs on the GPU (rocSOLVER LU with partial pivoting through
+    `hpf_dense_solve`); J may be a SciPy sparse matrix (as `build_harmonic_jacobian` returns it) or a dense array."""
+    lib = _lib.load()
+    Jd = np.asfortranarray(J.toarray() if hasattr(J, "toarray") else np.asarray(J), dtype=np.float64)
+    fv = np.ascontiguousarray(f, dtype=np.float64)
+    N = fv.size
+    if Jd.shape != (N, N):
+        raise ValueError("J must be %d x %d" % (N, N))
+    dx = np.empty(N)
+    dp = C.POINTER(C.c_double)
+    rc = lib.hpf_dense_solve(int(device), N, Jd.ctypes.data_as(dp), fv.ctypes.data_as(dp), dx.ctypes.data_as(dp))
+    if rc != 0:
+        raise RuntimeError("hpf_dense_solve failed: %s (code %d)" % (lib.hpf_strerror(rc).decode(), rc))
+    return np.asarray(x, dtype=np.float64) - dx
 
 
 def get_THD(V):

@@ -967,6 +967,36 @@ int hpf_timing_reset(hpf_handle* h) {
     return r;
 }
 
+// update_harmonic_state_vec (HG:476-479) as a standalone call: dx = J^-1 f for a caller-supplied dense column-major J
+// (rocSOLVER getrf / getrs, partial pivoting).  No handle: the reference function is stateless too.
+int hpf_dense_solve(int device, int N, const double* J_colmajor, const double* f, double* dx) {
+    if (N < 1 || !J_colmajor || !f || !dx) return HPF_E_ARG;
+    if (hipSetDevice(device) != hipSuccess) return HPF_E_HIP;
+    rocblas_handle blas = nullptr;
+    double *dJ = nullptr, *df = nullptr;
+    int *dip = nullptr, *dinfo = nullptr, info = 0, rc = HPF_OK;
+    if (rocblas_create_handle(&blas) != rocblas_status_success) return HPF_E_ROCSOLVER;
+    if (hipMalloc((void**)&dJ, sizeof(double) * (size_t)N * N) != hipSuccess || hipMalloc((void**)&df, sizeof(double) * N) != hipSuccess ||
+        hipMalloc((void**)&dip, sizeof(int) * N) != hipSuccess || hipMalloc((void**)&dinfo, sizeof(int)) != hipSuccess)
+        rc = HPF_E_NOMEM;
+    if (!rc && (hipMemcpy(dJ, J_colmajor, sizeof(double) * (size_t)N * N, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(df, f, sizeof(double) * N, hipMemcpyHostToDevice) != hipSuccess))
+        rc = HPF_E_HIP;
+    if (!rc && (rocsolver_dgetrf(blas, N, N, dJ, N, dip, dinfo) != rocblas_status_success ||
+                rocsolver_dgetrs(blas, rocblas_operation_none, N, 1, dJ, N, dip, df, N) != rocblas_status_success))
+        rc = HPF_E_ROCSOLVER;
+    if (!rc && (hipMemcpy(&info, dinfo, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
+                hipMemcpy(dx, df, sizeof(double) * N, hipMemcpyDeviceToHost) != hipSuccess))
+        rc = HPF_E_HIP;
+    if (!rc && info != 0) rc = HPF_E_SINGULAR;
+    hipFree(dJ);
+    hipFree(df);
+    hipFree(dip);
+    hipFree(dinfo);
+    rocblas_destroy_handle(blas);
+    return rc;
+}
+
 double hpf_solve_flops(const hpf_handle* h) {
     if (!h) return 0.0;
     if (h->solver == HPF_SOLVER_BLOCK_TREE) return active_tree(const_cast<hpf_handle*>(h)).flops_factor;

@@ -121,6 +121,10 @@ int  hpf_solve(hpf_handle* h, double thresh, int max_iter, int* n_iter, double* 
  * update_harmonic_voltages HG:482-485).  Requires a valid mismatch (hpf_mismatch or hpf_solve first). */
 int  hpf_iterate(hpf_handle* h, int iters);
 
+/* update_harmonic_state_vec (HG:476-479) as a standalone, stateless call like the reference's: dx = J^-1 f for a dense
+ * column-major N x N Jacobian supplied by the caller (rocSOLVER LU, partial pivoting); the caller forms x - dx. */
+int  hpf_dense_solve(int device, int N, const double* J_colmajor, const double* f, double* dx);
+
 /* Per-scenario statistics after hpf_solve; `thd_max` from get_THD (HG:563-572) evaluated on device. */
 int  hpf_get_stats(hpf_handle* h, hpf_stat* stats /* [S] host */);
 int  hpf_get_stats_dev(hpf_handle* h, void* stats_dev /* [S] hpf_stat, device memory of the caller (RCCL gather) */);

@@ -428,3 +428,22 @@ def test_k49_generic_block_path_matches_dense(tmp_path):
     assert step > 1e-3
     assert np.abs(v1d[0] - v1b[0]).max() <= 1e-9 * max(1.0, step)
     assert np.abs(v1d[1] - v1b[1]).max() <= 1e-9 * max(1.0, np.abs(v1d[1] - v0d[1]).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["net2_H11_c", "net1_H11_uc", "net3_H51_c"])
+def test_update_harmonic_state_vec_vs_reference_first_step(name):
+    """`update_harmonic_state_vec(J, x, f)` (HG:476-479) as a standalone call: with the reference's own iteration-0 Jacobian
+    and mismatch (goldens) the GPU solve must land on the reference's iteration-1 state (its SuperLU step) to solver rounding."""
+    hp = _hp()
+    g = np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=True)
+    import scipy.sparse as sp
+    J = sp.csr_matrix((g["J0_data"], (g["J0_row"], g["J0_col"])), shape=tuple(g["J0_shape"]))
+    c = int(g["c"]) if "c" in g.files else 1
+    Vm0, Va0 = g["V_traj"][0][:, 0], g["V_traj"][0][:, 1]
+    x0 = np.append(Va0[1:], Vm0[c:])
+    x1 = hp.update_harmonic_state_vec(J, x0, g["f0"])
+    Vm1, Va1 = g["V_traj"][1][:, 0], g["V_traj"][1][:, 1]
+    ref = np.append(Va1[1:], Vm1[c:])
+    assert x1.shape == ref.shape
+    assert np.abs(x1 - ref).max() < 1e-9 * max(1.0, np.abs(ref).max())
