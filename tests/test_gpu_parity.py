@@ -447,3 +447,55 @@ def test_update_harmonic_state_vec_vs_reference_first_step(name):
     ref = np.append(Va1[1:], Vm1[c:])
     assert x1.shape == ref.shape
     assert np.abs(x1 - ref).max() < 1e-9 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.gpu
+def test_block_tree_with_pv_buses_matches_dense(tmp_path):
+    """Radial feeder with PV buses (c = 3: no V_m unknown / Q equation at the fundamental of buses 1, 2): the tree path's identity
+    padding (2x2 kernels, contracted chains, Gauss-Jordan blocks, constant-inverse leaves) against the dense rocSOLVER path --
+    fundamental power flow seed, first Newton step, converged voltages."""
+    hp = _hp()
+    from harmonic_power_flow_amd import api, synth
+    fb, fl = synth.gen(120, seed=3, outdir=str(tmp_path))
+    rows = open(fb).read().splitlines()
+    for bid in (2, 3):                                  # IDs 2, 3 -> PV generators (reference dialect of net3_buses.csv)
+        cols = rows[bid].split(";")
+        cols[1], cols[2], cols[4], cols[5] = "PV", "gen_%d" % bid, "-150", "0"
+        rows[bid] = ";".join(cols)
+    open(fb, "w").write("\n".join(rows) + "\n")
+    st = hp.Settings(H_MAX=11)
+    buses, lines, m, n, c = hp.init_network(fb, fl, settings=st)
+    assert c == 3
+    Y = hp.build_admittance_matrices(buses, lines, st.HARMONICS)
+    NE = hp.import_Norton_Equivalents(buses, True, st, INPUTS)
+    out = {}
+    for solver in ("dense", "block_tree"):
+        dm = api._device_model(buses, Y, NE, True, st.HARMONICS, solver=solver)
+        try:
+            dm.set_loads(buses["P"].to_numpy(float), buses["Q"].to_numpy(float))
+            dm.set_state(None, None, n_scen=1)
+            dm.fund_pf(1e-6, 30)
+            v0 = dm.get_state()
+            if "dense" in out:
+                np.testing.assert_allclose(v0[0], out["dense"][0][0], rtol=0, atol=1e-12)
+                np.testing.assert_allclose(v0[1], out["dense"][0][1], rtol=0, atol=1e-12)
+                dm.set_state(*out["dense"][0])
+            dm.mismatch()
+            dm.iterate(1)
+            dm.sync()
+            v1 = dm.get_state()
+            dm.set_state(*(out["dense"][0] if "dense" in out else v0))
+            n_iter, err, _ = dm.solve(1e-4, 50)
+            out[solver] = (v0, v1, dm.get_state(), int(n_iter[0]), float(err[0]))
+        finally:
+            dm.close()
+    (v0d, v1d, vfd, itd, ed), (v0b, v1b, vfb, itb, eb) = out["dense"], out["block_tree"]
+    assert ed <= 1e-4 and eb <= 1e-4 and itd < 50 and itb < 50
+    step = np.abs(v1d[0] - v0d[0]).max()
+    assert np.abs(v1d[0] - v1b[0]).max() <= 1e-9 * max(1.0, step)
+    assert np.abs(v1d[1] - v1b[1]).max() <= 1e-9 * max(1.0, np.abs(v1d[1] - v0d[1]).max())
+    from harmonic_power_flow_amd.api import _postprocess
+    Ud = (lambda a: a[0] * np.exp(1j * a[1]))(_postprocess(vfd[0][0], vfd[1][0]))
+    Ub = (lambda a: a[0] * np.exp(1j * a[1]))(_postprocess(vfb[0][0], vfb[1][0]))
+    print(f"\nPV feeder: dense {itd} it (err {ed:.2e}), block_tree {itb} it (err {eb:.2e}), max|dU| {np.abs(Ud - Ub).max():.2e}")
+    assert np.abs(Ud - Ub).max() < TOL_V
