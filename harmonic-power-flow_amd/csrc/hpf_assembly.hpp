@@ -50,6 +50,8 @@ struct Model {
     const cplx* Y;        // [Hn][nnz]
     const int* dev;       // [n] device type or -1
     const cplx* YN;       // coupled [n_dev][Hn][Hn]; uncoupled [n_dev][Hn]
+    const cplx* YNt = nullptr;   // device only, coupled: transposed copy [n_dev][p][q] -- the mismatch kernel's threads of one bus
+                                 // (harmonic position q fastest) then read contiguous runs while they walk the columns p
     const cplx* IN;       // [n_dev][Hn]
 };
 
@@ -127,26 +129,28 @@ HPF_HD cplx norton_injection(const Model& M, const cplx* U, int q, int i) {
     const cplx in = M.IN[(size_t)d * M.Hn + q];
     cplx acc = {0.0, 0.0};
     if (M.coupled) {
-        const cplx* yn = M.YN + ((size_t)d * M.Hn + q) * M.Hn;
+        // Y_N[q, p]: row q of the device's matrix, or column q of its transposed copy (same values, coalesced on the device)
+        const cplx* yn = M.YNt ? M.YNt + (size_t)d * M.Hn * M.Hn + q : M.YN + ((size_t)d * M.Hn + q) * M.Hn;
+        const size_t ys = M.YNt ? (size_t)M.Hn : 1;
         if (q < (M.Hn & ~3)) {
             for (int p0 = 0; p0 < M.Hn; p0 += 4) {
                 double rr = 0, ii = 0, ri = 0, ir = 0;
                 const int p1 = p0 + 4 < M.Hn ? p0 + 4 : M.Hn;
                 for (int p = p0; p < p1; ++p) {
-                    const cplx u = U[M.vi(p, i)];
-                    rr = fma(yn[p].re, u.re, rr);
-                    ri = fma(yn[p].re, u.im, ri);
-                    ii = fma(yn[p].im, u.im, ii);
-                    ir = fma(yn[p].im, u.re, ir);
+                    const cplx u = U[M.vi(p, i)], y = yn[p * ys];
+                    rr = fma(y.re, u.re, rr);
+                    ri = fma(y.re, u.im, ri);
+                    ii = fma(y.im, u.im, ii);
+                    ir = fma(y.im, u.re, ir);
                 }
                 acc.re += rr - ii;
                 acc.im += ri + ir;
             }
         } else {
             for (int p = 0; p < M.Hn; ++p) {
-                const cplx u = U[M.vi(p, i)];
-                acc.re += fma(yn[p].re, u.re, -(yn[p].im * u.im));
-                acc.im += fma(yn[p].re, u.im, yn[p].im * u.re);
+                const cplx u = U[M.vi(p, i)], y = yn[p * ys];
+                acc.re += fma(y.re, u.re, -(y.im * u.im));
+                acc.im += fma(y.re, u.im, y.im * u.re);
             }
         }
     } else {

@@ -100,7 +100,7 @@ struct hpf_handle {
 
     // model (device)
     int *d_rowptr = nullptr, *d_col = nullptr, *d_diag = nullptr, *d_erow = nullptr, *d_dev = nullptr;
-    hpf::cplx *d_Y = nullptr, *d_YN = nullptr, *d_IN = nullptr;
+    hpf::cplx *d_Y = nullptr, *d_YN = nullptr, *d_IN = nullptr, *d_YNt = nullptr;
     // per-scenario state (device)
     double *d_P = nullptr, *d_Q = nullptr, *d_Vm = nullptr, *d_Va = nullptr;
     hpf::cplx *d_U = nullptr, *d_E = nullptr;

@@ -569,7 +569,7 @@ int nr_loop(hpf_handle* h, double thresh, int max_iter, int* n_iter, double* err
 }
 
 void free_all(hpf_handle* h) {
-    void* ptrs[] = {h->d_rowptr, h->d_col, h->d_diag, h->d_erow, h->d_dev, h->d_Y, h->d_YN, h->d_IN, h->d_P, h->d_Q,
+    void* ptrs[] = {h->d_rowptr, h->d_col, h->d_diag, h->d_erow, h->d_dev, h->d_Y, h->d_YN, h->d_YNt, h->d_IN, h->d_P, h->d_Q,
                     h->d_Vm, h->d_Va, h->d_U, h->d_E, h->d_I0, h->d_f, h->d_errbits, h->d_err, h->d_niter, h->d_active,
                     h->d_nactive, h->d_hist, h->d_stats, h->d_J, h->d_ipiv, h->d_info, h->d_Z, h->d_w, h->d_x, h->d_linA, h->d_C, h->d_dbg, h->d_H, h->d_chG, h->d_chH, h->d_chD, h->d_chy, h->d_chZ, h->d_lfK, h->d_lfS, h->d_fb};
     for (void* p : ptrs)
@@ -672,6 +672,15 @@ int hpf_create(hpf_handle** out, const hpf_desc* d) {
     if ((r = dev_upload(h, &h->d_dev, d->dev_of_bus, (size_t)d->n))) return fail(r);
     if ((r = dev_upload(h, &h->d_Y, (const cplx*)d->Yval, (size_t)d->Hn * d->nnz))) return fail(r);
     if ((r = dev_upload(h, &h->d_YN, (const cplx*)d->Y_N, ynsz))) return fail(r);
+    if (h->coupled) {                                     // transposed copy for the mismatch kernel (Model::YNt)
+        std::vector<cplx> yt(ynsz);
+        const cplx* src = (const cplx*)d->Y_N;
+        for (int dv = 0; dv < d->n_dev; ++dv)
+            for (int q = 0; q < d->Hn; ++q)
+                for (int p2 = 0; p2 < d->Hn; ++p2)
+                    yt[((size_t)dv * d->Hn + p2) * d->Hn + q] = src[((size_t)dv * d->Hn + q) * d->Hn + p2];
+        if ((r = dev_upload(h, &h->d_YNt, yt.data(), ynsz))) return fail(r);
+    }
     if ((r = dev_upload(h, &h->d_IN, (const cplx*)d->I_N, (size_t)d->n_dev * d->Hn))) return fail(r);
     if ((r = dev_alloc(h, &h->d_P, S * d->n))) return fail(r);
     if ((r = dev_alloc(h, &h->d_Q, S * d->n))) return fail(r);
@@ -690,7 +699,7 @@ int hpf_create(hpf_handle** out, const hpf_desc* d) {
     Model& M = h->M;
     M.n = d->n; M.m = d->m; M.c = d->c; M.Hn = d->Hn; M.nnz = d->nnz; M.n_dev = d->n_dev; M.coupled = h->coupled; M.bus_major = 1;
     M.rowptr = h->d_rowptr; M.col = h->d_col; M.diag = h->d_diag; M.Y = h->d_Y; M.dev = h->d_dev;
-    M.YN = h->d_YN; M.IN = h->d_IN;
+    M.YN = h->d_YN; M.IN = h->d_IN; M.YNt = h->d_YNt;
     if (d->solver == HPF_SOLVER_BLOCK_TREE) {
         if ((r = tree_build(h, d))) return fail(r);
         if ((r = tree_alloc_scenarios(h))) return fail(r);
