@@ -44,6 +44,9 @@ struct Model {
                           // order, HG:139-143; host emulation), 1 bus-major i*Hn + q (device: every kernel that walks a bus or a
                           // tree reads the Hn harmonics of a bus as one contiguous run)
     HPF_HD size_t vi(int q, int i) const { return bus_major ? (size_t)i * Hn + q : (size_t)q * n + i; }
+    // admittance of stored entry e at harmonic position q: Y[Hn][nnz] (host emulation) or entry-major [nnz][Hn] (device: the
+    // Hn harmonics of an entry are contiguous, like the voltages of a bus)
+    HPF_HD size_t yi(int q, int e) const { return bus_major ? (size_t)e * Hn + q : (size_t)q * nnz + e; }
     const int* rowptr;    // [n+1]
     const int* col;       // [nnz]
     const int* diag;      // [n] position of the diagonal entry of each row
@@ -77,8 +80,7 @@ HPF_HD void polar(double vm, double va, cplx& U, cplx& E) {
 // I = sum_e Y[q][e] * U[q*n + col[e]] over row i, ascending column order (csr_matvec; HG:339,345,379).
 HPF_HD cplx row_current(const Model& M, const cplx* U, int q, int i) {
     cplx acc = {0.0, 0.0};
-    const cplx* Yq = M.Y + (size_t)q * M.nnz;
-    for (int e = M.rowptr[i]; e < M.rowptr[i + 1]; ++e) acc = cadd(acc, cmul_unf(Yq[e], U[M.vi(q, M.col[e])]));
+    for (int e = M.rowptr[i]; e < M.rowptr[i + 1]; ++e) acc = cadd(acc, cmul_unf(M.Y[M.yi(q, e)], U[M.vi(q, M.col[e])]));
     return acc;
 }
 
@@ -95,7 +97,7 @@ HPF_HD cplx row_current_fund(const Model& M, const cplx* U, int i) {
     cplx t = {0.0, 0.0};
     for (int e = M.rowptr[i]; e < M.rowptr[i + 1]; ++e) {
         const int j = M.col[e];
-        const cplx y = M.Y[e], u = U[M.vi(0, j)];
+        const cplx y = M.Y[M.yi(0, e)], u = U[M.vi(0, j)];
         if (j < n1) {
             const int l = j & 1;
             a[l][0] = fma(y.re, u.re, a[l][0]);
@@ -192,7 +194,7 @@ struct Blk2 {
 
 // Current-balance rows (k >= m), HG:403-411 and the p == h Norton terms of HG:432-435 / HG:442-443.
 HPF_HD Blk2 jac_current_entry(const Model& M, const cplx* U, const cplx* E, int q, int i, int j, int e) {
-    const cplx y = M.Y[(size_t)q * M.nnz + e];
+    const cplx y = M.Y[M.yi(q, e)];
     const size_t kc = M.vi(q, j);
     Blk2 b;
     b.dV = cmul_unf(y, E[kc]);               // Y_diag @ V_norm_diag
@@ -208,7 +210,7 @@ HPF_HD Blk2 jac_current_entry(const Model& M, const cplx* U, const cplx* E, int 
 
 // Diagonal current-balance entry (i == j) with the device type of the bus supplied by the caller (-1: linear bus).
 HPF_HD Blk2 jac_current_diag(const Model& M, const cplx* U, const cplx* E, int q, int i, int e, int d) {
-    const cplx y = M.Y[(size_t)q * M.nnz + e];
+    const cplx y = M.Y[M.yi(q, e)];
     const size_t kc = M.vi(q, i);
     Blk2 b;
     b.dV = cmul_unf(y, E[kc]);
@@ -236,7 +238,7 @@ HPF_HD Blk2 jac_norton_cross(const Model& M, const cplx* U, const cplx* E, int q
 //   dSdA = 1j*diag(U) @ conj(diag(I) - Y1 @ diag(U)),   dSdV = diag(E) @ conj(diag(I)) + diag(U) @ conj(Y1 @ diag(E)).
 // (jac_power_diag: the diagonal entry with the row current I supplied by the caller)
 HPF_HD Blk2 jac_power_diag(const Model& M, const cplx* U, const cplx* E, int i, int e, cplx I) {
-    const cplx y = M.Y[e];
+    const cplx y = M.Y[M.yi(0, e)];
     const cplx ui = U[M.vi(0, i)], ei = E[M.vi(0, i)];
     const cplx yu = cmul_unf(y, ui);
     const cplx ye = cmul_unf(y, ei);
@@ -249,7 +251,7 @@ HPF_HD Blk2 jac_power_diag(const Model& M, const cplx* U, const cplx* E, int i, 
 
 template <bool FUND>
 HPF_HD Blk2 jac_power_entry(const Model& M, const cplx* U, const cplx* E, int i, int j, int e) {
-    const cplx y = M.Y[e];
+    const cplx y = M.Y[M.yi(0, e)];
     const cplx ui = U[M.vi(0, i)];
     const cplx yu = cmul_unf(y, U[M.vi(0, j)]);
     const cplx ye = cmul_unf(y, E[M.vi(0, j)]);

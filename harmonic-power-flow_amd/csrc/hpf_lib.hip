@@ -670,7 +670,13 @@ int hpf_create(hpf_handle** out, const hpf_desc* d) {
     if ((r = dev_upload(h, &h->d_diag, diag.data(), (size_t)d->n))) return fail(r);
     if ((r = dev_upload(h, &h->d_erow, erow.data(), (size_t)d->nnz))) return fail(r);
     if ((r = dev_upload(h, &h->d_dev, d->dev_of_bus, (size_t)d->n))) return fail(r);
-    if ((r = dev_upload(h, &h->d_Y, (const cplx*)d->Yval, (size_t)d->Hn * d->nnz))) return fail(r);
+    {   // device copy of the admittances: entry-major [nnz][Hn] (Model::yi)
+        std::vector<cplx> yt((size_t)d->Hn * d->nnz);
+        const cplx* src = (const cplx*)d->Yval;
+        for (int q = 0; q < d->Hn; ++q)
+            for (int e = 0; e < d->nnz; ++e) yt[(size_t)e * d->Hn + q] = src[(size_t)q * d->nnz + e];
+        if ((r = dev_upload(h, &h->d_Y, yt.data(), yt.size()))) return fail(r);
+    }
     if ((r = dev_upload(h, &h->d_YN, (const cplx*)d->Y_N, ynsz))) return fail(r);
     if (h->coupled) {                                     // transposed copy for the mismatch kernel (Model::YNt)
         std::vector<cplx> yt(ynsz);

@@ -190,7 +190,7 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
                 g4[0] = ga.x; g4[1] = ga.y; g4[2] = gb.x; g4[3] = gb.y;
                 h4[0] = ha.x; h4[1] = ha.y; h4[2] = hb.x; h4[3] = hb.y;
             } else {
-                const cplx ydn = M.Y[(size_t)q * M.nnz + e_dn_k], yup = M.Y[(size_t)q * M.nnz + e_up_k];
+                const cplx ydn = M.Y[(size_t)e_dn_k * Hn + q], yup = M.Y[(size_t)e_up_k * Hn + q];
                 const cplx uk = U[(size_t)k * Hn + q], ek = E[(size_t)k * Hn + q];
                 const cplx up = U[(size_t)par * Hn + q], ep = E[(size_t)par * Hn + q];
                 __builtin_amdgcn_sched_barrier(0);
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
             if (rowvalid) {
                 const bool prow = q == 0 && k < M.m;                     // power row (HG:451-459)
                 const double fy = fall[((size_t)s * n + k) * B + lane];  // bus-major mismatch image (k_mismatch)
-                const cplx yd = M.Y[(size_t)q * M.nnz + diag_e];
+                const cplx yd = M.Y[(size_t)diag_e * Hn + q];
                 const cplx uk = U[kq], ek = E[kq];
                 cplx yn = {0.0, 0.0}, I0v = {0.0, 0.0};
                 if (k >= M.m) yn = M.coupled ? M.YN[((size_t)devk * Hn + q) * Hn + q] : M.YN[(size_t)devk * Hn + q];
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
                 for (int cp = lin_beg + slot; cp < lin_end; cp += NT) {
                     const int4 cr = c3[cp];
                     const int ch = cr.x;
-                    const cplx ydn = M.Y[(size_t)q * M.nnz + cr.y], yup = M.Y[(size_t)q * M.nnz + cr.z];
+                    const cplx ydn = M.Y[(size_t)cr.y * Hn + q], yup = M.Y[(size_t)cr.z * Hn + q];
                     const cplx uc = U[(size_t)ch * Hn + q], ec = E[(size_t)ch * Hn + q];
                     const double2* pic = reinterpret_cast<const double2*>(linA + ((size_t)ch * Hn + q) * 4);
                     const double2 ic01 = pic[0], ic23 = pic[1];
@@ -775,7 +775,7 @@ __device__ __forceinline__ void fold_children(const Model& M, const TreeDev& T, 
     for (int j = 0; j < nch; ++j) {
         const int4 cr = c3[cbeg + j];
         const int ch = cr.x;
-        const cplx ydn = M.Y[(size_t)q * M.nnz + cr.y], yup = M.Y[(size_t)q * M.nnz + cr.z];
+        const cplx ydn = M.Y[(size_t)cr.y * Hn + q], yup = M.Y[(size_t)cr.z * Hn + q];
         const cplx uc = U[(size_t)ch * Hn + q], ec = E[(size_t)ch * Hn + q];
         const double2* pic = reinterpret_cast<const double2*>(linA + ((size_t)ch * Hn + q) * 4);
         const double2 ic01 = pic[0], ic23 = pic[1];
@@ -816,7 +816,7 @@ __global__ __launch_bounds__(128) void k_lin_level_factor(Model M, TreeDev T, co
     double* ws = wall + (size_t)s * n * Bst;
     const int4 r0 = reinterpret_cast<const int4*>(rec)[2 * pos], r1 = reinterpret_cast<const int4*>(rec)[2 * pos + 1];
     const int k = r0.x;
-    const cplx yd = M.Y[(size_t)q * M.nnz + r0.y];
+    const cplx yd = M.Y[(size_t)r0.y * Hn + q];
     const cplx uk = U[(size_t)k * Hn + q], ek = E[(size_t)k * Hn + q];
     cplx I0v = {0.0, 0.0}, yn = {0.0, 0.0};
     if (q == 0 && k < m_eff) I0v = I0all[(size_t)s * n + k];
@@ -870,7 +870,7 @@ __global__ __launch_bounds__(128) void k_lin_level_back(Model M, TreeDev T, cons
     const double2 wk = *reinterpret_cast<const double2*>(ws + (size_t)k * Bst + 2 * q);
     double x0 = wk.x, x1 = wk.y;
     if (par >= 0) {
-        const cplx yup = M.Y[(size_t)q * M.nnz + r0.w];
+        const cplx yup = M.Y[(size_t)r0.w * Hn + q];
         const cplx uk = U[(size_t)k * Hn + q];
         const cplx up = U[(size_t)par * Hn + q], ep = E[(size_t)par * Hn + q];
         const double2 xp = *reinterpret_cast<const double2*>(xs + (size_t)par * Bst + 2 * q);
@@ -916,16 +916,16 @@ __global__ __launch_bounds__(128) void k_chain_factor2(Model M, TreeDev T, const
     const int4 h0 = reinterpret_cast<const int4*>(crec)[2 * r], h1 = reinterpret_cast<const int4*>(crec)[2 * r + 1];
     const int ch = h0.x, beg = h0.w, len = h1.x;
     const cplx uch = U[(size_t)ch * Hn + q], ech = E[(size_t)ch * Hn + q];
-    const cplx y_kc = M.Y[(size_t)q * M.nnz + h0.y], y_ck = M.Y[(size_t)q * M.nnz + h0.z];
+    const cplx y_kc = M.Y[(size_t)h0.y * Hn + q], y_ck = M.Y[(size_t)h0.z * Hn + q];
     double a_kc[4], a_ck[4];
     double dD[4] = {0.0, 0.0, 0.0, 0.0}, dy[2] = {0.0, 0.0}, cD[4] = {0.0, 0.0, 0.0, 0.0}, cy[2] = {0.0, 0.0};
     for (int idx = 0; idx < len; ++idx) {
         const int4 r0 = reinterpret_cast<const int4*>(cnode)[2 * (beg + idx)], r1 = reinterpret_cast<const int4*>(cnode)[2 * (beg + idx) + 1];
         const int k = r0.x, up = r0.z;
-        const cplx yd = M.Y[(size_t)q * M.nnz + r0.y];
+        const cplx yd = M.Y[(size_t)r0.y * Hn + q];
         const cplx uk = U[(size_t)k * Hn + q], ek = E[(size_t)k * Hn + q];
         const cplx uu = U[(size_t)up * Hn + q], eu = E[(size_t)up * Hn + q];
-        const cplx y_ku = M.Y[(size_t)q * M.nnz + r0.w], y_uk = M.Y[(size_t)q * M.nnz + r1.x];
+        const cplx y_ku = M.Y[(size_t)r0.w * Hn + q], y_uk = M.Y[(size_t)r1.x * Hn + q];
         cplx I0v = {0.0, 0.0};
         if (q == 0 && k < M.m) I0v = I0all[(size_t)s * n + k];
         const double2 fy = *reinterpret_cast<const double2*>(fall + ((size_t)s * n + k) * Bst + 2 * q);
@@ -1012,7 +1012,7 @@ __global__ __launch_bounds__(128) void k_chain_back2(Model M, TreeDev T, const i
     for (int idx = len - 1; idx >= 0; --idx) {
         const int4 r0 = reinterpret_cast<const int4*>(cnode)[2 * (beg + idx)];
         const int k = r0.x, up = r0.z;
-        const cplx y_ku = M.Y[(size_t)q * M.nnz + r0.w];
+        const cplx y_ku = M.Y[(size_t)r0.w * Hn + q];
         const cplx uk = U[(size_t)k * Hn + q];
         const cplx uu = U[(size_t)up * Hn + q], eu = E[(size_t)up * Hn + q];
         const double2 xp = *reinterpret_cast<const double2*>(xs + (size_t)up * Bst + 2 * q);
