@@ -487,32 +487,6 @@ __device__ __forceinline__ void assemble_row(const Model& M, const TreeDev& T, c
     }
 }
 
-// Assembly of all dense buses of all scenarios in one launch (no dependence on the elimination): the row image is parked
-// in the bus's own Schur-complement slot C[k] ([B+1][B], column-major), where k_factor_w picks it up.
-template <int B>
-__global__ __launch_bounds__(64) void k_assemble_w(Model M, TreeDev T, const int* __restrict__ nodes, int b, int N, int Nc,
-                                                   const int* __restrict__ active, const cplx* __restrict__ Uall,
-                                                   const cplx* __restrict__ Eall, const double* __restrict__ fall,
-                                                   const double* __restrict__ wall, const double* __restrict__ linAall,
-                                                   double* __restrict__ Call, int ablate, int s0) {
-    const int s = blockIdx.y + s0;
-    if (active && !active[s]) return;
-    const int k = nodes[blockIdx.x];
-    const int lane = threadIdx.x;
-    const int n = M.n, Hn = M.Hn;
-    const size_t so = (size_t)s * n * Hn;
-    __shared__ double ue[(B / 2) * 8];
-    double a[B], y;
-    assemble_row<B>(M, T, Uall + so, Eall + so, fall + (size_t)s * N, wall + (size_t)s * n * B, linAall + so * 4, k, lane, b,
-                    Nc, ablate, ue, a, y);
-    if (lane < B) {
-        double* Ck = Call + ((size_t)s * n + k) * ((size_t)(B + 1) * B);
-#pragma unroll
-        for (int cc = 0; cc < B; ++cc) Ck[(size_t)cc * B + lane] = a[cc];
-        Ck[(size_t)B * B + lane] = y;
-    }
-}
-
 template <int B, int MODE>
 __global__ __launch_bounds__(64, MODE == 1 ? 2 : 1) void k_factor_w(Model M, TreeDev T, const int* __restrict__ nodes, int b, int N, int Nc,
                                                  const int* __restrict__ active, const cplx* __restrict__ Uall,
@@ -544,18 +518,9 @@ __global__ __launch_bounds__(64, MODE == 1 ? 2 : 1) void k_factor_w(Model M, Tre
     const int q = lane >> 1, t = lane & 1;
     const bool rowvalid = lane < b && loc_valid(n, c, k, lane);
 
-    // ---- A. row `lane` of D_k and y (assemble_row).  Diagnostic variant HPF_DEBUG_ABLATE&32: load the image that a separate
-    //      k_assemble_w launch parked in this bus's own Schur-complement slot (measured slower: +0.6 ms store/reload) ------
-    constexpr size_t CB = (size_t)(B + 1) * B;
+    // ---- A. row `lane` of D_k and y (assemble_row) --------------------------------------------------------------------
     double a[B], y;
-    if (false) {        // (split-assembly diagnostic variant retired: the C slot now holds accumulator tiles)
-        const double* Ck = Call + ((size_t)s * n + k) * CB;
-#pragma unroll
-        for (int cc = 0; cc < B; ++cc) a[cc] = lane < B ? Ck[(size_t)cc * B + lane] : 0.0;
-        y = lane < B ? Ck[(size_t)B * B + lane] : 0.0;
-    } else {
-        assemble_row<B>(M, T, U, E, f, ws, linAall + (size_t)s * n * Hn * 4, k, lane, b, Nc, ablate, bup, a, y);
-    }
+    assemble_row<B>(M, T, U, E, f, ws, linAall + (size_t)s * n * Hn * 4, k, lane, b, Nc, ablate, bup, a, y);
 
     // ---- B. dense children (fixed order).  MODE 1: every dense child has already formed its Schur complement
     //      C = A(k,ch) D_ch^-1 A(ch,k) (+ the right-hand-side column) in its own wave (schur_tiles): just subtract. -------
@@ -1721,22 +1686,6 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
             hipLaunchKernelGGL(k_chain_factor, dim3((unsigned)((T.n_chains * h->Hn + 127) / 128), (unsigned)h->cur_S), dim3(128), 0,
                                h->cur_stream, h->M, td, T.n_chains, h->N, h->Nc, Bst, active, h->d_U, h->d_E, h->d_f, h->d_linA,
                                h->d_w, h->d_I0, h->d_chG, h->d_chH, h->d_chD, h->d_chy, h->d_chZ, h->cur_s0);
-            hipError_t e = hipGetLastError();
-            if (e != hipSuccess) {
-                h->last_detail = (int)e;
-                return HPF_E_HIP;
-            }
-        }
-        if (false) {
-            // un-eliminated blocks of ALL dense buses in one launch (independent of the elimination order)
-            const dim3 grid((unsigned)T.n_dense, (unsigned)h->cur_S);
-#define HPF_LAUNCH_ASM(BB_)                                                                                              \
-    hipLaunchKernelGGL((k_assemble_w<BB_>), grid, dim3(64), 0, h->cur_stream, h->M, td, T.d_lvl_nodes, b, h->N, h->Nc, active, \
-                       h->d_U, h->d_E, h->d_f, h->d_w, h->d_linA, h->d_C, h->debug_ablate, h->cur_s0)
-            if (BW == 12) HPF_LAUNCH_ASM(12);
-            else if (BW == 28) HPF_LAUNCH_ASM(28);
-            else HPF_LAUNCH_ASM(52);
-#undef HPF_LAUNCH_ASM
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) {
                 h->last_detail = (int)e;

@@ -101,14 +101,10 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
     long long sa = 0, sc = 0, gown = 0, gwait = 0, gmf = 0;
 #endif
     HPF_STAMP(st0);
-    // grid (buses, scenarios), or (scenarios, buses) when gridDim.z == 2: consecutive workgroups then share the bus and with it
-    // the constant image of a leaf (26 KB from L2 instead of the Infinity Cache)
-    const bool sfast = gridDim.z == 2;
-    if (sfast && blockIdx.z) return;
-    const int s = (sfast ? blockIdx.x : blockIdx.y) + s0;
+    const int s = blockIdx.y + s0;
     if (active && !active[s]) return;
     // node record: everything the block needs to form its addresses, behind one scalar load (Tree::d_fdesc)
-    const int4* nd = reinterpret_cast<const int4*>(nodes) + 4 * (size_t)(sfast ? blockIdx.y : blockIdx.x);
+    const int4* nd = reinterpret_cast<const int4*>(nodes) + 4 * (size_t)blockIdx.x;
     const int4 nd0 = nd[0], nd1 = nd[1], nd2 = nd[2], nd3 = nd[3];
     const int k = nd0.x, par = nd0.y, diag_e = nd0.z, devk = nd0.w;
     const int e_dn_k = nd1.x, e_up_k = nd1.y, lin_beg = nd1.z, lin_end = nd1.z + nd1.w;
@@ -297,14 +293,12 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
     double sumc[NT * 4];
 #pragma unroll
     for (int e = 0; e < NT * 4; ++e) sumc[e] = 0.0;
-#ifndef HPF_Q_NOPREFETCH
     if (n_den > 0) {
         const double* Cc = Cs + (size_t)nd2.z * CT + lane;
 #pragma unroll
         for (int e = 0; e < NT * 4; ++e)
             if (16 * (e >> 2) + 4 * (e & 3) < B) sumc[e] = Cc[(size_t)(((e >> 2) * NT + wv) * 4 + (e & 3)) * 64];
     }
-#endif
     HPF_STAMP(sd3);
     __syncthreads();
     HPF_STAMP(sa);
@@ -442,13 +436,8 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
     HPF_STAMP(st1);
 
     // ---- B. remaining dense children (fixed order), then subtract the sum -----------------------------------------------------
-#ifdef HPF_Q_NOPREFETCH
-    for (int i = 0; i < n_den; ++i) {
-        const int ch = i == 0 ? nd2.z : i == 1 ? nd2.w : (i == 2 ? nd3.x : (i == 3 ? nd3.y : T.dchild[den_beg + i]));
-#else
     for (int i = 1; i < n_den; ++i) {
         const int ch = i == 1 ? nd2.w : (i == 2 ? nd3.x : (i == 3 ? nd3.y : T.dchild[den_beg + i]));
-#endif
         const double* Cc = Cs + (size_t)ch * CT + lane;
         double tmp[NT * 4];
 #pragma unroll
@@ -473,11 +462,6 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
         {
             const int tP = st >> 2, rg = st & 3, j0 = 4 * (st & 3), buf = st & 1;
             const bool incol = jj >= j0 && jj < j0 + 4;
-#ifdef HPF_Q_PRIO
-            // the wave that owns the NEXT pivot block is the critical path of the block (its update MFMAs gate the pivot
-            // inverse): let it issue first on its SIMD
-            if (((st + 1) >> 2) == wv || tP == wv) __builtin_amdgcn_s_setprio(HPF_Q_PRIO); else __builtin_amdgcn_s_setprio(0);
-#endif
 #ifdef HPF_FACTOR_STAMPS
             const long long g0_ = __builtin_amdgcn_s_memtime();
 #endif
@@ -533,9 +517,6 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
     }
 
     }
-#ifdef HPF_Q_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
     HPF_STAMP(st4);
     // ---- D. inverse (tile layout) and w = A^-1 y ------------------------------------------------------------------------
     {
@@ -706,8 +687,7 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16)) void k_back_q(
 template <int B, bool LEAF>
 int launch_factor_q2(hpf_handle* h, const TreeDev& T, const int* nodes, int count, const int* active) {
     constexpr int NT = (B + 16) / 16;
-    static const int sfast = getenv("HPF_SFAST") ? atoi(getenv("HPF_SFAST")) : 0;
-    const dim3 grid = sfast ? dim3((unsigned)h->cur_S, (unsigned)count, 2) : dim3((unsigned)count, (unsigned)h->cur_S);
+    const dim3 grid((unsigned)count, (unsigned)h->cur_S);
     hipLaunchKernelGGL((k_factor_q<B, LEAF>), grid, dim3(64 * NT), 0, h->cur_stream, h->M, T, nodes,
                        2 * h->Hn, h->N, h->Nc, active, h->d_U, h->d_E, h->d_fb, h->d_Z, h->d_w, h->d_linA, h->d_C, h->d_H,
                        h->d_I0, h->d_chG, h->d_chH, h->d_chD, h->d_chy, active_tree(h).d_Minv, h->d_lfK, h->d_lfS, h->d_dbg, h->debug_ablate, h->cur_s0);

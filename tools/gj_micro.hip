@@ -70,7 +70,7 @@ __global__ __launch_bounds__(64) void k_gj_mfma(const double* __restrict__ Ain, 
                 c[tr][tc][reg] = (i < B && cc < B) ? A[(size_t)cc * B + i] : (i == cc ? 1.0 : 0.0);
             }
     const long long t0 = __builtin_amdgcn_s_memtime();
-    gauss_jordan_mfma<NT>(c, nsteps == B ? (B + 3) / 4 : (nsteps < 0 ? -nsteps : 0), panel);
+    if (nsteps == B) gauss_jordan_mfma<NT, (B + 3) / 4>(c, panel);      // (step count is a compile-time parameter now)
     const long long t1 = __builtin_amdgcn_s_memtime();
     double* O = Aout + blk * B * B;
 #pragma unroll
