@@ -1500,7 +1500,9 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
     T.bytes_back = 0.0;
     int n_dense_nonroot = 0;
     const int BWf = wave_block_size(b);
-    const double TB = BWf ? (double)((BWf + 3) / 4) * ((BWf + 16) / 16) * 512.0 : 8.0 * bd * bd;
+    // bytes of a block's tile image (TileIO: the last tile column is stored 8 wide when it holds at most 8 columns)
+    const int NTf = (BWf + 16) / 16, LWf = (BWf + 1 - 16 * (NTf - 1)) <= 8 ? 8 : 16;
+    const double TB = BWf ? (double)((BWf + 3) / 4) * ((NTf - 1) * 64 + 4 * LWf) * 8.0 : 8.0 * bd * bd;
     for (int i = 0; i < n; ++i) {
         if (!kept(i)) continue;
         const int nch = dchild_ptr[i + 1] - dchild_ptr[i];

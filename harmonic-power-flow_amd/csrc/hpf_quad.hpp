@@ -79,6 +79,20 @@ __device__ __forceinline__ void mask_block(int n, int c, int q, int i, int j, co
             out[tr * 2 + tc] = (loc_valid(n, c, i, 2 * q + tr) && loc_valid(n, c, j, 2 * q + tc)) ? pick(blk, tr, tc) : 0.0;
 }
 
+// HBM image of a block in accumulator-tile layout (Schur complements C, inverses Z): per row group (tr, reg) the NT tile columns
+// one after the other, 64 doubles each = one 512-byte row per wave -- except the LAST tile column, of which only the first LW
+// columns exist (matrix columns 16(NT-1)..B-1 and the right-hand side in column B; B = 52: 5 of 16): its rows are stored LW wide.
+template <int B>
+struct TileIO {
+    static constexpr int NT = (B + 16) / 16;
+    static constexpr int LW = (B + 1 - 16 * (NT - 1)) <= 8 ? 8 : 16;
+    static constexpr int RG = (NT - 1) * 64 + 4 * LW;                  // doubles per row group
+    __device__ static __forceinline__ size_t off(int tr, int reg, int wv, int lg, int jj) {
+        return (size_t)(tr * 4 + reg) * RG + (wv < NT - 1 ? wv * 64 + lg * 16 + jj : (NT - 1) * 64 + lg * LW + jj);
+    }
+    __device__ static __forceinline__ bool ok(int wv, int jj) { return wv < NT - 1 || jj < LW; }
+};
+
 #ifndef HPF_Q_OCC
 #define HPF_Q_OCC 4        // waves per SIMD the B = 52 factor kernel is compiled for (register budget 512 / HPF_Q_OCC)
 #endif
@@ -294,10 +308,12 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
 #pragma unroll
     for (int e = 0; e < NT * 4; ++e) sumc[e] = 0.0;
     if (n_den > 0) {
-        const double* Cc = Cs + (size_t)nd2.z * CT + lane;
+        const double* Cc = Cs + (size_t)nd2.z * CT;
+        if (TileIO<B>::ok(wv, jj)) {
 #pragma unroll
-        for (int e = 0; e < NT * 4; ++e)
-            if (16 * (e >> 2) + 4 * (e & 3) < B) sumc[e] = Cc[(size_t)(((e >> 2) * NT + wv) * 4 + (e & 3)) * 64];
+            for (int e = 0; e < NT * 4; ++e)
+                if (16 * (e >> 2) + 4 * (e & 3) < B) sumc[e] = Cc[TileIO<B>::off(e >> 2, e & 3, wv, lg, jj)];
+        }
     }
     HPF_STAMP(sd3);
     __syncthreads();
@@ -438,11 +454,13 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
     // ---- B. remaining dense children (fixed order), then subtract the sum -----------------------------------------------------
     for (int i = 1; i < n_den; ++i) {
         const int ch = i == 1 ? nd2.w : (i == 2 ? nd3.x : (i == 3 ? nd3.y : T.dchild[den_beg + i]));
-        const double* Cc = Cs + (size_t)ch * CT + lane;
+        const double* Cc = Cs + (size_t)ch * CT;
         double tmp[NT * 4];
 #pragma unroll
-        for (int e = 0; e < NT * 4; ++e)
-            if (16 * (e >> 2) + 4 * (e & 3) < B) tmp[e] = Cc[(size_t)(((e >> 2) * NT + wv) * 4 + (e & 3)) * 64];
+        for (int e = 0; e < NT * 4; ++e) {
+            tmp[e] = 0.0;
+            if (16 * (e >> 2) + 4 * (e & 3) < B && TileIO<B>::ok(wv, jj)) tmp[e] = Cc[TileIO<B>::off(e >> 2, e & 3, wv, lg, jj)];
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int e = 0; e < NT * 4; ++e)
@@ -520,13 +538,13 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
     HPF_STAMP(st4);
     // ---- D. inverse (tile layout) and w = A^-1 y ------------------------------------------------------------------------
     {
-        double* Zk = Zall + ((size_t)s * n + k) * CT + lane;
-        if (!cleaf) {
+        double* Zk = Zall + ((size_t)s * n + k) * CT;
+        if (!cleaf && TileIO<B>::ok(wv, jj)) {
 #pragma unroll
             for (int tr = 0; tr < NT; ++tr)
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg)
-                    if (16 * tr + 4 * reg < B) Zk[(size_t)((tr * NT + wv) * 4 + reg) * 64] = ct[tr][reg];
+                    if (16 * tr + 4 * reg < B) Zk[TileIO<B>::off(tr, reg, wv, lg, jj)] = ct[tr][reg];
         }
         if (wv == tcB && jj == jjB) {
             double* wk = wall + ((size_t)s * n + k) * B;
@@ -555,7 +573,7 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
             ha = 0.0;
             hb = 0.0;
         }
-        double* Ck = Call + ((size_t)s * n + k) * CT + lane;
+        double* Ck = Call + ((size_t)s * n + k) * CT;
 #pragma unroll
         for (int tr = 0; tr < NT; ++tr)
 #pragma unroll
@@ -568,7 +586,7 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
                 const double colp = xor1_f64(own);
                 const double both = xor1_f64(rowp);
                 const double v = fma(gb, fma(both, hb, rowp * ha), ga * fma(colp, hb, own * ha));
-                if (16 * tr + 4 * reg < B) Ck[(size_t)((tr * NT + wv) * 4 + reg) * 64] = v;
+                if (16 * tr + 4 * reg < B && TileIO<B>::ok(wv, jj)) Ck[TileIO<B>::off(tr, reg, wv, lg, jj)] = v;
             }
     }
 #ifdef HPF_FACTOR_STAMPS
@@ -614,11 +632,20 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16)) void k_back_q(
     double x = 0.0;
     if (tid < B) x = wall[((size_t)s * n + k) * B + tid];
     if (par >= 0) {
-        const double* Zk = (cleaf ? Minv + (size_t)(cleaf - 1) * CT : Zall + ((size_t)s * n + k) * CT) + lane;
         double zr[NT * 4];
+        if (cleaf) {                                              // per-model image: full tile rows
+            const double* Mk = Minv + (size_t)(cleaf - 1) * CT + lane;
 #pragma unroll
-        for (int e = 0; e < NT * 4; ++e)
-            if (16 * (e >> 2) + 4 * (e & 3) < B) zr[e] = Zk[(size_t)(((e >> 2) * NT + wv) * 4 + (e & 3)) * 64];
+            for (int e = 0; e < NT * 4; ++e)
+                if (16 * (e >> 2) + 4 * (e & 3) < B) zr[e] = Mk[(size_t)(((e >> 2) * NT + wv) * 4 + (e & 3)) * 64];
+        } else {
+            const double* Zk = Zall + ((size_t)s * n + k) * CT;
+#pragma unroll
+            for (int e = 0; e < NT * 4; ++e) {
+                zr[e] = 0.0;
+                if (16 * (e >> 2) + 4 * (e & 3) < B && TileIO<B>::ok(wv, jj)) zr[e] = Zk[TileIO<B>::off(e >> 2, e & 3, wv, lg, jj)];
+            }
+        }
         const int col = 16 * wv + jj, p = col >> 1, t1 = col & 1;
         double tv = 0.0;
         if (col < b) {
