@@ -46,7 +46,8 @@ def parse():
     ap.add_argument("--solver", default="block_tree", choices=["block_tree", "dense"])
     ap.add_argument("--cpu-iters", type=int, default=12, help="NR iterations of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-finish", action="store_true", help="skip the untimed solve-to-convergence + stats gather")
-    ap.add_argument("--single", action="store_true", help="also time a single-scenario solve (latency)")
+    ap.add_argument("--single", action="store_true", help="(default on rank 0 at N=1) also time a single-scenario solve: BASELINE config 3")
+    ap.add_argument("--no-single", action="store_true", help="skip the single-scenario latency leg")
     return ap.parse_args()
 
 
@@ -239,7 +240,7 @@ def main():
     }
     if sweep is not None:
         out["sweep"] = sweep
-    if args.single:
+    if (args.single or world == 1) and not args.no_single:
         out["single_scenario"] = single_scenario(hp, inp, args)
     if args.cpu_iters > 0 and world == 1:
         out["cpu_baseline"] = cpu_baseline(inp, args.cpu_iters)
