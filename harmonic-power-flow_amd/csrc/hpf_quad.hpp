@@ -315,6 +315,17 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
                 if (16 * (e >> 2) + 4 * (e & 3) < B) sumc[e] = Cc[TileIO<B>::off(e >> 2, e & 3, wv, lg, jj)];
         }
     }
+    // leaf-only launches: the per-model image of the leaf (L2 / Infinity Cache) is requested here, behind the role loads, and
+    // first touched after the barrier
+    d4_t ct[NT];
+#pragma unroll
+    for (int tr = 0; tr < NT; ++tr) ct[tr] = d4_t{0.0, 0.0, 0.0, 0.0};
+    if (LEAF) {
+        const double* Mk = Minv + (size_t)(cleafv - 1) * CT + lane;
+#pragma unroll
+        for (int e = 0; e < NT * 4; ++e)
+            if (16 * (e >> 2) + 4 * (e & 3) < B) ct[e >> 2][e & 3] = Mk[(size_t)(((e >> 2) * NT + wv) * 4 + (e & 3)) * 64];
+    }
     HPF_STAMP(sd3);
     __syncthreads();
     HPF_STAMP(sa);
@@ -327,19 +338,18 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
         }
     }
 
-    d4_t ct[NT];
-#pragma unroll
-    for (int tr = 0; tr < NT; ++tr) ct[tr] = d4_t{0.0, 0.0, 0.0, 0.0};
     if (cleaf) {
         // ================= constant-inverse leaf (Tree::d_Minv) =====================================================
         // In rectangular coordinates the block is  R(Yc) + E0 D E0^T : Yc constant, D = Delta_polar S_0^-1 the 2x2 term of the
         // fundamental.  With the per-model image  [c0 Lr; Lc Ahh^-1]  (tile layout):
         //     Drect^-1 = [0 0; 0 Ahh^-1] + [I; Lc] (c0 + D)^-1 [I Lr];
         // polar inverse = S^-1 Drect^-1 (row pairs scaled by the 2x2 S_q^-1);  w = A^-1 y by row sums.
-        const double* Mk = Minv + (size_t)(cleafv - 1) * CT + lane;
+        if (!LEAF) {
+            const double* Mk = Minv + (size_t)(cleafv - 1) * CT + lane;
 #pragma unroll
-        for (int e = 0; e < NT * 4; ++e)
-            if (16 * (e >> 2) + 4 * (e & 3) < B) ct[e >> 2][e & 3] = Mk[(size_t)(((e >> 2) * NT + wv) * 4 + (e & 3)) * 64];
+            for (int e = 0; e < NT * 4; ++e)
+                if (16 * (e >> 2) + 4 * (e & 3) < B) ct[e >> 2][e & 3] = Mk[(size_t)(((e >> 2) * NT + wv) * 4 + (e & 3)) * 64];
+        }
         double* mc = &panel[0][0];          // [I; Lc]  as mc[row*2 + a]
         double* mr = &panel[1][0];          // [I  Lr]  as mr[a*MRS + col]  (positions (a, 0..1) hold c0)
         constexpr int MRS = 16 * NT;        // columns of the padded block (panel[1] holds NT*64 doubles)
