@@ -34,12 +34,22 @@ __global__ __launch_bounds__(256, 4) void k_gj(long long* out, double* sink) {
         const int tP = st >> 2, rg = st & 3, j0 = 4 * (st & 3), buf = st & 1;
         const bool incol = jj >= j0 && jj < j0 + 4;
         if (wv == tP) {
-            if (!(ABL & 1)) {
+            if (ABL & 32) {                     // variant: pivot block, then the panel, then the inverse (its LDS reads behind the writes)
+                if (incol) pv[buf][lg * 4 + (jj - j0)] = ct[tP][rg];
+                if (incol) {
+#pragma unroll
+                    for (int tr = 0; tr < NT; ++tr)
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) panel[buf][(16 * tr + lg + 4 * reg) * 4 + (jj - j0)] = ct[tr][reg];
+                }
+                const double wji = inv4_cofactor_lane(pv[buf], lane);
+                if (lane < 16) wl[buf][(lane & 3) * 4 + (lane >> 2)] = wji;
+            } else if (!(ABL & 1)) {
                 if (incol) pv[buf][lg * 4 + (jj - j0)] = ct[tP][rg];
                 const double wji = inv4_cofactor_lane(pv[buf], lane);
                 if (lane < 16) wl[buf][(lane & 3) * 4 + (lane >> 2)] = wji;
             }
-            if (!(ABL & 16) && incol) {
+            if (!(ABL & 16) && !(ABL & 32) && incol) {
 #pragma unroll
                 for (int tr = 0; tr < NT; ++tr)
 #pragma unroll
@@ -248,6 +258,7 @@ int main() {
     for (int nblk : {1, 256, 1024, 4096}) {
         if (nblk > maxblk) continue;
         run<0>("full", nblk, d_out, d_sink);
+        run<32>("panel write before the inverse", nblk, d_out, d_sink);
         run2<0>("every wave inverts from the panel", nblk, d_out, d_sink);
         run<1>("no inverse", nblk, d_out, d_sink);
         run<2>("no update MFMAs", nblk, d_out, d_sink);
