@@ -499,3 +499,44 @@ def test_block_tree_with_pv_buses_matches_dense(tmp_path):
     Ub = (lambda a: a[0] * np.exp(1j * a[1]))(_postprocess(vfb[0][0], vfb[1][0]))
     print(f"\nPV feeder: dense {itd} it (err {ed:.2e}), block_tree {itb} it (err {eb:.2e}), max|dU| {np.abs(Ud - Ub).max():.2e}")
     assert np.abs(Ud - Ub).max() < TOL_V
+
+
+@pytest.mark.gpu
+def test_two_nonlinear_device_types_vs_oracle(tmp_path):
+    """Two Norton device types with different tables on one radial feeder (HG:285: one Norton entry per unique component):
+    the per-bus table lookup of the mismatch, the 2x2 / Gauss-Jordan kernels and the per-bus constant leaf images, block-tree
+    and dense path, against the oracle on the same inputs.  The second type is the smps table scaled by 0.6 (rotated by 0.3 rad)."""
+    import shutil
+    import pandas as pd
+    hp = _hp()
+    from harmonic_power_flow_amd import api, synth
+    ne_dir = tmp_path / "ne"
+    ne_dir.mkdir()
+    shutil.copy(os.path.join(INPUTS, "smps_NE.csv"), ne_dir / "smps_NE.csv")
+    d = pd.read_csv(os.path.join(INPUTS, "smps_NE.csv"), index_col=["Parameter", "Frequency"])
+    f = 0.6 * np.exp(0.3j)
+    def scaled(v):
+        z = complex(v.strip("()")) * f
+        return "(%.17g%+.17gj)" % (z.real, z.imag)
+    d2 = d.apply(lambda col: col.apply(scaled))
+    d2.to_csv(ne_dir / "led_NE.csv")
+    fb, fl = synth.gen(60, seed=5, outdir=str(tmp_path))
+    rows = open(fb).read().splitlines()
+    for i in range(1, len(rows)):
+        cols = rows[i].split(";")
+        if cols[1] == "nonlinear" and i % 2 == 0:
+            cols[2] = "led"
+            rows[i] = ";".join(cols)
+    open(fb, "w").write("\n".join(rows) + "\n")
+    st = hp.Settings(H_MAX=11)
+    buses, lines, m, n, c = hp.init_network(fb, fl, settings=st)
+    assert set(buses.component[buses.type == "nonlinear"]) == {"smps", "led"}
+    r = o.hpf(o.init_network(fb, fl), st.HARMONICS, True, str(ne_dir))
+    Uo = r["Vm"] * np.exp(1j * r["Va"])
+    for solver in ("dense", "block_tree"):
+        V, err_h, n_iter_h, _ = hp.hpf(buses, lines, True, settings=st, ne_dir=str(ne_dir), solver=solver, verbose=False,
+                                       return_jacobian=False)
+        Ud = V["V_m"].to_numpy() * np.exp(1j * V["V_a"].to_numpy())
+        print(f"\ntwo device types, {solver}: it {n_iter_h} (oracle {r['n_iter_h']}) err {err_h:.2e} max|dU| {np.abs(Ud - Uo).max():.2e}")
+        assert err_h <= 1e-4 and n_iter_h < 50
+        assert np.abs(Ud - Uo).max() < TOL_V
