@@ -540,3 +540,49 @@ def test_two_nonlinear_device_types_vs_oracle(tmp_path):
         print(f"\ntwo device types, {solver}: it {n_iter_h} (oracle {r['n_iter_h']}) err {err_h:.2e} max|dU| {np.abs(Ud - Uo).max():.2e}")
         assert err_h <= 1e-4 and n_iter_h < 50
         assert np.abs(Ud - Uo).max() < TOL_V
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,seed,frac_nl,n_pv", [(40, 11, 0.2, 0), (75, 12, 0.5, 1), (90, 13, 0.1, 2), (130, 14, 0.35, 0),
+                                                  (160, 15, 0.7, 1), (64, 16, 0.05, 0)])
+def test_random_feeders_block_tree_vs_dense(tmp_path, n, seed, frac_nl, n_pv):
+    """Topology sweep: random radial feeders with different shares of nonlinear buses (long contracted chains at low shares,
+    many constant leaves at high shares) and PV buses; converged voltages of the block-tree path vs the dense rocSOLVER path."""
+    hp = _hp()
+    from harmonic_power_flow_amd import api, synth
+    fb, fl = synth.gen(n, seed=seed, frac_nl=frac_nl, outdir=str(tmp_path))
+    if n_pv:
+        rows = open(fb).read().splitlines()
+        for bid in range(2, 2 + n_pv):
+            cols = rows[bid].split(";")
+            cols[1], cols[2], cols[4], cols[5] = "PV", "gen_%d" % bid, "-120", "0"
+            rows[bid] = ";".join(cols)
+        open(fb, "w").write("\n".join(rows) + "\n")
+    st = hp.Settings(H_MAX=15)
+    buses, lines, m, nn, c = hp.init_network(fb, fl, settings=st)
+    assert c == 1 + n_pv
+    Y = hp.build_admittance_matrices(buses, lines, st.HARMONICS)
+    NE = hp.import_Norton_Equivalents(buses, True, st, INPUTS)
+    out = {}
+    for solver in ("dense", "block_tree"):
+        dm = api._device_model(buses, Y, NE, True, st.HARMONICS, solver=solver)
+        try:
+            dm.set_loads(buses["P"].to_numpy(float), buses["Q"].to_numpy(float))
+            dm.set_state(None, None, n_scen=1)
+            dm.fund_pf(1e-6, 30)
+            if "dense" in out:
+                dm.set_state(*out["dense"][0])
+            seed_state = dm.get_state()
+            n_iter, err, _ = dm.solve(1e-4, 50)
+            if err[0] > 1e-7 and n_iter[0] < 50:            # compare at equal depth (see the syn1000 test)
+                dm.mismatch(want_f=False)
+                dm.iterate(1)
+            out[solver] = (seed_state, dm.get_state(), int(n_iter[0]), float(err[0]))
+        finally:
+            dm.close()
+    from harmonic_power_flow_amd.api import _postprocess
+    U = {k: (lambda a: a[0] * np.exp(1j * a[1]))(_postprocess(v[1][0][0], v[1][1][0])) for k, v in out.items()}
+    print(f"\nn={n} nl={frac_nl} pv={n_pv}: dense {out['dense'][2]} it, block_tree {out['block_tree'][2]} it, "
+          f"max|dU| {np.abs(U['dense'] - U['block_tree']).max():.2e}")
+    assert out["dense"][3] <= 1e-4 and out["block_tree"][3] <= 1e-4
+    assert np.abs(U["dense"] - U["block_tree"]).max() < TOL_V
