@@ -153,17 +153,30 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
     const int col = 16 * wv + jj, p = col >> 1, t1 = col & 1;      // own column = (harmonic position p, component t1)
     const int t = lg & 1;                                          // component of every row this lane holds
 
-    // ---- A0. the device type's Y_N (Hn x Hn complex, shared by every scenario: L2) is fetched once per block, all loads in
-    //      flight behind the node record; it reaches LDS just before the first barrier ---------------------------------------
-    constexpr int YNL = ((B / 2) * (B / 2) + 64 * NT - 1) / (64 * NT);
-    cplx ynr[YNL];
-    if (nl && !cleaf) {
-        const cplx* ynd = M.YN + (size_t)devk * Hn * Hn;
-#pragma unroll
-        for (int j = 0; j < YNL; ++j) {
-            const int idx = tid + 64 * NT * j;
-            ynr[j] = ynd[idx < Hn * Hn ? idx : 0];
-        }
+    // ---- A0. the device type's Y_N (Hn x Hn complex, shared by every scenario: L2) -> LDS, once per block, by the upper half of
+    //      the waves (their roles are the light ones): loaded and stored at once -- held in registers across the roles the values
+    //      get spilled to scratch, and the reload costs more than the L2 round trip exposed here --------------------------------
+    if (nl && !cleaf && wv >= NT / 2) {
+        constexpr int YT = 64 * (NT - NT / 2);                                   // staging threads
+        constexpr int YNL = ((B / 2) * (B / 2) + YT - 1) / YT;
+        const double2* ynd = reinterpret_cast<const double2*>(M.YN + (size_t)devk * Hn * Hn);
+        double2* yl = reinterpret_cast<double2*>(ynl);
+        const int t0 = tid - 64 * (NT / 2);
+        double2 y0 = {0.0, 0.0}, y1 = y0, y2 = y0, y3 = y0, y4 = y0, y5 = y0;      // (named scalars: an array here goes to scratch)
+        static_assert(YNL <= 6, "staging registers");
+        if (YNL > 0 && t0 < Hn * Hn) y0 = ynd[t0];
+        if (YNL > 1 && t0 + YT < Hn * Hn) y1 = ynd[t0 + YT];
+        if (YNL > 2 && t0 + 2 * YT < Hn * Hn) y2 = ynd[t0 + 2 * YT];
+        if (YNL > 3 && t0 + 3 * YT < Hn * Hn) y3 = ynd[t0 + 3 * YT];
+        if (YNL > 4 && t0 + 4 * YT < Hn * Hn) y4 = ynd[t0 + 4 * YT];
+        if (YNL > 5 && t0 + 5 * YT < Hn * Hn) y5 = ynd[t0 + 5 * YT];
+        __builtin_amdgcn_sched_barrier(0);
+        if (YNL > 0 && t0 < Hn * Hn) yl[t0] = y0;
+        if (YNL > 1 && t0 + YT < Hn * Hn) yl[t0 + YT] = y1;
+        if (YNL > 2 && t0 + 2 * YT < Hn * Hn) yl[t0 + 2 * YT] = y2;
+        if (YNL > 3 && t0 + 3 * YT < Hn * Hn) yl[t0 + 3 * YT] = y3;
+        if (YNL > 4 && t0 + 4 * YT < Hn * Hn) yl[t0 + 4 * YT] = y4;
+        if (YNL > 5 && t0 + 5 * YT < Hn * Hn) yl[t0 + 5 * YT] = y5;
     }
     // ---- A1. roles before the first barrier.  Every role FIRST issues all its loads (addresses come from the node record
     //      alone), then computes from registers with the value forms of the per-entry formulas (blk_current / blk_power_off /
@@ -294,12 +307,6 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
             cc[slot][lane * 3 + 1] = e1;
             cc[slot][lane * 3 + 2] = ey;
         }
-    }
-    if (nl && !cleaf) {  // Y_N of the device type -> LDS (loads issued at the top of the kernel); before the prefetch
-                         // below, whose loads nothing may wait for yet
-#pragma unroll
-        for (int j = 0; j < YNL; ++j)
-            if (tid + 64 * NT * j < Hn * Hn) ynl[tid + 64 * NT * j] = ynr[j];
     }
     // ---- B0. Schur complement of the FIRST dense child (accumulator layout, own tile column): the loads are issued here, after
     //      the role loads (loads return in order: a role must not wait behind them), and first touched after the assembly ----------
