@@ -196,6 +196,7 @@ def main():
     bytes_update = 16 * Hn * n + 2 * 8 * Hn * n + 2 * 8 * Hn * n + 2 * 16 * Hn * n
     step_bytes = S * (dm.solve_bytes() + bytes_mismatch + bytes_back + bytes_2x2 + bytes_update)
     traffic, traffic_note = pmc_traffic(args, S)
+    step_traffic = pmc_step_traffic(args, S)
     out = {
         "metric": "NR iterations/sec + ms/iter, 1 000-bus x 25-harmonic feeder; |dV| vs reference",
         "value": value, "unit": "NR iterations/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
@@ -231,6 +232,8 @@ def main():
         "roofline_hbm_step": {"bound": "hbm", "achieved": step_bytes / (ms_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                               "unit": "GB/s", "frac": step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                               "bytes_per_step": step_bytes,
+                              "traffic": step_traffic,
+                              "traffic_gbs_over_step_wall": step_traffic / (ms_step * 1e-3) / 1e9 if step_traffic else None,
                               "note": "algorithmic bytes of a whole NR step (factor sweep + back sweep + 2x2 kernels + mismatch "
                                       "+ update) over the step wall time"},
         "phase_ms_per_step": {k: (v[0] / max(v[1], 1)) for k, v in tim.items() if v[1]},
@@ -264,6 +267,15 @@ def pmc_traffic(args, S):
                                          "8 B/lane streams: loads calibrate at 1.0 (k_back_q), stores at ~0.5 (k_update, known "
                                          "bytes); includes the shared leaf images served by the Infinity Cache; separate "
                                          "rocprofv3 --pmc passes, see profiles/pmc_traffic_latest.json")
+
+
+def pmc_step_traffic(args, S):
+    """Counter bytes of a whole NR step (all kernels, fetch raw + calibrated stores) from the committed PMC passes."""
+    path = os.path.join(REPO, "profiles", "pmc_traffic_latest.json")
+    if not os.path.exists(path) or (args.buses, args.hmax, S, args.solver) != (1000, 51, 128, "block_tree"):
+        return None
+    t = json.load(open(path))["per_step_bytes"]
+    return sum(v["fetch_raw"] + v.get("write_calibrated", v["write"]) for v in t.values())
 
 
 def K_steps(args):
