@@ -586,3 +586,39 @@ def test_random_feeders_block_tree_vs_dense(tmp_path, n, seed, frac_nl, n_pv):
           f"max|dU| {np.abs(U['dense'] - U['block_tree']).max():.2e}")
     assert out["dense"][3] <= 1e-4 and out["block_tree"][3] <= 1e-4
     assert np.abs(U["dense"] - U["block_tree"]).max() < TOL_V
+
+
+@pytest.mark.gpu
+def test_batch_results_bit_identical_to_single_scenario_solves(tmp_path):
+    """A scenario's result must not depend on what else is in the batch, on its position, or on the scenario-group split (three
+    stream groups by default): every batched solve is bit-identical to the single-scenario solve, and repeatable."""
+    hp = _hp()
+    from harmonic_power_flow_amd import api, synth
+    fb, fl = synth.gen(300, seed=2, outdir=str(tmp_path))
+    st = hp.Settings(H_MAX=51)
+    buses, lines, m, n, c = hp.init_network(fb, fl, settings=st)
+    Y = hp.build_admittance_matrices(buses, lines, st.HARMONICS)
+    NE = hp.import_Norton_Equivalents(buses, True, st, INPUTS)
+    P0, Q0 = buses["P"].to_numpy(float), buses["Q"].to_numpy(float)
+
+    def run(ids):
+        dm = api._device_model(buses, Y, NE, True, st.HARMONICS, solver="block_tree", max_scenarios=len(ids))
+        try:
+            scale = np.stack([synth.scenario_scale(n, s) for s in ids])
+            dm.set_loads(P0 * scale, Q0 * scale)
+            dm.set_state(None, None, n_scen=len(ids))
+            dm.fund_pf(1e-6, 30)
+            it, err, _ = dm.solve(1e-4, 50)
+            Vm, Va = dm.get_state()
+        finally:
+            dm.close()
+        return it, Vm, Va
+
+    ref = {s: run([s]) for s in range(6)}
+    for ids in ([0, 1, 2, 3, 4], [5, 4, 3, 2, 1, 0], [3, 3, 1]):
+        it, Vm, Va = run(ids)
+        for j, s in enumerate(ids):
+            assert it[j] == ref[s][0][0]
+            assert np.array_equal(Vm[j], ref[s][1][0]) and np.array_equal(Va[j], ref[s][2][0])
+    a, b = run([0, 1, 2]), run([0, 1, 2])
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
