@@ -85,8 +85,8 @@ int  hpf_version(void);
 /* Sizes: N = 2*n*Hn - 1 - c unknowns of the harmonic NR (HG:388,397); Nf = 2*n - 1 - c of the fundamental NR. */
 int  hpf_num_unknowns(const hpf_handle* h);
 int  hpf_num_unknowns_fund(const hpf_handle* h);
-/* BLOCK_TREE: number of elimination levels (= k_tree_factor launches per Newton step) / of back-substitution
- * levels (= k_tree_back launches); 0 for DENSE. */
+/* BLOCK_TREE: number of elimination levels of the dense tree (= factor-kernel launches per Newton step and scenario group;
+ * pass-through buses are contracted first in the default mode) / of back-substitution levels; 0 for DENSE. */
 int  hpf_tree_levels(const hpf_handle* h);
 int  hpf_tree_depths(const hpf_handle* h);
 
@@ -130,14 +130,17 @@ int  hpf_get_stats(hpf_handle* h, hpf_stat* stats /* [S] host */);
 int  hpf_get_stats_dev(hpf_handle* h, void* stats_dev /* [S] hpf_stat, device memory of the caller (RCCL gather) */);
 
 /* Diagnostics: with env HPF_DEBUG_ABLATE & 16 the BLOCK_TREE factor kernel records shader-cycle stamps per (scenario, bus):
- * out[(s*n + k)*8 + 0..5] = assembly, children sums, rows->tiles, MFMA Gauss-Jordan, store, Schur push; [6] dense children,
+ * out[(s*n + k)*8 + 0..5] = assembly, packed sub-phases, packed Gauss-Jordan split, MFMA Gauss-Jordan, packed wave-0 roles,
+ * Schur push (tools/stamps.py decodes them; -DHPF_FACTOR_STAMPS build only); [6] dense children,
  * [7] nonlinear bus.  Timing-only; never read by any kernel. */
 int  hpf_debug_stamps(hpf_handle* h, long long* out, int count);
 
 /* Options.  "block_pivoting" (BLOCK_TREE only): 0 (default) inverts the 2Hn x 2Hn bus blocks on the FP64 matrix cores with
- * a static pivot order (4x4 blocks = two harmonics, 2x2 Schur inside); 1 uses wave-level Gauss-Jordan with partial pivoting
- * over the whole block (slower, for networks whose bus blocks are not block-diagonally dominant).  Env HPF_GJ_MODE=0 selects
- * the pivoted variant process-wide. */
+ * a static pivot order (4x4 blocks = two harmonics, lane-parallel cofactor inverse), after contracting pass-through buses and
+ * with per-model constant inverses for nonlinear leaf buses; 1 uses wave-level Gauss-Jordan with partial pivoting over the
+ * whole block on the uncontracted tree (slower, for networks whose bus blocks are not block-diagonally dominant).  Env
+ * HPF_GJ_MODE=0 selects the pivoted variant process-wide (2: the one-wave-per-bus MFMA variant).
+ * "scenario_groups" (1..8, default 3): independent scenario pipelines on separate HIP streams. */
 int  hpf_set_option(hpf_handle* h, const char* name, int value);
 
 /* Stream plumbing: run on a caller stream (e.g. torch's current stream) instead of the handle's own; NULL restores. */
@@ -146,9 +149,9 @@ int  hpf_sync(hpf_handle* h);
 
 /* Kernel timing with HIP events on the handle's stream, accumulated since the last reset.
  * which: 0 mismatch kernel, 1 Jacobian assembly kernels (DENSE only; BLOCK_TREE assembles inside the factor kernel),
- * 2 linear solve (DENSE: getrf+getrs, one span per step; BLOCK_TREE: one span per k_factor_w launch, i.e. per tree level
+ * 2 linear solve (DENSE: getrf+getrs, one span per step; BLOCK_TREE: one span per factor-kernel launch, i.e. per tree level
  *   and scenario group),
- * 3 state update, 4 back-substitution sweep (BLOCK_TREE only; one k_tree_back launch per tree depth).
+ * 3 state update, 4 back-substitution sweep (BLOCK_TREE only; one span per Newton step and scenario group).
  * Returns total milliseconds in *ms and the number of timed spans in *launches. */
 int  hpf_timing_enable(hpf_handle* h, int on);
 int  hpf_timing_get(hpf_handle* h, int which, double* ms, int64_t* launches);
