@@ -163,6 +163,16 @@ def hpf(buses, lines, coupled, thresh_h=1e-4, max_iter_h=50, plt_convergence=Fal
             else:
                 print("Warning! Maximum of " + str(int(nf[0])) + " iterations reached.")
         n_iter, err, hist = dm.solve(thresh_h, max_iter_h)                        # HG:530-542
+        if dm.solver == "block_tree" and not np.isfinite(err[0]) and 2 * dm.Hn <= 52:
+            # the default block-tree mode inverts the bus blocks with a STATIC pivot order; if that ever breaks down (a
+            # non-finite mismatch), repeat on the GPU with partial pivoting over the whole block before reporting failure
+            if verbose:
+                print("Warning! Static-pivot block elimination produced a non-finite mismatch; repeating with partial pivoting.")
+            dm.set_option("block_pivoting", 1)
+            dm.set_state(seed[0], seed[1])
+            n_iter, err, hist = dm.solve(thresh_h, max_iter_h)
+            if details is not None:
+                details["repeated_with_pivoting"] = True
         Vm_raw, Va_raw = dm.get_state()
         n_iter_h = int(n_iter[0])
         J = None
