@@ -5,7 +5,8 @@ from .api import (AdmittanceSet, build_admittance_matrices, build_harmonic_jacob
                   harmonic_state_vector, hpf, import_Norton_Equivalents, init_network, init_voltages, pf, solve,
                   update_harmonic_state_vec)
 from .device import DeviceModel
+from .ingest import export_Norton_Equivalents, read_Norton_file
 
 __all__ = ["Settings", "AdmittanceSet", "DeviceModel", "build_admittance_matrices", "build_harmonic_jacobian",
-           "get_THD", "harmonic_mismatch", "harmonic_state_vector", "hpf", "import_Norton_Equivalents",
-           "init_network", "init_voltages", "pf", "solve", "update_harmonic_state_vec"]
+           "export_Norton_Equivalents", "get_THD", "harmonic_mismatch", "harmonic_state_vector", "hpf", "import_Norton_Equivalents",
+           "init_network", "init_voltages", "pf", "read_Norton_file", "solve", "update_harmonic_state_vec"]

@@ -112,6 +112,45 @@ def import_Norton_Equivalents(buses, coupled, settings=None, ne_dir=None):
     return NE
 
 
+def _cstr(z):
+    z = complex(z)
+    im = repr(z.imag)
+    return "(%s%s%sj)" % (repr(z.real), "" if im.startswith("-") else "+", im)
+
+
+def export_Norton_Equivalents(filename, freqs, Y_N_c, I_N_c, Y_N_uc, I_N_uc):
+    """Write one device's Norton parameters (SI units) in the `<component>_NE.csv` layout the reference's fitting
+    script produces (`Circuit Simulation/NE_from_sim.py:195-209`) and `import_Norton_Equivalents` reads: index
+    (Parameter, Frequency), one column per frequency in Hz; rows `Y_N_c` x len(freqs) (row label = frequency),
+    then `I_N_c`, `Y_N_uc`, `I_N_uc` with Frequency 0.  Values are written as `(a+bj)` with shortest-round-trip
+    reprs, so write -> read reproduces every double bit for bit."""
+    freqs = [int(f) for f in freqs]
+    K = len(freqs)
+    Y_N_c = np.asarray(Y_N_c, dtype=np.complex128).reshape(K, K)
+    rows = [("Y_N_c", freqs[r], Y_N_c[r]) for r in range(K)]
+    for name, v in (("I_N_c", I_N_c), ("Y_N_uc", Y_N_uc), ("I_N_uc", I_N_uc)):
+        rows.append((name, 0, np.asarray(v, dtype=np.complex128).reshape(K)))
+    with open(filename, "w") as fh:
+        fh.write("Parameter,Frequency," + ",".join(str(f) for f in freqs) + "\n")
+        for name, f, vals in rows:
+            fh.write("%s,%d,%s\n" % (name, f, ",".join(_cstr(z) for z in vals)))
+    return filename
+
+
+def read_Norton_file(filename):
+    """Raw (SI) content of a `<component>_NE.csv`: (freqs, Y_N_c [K][K], I_N_c [K], Y_N_uc [K], I_N_uc [K]).
+    Parsed value by value with `complex()` (the reference's parser, HG:296) — not through a pandas object->complex
+    conversion, which drops the sign of a zero real part."""
+    df = pd.read_csv(filename, index_col=["Parameter", "Frequency"], dtype=str)
+    df.columns = df.columns.astype(int)
+    freqs = list(df.columns)
+
+    def rows(sel):
+        return np.array([[complex(v.strip("()")) for v in r] for r in sel.to_numpy()], dtype=np.complex128)
+    return (freqs, rows(df.loc[[("Y_N_c", f) for f in freqs], freqs]), rows(df.loc[["I_N_c"]]).reshape(-1),
+            rows(df.loc[["Y_N_uc"]]).reshape(-1), rows(df.loc[["I_N_uc"]]).reshape(-1))
+
+
 def norton_arrays(buses, NE, coupled, Hn):
     """Pack the Norton dict for the device: dev_of_bus[n] (-1 = linear), Y_N [n_dev][Hn][Hn] (coupled) or
     [n_dev][Hn] (uncoupled), I_N [n_dev][Hn], complex128 C-ordered."""

@@ -35,7 +35,13 @@ def summarize(raw):
            "iters_mean": float(st["n_iter"].mean()), "iters_total": int(st["n_iter"].sum())}
     if conv.any():
         out["err_max_converged"] = float(st["err"][conv].max())
-        out["thd_max"] = float(np.nanmax(st["thd_max"][conv]))
+        thd = st["thd_max"][conv]
+        thd = thd[np.isfinite(thd)]
+        if len(thd):
+            out["thd_max"] = float(thd.max())
+            # distribution over scenarios of the worst-bus THD_F (each record carries the max over buses, HG:563-572)
+            for q in (50, 95, 99):
+                out["thd_p%d" % q] = float(np.percentile(thd, q))
     return out
 
 
