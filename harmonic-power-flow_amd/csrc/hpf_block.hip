@@ -16,7 +16,9 @@
 // pulled from HBM; D_k is inverted in place by Gauss-Jordan with partial (row) pivoting, rows/columns of each step
 // broadcast through LDS (2 barriers per step); Z_k (b x b) and w_k (b) are the only HBM writes.
 // Bound: FP64 FMA rate (2 b^3 flop per bus) against 24 b^2 bytes of Z traffic per bus -> ~4.3 flop/B at b = 52.
+#include <algorithm>
 #include <complex>
+#include <cstdlib>
 #include "hpf_internal.hpp"
 #include "hpf_gj.hpp"
 #include "hpf_gj_mfma.hpp"
@@ -48,6 +50,8 @@ struct TreeDev {
     const int* chain_ptr;   // contracted chains of pass-through buses, bottom-up
     const int* chain_nodes;
     const int* chain_ch;    // the dense bus below the chain
+    const int* lzrec;       // lazy-leaf records of the parents (Tree::d_lzrec)
+    const double* lzimg;    // and their per-model images (Tree::d_lzimg)
 };
 
 // validity of local index l = 2q+t of bus i as an unknown / equation (same rule for both, see hpf_assembly.hpp)
@@ -1326,6 +1330,18 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
     std::vector<int> cleaf_of(n, -1);
     std::vector<double> minv;
     T.n_cleaf = 0;
+    // lazy leaves (Tree::d_lzrec): complex constants of leaf c under parent k, harmonics q, p:
+    //   C0[q][p] = y_kc[q] Ahh^-1[q][p] y_ck[p] (q, p >= 1),  Gc[q] = y_kc[q] [1; Lc][q],  Hr[p] = [1 Lr][p] y_ck[p]
+    struct LazyLeaf {
+        int k;
+        std::vector<std::complex<double>> C0, G, H;
+    };
+    std::vector<LazyLeaf> lazies;
+    std::vector<std::vector<int>> lazy_of(n);
+    std::vector<int> is_lazy(n, 0);
+    const char* lz_env = getenv("HPF_LAZY");
+    const bool lazy_on = !(lz_env && atoi(lz_env) == 0);
+    constexpr int LZ_MAX = 4;
     const int BWc = wave_block_size(b);
     if (contract && d->coupled && BWc) {
         typedef std::complex<double> cd;
@@ -1458,6 +1474,76 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
                     const int tr = row >> 4, tc = col >> 4, lg = row & 3, reg = (row & 15) >> 2, jj = col & 15;
                     Mt[(size_t)((tr * NTc + tc) * 4 + reg) * 64 + lg * 16 + jj] = v;
                 }
+            const int pk = T.parent[k];
+            if (lazy_on && pk >= (d->c > 1 ? d->c : 1) && kept(pk) && (int)lazy_of[pk].size() < LZ_MAX) {
+                LazyLeaf ll;
+                ll.k = k;
+                ll.C0.assign((size_t)Hn * Hn, cd(0.0, 0.0));
+                ll.G.assign(Hn, cd(0.0, 0.0));
+                ll.H.assign(Hn, cd(0.0, 0.0));
+                for (int q = 0; q < Hn; ++q) {
+                    const cd ydn = yv(q, e_dn[k]), yup = yv(q, e_up[k]);
+                    ll.G[q] = ydn * (q == 0 ? cd(1.0, 0.0) : img[(size_t)q * Hn]);
+                    ll.H[q] = (q == 0 ? cd(1.0, 0.0) : img[q]) * yup;
+                    if (q >= 1)
+                        for (int p2 = 1; p2 < Hn; ++p2) ll.C0[(size_t)q * Hn + p2] = ydn * img[(size_t)q * Hn + p2] * yv(p2, e_up[k]);
+                }
+                lazy_of[pk].push_back((int)lazies.size());
+                lazies.push_back(std::move(ll));
+                is_lazy[k] = 1;
+            }
+        }
+    }
+    // per-parent lazy records and images; the parent's dense-child list keeps its non-lazy children first
+    std::vector<int> lzrec, lz_idx(n, -1), n_lazy(n, 0);
+    std::vector<double> lzimg;
+    T.n_lazy_parents = 0;
+    T.n_lazy_leaves = (int)lazies.size();
+    if (!lazies.empty()) {
+        typedef std::complex<double> cd;
+        const int Hn = d->Hn;
+        const int NTc = (BWc + 16) / 16;
+        const size_t CTc = (size_t)NTc * NTc * 256;
+        auto R = [](cd z, int t, int t2) { return (t == t2) ? z.real() : (t ? z.imag() : -z.imag()); };   // R(z) = [re -im; im re]
+        for (int pk = 0; pk < n; ++pk) {
+            const int L = (int)lazy_of[pk].size();
+            if (L == 0) continue;
+            n_lazy[pk] = L;
+            lz_idx[pk] = T.n_lazy_parents++;
+            const int np = (L + 1) / 2;
+            const size_t off = lzimg.size();
+            lzimg.resize(off + CTc + (size_t)np * NTc * 64 + (size_t)np * NTc * 2 * 64, 0.0);
+            double* I0 = &lzimg[off];
+            double* IA = I0 + CTc;
+            double* IH = IA + (size_t)np * NTc * 64;
+            for (int row = 0; row < b; ++row)
+                for (int col = 0; col < b; ++col) {
+                    double v = 0.0;
+                    for (int li : lazy_of[pk]) v += R(lazies[li].C0[(size_t)(row >> 1) * Hn + (col >> 1)], row & 1, col & 1);
+                    const int tr = row >> 4, tc = col >> 4, lg = row & 3, reg = (row & 15) >> 2, jj = col & 15;
+                    I0[(size_t)((tr * NTc + tc) * 4 + reg) * 64 + lg * 16 + jj] = v;
+                }
+            for (int pr = 0; pr < np; ++pr)
+                for (int lg = 0; lg < 4; ++lg) {
+                    const int idx = 2 * pr + (lg >> 1), a = lg & 1;
+                    if (idx >= L) continue;
+                    const LazyLeaf& ll = lazies[lazy_of[pk][idx]];
+                    for (int tr = 0; tr < NTc; ++tr)                     // MFMA A operand: lane (jj, lg) = R(Gc)[16 tr + jj][a]
+                        for (int jj = 0; jj < 16; ++jj) {
+                            const int row = 16 * tr + jj;
+                            if (row < b) IA[((size_t)pr * NTc + tr) * 64 + lg * 16 + jj] = R(ll.G[row >> 1], row & 1, a);
+                        }
+                    for (int tc = 0; tc < NTc; ++tc)                     // rows of R(Hr): lane (lg, jj) = R(Hr)[a'][16 tc + jj] of leaf lg >> 1
+                        for (int a2 = 0; a2 < 2; ++a2)
+                            for (int jj = 0; jj < 16; ++jj) {
+                                const int col = 16 * tc + jj;
+                                if (col < b) IH[(((size_t)pr * NTc + tc) * 2 + a2) * 64 + lg * 16 + jj] = R(ll.H[col >> 1], a2, col & 1);
+                            }
+                }
+            int rec[8] = {(int)off, L, -1, -1, -1, -1, 0, 0};
+            for (int i = 0; i < L; ++i) rec[2 + i] = lazies[lazy_of[pk][i]].k;
+            lzrec.insert(lzrec.end(), rec, rec + 8);
+            std::stable_partition(dchild.begin() + dchild_ptr[pk], dchild.begin() + dchild_ptr[pk + 1], [&](int ch) { return !is_lazy[ch]; });
         }
     }
     T.lvl_all_leaf.assign(T.n_levels > 0 ? T.n_levels : 1, 1);
@@ -1477,10 +1563,10 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
         r[6] = T.child_ptr[k];
         r[7] = T.child_mid[k] - T.child_ptr[k];
         r[8] = dchild_ptr[k];
-        r[9] = dchild_ptr[k + 1] - dchild_ptr[k];
+        r[9] = dchild_ptr[k + 1] - dchild_ptr[k] - n_lazy[k];      // children whose Schur complement is read from HBM
         for (int i = 0; i < 4 && i < r[9]; ++i) r[10 + i] = dchild[dchild_ptr[k] + i];
-        r[14] = (k > 0 && pass[T.parent[k]]) ? 1 : 0;              // linked to its dense parent through a contracted chain
-        r[15] = cleaf_of[k] + 1;                                   // constant-inverse leaf: 1 + slot in Tree::d_Minv
+        r[14] = (k > 0 && pass[T.parent[k]]) ? 1 : (is_lazy[k] ? 2 : 0);   // 1: linked to its dense parent through a contracted chain; 2: lazy leaf
+        r[15] = lz_idx[k] >= 0 ? -(lz_idx[k] + 1) : cleaf_of[k] + 1;     // > 0: constant-inverse leaf, 1 + slot in Tree::d_Minv; < 0: -(1 + lazy record)
         if (cleaf_of[k] < 0) T.lvl_all_leaf[height[k]] = 0;
         const int kb = T.dep_nodes[pos];
         bdesc[(size_t)pos * 4 + 0] = kb;
@@ -1507,12 +1593,14 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
         if (!kept(i)) continue;
         const int nch = dchild_ptr[i + 1] - dchild_ptr[i];
         const bool leaf = cleaf_of[i] >= 0;
-        T.flops_factor += leaf ? 10.0 * bd * bd : 2.0 * bd * bd * bd + 2.0 * bd * bd + bd * bd * nch;
-        T.bytes_factor += TB * nch + (leaf ? 0.0 : TB) + 8.0 * (4.0 * bd + bd + bd + 2.0 * bd) +
+        const int nlz = n_lazy[i];                                   // lazy leaves: 2x2 core + G w column in, rank-2 MFMA update
+        T.flops_factor += leaf ? 10.0 * bd * bd : 2.0 * bd * bd * bd + 2.0 * bd * bd + bd * bd * (nch - nlz);
+        if (nlz) T.flops_factor += 4.0 * bd * bd * nlz + 4.0 * bd * bd;
+        T.bytes_factor += TB * (nch - nlz) + nlz * (32.0 + 8.0 * bd) + (leaf ? 0.0 : TB) + 8.0 * (4.0 * bd + bd + bd + 2.0 * bd) +
                           48.0 * d->Hn * (T.child_mid[i] - T.child_ptr[i]);
         if (i > 0) {
-            T.flops_factor += 8.0 * bd * bd;
-            T.bytes_factor += TB;
+            T.flops_factor += is_lazy[i] ? 8.0 * bd : 8.0 * bd * bd;
+            T.bytes_factor += is_lazy[i] ? 8.0 * bd : TB;
             // back sweep: inverse of a Gauss-Jordan bus in (leaves rebuild it from the shared image), w, A(k,parent), x of the
             // parent in, x out; leaves also their 2x2 core and S^-1
             T.bytes_back += (leaf ? 32.0 + 32.0 * d->Hn : TB) + 8.0 * (bd + 2.0 * bd + bd + bd);
@@ -1542,6 +1630,8 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
     if ((r = upload(h, &T.d_chain_nodes, T.chain_nodes))) return r;
     if ((r = upload(h, &T.d_chain_ch, T.chain_ch))) return r;
     if ((r = upload(h, &T.d_Minv, minv))) return r;
+    if ((r = upload(h, &T.d_lzrec, lzrec))) return r;
+    if ((r = upload(h, &T.d_lzimg, lzimg))) return r;
     if ((r = upload(h, &T.d_lrec, lrec))) return r;
     if ((r = upload(h, &T.d_crec, crec))) return r;
     if ((r = upload(h, &T.d_cnode, cnode))) return r;
@@ -1563,7 +1653,8 @@ Tree& active_tree(hpf_handle* h) { return (h->has_ctree && h->gj_mode == 1) ? h-
 static void tree_free_one(Tree& T) {
     void* ptrs[] = {T.d_parent, T.d_lvl_nodes, T.d_dep_nodes, T.d_child_ptr, T.d_child, T.d_e_up, T.d_e_dn,
                     T.d_child_mid, T.d_lin, T.d_lin_ptr, T.d_lin_post, T.d_all_ptr, T.d_all_post, T.d_fdesc, T.d_child3,
-                    T.d_bdesc, T.d_dchild, T.d_chain_ptr, T.d_chain_nodes, T.d_chain_ch, T.d_Minv, T.d_lrec, T.d_crec, T.d_cnode, T.d_arec};
+                    T.d_bdesc, T.d_dchild, T.d_chain_ptr, T.d_chain_nodes, T.d_chain_ch, T.d_Minv, T.d_lrec, T.d_crec, T.d_cnode, T.d_arec,
+                    T.d_lzrec, T.d_lzimg};
     for (void* p : ptrs)
         if (p) hipFree(p);
 }
@@ -1647,7 +1738,7 @@ int tree_fund_step(hpf_handle* h, bool only_active) {
 int tree_newton_step(hpf_handle* h, bool only_active) {
     Tree& T = active_tree(h);
     const int* active = only_active ? h->d_active : nullptr;
-    const TreeDev td{T.d_parent, T.d_child_ptr, T.d_child, T.d_e_up, T.d_e_dn, T.d_child_mid, T.d_lin_ptr, T.d_lin_post, T.d_child3, T.d_dchild, T.d_chain_ptr, T.d_chain_nodes, T.d_chain_ch};
+    const TreeDev td{T.d_parent, T.d_child_ptr, T.d_child, T.d_e_up, T.d_e_dn, T.d_child_mid, T.d_lin_ptr, T.d_lin_post, T.d_child3, T.d_dchild, T.d_chain_ptr, T.d_chain_nodes, T.d_chain_ch, T.d_lzrec, T.d_lzimg};
     const int b = 2 * h->Hn;
     const int R = (b + 15) / 16;
     const int BW = wave_block_size(b);

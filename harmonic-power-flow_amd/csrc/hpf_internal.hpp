@@ -80,6 +80,11 @@ struct Tree {
     std::vector<int> lvl_all_leaf;    // [n_levels] 1: every bus of the elimination level is a constant-inverse leaf
     int n_cleaf = 0;
     double* d_Minv = nullptr;         // [n_cleaf][NT*NT*256]
+    // lazy leaves: constant-inverse leaves directly under their dense parent never write their Schur complement; the parent
+    // rebuilds the sum from per-model images and the leaves' 2x2 cores (k_factor_q, "lazy" phase)
+    int n_lazy_parents = 0, n_lazy_leaves = 0;
+    int* d_lzrec = nullptr;           // [n_lazy_parents][8]: image offset (doubles), L, leaf ids[4] (-1: none), 0, 0
+    double* d_lzimg = nullptr;        // per parent: sum of constant parts (tile layout) | A operands [pair][tr][64] | row factors [pair][tc][2][64]
     double flops_per_solve = 0.0;     // factor sweep + back sweep
     double flops_factor = 0.0;        // factor sweep only (k_tree_factor, all levels)
     double bytes_back = 0.0;          // algorithmic HBM bytes of the dense back sweep, one scenario and step

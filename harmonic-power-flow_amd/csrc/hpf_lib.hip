@@ -303,6 +303,7 @@ inline dim3 grid2(int count, int S) { return dim3((unsigned)((count + TPB - 1) /
 
 int ensure_dense(hpf_handle* h, int Nsys) {
     size_t want = (size_t)Nsys * Nsys;
+    if (want >= ((size_t)1 << 31)) return HPF_E_ARG;           // 32-bit element offsets inside rocSOLVER
     if (h->solver == HPF_SOLVER_DENSE && (size_t)h->N * h->N > want) want = (size_t)h->N * h->N;
     if (h->d_J && h->J_elems_per_scen >= want) return HPF_OK;
     if (h->d_J) {
@@ -650,6 +651,12 @@ int hpf_create(hpf_handle** out, const hpf_desc* d) {
     h->Nc = d->n * d->Hn - 1;
     h->N = 2 * h->Nc - (d->c - 1);
     h->Nf = 2 * d->n - 1 - d->c;
+    // rocSOLVER's LU addresses the matrix with 32-bit element offsets: a dense system beyond N*N = 2^31 faults the GPU.
+    // (1 000 buses x 26 harmonics is already N = 51 998: such feeders need the block-tree solver.)
+    if (d->solver == HPF_SOLVER_DENSE && (long long)h->N * h->N >= (1ll << 31)) {
+        delete h;
+        return HPF_E_ARG;
+    }
     if (const char* ab = getenv("HPF_DEBUG_ABLATE")) h->debug_ablate = atoi(ab);
     if (const char* gm = getenv("HPF_GJ_MODE")) h->gj_mode = atoi(gm);
     if (hipSetDevice(d->device) != hipSuccess) return fail(HPF_E_HIP);

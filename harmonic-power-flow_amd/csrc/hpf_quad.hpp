@@ -123,9 +123,18 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
     const int k = nd0.x, par = nd0.y, diag_e = nd0.z, devk = nd0.w;
     const int e_dn_k = nd1.x, e_up_k = nd1.y, lin_beg = nd1.z, lin_end = nd1.z + nd1.w;
     const int den_beg = nd2.x, n_den = nd2.y;
-    const bool via_chain = nd3.z != 0;       // linked to the dense parent through a contracted chain (k_chain_factor)
-    const int cleafv = nd3.w;                // constant-inverse leaf: 1 + slot in Minv (0: general path)
-    const bool cleaf = LEAF || cleafv != 0;
+    const bool via_chain = nd3.z == 1;       // linked to the dense parent through a contracted chain (k_chain_factor)
+    const bool lazy_leaf = nd3.z == 2;       // the parent rebuilds this leaf's Schur complement itself: only G w goes to HBM
+    const int cleafv = nd3.w;                // constant-inverse leaf: 1 + slot in Minv (0: general path; < 0: lazy-leaf record)
+    const bool cleaf = LEAF || cleafv > 0;
+    const bool lazy = !LEAF && cleafv < 0;   // this bus has lazy leaves below it
+    // lazy-leaf record (Tree::d_lzrec, 8 ints: image offset, L, leaf ids[4]): uniform address -> scalar loads, issued with the node record
+    int4 lzA = {0, 0, -1, -1}, lzB = {-1, -1, 0, 0};
+    if (lazy) {
+        const int4* lz4 = reinterpret_cast<const int4*>(T.lzrec) + 2 * (size_t)(-cleafv - 1);
+        lzA = lz4[0];
+        lzB = lz4[1];
+    }
 #ifdef HPF_FACTOR_STAMPS
     long long sd1 = 0, sd2 = 0, sd3 = 0;
     {
@@ -140,6 +149,7 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
     const size_t so = (size_t)s * n * Hn;
     const cplx* U = Uall + so;
     const cplx* E = Eall + so;
+    const double* Cs = Call + (size_t)s * n * CT;
 
     __shared__ double tab[(B / 2) * 8];
     __shared__ double dgb[64 * 3];          // per row: harmonic-diagonal 2x2 part (d0, d1) and right-hand side y
@@ -182,7 +192,7 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
     //      alone), then computes from registers with the value forms of the per-entry formulas (blk_current / blk_power_off /
     //      blk_power_diag): one memory round trip per role instead of one per operand group.
     //      Last wave: bus voltages of the Norton cross terms -> LDS --------------------------------------------------------------
-    if (nl && wv == NT - 1 && lane < B / 2) {
+    if ((nl || lazy) && wv == NT - 1 && lane < B / 2) {
         cplx u = {0.0, -1.0}, e = {0.0, 1.0};               // padding harmonics: S = [-ui er; ur ei] = identity
         if (lane < Hn) {
             u = U[(size_t)k * Hn + lane];
@@ -251,11 +261,18 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
                 if (k >= M.m) yn = M.coupled ? M.YN[((size_t)devk * Hn + q) * Hn + q] : M.YN[(size_t)devk * Hn + q];
                 if (prow) I0v = I0all[(size_t)s * n + k];                // kept by the mismatch kernel of this very state
                 double a0 = 0.0, a1 = 0.0, ay = 0.0;
+                if (lazy) {                                              // G w of the lazy leaves (rows of their slots): y -= sum
+                    const double g0 = lzA.z >= 0 ? Cs[(size_t)lzA.z * CT + lane] : 0.0;
+                    const double g1 = lzA.w >= 0 ? Cs[(size_t)lzA.w * CT + lane] : 0.0;
+                    const double g2 = lzB.x >= 0 ? Cs[(size_t)lzB.x * CT + lane] : 0.0;
+                    const double g3 = lzB.y >= 0 ? Cs[(size_t)lzB.y * CT + lane] : 0.0;
+                    ay = -((g0 + g1) + (g2 + g3));
+                }
                 if (via_chain) {                                         // what the elimination of the chain above left here
                     const size_t o = so + (size_t)k * Hn + q;
                     a0 = chD[o * 4 + 2 * tr_];
                     a1 = chD[o * 4 + 2 * tr_ + 1];
-                    ay = chy[o * 2 + tr_];
+                    ay += chy[o * 2 + tr_];
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 const Blk2 blk = prow ? blk_power_diag(yd, uk, ek, I0v) : blk_current_diag(yd, uk, ek, yn, k >= M.m);
@@ -310,7 +327,6 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
     }
     // ---- B0. Schur complement of the FIRST dense child (accumulator layout, own tile column): the loads are issued here, after
     //      the role loads (loads return in order: a role must not wait behind them), and first touched after the assembly ----------
-    const double* Cs = Call + (size_t)s * n * CT;
     double sumc[NT * 4];
 #pragma unroll
     for (int e = 0; e < NT * 4; ++e) sumc[e] = 0.0;
@@ -320,6 +336,51 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
 #pragma unroll
             for (int e = 0; e < NT * 4; ++e)
                 if (16 * (e >> 2) + 4 * (e & 3) < B) sumc[e] = Cc[TileIO<B>::off(e >> 2, e & 3, wv, lg, jj)];
+        }
+    }
+    // ---- L. lazy leaves (Tree::d_lzrec): the Schur complements of the constant-inverse leaves c hanging directly under this bus,
+    //      sum_c A(k,c) D_c^-1 A(c,k) = W [ R(sum_c C0_c) + sum_c R(Gc_c) K_c R(Hr_c) ] S_k,
+    //      with per-model images (L2 / Infinity Cache), the leaves' 2x2 cores K_c = (c0 + D)^-1 (lfK, left by the leaf launch), the
+    //      polar map S_k of this bus on the columns and W = [ur ui; ui -ur] on the power-row pair (blk_power_off = U conj(current
+    //      row)).  Two leaves per rank-4 MFMA, at most 4 lazy leaves per bus.  Only G w comes from the leaves' slots (wave 0
+    //      subtracts it from the right-hand side).  Nothing here needs the staged LDS data: the accumulation runs before the
+    //      first barrier, the S / W maps are applied after it. ---------------------------------------------------------------------
+    d4_t xt[NT];
+    if (lazy) {
+        const int np = (lzA.y + 1) >> 1;
+        const double* img = T.lzimg + (size_t)lzA.x + lane;
+        const double* aimg = img + CT;
+        const double* himg = aimg + (size_t)np * NT * 64;
+        const double* Ks = lfK + (size_t)s * n * 4 + 2 * (lg & 1);
+        const int leaf0 = (lg >> 1) ? lzA.w : lzA.z, leaf1 = (lg >> 1) ? lzB.y : lzB.x;
+        // every load of the phase is issued at once (addresses from the scalar record), then the MFMAs
+        double2 k0 = {0.0, 0.0}, k1 = {0.0, 0.0};
+        double h00 = 0.0, h01 = 0.0, h10 = 0.0, h11 = 0.0, a0[NT], a1[NT];
+        if (leaf0 >= 0) k0 = *reinterpret_cast<const double2*>(Ks + (size_t)leaf0 * 4);
+        if (leaf1 >= 0) k1 = *reinterpret_cast<const double2*>(Ks + (size_t)leaf1 * 4);
+        h00 = himg[(size_t)(wv * 2 + 0) * 64];
+        h01 = himg[(size_t)(wv * 2 + 1) * 64];
+#pragma unroll
+        for (int tr = 0; tr < NT; ++tr) a0[tr] = aimg[(size_t)tr * 64];
+        if (np > 1) {
+            h10 = himg[(size_t)((NT + wv) * 2 + 0) * 64];
+            h11 = himg[(size_t)((NT + wv) * 2 + 1) * 64];
+#pragma unroll
+            for (int tr = 0; tr < NT; ++tr) a1[tr] = aimg[(size_t)(NT + tr) * 64];
+        } else {
+#pragma unroll
+            for (int tr = 0; tr < NT; ++tr) a1[tr] = 0.0;
+        }
+#pragma unroll
+        for (int e = 0; e < NT * 4; ++e)
+            xt[e >> 2][e & 3] = (16 * (e >> 2) + 4 * (e & 3) < B) ? img[(size_t)(((e >> 2) * NT + wv) * 4 + (e & 3)) * 64] : 0.0;
+        const double b0 = fma(k0.y, h01, k0.x * h00);                    // (K_c R(Hr_c))[a][col], a = lg & 1, c = leaf lg >> 1
+        const double b1 = fma(k1.y, h11, k1.x * h10);
+#pragma unroll
+        for (int tr = 0; tr < NT; ++tr) xt[tr] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[tr], b0, xt[tr], 0, 0, 0);
+        if (np > 1) {
+#pragma unroll
+            for (int tr = 0; tr < NT; ++tr) xt[tr] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[tr], b1, xt[tr], 0, 0, 0);
         }
     }
     // leaf-only launches: the per-model image of the leaf (L2 / Infinity Cache) is requested here, behind the role loads, and
@@ -343,6 +404,28 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
             for (int w2 = 0; w2 < nw; ++w2) v -= cc[w2][idx];       // fixed order
             dgb[idx] = v;
         }
+    }
+
+    if (lazy) {
+        const double* t0 = tab + (p < Hn ? p : 0) * 4;                   // [ur, ui, ei, -er] of the column's harmonic
+        const bool mcol = col < B;                                       // (column B already holds G w: untouched)
+        const double sown = mcol ? (t1 ? t0[2] : -t0[1]) : 1.0;          // S[t1][t1],  S = [-ui er; ur ei]
+        const double soth = mcol ? (t1 ? -t0[3] : t0[0]) : 0.0;          // S[t1^1][t1]
+#pragma unroll
+        for (int tr = 0; tr < NT; ++tr)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const double v = xt[tr][reg];
+                xt[tr][reg] = fma(xor1_f64(v), soth, v * sown);
+            }
+        if (k < M.m) {                                                   // power rows 0 / 1 of a PQ bus
+            const double ur = tab[0], ui = tab[1];
+            const double v = xt[0][0], pr = xor16_f64(v);
+            xt[0][0] = (mcol && lg < 2) ? (lg == 0 ? fma(ui, pr, ur * v) : fma(ui, pr, -(ur * v))) : v;
+        }
+#pragma unroll
+        for (int e = 0; e < NT * 4; ++e)
+            if (16 * (e >> 2) + 4 * (e & 3) < B) sumc[e] += xt[e >> 2][e & 3];
     }
 
     if (cleaf) {
@@ -578,7 +661,7 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
     HPF_STAMP(st5);
     // ---- E. push: Schur complement of this bus for its parent, C = G A^-1 H and G w in column B (schur_tiles on the own
     //      tile column; gl / hl were staged in A1) ---------------------------------------------------------------------------
-    if (par >= 0) {
+    if (par >= 0 && (!lazy_leaf || wv == tcB)) {            // (lazy leaf: only the right-hand-side column G w is needed)
         const int ti = lg & 1, tcn = jj & 1;
         double ha = hl[p * 4 + 2 * tcn + tcn];              // H[tcn][tcn]
         double hb = hl[p * 4 + 2 * (tcn ^ 1) + tcn];        // H[tcn^1][tcn]
@@ -603,7 +686,12 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
                 const double colp = xor1_f64(own);
                 const double both = xor1_f64(rowp);
                 const double v = fma(gb, fma(both, hb, rowp * ha), ga * fma(colp, hb, own * ha));
-                if (16 * tr + 4 * reg < B && TileIO<B>::ok(wv, jj)) Ck[TileIO<B>::off(tr, reg, wv, lg, jj)] = v;
+                if (16 * tr + 4 * reg < B && TileIO<B>::ok(wv, jj)) {
+                    if (!lazy_leaf)
+                        Ck[TileIO<B>::off(tr, reg, wv, lg, jj)] = v;
+                    else if (col == B)
+                        Ck[16 * tr + 4 * reg + lg] = v;              // lazy leaf: only G w, by rows, at the head of the slot
+                }
             }
     }
 #ifdef HPF_FACTOR_STAMPS

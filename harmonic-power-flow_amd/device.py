@@ -51,6 +51,10 @@ class DeviceModel:
         if solver == "auto":
             solver = "block_tree" if (is_radial(self.n, self.rowptr, self.col) and self.n >= 32) else "dense"
         self.solver = solver
+        N = 2 * self.n * self.Hn - 1 - self.c
+        if solver == "dense" and N * N >= 2 ** 31:
+            raise ValueError("dense solver: N = %d unknowns exceeds rocSOLVER's 32-bit element addressing (N*N < 2^31); "
+                             "radial feeders of this size use solver='block_tree'" % N)
         d = _lib.hpf_desc()
         d.n, d.m, d.c, d.Hn, d.nnz = self.n, self.m, self.c, self.Hn, len(self.col)
         d.n_dev, d.coupled = int(n_dev), int(self.coupled)

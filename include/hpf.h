@@ -30,7 +30,7 @@ extern "C" {
 typedef struct hpf_handle hpf_handle;
 
 enum {
-    HPF_SOLVER_DENSE = 0,      /* dense real FP64 Jacobian, rocSOLVER getrf/getrs (any topology)             */
+    HPF_SOLVER_DENSE = 0,      /* dense real FP64 Jacobian, rocSOLVER getrf/getrs (any topology); N*N < 2^31 (N <= 46 340), else HPF_E_ARG */
     HPF_SOLVER_BLOCK_TREE = 1  /* bus-major 2Hn x 2Hn block elimination along the feeder tree (radial only)  */
 };
 

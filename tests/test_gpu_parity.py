@@ -324,6 +324,9 @@ def test_scenario_batch_block_tree_matches_oracle(tmp_path):
         n_iter, err, hist = dm.solve(1e-4, 50)
         Vm, Va = dm.get_state()
         stats = dm.stats()
+        dm.mismatch(want_f=False)                   # one more Newton iteration on every scenario, for the shallow stops below
+        dm.iterate(1)
+        Vm2, Va2 = dm.get_state()
     finally:
         dm.close()
     for s in range(S):
@@ -336,7 +339,18 @@ def test_scenario_batch_block_tree_matches_oracle(tmp_path):
             assert int(n_iter[s]) == r["n_iter_h"], (s, int(n_iter[s]), r["n_iter_h"])
             Ud = Vm[s] * np.exp(1j * Va[s])
             Uo = r["Vm_raw"] * np.exp(1j * r["Va_raw"])
-            assert np.abs(Ud - Uo).max() < TOL_V
+            if r["err_h"] <= 1e-7:
+                assert np.abs(Ud - Uo).max() < TOL_V
+            else:
+                # The stop rule (1e-4) left the reference's last iterate shallow: what differs between two linear solvers there is
+                # the rounding of the last step times the remaining distance (solver-sensitive cases).  Compare at
+                # equal depth instead: one more Newton iteration on both sides.
+                assert np.abs(Ud - Uo).max() < 1e-6
+                r2 = o.hpf_from_model(r["model"], r["Vm_raw"].copy(), r["Va_raw"].copy(), thresh_h=0.0, max_iter_h=1)
+                Ud = Vm2[s] * np.exp(1j * Va2[s])
+                Uo = r2["Vm_raw"] * np.exp(1j * r2["Va_raw"])
+                print(f"\nscenario {s}: reference stopped at {r['err_h']:.1e}; after one more iteration max|dU| {np.abs(Ud - Uo).max():.2e}")
+                assert np.abs(Ud - Uo).max() < TOL_V
 
 
 def test_headline_feeder_syn1000_vs_reference_golden(tmp_path):

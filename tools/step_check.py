@@ -16,6 +16,9 @@ buses, lines, m, nn, c = hp.init_network(fb, fl, settings=st)
 Y = hp.build_admittance_matrices(buses, lines, st.HARMONICS)
 NE = hp.import_Norton_Equivalents(buses, True, st, INPUTS)
 res = {}
+N_unknowns = 2 * n * len(st.HARMONICS)
+if N_unknowns * N_unknowns >= 2 ** 31:
+    sys.exit("dense reference impossible at this size (N*N >= 2^31)")
 for solver in ("dense", "block_tree"):
     dm = api._device_model(buses, Y, NE, True, st.HARMONICS, solver=solver, max_scenarios=1)
     dm.set_loads(buses["P"].to_numpy(float), buses["Q"].to_numpy(float))
