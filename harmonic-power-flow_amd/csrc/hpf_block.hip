@@ -36,6 +36,8 @@ using namespace hpf;
 
 namespace {
 
+constexpr int FDESC = 36;   // ints per node record of the multi-wave factor kernel (Tree::d_fdesc)
+
 struct TreeDev {
     const int* parent;
     const int* child_ptr;
@@ -1319,7 +1321,7 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
         }
     }
     // node records of the multi-wave kernels (hpf_quad.hpp)
-    std::vector<int> fdesc((size_t)T.n_dense * 16, 0), child3((size_t)(n > 1 ? n - 1 : 0) * 4, 0), bdesc((size_t)T.n_dense * 4, 0);
+    std::vector<int> fdesc((size_t)T.n_dense * FDESC, 0), child3((size_t)(n > 1 ? n - 1 : 0) * 4, 0), bdesc((size_t)T.n_dense * 4, 0);
     for (size_t cp = 0; cp < T.child.size(); ++cp) {
         const int ch = T.child[cp];
         child3[cp * 4 + 0] = ch;
@@ -1343,6 +1345,16 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
     const bool lazy_on = !(lz_env && atoi(lz_env) == 0);
     constexpr int LZ_MAX = 4;
     const int BWc = wave_block_size(b);
+    // host twin of TileIO<B>::off (hpf_quad.hpp): offset of (row, col) in a tile image, -1 for the columns that are not stored
+    auto tile_off = [&](int row, int col) -> long long {
+        const int NTq = (BWc + 16) / 16, LW = (BWc + 1 - 16 * (NTq - 1)) <= 8 ? 8 : 16, RG = (NTq - 1) * 64 + 4 * LW;
+        const int NP = (BWc / 4) / 2;
+        const int tr = row >> 4, reg = (row & 15) >> 2, lg = row & 3, wv = col >> 4, jj = col & 15, e = tr * 4 + reg;
+        if (row >= BWc || (wv == NTq - 1 && jj >= LW)) return -1;
+        if (e < 2 * NP)
+            return (long long)(e >> 1) * 2 * RG + (wv < NTq - 1 ? wv * 128 + (lg * 16 + jj) * 2 : (NTq - 1) * 128 + (lg * LW + jj) * 2) + (e & 1);
+        return (long long)NP * 2 * RG + (wv < NTq - 1 ? wv * 64 + lg * 16 + jj : (NTq - 1) * 64 + lg * LW + jj);
+    };
     if (contract && d->coupled && BWc) {
         typedef std::complex<double> cd;
         const int Hn = d->Hn, nnz = d->nnz;
@@ -1461,18 +1473,12 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
             cleaf_of[k] = T.n_cleaf++;
             minv.resize((size_t)T.n_cleaf * CTc, 0.0);
             double* Mt = &minv[(size_t)cleaf_of[k] * CTc];
-            for (int row = 0; row < 16 * NTc; ++row)
-                for (int col = 0; col < 16 * NTc; ++col) {
-                    double v = (row == col) ? 1.0 : 0.0;              // identity padding beyond b
-                    if (row < b && col < b) {
-                        const cd z = img[(size_t)(row >> 1) * Hn + (col >> 1)];
-                        const int t = row & 1, t2 = col & 1;          // R(z) = [re -im; im re]
-                        v = (t == t2) ? z.real() : (t ? z.imag() : -z.imag());
-                    } else if (row < b || col < b) {
-                        v = 0.0;
-                    }
-                    const int tr = row >> 4, tc = col >> 4, lg = row & 3, reg = (row & 15) >> 2, jj = col & 15;
-                    Mt[(size_t)((tr * NTc + tc) * 4 + reg) * 64 + lg * 16 + jj] = v;
+            for (int row = 0; row < b; ++row)                          // (rows / columns beyond b: zeros)
+                for (int col = 0; col < b; ++col) {
+                    const cd z = img[(size_t)(row >> 1) * Hn + (col >> 1)];
+                    const int t = row & 1, t2 = col & 1;              // R(z) = [re -im; im re]
+                    const long long o = tile_off(row, col);
+                    if (o >= 0) Mt[o] = (t == t2) ? z.real() : (t ? z.imag() : -z.imag());
                 }
             const int pk = T.parent[k];
             if (lazy_on && pk >= (d->c > 1 ? d->c : 1) && kept(pk) && (int)lazy_of[pk].size() < LZ_MAX) {
@@ -1520,24 +1526,24 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
                 for (int col = 0; col < b; ++col) {
                     double v = 0.0;
                     for (int li : lazy_of[pk]) v += R(lazies[li].C0[(size_t)(row >> 1) * Hn + (col >> 1)], row & 1, col & 1);
-                    const int tr = row >> 4, tc = col >> 4, lg = row & 3, reg = (row & 15) >> 2, jj = col & 15;
-                    I0[(size_t)((tr * NTc + tc) * 4 + reg) * 64 + lg * 16 + jj] = v;
+                    const long long o = tile_off(row, col);
+                    if (o >= 0) I0[o] = v;
                 }
             for (int pr = 0; pr < np; ++pr)
                 for (int lg = 0; lg < 4; ++lg) {
                     const int idx = 2 * pr + (lg >> 1), a = lg & 1;
                     if (idx >= L) continue;
                     const LazyLeaf& ll = lazies[lazy_of[pk][idx]];
-                    for (int tr = 0; tr < NTc; ++tr)                     // MFMA A operand: lane (jj, lg) = R(Gc)[16 tr + jj][a]
+                    for (int tr = 0; tr < NTc; ++tr)                     // MFMA A operand: lane (jj, lg) = R(Gc)[16 tr + jj][a], stored [pair][lane][tr]
                         for (int jj = 0; jj < 16; ++jj) {
                             const int row = 16 * tr + jj;
-                            if (row < b) IA[((size_t)pr * NTc + tr) * 64 + lg * 16 + jj] = R(ll.G[row >> 1], row & 1, a);
+                            if (row < b) IA[((size_t)pr * 64 + lg * 16 + jj) * NTc + tr] = R(ll.G[row >> 1], row & 1, a);
                         }
-                    for (int tc = 0; tc < NTc; ++tc)                     // rows of R(Hr): lane (lg, jj) = R(Hr)[a'][16 tc + jj] of leaf lg >> 1
+                    for (int tc = 0; tc < NTc; ++tc)                     // rows of R(Hr): lane (lg, jj) = R(Hr)[a'][16 tc + jj] of leaf lg >> 1, [pair][tc][lane][a']
                         for (int a2 = 0; a2 < 2; ++a2)
                             for (int jj = 0; jj < 16; ++jj) {
                                 const int col = 16 * tc + jj;
-                                if (col < b) IH[(((size_t)pr * NTc + tc) * 2 + a2) * 64 + lg * 16 + jj] = R(ll.H[col >> 1], a2, col & 1);
+                                if (col < b) IH[(((size_t)pr * NTc + tc) * 64 + lg * 16 + jj) * 2 + a2] = R(ll.H[col >> 1], a2, col & 1);
                             }
                 }
             int rec[8] = {(int)off, L, -1, -1, -1, -1, 0, 0};
@@ -1549,7 +1555,7 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
     T.lvl_all_leaf.assign(T.n_levels > 0 ? T.n_levels : 1, 1);
     for (int pos = 0; pos < T.n_dense; ++pos) {
         const int k = T.lvl_nodes[pos];
-        int* r = &fdesc[(size_t)pos * 16];
+        int* r = &fdesc[(size_t)pos * FDESC];
         int diag_e = -1;
         for (int e = d->rowptr[k]; e < d->rowptr[k + 1]; ++e)
             if (d->col[e] == k) diag_e = e;
@@ -1568,6 +1574,16 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
         r[14] = (k > 0 && pass[T.parent[k]]) ? 1 : (is_lazy[k] ? 2 : 0);   // 1: linked to its dense parent through a contracted chain; 2: lazy leaf
         r[15] = lz_idx[k] >= 0 ? -(lz_idx[k] + 1) : cleaf_of[k] + 1;     // > 0: constant-inverse leaf, 1 + slot in Tree::d_Minv; < 0: -(1 + lazy record)
         if (cleaf_of[k] < 0) T.lvl_all_leaf[height[k]] = 0;
+        for (int i = 0; i < 4; ++i) {                              // first four 2x2-algebra children: (child, e_dn, e_up), no child3 hop
+            const int cp = T.child_ptr[k] + i;
+            const bool has = cp < T.child_mid[k];
+            r[16 + 3 * i] = has ? T.child[cp] : -1;
+            r[17 + 3 * i] = has ? e_dn[T.child[cp]] : 0;
+            r[18 + 3 * i] = has ? e_up[T.child[cp]] : 0;
+        }
+        for (int i = 28; i < 36; ++i) r[i] = (i >= 30 && i < 34) ? -1 : 0;
+        if (lz_idx[k] >= 0)                                        // lazy-leaf record inline: image offset, L, leaf ids[4]
+            for (int i = 0; i < 6; ++i) r[28 + i] = lzrec[(size_t)lz_idx[k] * 8 + i];
         const int kb = T.dep_nodes[pos];
         bdesc[(size_t)pos * 4 + 0] = kb;
         bdesc[(size_t)pos * 4 + 1] = pard[kb];
@@ -1794,7 +1810,7 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
             switch (BW) {
 #define HPF_FACTOR_CASE(BB_)                                                                                  \
     case BB_:                                                                                                 \
-        r = h->gj_mode == 1 ? launch_factor_q<BB_>(h, td, T.d_fdesc + 16 * (size_t)T.lvl_ptr[l], cnt, active, \
+        r = h->gj_mode == 1 ? launch_factor_q<BB_>(h, td, T.d_fdesc + FDESC * (size_t)T.lvl_ptr[l], cnt, active, \
                                                   T.lvl_all_leaf[l] != 0)                                       \
             : (h->gj_mode == 2 ? launch_factor_w<BB_, 1>(h, td, nodes, cnt, active)                           \
                                : launch_factor_w<BB_, 0>(h, td, nodes, cnt, active));                         \

@@ -79,19 +79,64 @@ __device__ __forceinline__ void mask_block(int n, int c, int q, int i, int j, co
             out[tr * 2 + tc] = (loc_valid(n, c, i, 2 * q + tr) && loc_valid(n, c, j, 2 * q + tc)) ? pick(blk, tr, tc) : 0.0;
 }
 
-// HBM image of a block in accumulator-tile layout (Schur complements C, inverses Z): per row group (tr, reg) the NT tile columns
-// one after the other, 64 doubles each = one 512-byte row per wave -- except the LAST tile column, of which only the first LW
-// columns exist (matrix columns 16(NT-1)..B-1 and the right-hand side in column B; B = 52: 5 of 16): its rows are stored LW wide.
+// HBM image of a block in accumulator-tile layout (Schur complements C, inverses Z).  A lane owns the B/4 row groups e = 4 tr + reg
+// (rows 16 tr + 4 reg + lg < B) of its column.  Consecutive row groups (2p, 2p+1) are interleaved so that the lane's two values are
+// adjacent: one 16-byte access per lane and pair (1 KB per wave instruction, half the memory requests of 8-byte accesses); B/4 is
+// odd, the last row group stays 8 bytes wide.  Of the LAST tile column only the first LW columns exist (matrix columns
+// 16(NT-1)..B-1 and the right-hand side in column B; B = 52: 5 of 16): its rows are stored LW wide.
 template <int B>
 struct TileIO {
     static constexpr int NT = (B + 16) / 16;
     static constexpr int LW = (B + 1 - 16 * (NT - 1)) <= 8 ? 8 : 16;
     static constexpr int RG = (NT - 1) * 64 + 4 * LW;                  // doubles per row group
+    static constexpr int NE = B / 4, NP = NE / 2;                      // row groups, pairs of row groups
+    static_assert(NE == 2 * NP + 1, "odd number of row groups");
+    __device__ static __forceinline__ size_t off2(int p, int wv, int lg, int jj) {      // first of the two adjacent values
+        return (size_t)p * 2 * RG + (wv < NT - 1 ? wv * 128 + (lg * 16 + jj) * 2 : (NT - 1) * 128 + (lg * LW + jj) * 2);
+    }
+    __device__ static __forceinline__ size_t off1(int wv, int lg, int jj) {             // the unpaired last row group
+        return (size_t)NP * 2 * RG + (wv < NT - 1 ? wv * 64 + lg * 16 + jj : (NT - 1) * 64 + lg * LW + jj);
+    }
     __device__ static __forceinline__ size_t off(int tr, int reg, int wv, int lg, int jj) {
-        return (size_t)(tr * 4 + reg) * RG + (wv < NT - 1 ? wv * 64 + lg * 16 + jj : (NT - 1) * 64 + lg * LW + jj);
+        const int e = tr * 4 + reg;
+        return e < 2 * NP ? off2(e >> 1, wv, lg, jj) + (e & 1) : off1(wv, lg, jj);
     }
     __device__ static __forceinline__ bool ok(int wv, int jj) { return wv < NT - 1 || jj < LW; }
+    // the lane's NE values, v[e] = row group e (entries e >= NE untouched); lanes outside the stored columns get zeros
+    __device__ static __forceinline__ void load(const double* base, int wv, int lg, int jj, double (&v)[NT * 4]) {
+        const bool in = ok(wv, jj);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            double2 t = {0.0, 0.0};
+            if (in) t = *reinterpret_cast<const double2*>(base + off2(p, wv, lg, jj));
+            v[2 * p] = t.x;
+            v[2 * p + 1] = t.y;
+        }
+        v[NE - 1] = in ? base[off1(wv, lg, jj)] : 0.0;
+    }
+    __device__ static __forceinline__ void store(double* base, int wv, int lg, int jj, const double (&v)[NT * 4]) {
+        if (!ok(wv, jj)) return;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) *reinterpret_cast<double2*>(base + off2(p, wv, lg, jj)) = double2{v[2 * p], v[2 * p + 1]};
+        base[off1(wv, lg, jj)] = v[NE - 1];
+    }
 };
+
+// the lane's NT A operands of one lazy-leaf pair, stored [lane][NT]
+template <int NT>
+__device__ __forceinline__ void lz_aop(const double* p, double (&a)[NT]) {
+    if constexpr (NT % 2 == 0) {
+#pragma unroll
+        for (int t2 = 0; t2 < NT / 2; ++t2) {
+            const double2 v = *reinterpret_cast<const double2*>(p + 2 * t2);
+            a[2 * t2] = v.x;
+            a[2 * t2 + 1] = v.y;
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) a[t] = p[t];
+    }
+}
 
 #ifndef HPF_Q_OCC
 #define HPF_Q_OCC 4        // waves per SIMD the B = 52 factor kernel is compiled for (register budget 512 / HPF_Q_OCC)
@@ -118,7 +163,7 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
     const int s = blockIdx.y + s0;
     if (active && !active[s]) return;
     // node record: everything the block needs to form its addresses, behind one scalar load (Tree::d_fdesc)
-    const int4* nd = reinterpret_cast<const int4*>(nodes) + 4 * (size_t)blockIdx.x;
+    const int4* nd = reinterpret_cast<const int4*>(nodes) + (FDESC / 4) * (size_t)blockIdx.x;
     const int4 nd0 = nd[0], nd1 = nd[1], nd2 = nd[2], nd3 = nd[3];
     const int k = nd0.x, par = nd0.y, diag_e = nd0.z, devk = nd0.w;
     const int e_dn_k = nd1.x, e_up_k = nd1.y, lin_beg = nd1.z, lin_end = nd1.z + nd1.w;
@@ -128,12 +173,11 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
     const int cleafv = nd3.w;                // constant-inverse leaf: 1 + slot in Minv (0: general path; < 0: lazy-leaf record)
     const bool cleaf = LEAF || cleafv > 0;
     const bool lazy = !LEAF && cleafv < 0;   // this bus has lazy leaves below it
-    // lazy-leaf record (Tree::d_lzrec, 8 ints: image offset, L, leaf ids[4]): uniform address -> scalar loads, issued with the node record
+    // lazy-leaf record (Tree::d_lzrec, 8 ints: image offset, L, leaf ids[4])
     int4 lzA = {0, 0, -1, -1}, lzB = {-1, -1, 0, 0};
-    if (lazy) {
-        const int4* lz4 = reinterpret_cast<const int4*>(T.lzrec) + 2 * (size_t)(-cleafv - 1);
-        lzA = lz4[0];
-        lzB = lz4[1];
+    if (lazy) {                               // (inline copy of the record: ints 28..35 of the node record, same scalar round trip)
+        lzA = nd[7];
+        lzB = nd[8];
     }
 #ifdef HPF_FACTOR_STAMPS
     long long sd1 = 0, sd2 = 0, sd3 = 0;
@@ -293,13 +337,17 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
         const int slot = (wv + NT - (2 % NT)) % NT;          // waves 2, 3 have the lightest roles: they take the first children
         if (lin_beg + slot < lin_end) {
             double e0 = 0.0, e1 = 0.0, ey = 0.0;
+            // the first child of the slot comes with the node record (ints 16..27: child, e_dn, e_up), later ones through child3
+            const int sl4 = slot < 4 ? slot : 0;
+            int4 cr = {nodes[FDESC * (size_t)blockIdx.x + 16 + 3 * sl4], nodes[FDESC * (size_t)blockIdx.x + 17 + 3 * sl4],
+                       nodes[FDESC * (size_t)blockIdx.x + 18 + 3 * sl4], 0};
             if (rowvalid) {
                 const double* ws = wall + (size_t)s * n * B;
                 const double* linA = linAall + so * 4;
                 const int4* c3 = reinterpret_cast<const int4*>(T.child3);
                 const cplx uk = U[kq], ek = E[kq];
                 for (int cp = lin_beg + slot; cp < lin_end; cp += NT) {
-                    const int4 cr = c3[cp];
+                    if (cp != lin_beg + slot || slot >= 4) cr = c3[cp];
                     const int ch = cr.x;
                     const cplx ydn = M.Y[(size_t)cr.y * Hn + q], yup = M.Y[(size_t)cr.z * Hn + q];
                     const cplx uc = U[(size_t)ch * Hn + q], ec = E[(size_t)ch * Hn + q];
@@ -330,14 +378,7 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
     double sumc[NT * 4];
 #pragma unroll
     for (int e = 0; e < NT * 4; ++e) sumc[e] = 0.0;
-    if (n_den > 0) {
-        const double* Cc = Cs + (size_t)nd2.z * CT;
-        if (TileIO<B>::ok(wv, jj)) {
-#pragma unroll
-            for (int e = 0; e < NT * 4; ++e)
-                if (16 * (e >> 2) + 4 * (e & 3) < B) sumc[e] = Cc[TileIO<B>::off(e >> 2, e & 3, wv, lg, jj)];
-        }
-    }
+    if (n_den > 0) TileIO<B>::load(Cs + (size_t)nd2.z * CT, wv, lg, jj, sumc);
     // ---- L. lazy leaves (Tree::d_lzrec): the Schur complements of the constant-inverse leaves c hanging directly under this bus,
     //      sum_c A(k,c) D_c^-1 A(c,k) = W [ R(sum_c C0_c) + sum_c R(Gc_c) K_c R(Hr_c) ] S_k,
     //      with per-model images (L2 / Infinity Cache), the leaves' 2x2 cores K_c = (c0 + D)^-1 (lfK, left by the leaf launch), the
@@ -348,8 +389,7 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
     d4_t xt[NT];
     if (lazy) {
         const int np = (lzA.y + 1) >> 1;
-        const double* img = T.lzimg + (size_t)lzA.x + lane;
-        const double* aimg = img + CT;
+        const double* aimg = T.lzimg + (size_t)lzA.x + CT;
         const double* himg = aimg + (size_t)np * NT * 64;
         const double* Ks = lfK + (size_t)s * n * 4 + 2 * (lg & 1);
         const int leaf0 = (lg >> 1) ? lzA.w : lzA.z, leaf1 = (lg >> 1) ? lzB.y : lzB.x;
@@ -358,22 +398,30 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
         double h00 = 0.0, h01 = 0.0, h10 = 0.0, h11 = 0.0, a0[NT], a1[NT];
         if (leaf0 >= 0) k0 = *reinterpret_cast<const double2*>(Ks + (size_t)leaf0 * 4);
         if (leaf1 >= 0) k1 = *reinterpret_cast<const double2*>(Ks + (size_t)leaf1 * 4);
-        h00 = himg[(size_t)(wv * 2 + 0) * 64];
-        h01 = himg[(size_t)(wv * 2 + 1) * 64];
-#pragma unroll
-        for (int tr = 0; tr < NT; ++tr) a0[tr] = aimg[(size_t)tr * 64];
+        // images: per pair the A operands [lane][NT] and the two rows of R(Hr) [tile column][lane][2] -- 16-byte accesses
+        {
+            const double2 h = *reinterpret_cast<const double2*>(himg + (size_t)(wv * 64 + lane) * 2);
+            h00 = h.x;
+            h01 = h.y;
+        }
+        lz_aop<NT>(aimg + (size_t)lane * NT, a0);
         if (np > 1) {
-            h10 = himg[(size_t)((NT + wv) * 2 + 0) * 64];
-            h11 = himg[(size_t)((NT + wv) * 2 + 1) * 64];
-#pragma unroll
-            for (int tr = 0; tr < NT; ++tr) a1[tr] = aimg[(size_t)(NT + tr) * 64];
+            const double2 h = *reinterpret_cast<const double2*>(himg + (size_t)((NT + wv) * 64 + lane) * 2);
+            h10 = h.x;
+            h11 = h.y;
+            lz_aop<NT>(aimg + (size_t)(64 + lane) * NT, a1);
         } else {
 #pragma unroll
             for (int tr = 0; tr < NT; ++tr) a1[tr] = 0.0;
         }
+        {
+            double xv[NT * 4];
 #pragma unroll
-        for (int e = 0; e < NT * 4; ++e)
-            xt[e >> 2][e & 3] = (16 * (e >> 2) + 4 * (e & 3) < B) ? img[(size_t)(((e >> 2) * NT + wv) * 4 + (e & 3)) * 64] : 0.0;
+            for (int e = 0; e < NT * 4; ++e) xv[e] = 0.0;
+            TileIO<B>::load(T.lzimg + (size_t)lzA.x, wv, lg, jj, xv);     // sum of the leaves' constant parts (tile image)
+#pragma unroll
+            for (int e = 0; e < NT * 4; ++e) xt[e >> 2][e & 3] = xv[e];
+        }
         const double b0 = fma(k0.y, h01, k0.x * h00);                    // (K_c R(Hr_c))[a][col], a = lg & 1, c = leaf lg >> 1
         const double b1 = fma(k1.y, h11, k1.x * h10);
 #pragma unroll
@@ -389,10 +437,12 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
 #pragma unroll
     for (int tr = 0; tr < NT; ++tr) ct[tr] = d4_t{0.0, 0.0, 0.0, 0.0};
     if (LEAF) {
-        const double* Mk = Minv + (size_t)(cleafv - 1) * CT + lane;
+        double mv[NT * 4];
 #pragma unroll
-        for (int e = 0; e < NT * 4; ++e)
-            if (16 * (e >> 2) + 4 * (e & 3) < B) ct[e >> 2][e & 3] = Mk[(size_t)(((e >> 2) * NT + wv) * 4 + (e & 3)) * 64];
+        for (int e = 0; e < NT * 4; ++e) mv[e] = 0.0;
+        TileIO<B>::load(Minv + (size_t)(cleafv - 1) * CT, wv, lg, jj, mv);
+#pragma unroll
+        for (int e = 0; e < NT * 4; ++e) ct[e >> 2][e & 3] = mv[e];
     }
     HPF_STAMP(sd3);
     __syncthreads();
@@ -435,10 +485,12 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
         //     Drect^-1 = [0 0; 0 Ahh^-1] + [I; Lc] (c0 + D)^-1 [I Lr];
         // polar inverse = S^-1 Drect^-1 (row pairs scaled by the 2x2 S_q^-1);  w = A^-1 y by row sums.
         if (!LEAF) {
-            const double* Mk = Minv + (size_t)(cleafv - 1) * CT + lane;
+            double mv[NT * 4];
 #pragma unroll
-            for (int e = 0; e < NT * 4; ++e)
-                if (16 * (e >> 2) + 4 * (e & 3) < B) ct[e >> 2][e & 3] = Mk[(size_t)(((e >> 2) * NT + wv) * 4 + (e & 3)) * 64];
+            for (int e = 0; e < NT * 4; ++e) mv[e] = 0.0;
+            TileIO<B>::load(Minv + (size_t)(cleafv - 1) * CT, wv, lg, jj, mv);
+#pragma unroll
+            for (int e = 0; e < NT * 4; ++e) ct[e >> 2][e & 3] = mv[e];
         }
         double* mc = &panel[0][0];          // [I; Lc]  as mc[row*2 + a]
         double* mr = &panel[1][0];          // [I  Lr]  as mr[a*MRS + col]  (positions (a, 0..1) hold c0)
@@ -556,11 +608,7 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
         const int ch = i == 1 ? nd2.w : (i == 2 ? nd3.x : (i == 3 ? nd3.y : T.dchild[den_beg + i]));
         const double* Cc = Cs + (size_t)ch * CT;
         double tmp[NT * 4];
-#pragma unroll
-        for (int e = 0; e < NT * 4; ++e) {
-            tmp[e] = 0.0;
-            if (16 * (e >> 2) + 4 * (e & 3) < B && TileIO<B>::ok(wv, jj)) tmp[e] = Cc[TileIO<B>::off(e >> 2, e & 3, wv, lg, jj)];
-        }
+        TileIO<B>::load(Cc, wv, lg, jj, tmp);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int e = 0; e < NT * 4; ++e)
@@ -639,12 +687,11 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
     // ---- D. inverse (tile layout) and w = A^-1 y ------------------------------------------------------------------------
     {
         double* Zk = Zall + ((size_t)s * n + k) * CT;
-        if (!cleaf && TileIO<B>::ok(wv, jj)) {
+        if (!cleaf) {
+            double zv[NT * 4];
 #pragma unroll
-            for (int tr = 0; tr < NT; ++tr)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg)
-                    if (16 * tr + 4 * reg < B) Zk[TileIO<B>::off(tr, reg, wv, lg, jj)] = ct[tr][reg];
+            for (int e = 0; e < NT * 4; ++e) zv[e] = ct[e >> 2][e & 3];
+            TileIO<B>::store(Zk, wv, lg, jj, zv);
         }
         if (wv == tcB && jj == jjB) {
             double* wk = wall + ((size_t)s * n + k) * B;
@@ -674,6 +721,7 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
             hb = 0.0;
         }
         double* Ck = Call + ((size_t)s * n + k) * CT;
+        double cv[NT * 4];
 #pragma unroll
         for (int tr = 0; tr < NT; ++tr)
 #pragma unroll
@@ -685,14 +733,15 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
                 const double rowp = xor16_f64(own);
                 const double colp = xor1_f64(own);
                 const double both = xor1_f64(rowp);
-                const double v = fma(gb, fma(both, hb, rowp * ha), ga * fma(colp, hb, own * ha));
-                if (16 * tr + 4 * reg < B && TileIO<B>::ok(wv, jj)) {
-                    if (!lazy_leaf)
-                        Ck[TileIO<B>::off(tr, reg, wv, lg, jj)] = v;
-                    else if (col == B)
-                        Ck[16 * tr + 4 * reg + lg] = v;              // lazy leaf: only G w, by rows, at the head of the slot
-                }
+                cv[tr * 4 + reg] = fma(gb, fma(both, hb, rowp * ha), ga * fma(colp, hb, own * ha));
             }
+        if (!lazy_leaf) {
+            TileIO<B>::store(Ck, wv, lg, jj, cv);
+        } else if (col == B) {                                   // lazy leaf: only G w, by rows, at the head of the slot
+#pragma unroll
+            for (int e = 0; e < NT * 4; ++e)
+                if (16 * (e >> 2) + 4 * (e & 3) < B) Ck[16 * (e >> 2) + 4 * (e & 3) + lg] = cv[e];
+        }
     }
 #ifdef HPF_FACTOR_STAMPS
     if ((ablate & 16) && tid == 0 && dbg) {
@@ -738,18 +787,10 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16)) void k_back_q(
     if (tid < B) x = wall[((size_t)s * n + k) * B + tid];
     if (par >= 0) {
         double zr[NT * 4];
-        if (cleaf) {                                              // per-model image: full tile rows
-            const double* Mk = Minv + (size_t)(cleaf - 1) * CT + lane;
-#pragma unroll
-            for (int e = 0; e < NT * 4; ++e)
-                if (16 * (e >> 2) + 4 * (e & 3) < B) zr[e] = Mk[(size_t)(((e >> 2) * NT + wv) * 4 + (e & 3)) * 64];
+        if (cleaf) {                                              // per-model image, same tile-image layout
+            TileIO<B>::load(Minv + (size_t)(cleaf - 1) * CT, wv, lg, jj, zr);
         } else {
-            const double* Zk = Zall + ((size_t)s * n + k) * CT;
-#pragma unroll
-            for (int e = 0; e < NT * 4; ++e) {
-                zr[e] = 0.0;
-                if (16 * (e >> 2) + 4 * (e & 3) < B && TileIO<B>::ok(wv, jj)) zr[e] = Zk[TileIO<B>::off(e >> 2, e & 3, wv, lg, jj)];
-            }
+            TileIO<B>::load(Zall + ((size_t)s * n + k) * CT, wv, lg, jj, zr);
         }
         const int col = 16 * wv + jj, p = col >> 1, t1 = col & 1;
         double tv = 0.0;
