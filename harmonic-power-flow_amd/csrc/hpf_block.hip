@@ -18,6 +18,7 @@
 // Bound: FP64 FMA rate (2 b^3 flop per bus) against 24 b^2 bytes of Z traffic per bus -> ~4.3 flop/B at b = 52.
 #include <algorithm>
 #include <complex>
+#include <cstdio>
 #include <cstdlib>
 #include "hpf_internal.hpp"
 #include "hpf_gj.hpp"
@@ -1624,6 +1625,9 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
         }
     }
     T.flops_per_solve = T.flops_factor + 2.0 * bd * bd * n_dense_nonroot;
+    if (getenv("HPF_TREE_INFO"))
+        fprintf(stderr, "hpf tree (%s): %d buses, %d dense in %d levels, %d chains, %d constant-inverse leaves, %d lazy under %d parents\n",
+                contract ? "contracted" : "plain", n, T.n_dense, T.n_levels, T.n_chains, T.n_cleaf, T.n_lazy_leaves, T.n_lazy_parents);
     int r;
     if ((r = upload(h, &T.d_parent, T.parent))) return r;
     if ((r = upload(h, &T.d_lvl_nodes, T.lvl_nodes))) return r;
