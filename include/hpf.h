@@ -140,7 +140,10 @@ int  hpf_debug_stamps(hpf_handle* h, long long* out, int count);
  * with per-model constant inverses for nonlinear leaf buses; 1 uses wave-level Gauss-Jordan with partial pivoting over the
  * whole block on the uncontracted tree (slower, for networks whose bus blocks are not block-diagonally dominant).  Env
  * HPF_GJ_MODE=0 selects the pivoted variant process-wide (2: the one-wave-per-bus MFMA variant).
- * "scenario_groups" (1..8, default 3): independent scenario pipelines on separate HIP streams. */
+ * "scenario_groups" (1..8, default 3): independent scenario pipelines on separate HIP streams.
+ * Environment read by hpf_create (diagnostics, A/B runs): HPF_LAZY=0 builds the elimination tree without lazy leaves (every
+ * leaf writes its Schur complement), HPF_TREE_INFO=1 prints the tree statistics to stderr, HPF_GROUPS=n presets
+ * "scenario_groups". */
 int  hpf_set_option(hpf_handle* h, const char* name, int value);
 
 /* Stream plumbing: run on a caller stream (e.g. torch's current stream) instead of the handle's own; NULL restores. */

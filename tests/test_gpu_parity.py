@@ -636,3 +636,33 @@ def test_batch_results_bit_identical_to_single_scenario_solves(tmp_path):
             assert np.array_equal(Vm[j], ref[s][1][0]) and np.array_equal(Va[j], ref[s][2][0])
     a, b = run([0, 1, 2]), run([0, 1, 2])
     assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,hmax", [(300, 51), (200, 25), (100, 11)])
+def test_lazy_leaves_give_the_same_newton_steps(n, hmax, tmp_path, monkeypatch):
+    """Parents that rebuild their constant-inverse leaves' Schur complements from per-model images (lazy leaves)
+    must take the same Newton steps as the tree built without them (HPF_LAZY=0 at hpf_create): first three iterations from the
+    pf seed agree at rounding level, scenario by scenario (b = 52, 26 -> padded 28, 12)."""
+    hp = _hp()
+    from harmonic_power_flow_amd import synth
+    S = 3
+    out = {}
+    for lazy in ("1", "0"):
+        monkeypatch.setenv("HPF_LAZY", lazy)
+        st, buses, lines, dm, _ = _syn_model(hp, n, hmax, "block_tree", tmp_path, max_scenarios=S)
+        P0, Q0 = buses["P"].to_numpy(float), buses["Q"].to_numpy(float)
+        scale = np.stack([synth.scenario_scale(n, s) for s in range(S)])
+        try:
+            dm.set_loads(P0 * scale, Q0 * scale)
+            dm.set_state(None, None, n_scen=S)
+            dm.fund_pf(1e-6, 30)
+            dm.mismatch(want_f=False)
+            dm.iterate(1)
+            out[lazy] = dm.get_state()
+        finally:
+            dm.close()
+    dVm = np.abs(out["1"][0] - out["0"][0]).max()
+    dVa = np.abs(out["1"][1] - out["0"][1]).max()
+    print(f"\nn={n} H_MAX={hmax}: first step lazy vs plain leaves max|dVm| {dVm:.1e} max|dVa| {dVa:.1e}")
+    assert dVm < 1e-10 and dVa < 1e-9
