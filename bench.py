@@ -264,7 +264,7 @@ def pmc_traffic(args, S):
     if not d:
         return None, "no PMC pass for this kernel"
     return d["fetch_raw"] + d.get("write_calibrated", d["write"]), ("per launch: (FETCH_SIZE*1024 raw + WRITE_SIZE*1024 x store calibration) of a factor sweep / launches; "
-                                         "8 B/lane streams: loads calibrate at 1.0 (k_back_q), stores at ~0.5 (k_update, known "
+                                         "tile-image loads calibrate at 1.0 (k_back_q, known bytes), stores at ~0.55 (k_update, known "
                                          "bytes); includes the shared leaf images served by the Infinity Cache; separate "
                                          "rocprofv3 --pmc passes, see profiles/pmc_traffic_latest.json")
 

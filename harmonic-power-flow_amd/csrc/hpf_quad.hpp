@@ -13,9 +13,9 @@
 // two per-lane constants.  The harmonic-diagonal part (network entry, linear children) is computed per row by wave 0 and
 // patched in through LDS.
 //
-// HBM layout of the inverse for the back sweep: accumulator tiles [tile tr*NT+tc][reg][lane] (512-byte coalesced rows), the
-// same layout as the Schur-complement slots; w = A^-1 y additionally goes to the [bus][B] array shared with the linear-subtree
-// kernels.
+// HBM layout of the inverse for the back sweep: the tile image of TileIO (a lane's row groups pairwise adjacent: 16-byte
+// accesses, 1 KB coalesced rows), the same layout as the Schur-complement slots and the per-model leaf images; w = A^-1 y
+// additionally goes to the [bus][B] array shared with the linear-subtree kernels.
 #pragma once
 
 template <int CTRL>

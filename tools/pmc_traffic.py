@@ -47,13 +47,15 @@ def main():
     if upd and upd["write"] > 0:
         cal = known / upd["write"]
         out["write_calibration"] = {"kernel": "k_update", "known_bytes": known, "counter_bytes": upd["write"], "factor": cal,
-                                    "note": "WRITE_SIZE over-counts the 8 B/lane stores of these kernels; the 8 B/lane LOADS "
-                                            "calibrate at 1.0 on k_back_q (raw FETCH_SIZE = inverse tiles + operands)"}
+                                    "note": "WRITE_SIZE over-counts the stores of these kernels; the tile-image LOADS calibrate at 1.0 "
+                                            "on k_back_q (raw FETCH_SIZE = inverse tiles + operands), with 8-byte accesses per "
+                                            "lane (up to v14) and with 16-byte accesses (v15: 0.83 -> 0.81 GB) alike"}
         for k in out["per_step_bytes"]:
             out["per_step_bytes"][k]["write_calibrated"] = out["per_step_bytes"][k]["write"] * cal
     out["note"] = ("FETCH_SIZE/WRITE_SIZE are KB. MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reads exactly 1/2 of the bytes of a "
-                   "wide coalesced 16 B/lane stream and other widths are uncalibrated; the factor / back kernels stream 8 B/lane "
-                   "(512-byte tile rows), so raw and doubled values are both given.")
+                   "wide coalesced 16 B/lane stream and other widths are uncalibrated; on the tile images of the factor / back kernels "
+                   "(16 B/lane pairs + one 8 B/lane row group per lane, 1 KB / 512 B rows) the RAW value matches the known bytes "
+                   "(see write_calibration.note), so raw and doubled values are both given and the raw one is used.")
     json.dump(out, open(out_path, "w"), indent=1)
     print(json.dumps(out["per_step_bytes"], indent=1))
 
