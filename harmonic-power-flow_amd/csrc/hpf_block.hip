@@ -1625,6 +1625,16 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
         }
     }
     T.flops_per_solve = T.flops_factor + 2.0 * bd * bd * n_dense_nonroot;
+    if (getenv("HPF_TREE_INFO")) {
+        int sl_nl = 0, sl_lin = 0, sl_lvl[4] = {0, 0, 0, 0};
+        for (int i = 1; i < n; ++i)
+            if (kept(i) && n_lazy[i] > 0 && dchild_ptr[i + 1] - dchild_ptr[i] == n_lazy[i]) {
+                (i >= d->m ? sl_nl : sl_lin)++;
+                sl_lvl[height[i] < 3 ? height[i] : 3]++;
+            }
+        fprintf(stderr, "hpf tree: buses whose dense children are all lazy leaves: %d nonlinear + %d linear (levels 1/2/3+: %d/%d/%d)\n",
+                sl_nl, sl_lin, sl_lvl[1], sl_lvl[2], sl_lvl[3]);
+    }
     if (getenv("HPF_TREE_INFO"))
         fprintf(stderr, "hpf tree (%s): %d buses, %d dense in %d levels, %d chains, %d constant-inverse leaves, %d lazy under %d parents\n",
                 contract ? "contracted" : "plain", n, T.n_dense, T.n_levels, T.n_chains, T.n_cleaf, T.n_lazy_leaves, T.n_lazy_parents);

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep on the GPU: the first Newton step (pf seed -> one iteration) of the block-tree path against the dense
+rocSOLVER path over random radial feeders (size, share of nonlinear buses, PV buses, harmonic count -> block sizes 12 / 28 / 52 and
+the generic kernels).  One step is compared (not converged states) because later iterates of the solver-sensitive cases amplify
+rounding differences.  python tools/fuzz_parity.py [cases=24] [seed=0]"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import harmonic_power_flow_amd as hp
+from harmonic_power_flow_amd import api, synth
+
+INPUTS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "inputs")
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+worst = 0.0
+for case in range(cases):
+    n = int(rng.integers(33, 420))
+    hmax = int(rng.choice([5, 11, 15, 19, 25, 27, 35, 51, 59]))
+    frac = float(rng.choice([0.05, 0.15, 0.35, 0.6, 0.85]))
+    n_pv = int(rng.choice([0, 0, 1, 2]))
+    seed = int(rng.integers(0, 10 ** 6))
+    tmp = tempfile.mkdtemp()
+    fb, fl = synth.gen(n, seed=seed, frac_nl=frac, outdir=tmp)
+    if n_pv:
+        rows = open(fb).read().splitlines()
+        for bid in range(2, 2 + n_pv):
+            cols = rows[bid].split(";")
+            cols[1], cols[2], cols[4], cols[5] = "PV", "gen_%d" % bid, "-120", "0"
+            rows[bid] = ";".join(cols)
+        open(fb, "w").write("\n".join(rows) + "\n")
+    st = hp.Settings(H_MAX=hmax)
+    buses, lines, m, nn, c = hp.init_network(fb, fl, settings=st)
+    Hn = len(st.HARMONICS)
+    if (2 * nn * Hn) ** 2 >= 2 ** 31:
+        continue
+    Y = hp.build_admittance_matrices(buses, lines, st.HARMONICS)
+    NE = hp.import_Norton_Equivalents(buses, True, st, INPUTS)
+    S = 2
+    P0, Q0 = buses["P"].to_numpy(float), buses["Q"].to_numpy(float)
+    scale = np.stack([synth.scenario_scale(nn, s) for s in range(S)])
+    res = {}
+    for solver in ("dense", "block_tree"):
+        dm = api._device_model(buses, Y, NE, True, st.HARMONICS, solver=solver, max_scenarios=S)
+        try:
+            dm.set_loads(P0 * scale, Q0 * scale)
+            dm.set_state(None, None, n_scen=S)
+            dm.fund_pf(1e-6, 30)
+            dm.mismatch(want_f=False)
+            dm.iterate(1)
+            res[solver] = dm.get_state()
+        finally:
+            dm.close()
+    dVm = np.abs(res["dense"][0] - res["block_tree"][0]).max()
+    dVa = np.abs(res["dense"][1] - res["block_tree"][1]).max()
+    step = np.abs(res["dense"][0]).max()
+    worst = max(worst, dVm, dVa)
+    print("case %2d: n=%3d Hn=%2d (b=%3d) nl=%.2f pv=%d seed=%6d   first step max|dVm| %.1e max|dVa| %.1e" %
+          (case, nn, Hn, 2 * Hn, frac, n_pv, seed, dVm, dVa), flush=True)
+    assert np.isfinite(dVm) and np.isfinite(dVa)
+print("worst deviation %.2e" % worst)
+sys.exit(0 if worst < 1e-7 else 1)
