@@ -1344,6 +1344,7 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
     std::vector<int> is_lazy(n, 0);
     const char* lz_env = getenv("HPF_LAZY");
     const bool lazy_on = !(lz_env && atoi(lz_env) == 0);
+    const int lazy_mode = lz_env ? atoi(lz_env) : 2;          // 1: only leaves hanging directly under their dense parent
     constexpr int LZ_MAX = 4;
     const int BWc = wave_block_size(b);
     // host twin of TileIO<B>::off (hpf_quad.hpp): offset of (row, col) in a tile image, -1 for the columns that are not stored
@@ -1385,6 +1386,13 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
             const int k = T.lvl_nodes[pos];
             if (k < d->m || dchild_ptr[k + 1] != dchild_ptr[k] || d->dev_of_bus[k] < 0) continue;
             std::vector<cd> Yc((size_t)Hn * Hn);
+            // effective coupling with the dense parent at the harmonics q >= 1: the line itself, or what the contracted chain
+            // in between leaves of it (constant there: the chain buses are linear, their current rows complex-linear)
+            std::vector<cd> geff(Hn), heff(Hn);              // A'(parent, k), A'(k, parent)
+            for (int q = 0; q < Hn; ++q) {
+                geff[q] = yv(q, e_dn[k]);
+                heff[q] = yv(q, e_up[k]);
+            }
             const double* yn = d->Y_N + (size_t)d->dev_of_bus[k] * Hn * Hn * 2;
             for (int q = 0; q < Hn; ++q)
                 for (int p2 = 0; p2 < Hn; ++p2) Yc[(size_t)q * Hn + p2] = -cd(yn[((size_t)q * Hn + p2) * 2], yn[((size_t)q * Hn + p2) * 2 + 1]);
@@ -1413,6 +1421,8 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
                             a_kc = n_kc;
                         }
                         v += dD;
+                        geff[q] = a_kc;
+                        heff[q] = a_ck;
                     }
                 }
                 Yc[(size_t)q * Hn + q] += v;
@@ -1481,19 +1491,20 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
                     const long long o = tile_off(row, col);
                     if (o >= 0) Mt[o] = (t == t2) ? z.real() : (t ? z.imag() : -z.imag());
                 }
-            const int pk = T.parent[k];
-            if (lazy_on && pk >= (d->c > 1 ? d->c : 1) && kept(pk) && (int)lazy_of[pk].size() < LZ_MAX) {
+            const int pk = pard[k];                                   // dense parent, directly or through a contracted chain
+            const bool direct = chain_of[k] < 0;
+            if (lazy_on && (direct || lazy_mode >= 2) && pk >= (d->c > 1 ? d->c : 1) && (int)lazy_of[pk].size() < LZ_MAX) {
                 LazyLeaf ll;
                 ll.k = k;
                 ll.C0.assign((size_t)Hn * Hn, cd(0.0, 0.0));
                 ll.G.assign(Hn, cd(0.0, 0.0));
                 ll.H.assign(Hn, cd(0.0, 0.0));
-                for (int q = 0; q < Hn; ++q) {
-                    const cd ydn = yv(q, e_dn[k]), yup = yv(q, e_up[k]);
-                    ll.G[q] = ydn * (q == 0 ? cd(1.0, 0.0) : img[(size_t)q * Hn]);
-                    ll.H[q] = (q == 0 ? cd(1.0, 0.0) : img[q]) * yup;
-                    if (q >= 1)
-                        for (int p2 = 1; p2 < Hn; ++p2) ll.C0[(size_t)q * Hn + p2] = ydn * img[(size_t)q * Hn + p2] * yv(p2, e_up[k]);
+                // (harmonic position 0 of the borders is state dependent -- power rows of a PQ parent, chain buses -- and comes
+                //  from the leaf per scenario: G0 S_c^-1 and H0 S_k^-1 next to its 2x2 core)
+                for (int q = 1; q < Hn; ++q) {
+                    ll.G[q] = geff[q] * img[(size_t)q * Hn];
+                    ll.H[q] = img[q] * heff[q];
+                    for (int p2 = 1; p2 < Hn; ++p2) ll.C0[(size_t)q * Hn + p2] = geff[q] * img[(size_t)q * Hn + p2] * heff[p2];
                 }
                 lazy_of[pk].push_back((int)lazies.size());
                 lazies.push_back(std::move(ll));
@@ -1572,7 +1583,7 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
         r[8] = dchild_ptr[k];
         r[9] = dchild_ptr[k + 1] - dchild_ptr[k] - n_lazy[k];      // children whose Schur complement is read from HBM
         for (int i = 0; i < 4 && i < r[9]; ++i) r[10 + i] = dchild[dchild_ptr[k] + i];
-        r[14] = (k > 0 && pass[T.parent[k]]) ? 1 : (is_lazy[k] ? 2 : 0);   // 1: linked to its dense parent through a contracted chain; 2: lazy leaf
+        r[14] = ((k > 0 && pass[T.parent[k]]) ? 1 : 0) | (is_lazy[k] ? 2 : 0);   // bit 0: linked to its dense parent through a contracted chain; bit 1: lazy leaf
         r[15] = lz_idx[k] >= 0 ? -(lz_idx[k] + 1) : cleaf_of[k] + 1;     // > 0: constant-inverse leaf, 1 + slot in Tree::d_Minv; < 0: -(1 + lazy record)
         if (cleaf_of[k] < 0) T.lvl_all_leaf[height[k]] = 0;
         for (int i = 0; i < 4; ++i) {                              // first four 2x2-algebra children: (child, e_dn, e_up), no child3 hop
@@ -1710,7 +1721,7 @@ int tree_alloc_scenarios(hpf_handle* h) {
                           (e = hipMalloc((void**)&h->d_chD, sizeof(double) * S * n * (size_t)h->Hn * 4)) != hipSuccess ||
                           (e = hipMalloc((void**)&h->d_chy, sizeof(double) * S * n * (size_t)h->Hn * 2)) != hipSuccess ||
                           (e = hipMalloc((void**)&h->d_chZ, sizeof(double) * S * n * (size_t)h->Hn * 4)) != hipSuccess ||
-                          (e = hipMalloc((void**)&h->d_lfK, sizeof(double) * S * n * 4)) != hipSuccess ||
+                          (e = hipMalloc((void**)&h->d_lfK, sizeof(double) * S * n * 12)) != hipSuccess ||
                           (e = hipMalloc((void**)&h->d_lfS, sizeof(double) * S * n * (size_t)h->Hn * 4)) != hipSuccess)) ||
         ((h->debug_ablate & 16) && (e = hipMalloc((void**)&h->d_dbg, sizeof(long long) * S * n * 8)) != hipSuccess) ||
         (bw && (e = hipMalloc((void**)&h->d_C, sizeof(double) * S * n * (size_t)(((bw + 16) / 16) * ((bw + 16) / 16) * 256))) != hipSuccess)) {

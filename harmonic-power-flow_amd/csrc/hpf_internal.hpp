@@ -143,7 +143,7 @@ struct hpf_handle {
     double* d_chD = nullptr;          // [S][n][Hn][4] harmonic-diagonal addend to the diagonal block of ch
     double* d_chy = nullptr;          // [S][n][Hn][2] addend to the right-hand side of ch
     double* d_fb = nullptr;           // [S][n][Bst] bus-major image of the harmonic mismatch (zeros where there is no equation)
-    double* d_lfK = nullptr;          // [S][n][4]     constant-inverse leaves: (c0 + D)^-1 of the bus (back sweep)
+    double* d_lfK = nullptr;          // [S][n][12]    constant-inverse leaves: (c0 + D)^-1 (back sweep, lazy rebuild), G0 S_c^-1, H0 S_parent^-1 (lazy rebuild)
     double* d_lfS = nullptr;          // [S][n][Hn][4] constant-inverse leaves: S_q^-1 (polar <- rectangular), row-major
     double* d_chZ = nullptr;          // [S][n][Hn][4] D_k^-1 A'(k, ch) of the chain buses k (back substitution)
     double* d_linA = nullptr;         // [S][n][Hn][4] inverse 2x2 blocks of the all-linear-subtree buses

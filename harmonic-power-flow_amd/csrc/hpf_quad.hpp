@@ -168,8 +168,8 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
     const int k = nd0.x, par = nd0.y, diag_e = nd0.z, devk = nd0.w;
     const int e_dn_k = nd1.x, e_up_k = nd1.y, lin_beg = nd1.z, lin_end = nd1.z + nd1.w;
     const int den_beg = nd2.x, n_den = nd2.y;
-    const bool via_chain = nd3.z == 1;       // linked to the dense parent through a contracted chain (k_chain_factor)
-    const bool lazy_leaf = nd3.z == 2;       // the parent rebuilds this leaf's Schur complement itself: only G w goes to HBM
+    const bool via_chain = (nd3.z & 1) != 0; // linked to the dense parent through a contracted chain (k_chain_factor)
+    const bool lazy_leaf = (nd3.z & 2) != 0; // the parent rebuilds this leaf's Schur complement itself: only G w goes to HBM
     const int cleafv = nd3.w;                // constant-inverse leaf: 1 + slot in Minv (0: general path; < 0: lazy-leaf record)
     const bool cleaf = LEAF || cleafv > 0;
     const bool lazy = !LEAF && cleafv < 0;   // this bus has lazy leaves below it
@@ -258,6 +258,13 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
     // wave 1: coupling blocks with the parent, G = A(parent, k) and H = A(k, parent), for the push (E) and the back sweep
     if (par >= 0 && wv == (NT > 1 ? 1 : 0) && lane < NT * 8) {
         double g4[4] = {0.0, 0.0, 0.0, 0.0}, h4[4] = {0.0, 0.0, 0.0, 0.0};
+        cplx lzu = {0.0, -1.0}, lze = {0.0, 1.0}, lzup = {0.0, -1.0}, lzep = {0.0, 1.0};
+        if (lazy_leaf && lane == 0) {        // fundamental voltages of the leaf and of its dense parent (polar maps S_c, S_p at q = 0)
+            lzu = U[(size_t)k * Hn];
+            lze = E[(size_t)k * Hn];
+            lzup = U[(size_t)par * Hn];
+            lzep = E[(size_t)par * Hn];
+        }
         if (lane < Hn) {
             const int q = lane;
             if (via_chain) {
@@ -281,6 +288,18 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
         for (int e = 0; e < 4; ++e) {
             gl[lane * 4 + e] = g4[e];
             hl[lane * 4 + e] = h4[e];
+        }
+        if (lazy_leaf && lane == 0) {
+            // the state-dependent harmonic position 0 of the borders the parent rebuilds the Schur complement from:
+            // G0 S_c^-1 and H0 S_p^-1 (G0, H0 = the polar 2x2 blocks just formed: line, power row or contracted chain alike)
+            const double ic = 1.0 / (-(lzu.im * lze.im) - lze.re * lzu.re), ip = 1.0 / (-(lzup.im * lzep.im) - lzep.re * lzup.re);
+            const double sc0 = lze.im * ic, sc1 = -lze.re * ic, sc2 = -lzu.re * ic, sc3 = -lzu.im * ic;
+            const double sp0 = lzep.im * ip, sp1 = -lzep.re * ip, sp2 = -lzup.re * ip, sp3 = -lzup.im * ip;
+            double* kk = lfK + ((size_t)s * n + k) * 12 + 4;
+            kk[0] = fma(g4[1], sc2, g4[0] * sc0);  kk[1] = fma(g4[1], sc3, g4[0] * sc1);
+            kk[2] = fma(g4[3], sc2, g4[2] * sc0);  kk[3] = fma(g4[3], sc3, g4[2] * sc1);
+            kk[4] = fma(h4[1], sp2, h4[0] * sp0);  kk[5] = fma(h4[1], sp3, h4[0] * sp1);
+            kk[6] = fma(h4[3], sp2, h4[2] * sp0);  kk[7] = fma(h4[3], sp3, h4[2] * sp1);
         }
         if (lane < Hn) {
             double* Hk = Hall + ((size_t)s * n + k) * Hn * 4 + lane * 4;
@@ -380,10 +399,11 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
     for (int e = 0; e < NT * 4; ++e) sumc[e] = 0.0;
     if (n_den > 0) TileIO<B>::load(Cs + (size_t)nd2.z * CT, wv, lg, jj, sumc);
     // ---- L. lazy leaves (Tree::d_lzrec): the Schur complements of the constant-inverse leaves c hanging directly under this bus,
-    //      sum_c A(k,c) D_c^-1 A(c,k) = W [ R(sum_c C0_c) + sum_c R(Gc_c) K_c R(Hr_c) ] S_k,
-    //      with per-model images (L2 / Infinity Cache), the leaves' 2x2 cores K_c = (c0 + D)^-1 (lfK, left by the leaf launch), the
-    //      polar map S_k of this bus on the columns and W = [ur ui; ui -ur] on the power-row pair (blk_power_off = U conj(current
-    //      row)).  Two leaves per rank-4 MFMA, at most 4 lazy leaves per bus.  Only G w comes from the leaves' slots (wave 0
+    //      sum_c A(k,c) D_c^-1 A(c,k) = [ R(sum_c C0_c) + sum_c Gc_c K_c Hr_c ] S_k,
+    //      with per-model images (L2 / Infinity Cache) for the harmonics q >= 1 of the borders Gc (b x 2), Hr (2 x b) -- constant
+    //      there even through a contracted chain --, their state-dependent position 0 (G0 S_c^-1, H0 S_k^-1: power rows of a PQ
+    //      bus, chain buses) and the 2x2 cores K_c = (c0 + D)^-1 left by the leaf launch (lfK), and the polar map S_k of this bus
+    //      on the columns.  Two leaves per rank-4 MFMA, at most 4 lazy leaves per bus.  Only G w comes from the leaves' slots (wave 0
     //      subtracts it from the right-hand side).  Nothing here needs the staged LDS data: the accumulation runs before the
     //      first barrier, the S / W maps are applied after it. ---------------------------------------------------------------------
     d4_t xt[NT];
@@ -391,13 +411,13 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
         const int np = (lzA.y + 1) >> 1;
         const double* aimg = T.lzimg + (size_t)lzA.x + CT;
         const double* himg = aimg + (size_t)np * NT * 64;
-        const double* Ks = lfK + (size_t)s * n * 4 + 2 * (lg & 1);
+        const double* Ks = lfK + (size_t)s * n * 12 + 2 * (lg & 1);
         const int leaf0 = (lg >> 1) ? lzA.w : lzA.z, leaf1 = (lg >> 1) ? lzB.y : lzB.x;
         // every load of the phase is issued at once (addresses from the scalar record), then the MFMAs
         double2 k0 = {0.0, 0.0}, k1 = {0.0, 0.0};
         double h00 = 0.0, h01 = 0.0, h10 = 0.0, h11 = 0.0, a0[NT], a1[NT];
-        if (leaf0 >= 0) k0 = *reinterpret_cast<const double2*>(Ks + (size_t)leaf0 * 4);
-        if (leaf1 >= 0) k1 = *reinterpret_cast<const double2*>(Ks + (size_t)leaf1 * 4);
+        if (leaf0 >= 0) k0 = *reinterpret_cast<const double2*>(Ks + (size_t)leaf0 * 12);
+        if (leaf1 >= 0) k1 = *reinterpret_cast<const double2*>(Ks + (size_t)leaf1 * 12);
         // images: per pair the A operands [lane][NT] and the two rows of R(Hr) [tile column][lane][2] -- 16-byte accesses
         {
             const double2 h = *reinterpret_cast<const double2*>(himg + (size_t)(wv * 64 + lane) * 2);
@@ -413,6 +433,24 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
         } else {
 #pragma unroll
             for (int tr = 0; tr < NT; ++tr) a1[tr] = 0.0;
+        }
+        // harmonic position 0 of the borders is per scenario (left by the leaves next to their cores): rows 0 / 1 of the A
+        // operand = G0 S_c^-1, columns 0 / 1 of R(Hr) = H0 S_k^-1 (the S_k map below then restores H0)
+        if (jj < 2) {
+            const double* L0 = lfK + ((size_t)s * n + (leaf0 >= 0 ? leaf0 : 0)) * 12;
+            const double* L1 = lfK + ((size_t)s * n + (leaf1 >= 0 ? leaf1 : 0)) * 12;
+            if (leaf0 >= 0) a0[0] = L0[4 + jj * 2 + (lg & 1)];
+            if (leaf1 >= 0) a1[0] = L1[4 + jj * 2 + (lg & 1)];
+            if (wv == 0) {
+                if (leaf0 >= 0) {
+                    h00 = L0[8 + jj];
+                    h01 = L0[10 + jj];
+                }
+                if (leaf1 >= 0) {
+                    h10 = L1[8 + jj];
+                    h11 = L1[10 + jj];
+                }
+            }
         }
         {
             double xv[NT * 4];
@@ -468,11 +506,6 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
                 const double v = xt[tr][reg];
                 xt[tr][reg] = fma(xor1_f64(v), soth, v * sown);
             }
-        if (k < M.m) {                                                   // power rows 0 / 1 of a PQ bus
-            const double ur = tab[0], ui = tab[1];
-            const double v = xt[0][0], pr = xor16_f64(v);
-            xt[0][0] = (mcol && lg < 2) ? (lg == 0 ? fma(ui, pr, ur * v) : fma(ui, pr, -(ur * v))) : v;
-        }
 #pragma unroll
         for (int e = 0; e < NT * 4; ++e)
             if (16 * (e >> 2) + 4 * (e & 3) < B) sumc[e] += xt[e >> 2][e & 3];
@@ -516,7 +549,7 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
             kv0 = fma(k01, r1, k00 * r0);
             kv1 = fma(k11, r1, k10 * r0);
             if (tid == 0) {                 // the back sweep rebuilds  A^-1 t  from the image, this 2x2 and S^-1: no inverse goes to HBM
-                double* kk = lfK + ((size_t)s * n + k) * 4;
+                double* kk = lfK + ((size_t)s * n + k) * 12;
                 kk[0] = k00; kk[1] = k01; kk[2] = k10; kk[3] = k11;
             }
             if (tid < Hn * 4) lfS[(so + (size_t)k * Hn) * 4 + tid] = tab[tid];
@@ -827,7 +860,7 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16)) void k_back_q(
             if (tid < 2) zl[tid] = acc + (tid == 0 ? t0 : t1v);   // [I Lr] t
             __syncthreads();
             if (tid < B) {
-                const double* kk = lfK + ((size_t)s * n + k) * 4;
+                const double* kk = lfK + ((size_t)s * n + k) * 12;
                 const double u0 = fma(kk[1], zl[1], kk[0] * zl[0]), u1 = fma(kk[3], zl[1], kk[2] * zl[0]);     // (c0 + D)^-1 [I Lr] t
                 const double c0r = tid < 2 ? (tid == 0 ? 1.0 : 0.0) : mcl[tid * 2];
                 const double c1r = tid < 2 ? (tid == 1 ? 1.0 : 0.0) : mcl[tid * 2 + 1];
