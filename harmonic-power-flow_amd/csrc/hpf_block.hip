@@ -1382,13 +1382,13 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
         for (int r2 = 0; r2 < T.n_chains; ++r2) chain_of[T.chain_ch[r2]] = r2;
         const int NTc = (BWc + 16) / 16;
         const size_t CTc = (size_t)NTc * NTc * 256;
-        for (int pos = 0; pos < T.n_dense; ++pos) {
-            const int k = T.lvl_nodes[pos];
-            if (k < d->m || dchild_ptr[k + 1] != dchild_ptr[k] || d->dev_of_bus[k] < 0) continue;
-            std::vector<cd> Yc((size_t)Hn * Hn);
+        // constant complex block of a nonlinear bus k in rectangular coordinates and its effective couplings
+        auto build_Yc = [&](int k, std::vector<cd>& Yc, std::vector<cd>& geff, std::vector<cd>& heff) {
+            Yc.assign((size_t)Hn * Hn, cd(0.0, 0.0));
             // effective coupling with the dense parent at the harmonics q >= 1: the line itself, or what the contracted chain
             // in between leaves of it (constant there: the chain buses are linear, their current rows complex-linear)
-            std::vector<cd> geff(Hn), heff(Hn);              // A'(parent, k), A'(k, parent)
+            geff.assign(Hn, cd(0.0, 0.0));                   // A'(parent, k), A'(k, parent)
+            heff.assign(Hn, cd(0.0, 0.0));
             for (int q = 0; q < Hn; ++q) {
                 geff[q] = yv(q, e_dn[k]);
                 heff[q] = yv(q, e_up[k]);
@@ -1427,12 +1427,14 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
                 }
                 Yc[(size_t)q * Hn + q] += v;
             }
+        };
+        auto border_image = [&](const std::vector<cd>& Yc, std::vector<cd>& img) -> bool {
+            const int Hh = Hn - 1;
             // Bordered form around the fundamental (index 0), the only place where a state-dependent 2x2 term D enters:
             //     [a00 + D  A0h]^-1        [0   0    ]   [  I   ]                     [        ]
             //     [Ah0      Ahh]      =    [0  Ahh^-1] + [ Lc_h ] (c0 + D)^-1  [ I  Lr_h ],   Lc_h = -Ahh^-1 Ah0,  Lr_h = -A0h Ahh^-1,
             // c0 = a00 - A0h Ahh^-1 Ah0.  Everything but D is constant: keep R(Ahh^-1), R(Lc_h), R(Lr_h), R(c0) as ONE b x b image
             // (additive rank-2 update on the device: no cancellation, unlike a Woodbury correction of the full inverse).
-            const int Hh = Hn - 1;
             std::vector<cd> Ah((size_t)Hh * Hh), Bh((size_t)Hh * Hh, cd(0.0, 0.0));
             for (int q = 0; q < Hh; ++q)
                 for (int p2 = 0; p2 < Hh; ++p2) Ah[(size_t)q * Hh + p2] = Yc[(size_t)(q + 1) * Hn + p2 + 1];
@@ -1466,8 +1468,8 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
                     }
                 }
             }
-            if (!ok) continue;                                       // singular constant part: leave the bus on the general path
-            std::vector<cd> img((size_t)Hn * Hn, cd(0.0, 0.0));      // complex image: [c0 Lr_h; Lc_h Ahh^-1]
+            if (!ok) return false;                                   // singular constant part: leave the bus on the general path
+            img.assign((size_t)Hn * Hn, cd(0.0, 0.0));               // complex image: [c0 Lr_h; Lc_h Ahh^-1]
             cd c0 = Yc[0];
             for (int q = 0; q < Hh; ++q) {
                 cd lc(0.0, 0.0), lr(0.0, 0.0);
@@ -1481,6 +1483,14 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
             }
             for (int p2 = 0; p2 < Hh; ++p2) c0 += Yc[p2 + 1] * img[(size_t)(p2 + 1) * Hn];   // a00 + A0h Lc_h
             img[0] = c0;
+            return true;
+        };
+        for (int pos = 0; pos < T.n_dense; ++pos) {
+            const int k = T.lvl_nodes[pos];
+            if (k < d->m || dchild_ptr[k + 1] != dchild_ptr[k] || d->dev_of_bus[k] < 0) continue;
+            std::vector<cd> Yc, geff, heff, img;
+            build_Yc(k, Yc, geff, heff);
+            if (!border_image(Yc, img)) continue;
             cleaf_of[k] = T.n_cleaf++;
             minv.resize((size_t)T.n_cleaf * CTc, 0.0);
             double* Mt = &minv[(size_t)cleaf_of[k] * CTc];
