@@ -1340,6 +1340,13 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
         std::vector<std::complex<double>> C0, G, H;
     };
     std::vector<LazyLeaf> lazies;
+    // super-leaves: nonlinear buses whose dense children are all lazy leaves -- bordered low-rank inverse instead of Gauss-Jordan
+    std::vector<int> sl_slot(n, 0);                            // 1 + slot of the bus's Z0 image in Tree::d_Minv
+    std::vector<long long> sl_off(n, -1);                      // offset of [Tc | Pb | Qb] in slimg
+    std::vector<double> slimg;
+    const char* sl_env = getenv("HPF_SLEAF");
+    const bool sleaf_on = sl_env && atoi(sl_env) != 0;
+    int n_sleaf = 0;
     std::vector<std::vector<int>> lazy_of(n);
     std::vector<int> is_lazy(n, 0);
     const char* lz_env = getenv("HPF_LAZY");
@@ -1378,8 +1385,11 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
                 }
                 dl[(size_t)q * n + i] = v;
             }
-        std::vector<int> chain_of(n, -1);
-        for (int r2 = 0; r2 < T.n_chains; ++r2) chain_of[T.chain_ch[r2]] = r2;
+        std::vector<int> chain_of(n, -1), chain_top(n, -1);
+        for (int r2 = 0; r2 < T.n_chains; ++r2) {
+            chain_of[T.chain_ch[r2]] = r2;
+            chain_top[T.chain_nodes[T.chain_ptr[r2 + 1] - 1]] = r2;
+        }
         const int NTc = (BWc + 16) / 16;
         const size_t CTc = (size_t)NTc * NTc * 256;
         // constant complex block of a nonlinear bus k in rectangular coordinates and its effective couplings
@@ -1401,7 +1411,24 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
                 if (q >= 1) {
                     for (int cp = T.child_ptr[k]; cp < T.child_mid[k]; ++cp) {         // linear subtrees below k
                         const int g = T.child[cp];
-                        v -= yv(q, e_dn[g]) * yv(q, e_up[g]) / dl[(size_t)q * n + g];
+                        if (!pass[g]) {
+                            v -= yv(q, e_dn[g]) * yv(q, e_up[g]) / dl[(size_t)q * n + g];
+                            continue;
+                        }
+                        // top of a contracted chain below k (only at buses with dense children: super-leaves): what the chain's
+                        // elimination leaves on k's diagonal -- independent of the dense bus at its lower end, which comes later
+                        const int r3 = chain_top[g];
+                        cd carry(0.0, 0.0);
+                        for (int idx = T.chain_ptr[r3]; idx < T.chain_ptr[r3 + 1]; ++idx) {
+                            const int kk = T.chain_nodes[idx];
+                            cd dk = yv(q, diag[kk]) + carry;
+                            for (int cp2 = T.child_ptr[kk]; cp2 < T.child_mid[kk]; ++cp2) {
+                                const int g2 = T.child[cp2];
+                                dk -= yv(q, e_dn[g2]) * yv(q, e_up[g2]) / dl[(size_t)q * n + g2];
+                            }
+                            carry = -yv(q, e_dn[kk]) * yv(q, e_up[kk]) / dk;
+                        }
+                        v += carry;
                     }
                     if (chain_of[k] >= 0) {                                              // contracted chain above k (k_chain_factor)
                         const int r2 = chain_of[k];
@@ -1521,6 +1548,71 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
                 is_lazy[k] = 1;
             }
         }
+        // ---- super-leaves: M_k = A_k - sum_c Gc_c K_c Hr_c + E0 D_k E0^T,  A_k = Yc_k - sum_c C0_c.  Border the
+        //      system with z_c = K_c Hr_c x and eliminate the harmonic part of x with the constant Ahh_k^-1:
+        //          M_k^-1 = [0 0; 0 Ahh^-1] + Pb T^-1 Qb,    T = Tc + blockdiag(D_k, K_1^-1, ..., K_L^-1) - (G0/H0 borders),
+        //      Tc, Pb (b x m), Qb (m x b), m = 2 + 2L constant per model; T is m x m per scenario (k_factor_q, "sleaf" branch).
+        for (int pos = 0; sleaf_on && pos < T.n_dense; ++pos) {
+            const int k = T.lvl_nodes[pos];
+            const int L = (int)lazy_of[k].size();
+            if (k < d->m || k == 0 || d->dev_of_bus[k] < 0 || L == 0 || dchild_ptr[k + 1] - dchild_ptr[k] != L) continue;
+            std::vector<cd> A, geff, heff, imgk;
+            build_Yc(k, A, geff, heff);
+            for (int li : lazy_of[k])
+                for (int q = 1; q < Hn; ++q)
+                    for (int p2 = 1; p2 < Hn; ++p2) A[(size_t)q * Hn + p2] -= lazies[li].C0[(size_t)q * Hn + p2];
+            if (!border_image(A, imgk)) continue;
+            const int m1 = 1 + L, mr = 2 * m1;
+            auto Ainv = [&](int q, int p2) { return imgk[(size_t)q * Hn + p2]; };          // q, p2 >= 1
+            std::vector<cd> Tc((size_t)m1 * m1, cd(0.0, 0.0)), Pb((size_t)Hn * m1, cd(0.0, 0.0)), Qb((size_t)m1 * Hn, cd(0.0, 0.0));
+            Tc[0] = imgk[0];
+            Pb[0] = cd(1.0, 0.0);
+            Qb[0] = cd(1.0, 0.0);
+            for (int q = 1; q < Hn; ++q) {
+                Pb[(size_t)q * m1] = imgk[(size_t)q * Hn];                                    // Lc
+                Qb[q] = imgk[q];                                                              // Lr
+            }
+            for (int i = 0; i < L; ++i) {
+                const LazyLeaf& li = lazies[lazy_of[k][i]];
+                cd t0c(0.0, 0.0), tc0(0.0, 0.0);
+                for (int q = 1; q < Hn; ++q) {
+                    t0c -= imgk[q] * li.G[q];                                                 // -Lr gh_c
+                    tc0 -= li.H[q] * imgk[(size_t)q * Hn];                                    // -hh_c Lc
+                    cd pbv(0.0, 0.0), qbv(0.0, 0.0);
+                    for (int p2 = 1; p2 < Hn; ++p2) {
+                        pbv += Ainv(q, p2) * li.G[p2];                                        // Ahh^-1 gh_c
+                        qbv += li.H[p2] * Ainv(p2, q);                                        // hh_c Ahh^-1
+                    }
+                    Pb[(size_t)q * m1 + 1 + i] = pbv;
+                    Qb[(size_t)(1 + i) * Hn + q] = qbv;
+                }
+                Tc[1 + i] = t0c;
+                Tc[(size_t)(1 + i) * m1] = tc0;
+                for (int j = 0; j < L; ++j) {
+                    const LazyLeaf& lj = lazies[lazy_of[k][j]];
+                    cd v(0.0, 0.0);
+                    for (int q = 1; q < Hn; ++q) v -= Qb[(size_t)(1 + i) * Hn + q] * lj.G[q];   // -hh_i Ahh^-1 gh_j
+                    Tc[(size_t)(1 + i) * m1 + 1 + j] = v;
+                }
+            }
+            auto R = [](cd z, int t, int t2) { return (t == t2) ? z.real() : (t ? z.imag() : -z.imag()); };
+            sl_slot[k] = ++T.n_cleaf;                                                         // Z0 image: [0 0; 0 Ahh^-1]
+            minv.resize((size_t)T.n_cleaf * CTc, 0.0);
+            double* Mt = &minv[(size_t)(T.n_cleaf - 1) * CTc];
+            for (int row = 2; row < b; ++row)
+                for (int col = 2; col < b; ++col) {
+                    const long long o = tile_off(row, col);
+                    if (o >= 0) Mt[o] = R(Ainv(row >> 1, col >> 1), row & 1, col & 1);
+                }
+            sl_off[k] = (long long)slimg.size();
+            for (int r2 = 0; r2 < mr; ++r2)
+                for (int c2 = 0; c2 < mr; ++c2) slimg.push_back(R(Tc[(size_t)(r2 >> 1) * m1 + (c2 >> 1)], r2 & 1, c2 & 1));
+            for (int row = 0; row < b; ++row)
+                for (int c2 = 0; c2 < mr; ++c2) slimg.push_back(R(Pb[(size_t)(row >> 1) * m1 + (c2 >> 1)], row & 1, c2 & 1));
+            for (int r2 = 0; r2 < mr; ++r2)
+                for (int col = 0; col < b; ++col) slimg.push_back(R(Qb[(size_t)(r2 >> 1) * Hn + (col >> 1)], r2 & 1, col & 1));
+            ++n_sleaf;
+        }
     }
     // per-parent lazy records and images; the parent's dense-child list keeps its non-lazy children first
     std::vector<int> lzrec, lz_idx(n, -1), n_lazy(n, 0);
@@ -1574,6 +1666,8 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
             std::stable_partition(dchild.begin() + dchild_ptr[pk], dchild.begin() + dchild_ptr[pk + 1], [&](int ch) { return !is_lazy[ch]; });
         }
     }
+    const long long sl_base = (long long)lzimg.size();          // super-leaf constants ride behind the lazy images
+    lzimg.insert(lzimg.end(), slimg.begin(), slimg.end());
     T.lvl_all_leaf.assign(T.n_levels > 0 ? T.n_levels : 1, 1);
     for (int pos = 0; pos < T.n_dense; ++pos) {
         const int k = T.lvl_nodes[pos];
@@ -1606,6 +1700,11 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
         for (int i = 28; i < 36; ++i) r[i] = (i >= 30 && i < 34) ? -1 : 0;
         if (lz_idx[k] >= 0)                                        // lazy-leaf record inline: image offset, L, leaf ids[4]
             for (int i = 0; i < 6; ++i) r[28 + i] = lzrec[(size_t)lz_idx[k] * 8 + i];
+        if (sl_off[k] >= 0 && lz_idx[k] >= 0) {                    // super-leaf: Z0 image slot, offset of [Tc | Pb | Qb]
+            r[14] |= 4;
+            r[34] = sl_slot[k];
+            r[35] = (int)(sl_base + sl_off[k]);
+        }
         const int kb = T.dep_nodes[pos];
         bdesc[(size_t)pos * 4 + 0] = kb;
         bdesc[(size_t)pos * 4 + 1] = pard[kb];
@@ -1653,8 +1752,8 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
                 (i >= d->m ? sl_nl : sl_lin)++;
                 sl_lvl[height[i] < 3 ? height[i] : 3]++;
             }
-        fprintf(stderr, "hpf tree: buses whose dense children are all lazy leaves: %d nonlinear + %d linear (levels 1/2/3+: %d/%d/%d)\n",
-                sl_nl, sl_lin, sl_lvl[1], sl_lvl[2], sl_lvl[3]);
+        fprintf(stderr, "hpf tree: buses whose dense children are all lazy leaves: %d nonlinear + %d linear (levels 1/2/3+: %d/%d/%d), %d built as super-leaves\n",
+                sl_nl, sl_lin, sl_lvl[1], sl_lvl[2], sl_lvl[3], n_sleaf);
     }
     if (getenv("HPF_TREE_INFO"))
         fprintf(stderr, "hpf tree (%s): %d buses, %d dense in %d levels, %d chains, %d constant-inverse leaves, %d lazy under %d parents\n",

@@ -172,7 +172,9 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
     const bool lazy_leaf = (nd3.z & 2) != 0; // the parent rebuilds this leaf's Schur complement itself: only G w goes to HBM
     const int cleafv = nd3.w;                // constant-inverse leaf: 1 + slot in Minv (0: general path; < 0: lazy-leaf record)
     const bool cleaf = LEAF || cleafv > 0;
+    const bool sleaf = !LEAF && (nd3.z & 4) != 0;   // super-leaf: every dense child is a lazy leaf -> bordered low-rank inverse, no Gauss-Jordan
     const bool lazy = !LEAF && cleafv < 0;   // this bus has lazy leaves below it
+    const bool cleafr = cleaf || sleaf;      // roles of a constant-part bus: S^-1 staged, network diagonal lives in the images
     // lazy-leaf record (Tree::d_lzrec, 8 ints: image offset, L, leaf ids[4])
     int4 lzA = {0, 0, -1, -1}, lzB = {-1, -1, 0, 0};
     if (lazy) {                               // (inline copy of the record: ints 28..35 of the node record, same scalar round trip)
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
     // ---- A0. the device type's Y_N (Hn x Hn complex, shared by every scenario: L2) -> LDS, once per block, by the upper half of
     //      the waves (their roles are the light ones): loaded and stored at once -- held in registers across the roles the values
     //      get spilled to scratch, and the reload costs more than the L2 round trip exposed here --------------------------------
-    if (nl && !cleaf && wv >= NT / 2) {
+    if (nl && !cleafr && wv >= NT / 2) {
         constexpr int YT = 64 * (NT - NT / 2);                                   // staging threads
         constexpr int YNL = ((B / 2) * (B / 2) + YT - 1) / YT;
         const double2* ynd = reinterpret_cast<const double2*>(M.YN + (size_t)devk * Hn * Hn);
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
         }
         __builtin_amdgcn_sched_barrier(0);
         double* t0 = tab + lane * 4;
-        if (cleaf) {
+        if (cleafr) {
             // polar -> rectangular map of harmonic q: S = [dU/dtheta | dU/dV] = [-ui er; ur ei]; keep S^-1 (row-major)
             const double idet = 1.0 / (-(u.im * e.im) - e.re * u.re);
             t0[0] = e.im * idet;   t0[1] = -e.re * idet;
@@ -341,8 +343,8 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
                 const Blk2 blk = prow ? blk_power_diag(yd, uk, ek, I0v) : blk_current_diag(yd, uk, ek, yn, k >= M.m);
                 // (constant-inverse leaf: the network part lives in the precomputed inverse; rows 0/1 carry the state-dependent
                 //  2x2 term of the fundamental, i.e. what the 2x2-algebra neighbours left there)
-                d0 = (cleaf ? 0.0 : pick(blk, tr_, 0)) + a0;
-                d1 = (cleaf ? 0.0 : pick(blk, tr_, 1)) + a1;
+                d0 = (cleafr ? 0.0 : pick(blk, tr_, 0)) + a0;
+                d1 = (cleafr ? 0.0 : pick(blk, tr_, 1)) + a1;
                 y = fy + ay;
             }
 #ifdef HPF_FACTOR_STAMPS
@@ -407,7 +409,7 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
     //      subtracts it from the right-hand side).  Nothing here needs the staged LDS data: the accumulation runs before the
     //      first barrier, the S / W maps are applied after it. ---------------------------------------------------------------------
     d4_t xt[NT];
-    if (lazy) {
+    if (lazy && !sleaf) {
         const int np = (lzA.y + 1) >> 1;
         const double* aimg = T.lzimg + (size_t)lzA.x + CT;
         const double* himg = aimg + (size_t)np * NT * 64;
@@ -494,7 +496,7 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
         }
     }
 
-    if (lazy) {
+    if (lazy && !sleaf) {
         const double* t0 = tab + (p < Hn ? p : 0) * 4;                   // [ur, ui, ei, -er] of the column's harmonic
         const bool mcol = col < B;                                       // (column B already holds G w: untouched)
         const double sown = mcol ? (t1 ? t0[2] : -t0[1]) : 1.0;          // S[t1][t1],  S = [-ui er; ur ei]
@@ -583,6 +585,162 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
                     double acc = cc[0][row];
 #pragma unroll
                     for (int w2 = 1; w2 < NT; ++w2) acc += cc[w2][row];
+                    ct[tr][reg] = acc;
+                }
+        }
+        HPF_STAMP(st1);
+        HPF_STAMP(st3);
+    } else if (sleaf) {
+        // ================= super-leaf: all dense children are lazy leaves =================================
+        //   Drect^-1 = [0 0; 0 Ahh^-1] + Pb T^-1 Qb,   T = Tc + blockdiag(D, K_1^-1, ..., K_L^-1) - borders(G0 S_c^-1, H0 S_k^-1),
+        //   m = 2 + 2L <= 10: T is inverted in LDS by wave 0 (Gauss-Jordan, partial pivoting); Tc, Pb, Qb, the Ahh^-1 image: per model.
+        const int L = lzA.y, m = 2 + 2 * L, m2 = 2 * m;
+        const double* simg = T.lzimg + (size_t)lzB.w;                    // Tc [m][m] | Pb [b][m] | Qb [m][b]
+        __shared__ double slb[2 * B * 10 + 200];
+        double* aug = slb + 2 * B * 10;                                  // [m][20]: T | I  ->  I | T^-1
+        double* pbl = slb;                                               // Pb, then Qb
+        double* qbl = pbl + B * 10;
+        {
+            double mv[NT * 4];
+#pragma unroll
+            for (int e = 0; e < NT * 4; ++e) mv[e] = 0.0;
+            TileIO<B>::load(Minv + (size_t)(lzB.z - 1) * CT, wv, lg, jj, mv);
+#pragma unroll
+            for (int e = 0; e < NT * 4; ++e) ct[e >> 2][e & 3] = mv[e];
+        }
+        for (int idx = tid; idx < b * m; idx += 64 * NT) {
+            pbl[idx] = simg[m * m + idx];
+            qbl[idx] = simg[m * m + b * m + idx];
+        }
+        if (wv == 0) {
+            for (int idx = lane; idx < m * m2; idx += 64) {
+                const int r2 = idx / m2, c2 = idx - r2 * m2;
+                aug[r2 * 20 + c2] = c2 < m ? simg[r2 * m + c2] : (c2 - m == r2 ? 1.0 : 0.0);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) {                                             // D = Delta_polar S_0^-1 (the 2x2 term of the fundamental)
+                const double si0 = tab[0], si1 = tab[1], si2 = tab[2], si3 = tab[3];
+                const double p00 = dgb[0], p01 = dgb[1], p10 = dgb[3], p11 = dgb[4];
+                aug[0] += fma(p01, si2, p00 * si0);
+                aug[1] += fma(p01, si3, p00 * si1);
+                aug[20] += fma(p11, si2, p10 * si0);
+                aug[21] += fma(p11, si3, p10 * si1);
+            } else if (lane <= L) {                                      // leaf i: K_i^-1 on the diagonal, -G0 S_c^-1 / -H0 S_k^-1 borders
+                const int i = lane - 1, bc = 2 + 2 * i;
+                const int leaf = i == 0 ? lzA.z : (i == 1 ? lzA.w : (i == 2 ? lzB.x : lzB.y));
+                const double* kk = lfK + ((size_t)s * n + leaf) * 12;
+                double q00, q01, q10, q11;
+                inv2(kk[0], kk[1], kk[2], kk[3], q00, q01, q10, q11);
+                aug[bc * 20 + bc] += q00;
+                aug[bc * 20 + bc + 1] += q01;
+                aug[(bc + 1) * 20 + bc] += q10;
+                aug[(bc + 1) * 20 + bc + 1] += q11;
+                aug[bc] -= kk[4];
+                aug[bc + 1] -= kk[5];
+                aug[20 + bc] -= kk[6];
+                aug[20 + bc + 1] -= kk[7];
+                aug[bc * 20] -= kk[8];
+                aug[bc * 20 + 1] -= kk[9];
+                aug[(bc + 1) * 20] -= kk[10];
+                aug[(bc + 1) * 20 + 1] -= kk[11];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int j = 0; j < m; ++j) {
+                // pivot row: largest |aug[i][j]|, i >= j (lanes 0..15 hold the candidates, butterfly over the DPP row)
+                double av = (lane >= j && lane < m) ? fabs(aug[lane * 20 + j]) : -1.0;
+                int pi = lane;
+#pragma unroll
+                for (int off = 8; off >= 1; off >>= 1) {
+                    const double ov = __shfl_xor(av, off, 16);
+                    const int op = __shfl_xor(pi, off, 16);
+                    if (ov > av || (ov == av && op < pi)) {
+                        av = ov;
+                        pi = op;
+                    }
+                }
+                pi = __builtin_amdgcn_readfirstlane(pi);
+                if (pi != j && lane < m2) {
+                    const double a = aug[j * 20 + lane], b2 = aug[pi * 20 + lane];
+                    aug[j * 20 + lane] = b2;
+                    aug[pi * 20 + lane] = a;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const double ipv = 1.0 / aug[j * 20 + j];
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (lane < m2) aug[j * 20 + lane] *= ipv;
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                double nv[4];                                            // up to 200 entries: 4 per lane, all read before any is written
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4) {
+                    const int idx = lane + 64 * t4;
+                    const int r2 = idx / m2, c2 = idx - r2 * m2;
+                    nv[t4] = 0.0;
+                    if (idx < m * m2 && r2 != j) nv[t4] = aug[r2 * 20 + c2] - aug[r2 * 20 + j] * aug[j * 20 + c2];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4) {
+                    const int idx = lane + 64 * t4;
+                    const int r2 = idx / m2, c2 = idx - r2 * m2;
+                    if (idx < m * m2 && r2 != j) aug[r2 * 20 + c2] = nv[t4];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        __syncthreads();
+        // own column of  T^-1 Qb  (m values), then the elements  [0 0; 0 Ahh^-1] + Pb (T^-1 Qb)
+        double wq[10];
+        {
+            double qb[10];
+#pragma unroll
+            for (int j = 0; j < 10; ++j) qb[j] = (j < m && col < b) ? qbl[j * b + col] : 0.0;
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                double acc = 0.0;
+#pragma unroll
+                for (int j = 0; j < 10; ++j)
+                    if (j < m) acc = fma(aug[(i < m ? i : 0) * 20 + m + j], qb[j], acc);
+                wq[i] = i < m ? acc : 0.0;
+            }
+        }
+        const double yc = col < B ? dgb[col * 3 + 2] : 0.0;
+#pragma unroll
+        for (int tr = 0; tr < NT; ++tr)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                if (16 * tr + 4 * reg >= B) continue;
+                const int row = 16 * tr + 4 * reg + lg;
+                double v = ct[tr][reg];
+                const double* pr_ = pbl + (row < b ? row : 0) * m;
+#pragma unroll
+                for (int i = 0; i < 10; ++i)
+                    if (i < m) v = fma(pr_[i], wq[i], v);
+                v = row < b ? v : 0.0;
+                const double pr = xor16_f64(v);                                             // the other row of the harmonic
+                const double* si = tab + (row >> 1) * 4 + 2 * t;
+                v = t ? fma(si[1], v, si[0] * pr) : fma(si[1], pr, si[0] * v);              // S_q^-1 from the left
+                ct[tr][reg] = v;
+                const double sm = row_sum16(v * yc);
+                if (jj == 0) panel[0][wv * 64 + row] = sm;
+            }
+        __syncthreads();
+        if (wv == tcB && jj == jjB) {                                                       // w = A^-1 y into column B
+#pragma unroll
+            for (int tr = 0; tr < NT; ++tr)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    if (16 * tr + 4 * reg >= B) continue;
+                    const int row = 16 * tr + 4 * reg + lg;
+                    double acc = panel[0][row];
+#pragma unroll
+                    for (int w2 = 1; w2 < NT; ++w2) acc += panel[0][w2 * 64 + row];
                     ct[tr][reg] = acc;
                 }
         }
