@@ -647,51 +647,41 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            for (int j = 0; j < m; ++j) {
-                // pivot row: largest |aug[i][j]|, i >= j (lanes 0..15 hold the candidates, butterfly over the DPP row)
-                double av = (lane >= j && lane < m) ? fabs(aug[lane * 20 + j]) : -1.0;
-                int pi = lane;
+            // Gauss-Jordan with partial pivoting in registers: lane r owns row r of [T | I]; the pivot row is broadcast with
+            // v_readlane, rows are never swapped (the lane that was the pivot of column j ends up holding row j of T^-1)
+            double row[20];
 #pragma unroll
-                for (int off = 8; off >= 1; off >>= 1) {
-                    const double ov = __shfl_xor(av, off, 16);
-                    const int op = __shfl_xor(pi, off, 16);
-                    if (ov > av || (ov == av && op < pi)) {
-                        av = ov;
-                        pi = op;
-                    }
-                }
-                pi = __builtin_amdgcn_readfirstlane(pi);
-                if (pi != j && lane < m2) {
-                    const double a = aug[j * 20 + lane], b2 = aug[pi * 20 + lane];
-                    aug[j * 20 + lane] = b2;
-                    aug[pi * 20 + lane] = a;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                const double ipv = 1.0 / aug[j * 20 + j];
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                if (lane < m2) aug[j * 20 + lane] *= ipv;
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                double nv[4];                                            // up to 200 entries: 4 per lane, all read before any is written
+            for (int c2 = 0; c2 < 20; ++c2) row[c2] = (lane < m && c2 < m2) ? aug[lane * 20 + c2] : 0.0;
+            bool used = lane >= m;
+            int mycol = -1;
 #pragma unroll
-                for (int t4 = 0; t4 < 4; ++t4) {
-                    const int idx = lane + 64 * t4;
-                    const int r2 = idx / m2, c2 = idx - r2 * m2;
-                    nv[t4] = 0.0;
-                    if (idx < m * m2 && r2 != j) nv[t4] = aug[r2 * 20 + c2] - aug[r2 * 20 + j] * aug[j * 20 + c2];
-                }
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                __builtin_amdgcn_wave_barrier();
+            for (int j = 0; j < 10; ++j) {
+                if (j < m) {                                             // (m is workgroup-uniform)
+                    const double cand = used ? -1.0 : fabs(row[j]);
+                    double mx = cand;                                    // max over the 16 lanes of the DPP row (all receive it)
+                    mx = fmax(mx, dpp_f64<0xB1>(mx));
+                    mx = fmax(mx, dpp_f64<0x4E>(mx));
+                    mx = fmax(mx, dpp_f64<0x141>(mx));
+                    mx = fmax(mx, dpp_f64<0x140>(mx));
+                    const unsigned long long bal = __builtin_amdgcn_ballot_w64(!used && cand == mx);
+                    const int pi = __builtin_ctzll(bal | (1ull << 63));
+                    double prow[20];
 #pragma unroll
-                for (int t4 = 0; t4 < 4; ++t4) {
-                    const int idx = lane + 64 * t4;
-                    const int r2 = idx / m2, c2 = idx - r2 * m2;
-                    if (idx < m * m2 && r2 != j) aug[r2 * 20 + c2] = nv[t4];
+                    for (int c2 = 0; c2 < 20; ++c2)
+                        prow[c2] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(row[c2]), pi),
+                                                    __builtin_amdgcn_readlane(__double2loint(row[c2]), pi));
+                    const double ipv = 1.0 / prow[j];
+                    const bool me = lane == pi;
+                    const double f = me ? 0.0 : row[j] * ipv;
+#pragma unroll
+                    for (int c2 = 0; c2 < 20; ++c2) row[c2] = me ? prow[c2] * ipv : fma(-f, prow[c2], row[c2]);
+                    used = used || me;
+                    mycol = me ? j : mycol;
                 }
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                __builtin_amdgcn_wave_barrier();
+            }
+            if (lane < m) {
+#pragma unroll
+                for (int c2 = 0; c2 < 20; ++c2) aug[mycol * 20 + c2] = row[c2];   // columns m .. 2m-1: T^-1
             }
         }
         __syncthreads();

@@ -545,15 +545,20 @@ def test_two_nonlinear_device_types_vs_oracle(tmp_path):
     st = hp.Settings(H_MAX=11)
     buses, lines, m, n, c = hp.init_network(fb, fl, settings=st)
     assert set(buses.component[buses.type == "nonlinear"]) == {"smps", "led"}
-    r = o.hpf(o.init_network(fb, fl), st.HARMONICS, True, str(ne_dir))
-    Uo = r["Vm"] * np.exp(1j * r["Va"])
-    for solver in ("dense", "block_tree"):
-        V, err_h, n_iter_h, _ = hp.hpf(buses, lines, True, settings=st, ne_dir=str(ne_dir), solver=solver, verbose=False,
-                                       return_jacobian=False)
-        Ud = V["V_m"].to_numpy() * np.exp(1j * V["V_a"].to_numpy())
-        print(f"\ntwo device types, {solver}: it {n_iter_h} (oracle {r['n_iter_h']}) err {err_h:.2e} max|dU| {np.abs(Ud - Uo).max():.2e}")
-        assert err_h <= 1e-4 and n_iter_h < 50
-        assert np.abs(Ud - Uo).max() < TOL_V
+    # at the reference's stop rule (1e-4) the last iterate may be shallow, and what two linear solvers differ by there is rounding
+    # times the remaining distance (solver-sensitive cases): bound that loosely, and compare tightly where both
+    # sides have converged all the way (threshold 1e-10)
+    for thresh, tol in ((1e-4, 1e-6), (1e-10, TOL_V)):
+        r = o.hpf(o.init_network(fb, fl), st.HARMONICS, True, str(ne_dir), thresh_h=thresh)
+        Uo = r["Vm"] * np.exp(1j * r["Va"])
+        for solver in ("dense", "block_tree"):
+            V, err_h, n_iter_h, _ = hp.hpf(buses, lines, True, thresh_h=thresh, settings=st, ne_dir=str(ne_dir), solver=solver,
+                                           verbose=False, return_jacobian=False)
+            Ud = V["V_m"].to_numpy() * np.exp(1j * V["V_a"].to_numpy())
+            print(f"\ntwo device types, {solver}, thresh {thresh:g}: it {n_iter_h} (oracle {r['n_iter_h']}) err {err_h:.2e} "
+                  f"max|dU| {np.abs(Ud - Uo).max():.2e}")
+            assert err_h <= thresh and n_iter_h < 50
+            assert np.abs(Ud - Uo).max() < tol
 
 
 @pytest.mark.gpu
