@@ -937,7 +937,7 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
         o[2] = ((gown >> 4) & 0xfffff) | (((gwait >> 4) & 0xfffff) << 20) | (((gmf >> 4) & 0xfffff) << 40);   // GJ split
         o[3] = st4 - st3;   // MFMA Gauss-Jordan
         o[5] = st6 - st5;   // Schur push
-        o[6] = n_den;
+        o[6] = n_den + (sleaf ? 100 : 0);
         o[7] = (k >= M.m) | ((lin_end - lin_beg) << 1);
     }
 #endif

@@ -39,10 +39,12 @@ d = buf.reshape(S, n, 8)
 dense = d[:, :, 3].sum(axis=0) > 0
 names = ["assembly", "rows->tiles", "child sums", "MFMA GJ", "store", "push"]
 print("dense buses: %d; cycles per block (median over scenarios and buses)" % dense.sum())
-for label, sel in (("nonlinear leaf (0 dense children)", dense & (d[0, :, 6] == 0) & (d[0, :, 7] == 1)),
+for label, sel in (("nonlinear leaf (0 dense children)", dense & (d[0, :, 6] == 0) & ((d[0, :, 7] & 1) == 1)),
+                   ("super-leaf (HPF_SLEAF=1)", dense & (d[0, :, 6] >= 100)),
+                   ("linear dense bus, lazy children only", dense & (d[0, :, 6] == 0) & ((d[0, :, 7] & 1) == 0)),
                    ("linear dense bus, 1-2 dense children", dense & (d[0, :, 6] >= 1) & (d[0, :, 6] <= 2) & ((d[0, :, 7] & 1) == 0)),
                    ("nonlinear bus, 1-2 dense children", dense & (d[0, :, 6] >= 1) & (d[0, :, 6] <= 2) & ((d[0, :, 7] & 1) == 1)),
-                   (">=4 dense children", dense & (d[0, :, 6] >= 4))):
+                   (">=4 dense children", dense & (d[0, :, 6] >= 4) & (d[0, :, 6] < 100))):
     if sel.sum() == 0:
         continue
     x = d[:, sel, :6].reshape(-1, 6)
