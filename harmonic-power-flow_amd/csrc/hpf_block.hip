@@ -1345,7 +1345,7 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
     std::vector<long long> sl_off(n, -1);                      // offset of [Tc | Pb | Qb] in slimg
     std::vector<double> slimg;
     const char* sl_env = getenv("HPF_SLEAF");
-    const bool sleaf_on = sl_env && atoi(sl_env) != 0;
+    const bool sleaf_on = !(sl_env && atoi(sl_env) == 0);      // HPF_SLEAF=0: every bus with dense children takes the Gauss-Jordan path
     int n_sleaf = 0;
     std::vector<std::vector<int>> lazy_of(n);
     std::vector<int> is_lazy(n, 0);

@@ -471,6 +471,45 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
             for (int tr = 0; tr < NT; ++tr) xt[tr] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[tr], b1, xt[tr], 0, 0, 0);
         }
     }
+    // super-leaf: stage the per-model constants and everything of T that does not depend on this bus's own roles (all of it but
+    // the 2x2 term of the fundamental) while the roles' loads are in flight
+    __shared__ double slb[2 * B * 10 + 200];
+    if (sleaf) {
+        const int L = lzA.y, m = 2 + 2 * L, m2 = 2 * m;
+        const double* simg = T.lzimg + (size_t)lzB.w;                    // Tc [m][m] | Pb [b][m] | Qb [m][b]
+        double* aug = slb + 2 * B * 10;
+        for (int idx = tid; idx < b * m; idx += 64 * NT) {
+            slb[idx] = simg[m * m + idx];
+            slb[B * 10 + idx] = simg[m * m + b * m + idx];
+        }
+        if (wv == (NT > 2 ? 2 : 0)) {
+            for (int idx = lane; idx < m * m2; idx += 64) {
+                const int r2 = idx / m2, c2 = idx - r2 * m2;
+                aug[r2 * 20 + c2] = c2 < m ? simg[r2 * m + c2] : (c2 - m == r2 ? 1.0 : 0.0);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane >= 1 && lane <= L) {                                // leaf i: K_i^-1 on the diagonal, -G0 S_c^-1 / -H0 S_k^-1 borders
+                const int i = lane - 1, bc = 2 + 2 * i;
+                const int leaf = i == 0 ? lzA.z : (i == 1 ? lzA.w : (i == 2 ? lzB.x : lzB.y));
+                const double* kk = lfK + ((size_t)s * n + leaf) * 12;
+                double q00, q01, q10, q11;
+                inv2(kk[0], kk[1], kk[2], kk[3], q00, q01, q10, q11);
+                aug[bc * 20 + bc] += q00;
+                aug[bc * 20 + bc + 1] += q01;
+                aug[(bc + 1) * 20 + bc] += q10;
+                aug[(bc + 1) * 20 + bc + 1] += q11;
+                aug[bc] -= kk[4];
+                aug[bc + 1] -= kk[5];
+                aug[20 + bc] -= kk[6];
+                aug[20 + bc + 1] -= kk[7];
+                aug[bc * 20] -= kk[8];
+                aug[bc * 20 + 1] -= kk[9];
+                aug[(bc + 1) * 20] -= kk[10];
+                aug[(bc + 1) * 20 + 1] -= kk[11];
+            }
+        }
+    }
     // leaf-only launches: the per-model image of the leaf (L2 / Infinity Cache) is requested here, behind the role loads, and
     // first touched after the barrier
     d4_t ct[NT];
@@ -595,30 +634,10 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
         //   Drect^-1 = [0 0; 0 Ahh^-1] + Pb T^-1 Qb,   T = Tc + blockdiag(D, K_1^-1, ..., K_L^-1) - borders(G0 S_c^-1, H0 S_k^-1),
         //   m = 2 + 2L <= 10: T is inverted in LDS by wave 0 (Gauss-Jordan, partial pivoting); Tc, Pb, Qb, the Ahh^-1 image: per model.
         const int L = lzA.y, m = 2 + 2 * L, m2 = 2 * m;
-        const double* simg = T.lzimg + (size_t)lzB.w;                    // Tc [m][m] | Pb [b][m] | Qb [m][b]
-        __shared__ double slb[2 * B * 10 + 200];
-        double* aug = slb + 2 * B * 10;                                  // [m][20]: T | I  ->  I | T^-1
-        double* pbl = slb;                                               // Pb, then Qb
+        double* aug = slb + 2 * B * 10;                                  // [m][20]: T | I  ->  I | T^-1   (staged before barrier 1)
+        double* pbl = slb;                                               // Pb [b][m], then Qb [m][b]
         double* qbl = pbl + B * 10;
-        {
-            double mv[NT * 4];
-#pragma unroll
-            for (int e = 0; e < NT * 4; ++e) mv[e] = 0.0;
-            TileIO<B>::load(Minv + (size_t)(lzB.z - 1) * CT, wv, lg, jj, mv);
-#pragma unroll
-            for (int e = 0; e < NT * 4; ++e) ct[e >> 2][e & 3] = mv[e];
-        }
-        for (int idx = tid; idx < b * m; idx += 64 * NT) {
-            pbl[idx] = simg[m * m + idx];
-            qbl[idx] = simg[m * m + b * m + idx];
-        }
         if (wv == 0) {
-            for (int idx = lane; idx < m * m2; idx += 64) {
-                const int r2 = idx / m2, c2 = idx - r2 * m2;
-                aug[r2 * 20 + c2] = c2 < m ? simg[r2 * m + c2] : (c2 - m == r2 ? 1.0 : 0.0);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            __builtin_amdgcn_wave_barrier();
             if (lane == 0) {                                             // D = Delta_polar S_0^-1 (the 2x2 term of the fundamental)
                 const double si0 = tab[0], si1 = tab[1], si2 = tab[2], si3 = tab[3];
                 const double p00 = dgb[0], p01 = dgb[1], p10 = dgb[3], p11 = dgb[4];
@@ -626,24 +645,6 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
                 aug[1] += fma(p01, si3, p00 * si1);
                 aug[20] += fma(p11, si2, p10 * si0);
                 aug[21] += fma(p11, si3, p10 * si1);
-            } else if (lane <= L) {                                      // leaf i: K_i^-1 on the diagonal, -G0 S_c^-1 / -H0 S_k^-1 borders
-                const int i = lane - 1, bc = 2 + 2 * i;
-                const int leaf = i == 0 ? lzA.z : (i == 1 ? lzA.w : (i == 2 ? lzB.x : lzB.y));
-                const double* kk = lfK + ((size_t)s * n + leaf) * 12;
-                double q00, q01, q10, q11;
-                inv2(kk[0], kk[1], kk[2], kk[3], q00, q01, q10, q11);
-                aug[bc * 20 + bc] += q00;
-                aug[bc * 20 + bc + 1] += q01;
-                aug[(bc + 1) * 20 + bc] += q10;
-                aug[(bc + 1) * 20 + bc + 1] += q11;
-                aug[bc] -= kk[4];
-                aug[bc + 1] -= kk[5];
-                aug[20 + bc] -= kk[6];
-                aug[20 + bc + 1] -= kk[7];
-                aug[bc * 20] -= kk[8];
-                aug[bc * 20 + 1] -= kk[9];
-                aug[(bc + 1) * 20] -= kk[10];
-                aug[(bc + 1) * 20 + 1] -= kk[11];
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -685,19 +686,38 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
             }
         }
         __syncthreads();
-        // own column of  T^-1 Qb  (m values), then the elements  [0 0; 0 Ahh^-1] + Pb (T^-1 Qb)
-        double wq[10];
+        // [0 0; 0 Ahh^-1] + Pb (T^-1 Qb) on the matrix cores: per chunk of four border unknowns one rank-4 MFMA per tile
+        // (A operand = rows of Pb, B operand = the own column of T^-1 Qb: 10 FMAs per chunk and lane).  The image is fetched
+        // here and not earlier: held across the inversion it would push the kernel over its register budget.
+        {
+            double mv[NT * 4];
+#pragma unroll
+            for (int e = 0; e < NT * 4; ++e) mv[e] = 0.0;
+            TileIO<B>::load(Minv + (size_t)(lzB.z - 1) * CT, wv, lg, jj, mv);
+#pragma unroll
+            for (int e = 0; e < NT * 4; ++e) ct[e >> 2][e & 3] = mv[e];
+        }
         {
             double qb[10];
 #pragma unroll
             for (int j = 0; j < 10; ++j) qb[j] = (j < m && col < b) ? qbl[j * b + col] : 0.0;
 #pragma unroll
-            for (int i = 0; i < 10; ++i) {
-                double acc = 0.0;
+            for (int ch = 0; ch < 3; ++ch) {
+                if (4 * ch < m) {                                        // (workgroup-uniform)
+                    const int i = 4 * ch + lg;                           // border unknown of this lane's operand element
+                    const double* wr = aug + (i < m ? i : 0) * 20 + m;
+                    double bop = 0.0;
 #pragma unroll
-                for (int j = 0; j < 10; ++j)
-                    if (j < m) acc = fma(aug[(i < m ? i : 0) * 20 + m + j], qb[j], acc);
-                wq[i] = i < m ? acc : 0.0;
+                    for (int j = 0; j < 10; ++j)
+                        if (j < m) bop = fma(wr[j], qb[j], bop);
+                    bop = i < m ? bop : 0.0;
+#pragma unroll
+                    for (int tr = 0; tr < NT; ++tr) {
+                        const int prow_ = 16 * tr + jj;
+                        const double aop = (prow_ < b && i < m) ? pbl[prow_ * m + i] : 0.0;
+                        ct[tr] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, ct[tr], 0, 0, 0);
+                    }
+                }
             }
         }
         const double yc = col < B ? dgb[col * 3 + 2] : 0.0;
@@ -707,12 +727,7 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
             for (int reg = 0; reg < 4; ++reg) {
                 if (16 * tr + 4 * reg >= B) continue;
                 const int row = 16 * tr + 4 * reg + lg;
-                double v = ct[tr][reg];
-                const double* pr_ = pbl + (row < b ? row : 0) * m;
-#pragma unroll
-                for (int i = 0; i < 10; ++i)
-                    if (i < m) v = fma(pr_[i], wq[i], v);
-                v = row < b ? v : 0.0;
+                double v = row < b ? ct[tr][reg] : 0.0;
                 const double pr = xor16_f64(v);                                             // the other row of the harmonic
                 const double* si = tab + (row >> 1) * 4 + 2 * t;
                 v = t ? fma(si[1], v, si[0] * pr) : fma(si[1], pr, si[0] * v);              // S_q^-1 from the left

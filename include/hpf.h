@@ -142,8 +142,8 @@ int  hpf_debug_stamps(hpf_handle* h, long long* out, int count);
  * HPF_GJ_MODE=0 selects the pivoted variant process-wide (2: the one-wave-per-bus MFMA variant).
  * "scenario_groups" (1..8, default 3): independent scenario pipelines on separate HIP streams.
  * Environment read by hpf_create (diagnostics, A/B runs): HPF_LAZY=0 builds the elimination tree without lazy leaves (every
- * leaf writes its Schur complement; 1: only leaves directly under their dense parent), HPF_SLEAF=1 builds nonlinear buses
- * whose dense children are all lazy leaves as super-leaves (bordered low-rank inverse instead of Gauss-Jordan; experimental),
+ * leaf writes its Schur complement; 1: only leaves directly under their dense parent), HPF_SLEAF=0 sends the nonlinear buses
+ * whose dense children are all lazy leaves (super-leaves: bordered low-rank inverse) through Gauss-Jordan like every other bus,
  * HPF_TREE_INFO=1 prints the tree statistics to stderr, HPF_GROUPS=n presets "scenario_groups". */
 int  hpf_set_option(hpf_handle* h, const char* name, int value);
 

@@ -647,8 +647,9 @@ def test_batch_results_bit_identical_to_single_scenario_solves(tmp_path):
 @pytest.mark.parametrize("n,hmax", [(300, 51), (200, 25), (100, 11)])
 def test_lazy_leaves_give_the_same_newton_steps(n, hmax, tmp_path, monkeypatch):
     """Parents that rebuild their constant-inverse leaves' Schur complements from per-model images (lazy leaves)
-    must take the same Newton steps as the tree built without them (HPF_LAZY=0 at hpf_create): first three iterations from the
-    pf seed agree at rounding level, scenario by scenario (b = 52, 26 -> padded 28, 12)."""
+    and super-leaves (bordered low-rank inverse instead of Gauss-Jordan, §5a) must take the same Newton step as the tree built
+    without either (HPF_LAZY=0 at hpf_create): the first iteration from the pf seed agrees at rounding level, scenario by
+    scenario (b = 52, 26 -> padded 28, 12)."""
     hp = _hp()
     from harmonic_power_flow_amd import synth
     S = 3

@@ -2,7 +2,7 @@
 """Randomised parity sweep on the GPU: the first Newton step (pf seed -> one iteration) of the block-tree path against the dense
 rocSOLVER path over random radial feeders (size, share of nonlinear buses, PV buses, harmonic count -> block sizes 12 / 28 / 52 and
 the generic kernels).  One step is compared (not converged states) because later iterates of the solver-sensitive cases amplify
-rounding differences.  python tools/fuzz_parity.py [cases=24] [seed=0]"""
+rounding differences; the deviation is judged relative to the size of the step (first steps of 10-100 rad occur).  python tools/fuzz_parity.py [cases=24] [seed=0]"""
 import os
 import sys
 import tempfile
@@ -49,6 +49,7 @@ for case in range(cases):
             dm.set_loads(P0 * scale, Q0 * scale)
             dm.set_state(None, None, n_scen=S)
             dm.fund_pf(1e-6, 30)
+            seed_state = dm.get_state()
             dm.mismatch(want_f=False)
             dm.iterate(1)
             res[solver] = dm.get_state()
@@ -56,10 +57,10 @@ for case in range(cases):
             dm.close()
     dVm = np.abs(res["dense"][0] - res["block_tree"][0]).max()
     dVa = np.abs(res["dense"][1] - res["block_tree"][1]).max()
-    step = np.abs(res["dense"][0]).max()
-    worst = max(worst, dVm, dVa)
-    print("case %2d: n=%3d Hn=%2d (b=%3d) nl=%.2f pv=%d seed=%6d   first step max|dVm| %.1e max|dVa| %.1e" %
-          (case, nn, Hn, 2 * Hn, frac, n_pv, seed, dVm, dVa), flush=True)
+    step = max(np.abs(res["dense"][0] - seed_state[0]).max(), np.abs(res["dense"][1] - seed_state[1]).max(), 1.0)
+    worst = max(worst, dVm / step, dVa / step)
+    print("case %2d: n=%3d Hn=%2d (b=%3d) nl=%.2f pv=%d seed=%6d   first step max|dVm| %.1e max|dVa| %.1e   (step size %.1e)" %
+          (case, nn, Hn, 2 * Hn, frac, n_pv, seed, dVm, dVa, step), flush=True)
     assert np.isfinite(dVm) and np.isfinite(dVa)
-print("worst deviation %.2e" % worst)
-sys.exit(0 if worst < 1e-7 else 1)
+print("worst deviation relative to the step size %.2e" % worst)
+sys.exit(0 if worst < 1e-8 else 1)
