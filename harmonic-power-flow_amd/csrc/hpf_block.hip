@@ -1731,8 +1731,14 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
         const int nch = dchild_ptr[i + 1] - dchild_ptr[i];
         const bool leaf = cleaf_of[i] >= 0;
         const int nlz = n_lazy[i];                                   // lazy leaves: 2x2 core + G w column in, rank-2 MFMA update
-        T.flops_factor += leaf ? 10.0 * bd * bd : 2.0 * bd * bd * bd + 2.0 * bd * bd + bd * bd * (nch - nlz);
-        if (nlz) T.flops_factor += 4.0 * bd * bd * nlz + 4.0 * bd * bd;
+        const bool sl = nlz > 0 && sl_off[i] >= 0;                    // super-leaf: m x m inversion, rank-4 MFMAs per 4 border unknowns, S^-1, w
+        const double msl = 2.0 + 2.0 * nlz;
+        if (sl)
+            T.flops_factor += 2.0 * msl * msl * msl + 2.0 * bd * bd * 4.0 * (double)((2 + 2 * nlz + 3) / 4) + 2.0 * bd * msl * 3.0 +
+                              4.0 * bd * bd + 2.0 * bd * bd;
+        else
+            T.flops_factor += leaf ? 10.0 * bd * bd : 2.0 * bd * bd * bd + 2.0 * bd * bd + bd * bd * (nch - nlz);
+        if (nlz && !sl) T.flops_factor += 4.0 * bd * bd * nlz + 4.0 * bd * bd;
         T.bytes_factor += TB * (nch - nlz) + nlz * (32.0 + 8.0 * bd) + (leaf ? 0.0 : TB) + 8.0 * (4.0 * bd + bd + bd + 2.0 * bd) +
                           48.0 * d->Hn * (T.child_mid[i] - T.child_ptr[i]);
         if (i > 0) {

@@ -162,10 +162,12 @@ int  hpf_timing_get(hpf_handle* h, int which, double* ms, int64_t* launches);
 int  hpf_timing_reset(hpf_handle* h);
 /* FP64 flop count of the span `which == 2` for ONE scenario and ONE Newton step (roofline numerator):
  * DENSE 2/3 N^3 + 2 N^2; BLOCK_TREE (b = 2 Hn) per Gauss-Jordan bus 2 b^3 + 2 b^2 + b^2 per dense child (+ 8 b^2 non-root),
- * per constant-inverse leaf 18 b^2. */
+ * per constant-inverse leaf 10 b^2 (+ 8 b^2 push unless lazy: then only G w), per lazy leaf 4 b^2 + 4 b^2 per parent for the
+ * rebuild, per super-leaf (m = 2 + 2 L border unknowns) 2 m^3 + 8 b^2 ceil(m/4) + 6 b^2 + 6 b m. */
 double hpf_solve_flops(const hpf_handle* h);
 /* Algorithmic HBM bytes of the same span (one scenario, one Newton step): BLOCK_TREE every Schur complement once out and once
- * in, every Gauss-Jordan inverse once out, per-scenario bus operands; DENSE the Jacobian out and through getrf. */
+ * in (lazy leaves: 2x2 core + G w instead), every Gauss-Jordan / super-leaf inverse once out, per-scenario bus operands; DENSE
+ * the Jacobian out and through getrf. */
 double hpf_solve_bytes(const hpf_handle* h);
 /* ... and of the span `which == 4` (BLOCK_TREE back sweep: Gauss-Jordan inverses in, w, A(k,parent), x in / out); 0 for DENSE. */
 double hpf_back_bytes(const hpf_handle* h);
