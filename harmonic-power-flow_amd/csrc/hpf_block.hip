@@ -1346,6 +1346,7 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
     std::vector<double> slimg;
     const char* sl_env = getenv("HPF_SLEAF");
     const bool sleaf_on = !(sl_env && atoi(sl_env) == 0);      // HPF_SLEAF=0: every bus with dense children takes the Gauss-Jordan path
+    const int sleaf_mode = sl_env ? atoi(sl_env) : 2;          // 1: nonlinear buses only
     int n_sleaf = 0;
     std::vector<std::vector<int>> lazy_of(n);
     std::vector<int> is_lazy(n, 0);
@@ -1403,10 +1404,13 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
                 geff[q] = yv(q, e_dn[k]);
                 heff[q] = yv(q, e_up[k]);
             }
-            const double* yn = d->Y_N + (size_t)d->dev_of_bus[k] * Hn * Hn * 2;
-            for (int q = 0; q < Hn; ++q)
-                for (int p2 = 0; p2 < Hn; ++p2) Yc[(size_t)q * Hn + p2] = -cd(yn[((size_t)q * Hn + p2) * 2], yn[((size_t)q * Hn + p2) * 2 + 1]);
-            for (int q = 0; q < Hn; ++q) {
+            const bool linear_k = k < d->m;                    // PQ bus: no Norton term; its fundamental (power rows) is state dependent
+            if (!linear_k) {
+                const double* yn = d->Y_N + (size_t)d->dev_of_bus[k] * Hn * Hn * 2;
+                for (int q = 0; q < Hn; ++q)
+                    for (int p2 = 0; p2 < Hn; ++p2) Yc[(size_t)q * Hn + p2] = -cd(yn[((size_t)q * Hn + p2) * 2], yn[((size_t)q * Hn + p2) * 2 + 1]);
+            }
+            for (int q = linear_k ? 1 : 0; q < Hn; ++q) {
                 cd v = yv(q, diag[k]);
                 if (q >= 1) {
                     for (int cp = T.child_ptr[k]; cp < T.child_mid[k]; ++cp) {         // linear subtrees below k
@@ -1555,7 +1559,8 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
         for (int pos = 0; sleaf_on && pos < T.n_dense; ++pos) {
             const int k = T.lvl_nodes[pos];
             const int L = (int)lazy_of[k].size();
-            if (k < d->m || k == 0 || d->dev_of_bus[k] < 0 || L == 0 || dchild_ptr[k + 1] - dchild_ptr[k] != L) continue;
+            if (k < (d->c > 1 ? d->c : 1) || L == 0 || dchild_ptr[k + 1] - dchild_ptr[k] != L) continue;
+            if (k < d->m && sleaf_mode < 2) continue;                  // linear (PQ) buses: power-row map W_k on the fundamental
             std::vector<cd> A, geff, heff, imgk;
             build_Yc(k, A, geff, heff);
             for (int li : lazy_of[k])

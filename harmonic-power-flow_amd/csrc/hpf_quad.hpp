@@ -343,8 +343,8 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
                 const Blk2 blk = prow ? blk_power_diag(yd, uk, ek, I0v) : blk_current_diag(yd, uk, ek, yn, k >= M.m);
                 // (constant-inverse leaf: the network part lives in the precomputed inverse; rows 0/1 carry the state-dependent
                 //  2x2 term of the fundamental, i.e. what the 2x2-algebra neighbours left there)
-                d0 = (cleafr ? 0.0 : pick(blk, tr_, 0)) + a0;
-                d1 = (cleafr ? 0.0 : pick(blk, tr_, 1)) + a1;
+                d0 = ((cleafr && !prow) ? 0.0 : pick(blk, tr_, 0)) + a0;     // (power rows of a linear super-leaf: state dependent, kept)
+                d1 = ((cleafr && !prow) ? 0.0 : pick(blk, tr_, 1)) + a1;
                 y = fy + ay;
             }
 #ifdef HPF_FACTOR_STAMPS
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
     }
     // super-leaf: stage the per-model constants and everything of T that does not depend on this bus's own roles (all of it but
     // the 2x2 term of the fundamental) while the roles' loads are in flight
-    __shared__ double slb[2 * B * 10 + 200];
+    __shared__ double slb[2 * B * 10 + 200 + 4];
     if (sleaf) {
         const int L = lzA.y, m = 2 + 2 * L, m2 = 2 * m;
         const double* simg = T.lzimg + (size_t)lzB.w;                    // Tc [m][m] | Pb [b][m] | Qb [m][b]
@@ -489,6 +489,21 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            // linear (PQ) bus: its row pair 0 is  W_k (current-row form),  W_k = [ur ui; ui -ur]  (U conj(.)),  W_k^-1 = W_k / |U|^2:
+            // the system is solved in the current-row form, W_k^-1 goes on row pair 0 of the borders and on columns 0 / 1 of Qb
+            double w00 = 1.0, w01 = 0.0, w10 = 0.0, w11 = 1.0;
+            if (k < M.m && lane <= L) {
+                const cplx u0 = U[(size_t)k * Hn];
+                const double iu = 1.0 / fma(u0.re, u0.re, u0.im * u0.im);
+                w00 = u0.re * iu;
+                w01 = u0.im * iu;
+                w10 = w01;
+                w11 = -w00;
+            }
+            if (lane == 0) {
+                double* wi = aug + 10 * 20;                              // behind the 10 x 20 matrix: W_k^-1 for the later phases
+                wi[0] = w00; wi[1] = w01; wi[2] = w10; wi[3] = w11;
+            }
             if (lane >= 1 && lane <= L) {                                // leaf i: K_i^-1 on the diagonal, -G0 S_c^-1 / -H0 S_k^-1 borders
                 const int i = lane - 1, bc = 2 + 2 * i;
                 const int leaf = i == 0 ? lzA.z : (i == 1 ? lzA.w : (i == 2 ? lzB.x : lzB.y));
@@ -499,10 +514,10 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
                 aug[bc * 20 + bc + 1] += q01;
                 aug[(bc + 1) * 20 + bc] += q10;
                 aug[(bc + 1) * 20 + bc + 1] += q11;
-                aug[bc] -= kk[4];
-                aug[bc + 1] -= kk[5];
-                aug[20 + bc] -= kk[6];
-                aug[20 + bc + 1] -= kk[7];
+                aug[bc] -= fma(w01, kk[6], w00 * kk[4]);                   // W_k^-1 (G0 S_c^-1)
+                aug[bc + 1] -= fma(w01, kk[7], w00 * kk[5]);
+                aug[20 + bc] -= fma(w11, kk[6], w10 * kk[4]);
+                aug[20 + bc + 1] -= fma(w11, kk[7], w10 * kk[5]);
                 aug[bc * 20] -= kk[8];
                 aug[bc * 20 + 1] -= kk[9];
                 aug[(bc + 1) * 20] -= kk[10];
@@ -641,10 +656,13 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
             if (lane == 0) {                                             // D = Delta_polar S_0^-1 (the 2x2 term of the fundamental)
                 const double si0 = tab[0], si1 = tab[1], si2 = tab[2], si3 = tab[3];
                 const double p00 = dgb[0], p01 = dgb[1], p10 = dgb[3], p11 = dgb[4];
-                aug[0] += fma(p01, si2, p00 * si0);
-                aug[1] += fma(p01, si3, p00 * si1);
-                aug[20] += fma(p11, si2, p10 * si0);
-                aug[21] += fma(p11, si3, p10 * si1);
+                const double e00 = fma(p01, si2, p00 * si0), e01 = fma(p01, si3, p00 * si1);
+                const double e10 = fma(p11, si2, p10 * si0), e11 = fma(p11, si3, p10 * si1);
+                const double* wi = aug + 10 * 20;                        // W_k^-1 (identity for a nonlinear bus)
+                aug[0] += fma(wi[1], e10, wi[0] * e00);
+                aug[1] += fma(wi[1], e11, wi[0] * e01);
+                aug[20] += fma(wi[3], e10, wi[2] * e00);
+                aug[21] += fma(wi[3], e11, wi[2] * e01);
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -701,6 +719,11 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
             double qb[10];
 #pragma unroll
             for (int j = 0; j < 10; ++j) qb[j] = (j < m && col < b) ? qbl[j * b + col] : 0.0;
+            if (col < 2) {                                               // right-hand side rows 0 / 1 arrive in polar power-row form: W_k^-1
+                const double* wi = aug + 10 * 20;
+                qb[0] = wi[col];
+                qb[1] = wi[2 + col];
+            }
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
                 if (4 * ch < m) {                                        // (workgroup-uniform)
