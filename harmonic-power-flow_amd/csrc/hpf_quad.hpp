@@ -483,10 +483,8 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
             slb[B * 10 + idx] = simg[m * m + b * m + idx];
         }
         if (wv == (NT > 2 ? 2 : 0)) {
-            for (int idx = lane; idx < m * m2; idx += 64) {
-                const int r2 = idx / m2, c2 = idx - r2 * m2;
-                aug[r2 * 20 + c2] = c2 < m ? simg[r2 * m + c2] : (c2 - m == r2 ? 1.0 : 0.0);
-            }
+            if (lane < m)
+                for (int r2 = 0; r2 < m; ++r2) aug[r2 * 20 + lane] = simg[r2 * m + lane];       // T <- Tc (columns m.. receive T^-1 later)
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             __builtin_amdgcn_wave_barrier();
             // linear (PQ) bus: its row pair 0 is  W_k (current-row form),  W_k = [ur ui; ui -ur]  (U conj(.)),  W_k^-1 = W_k / |U|^2:
@@ -666,15 +664,17 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            // Gauss-Jordan with partial pivoting in registers: lane r owns row r of [T | I]; the pivot row is broadcast with
-            // v_readlane, rows are never swapped (the lane that was the pivot of column j ends up holding row j of T^-1)
-            double row[20];
+            // In-place Gauss-Jordan inversion with partial pivoting in registers: lane r owns row r of T; the pivot row is broadcast
+            // with v_readlane, rows are never swapped.  The lane that was the pivot of column j ends up with row j of T^-1, and
+            // its column position c belongs to the unit vector of the pivot lane of column c (pcol): T^-1[j][pcol[c]] = row[c].
+            double row[10];
 #pragma unroll
-            for (int c2 = 0; c2 < 20; ++c2) row[c2] = (lane < m && c2 < m2) ? aug[lane * 20 + c2] : 0.0;
+            for (int c2 = 0; c2 < 10; ++c2) row[c2] = (lane < m && c2 < m) ? aug[lane * 20 + c2] : 0.0;
             bool used = lane >= m;
-            int mycol = -1;
+            int mycol = 0, pcol[10];
 #pragma unroll
             for (int j = 0; j < 10; ++j) {
+                pcol[j] = 0;
                 if (j < m) {                                             // (m is workgroup-uniform)
                     const double cand = used ? -1.0 : fabs(row[j]);
                     double mx = cand;                                    // max over the 16 lanes of the DPP row (all receive it)
@@ -684,23 +684,26 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
                     mx = fmax(mx, dpp_f64<0x140>(mx));
                     const unsigned long long bal = __builtin_amdgcn_ballot_w64(!used && cand == mx);
                     const int pi = __builtin_ctzll(bal | (1ull << 63));
-                    double prow[20];
+                    double prow[10];
 #pragma unroll
-                    for (int c2 = 0; c2 < 20; ++c2)
+                    for (int c2 = 0; c2 < 10; ++c2)
                         prow[c2] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(row[c2]), pi),
                                                     __builtin_amdgcn_readlane(__double2loint(row[c2]), pi));
                     const double ipv = 1.0 / prow[j];
                     const bool me = lane == pi;
                     const double f = me ? 0.0 : row[j] * ipv;
 #pragma unroll
-                    for (int c2 = 0; c2 < 20; ++c2) row[c2] = me ? prow[c2] * ipv : fma(-f, prow[c2], row[c2]);
+                    for (int c2 = 0; c2 < 10; ++c2)
+                        row[c2] = c2 == j ? (me ? ipv : -f) : (me ? prow[c2] * ipv : fma(-f, prow[c2], row[c2]));
                     used = used || me;
                     mycol = me ? j : mycol;
+                    pcol[j] = pi;
                 }
             }
             if (lane < m) {
 #pragma unroll
-                for (int c2 = 0; c2 < 20; ++c2) aug[mycol * 20 + c2] = row[c2];   // columns m .. 2m-1: T^-1
+                for (int c2 = 0; c2 < 10; ++c2)
+                    if (c2 < m) aug[mycol * 20 + m + pcol[c2]] = row[c2];
             }
         }
         __syncthreads();
