@@ -1047,6 +1047,7 @@ int launch_back_w(hpf_handle* h, const TreeDev& T, const int* nodes, int count, 
 }
 
 #include "hpf_quad.hpp"
+#include "hpf_leafbatch.hpp"
 
 // padded block size of the wave-per-bus path (0: use the 256-thread generic kernels)
 int wave_block_size(int b) { return b <= 12 ? 12 : (b <= 28 ? 28 : (b <= 52 ? 52 : 0)); }
@@ -1343,7 +1344,7 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
     // super-leaves: nonlinear buses whose dense children are all lazy leaves -- bordered low-rank inverse instead of Gauss-Jordan
     std::vector<int> sl_slot(n, 0);                            // 1 + slot of the bus's Z0 image in Tree::d_Minv
     std::vector<long long> sl_off(n, -1);                      // offset of [Tc | Pb | Qb] in slimg
-    std::vector<double> slimg;
+    std::vector<double> slimg, lbimg;
     const char* sl_env = getenv("HPF_SLEAF");
     const bool sleaf_on = !(sl_env && atoi(sl_env) == 0);      // HPF_SLEAF=0: every bus with dense children takes the Gauss-Jordan path
     const int sleaf_mode = sl_env ? atoi(sl_env) : 2;          // 1: nonlinear buses only
@@ -1532,6 +1533,27 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
                     const long long o = tile_off(row, col);
                     if (o >= 0) Mt[o] = (t == t2) ? z.real() : (t ? z.imag() : -z.imag());
                 }
+            {   // the same constants for k_leaf_batch: [0 Lr; 0 Ahh^-1] in MFMA A-operand layout, R(Lc), R(c0)
+                const int NTR = (BWc + 15) / 16, KS = (BWc + 3) / 4, SZ = NTR * KS * 64 + 2 * BWc + 4;
+                lbimg.resize((size_t)T.n_cleaf * SZ, 0.0);
+                double* L = &lbimg[(size_t)cleaf_of[k] * SZ];
+                auto Rz = [](cd z, int t, int t2) { return (t == t2) ? z.real() : (t ? z.imag() : -z.imag()); };
+                for (int w2 = 0; w2 < NTR; ++w2)
+                    for (int ks = 0; ks < KS; ++ks)
+                        for (int lg = 0; lg < 4; ++lg)
+                            for (int jj = 0; jj < 16; ++jj) {
+                                const int row = 16 * w2 + jj, col = 4 * ks + lg;
+                                double v = 0.0;
+                                if (row < b && col < b && col >= 2) v = Rz(img[(size_t)(row >> 1) * Hn + (col >> 1)], row & 1, col & 1);
+                                L[((size_t)w2 * KS + ks) * 64 + lg * 16 + jj] = v;
+                            }
+                double* Lc = L + (size_t)NTR * KS * 64;
+                Lc[0] = 1.0; Lc[1] = 0.0; Lc[2] = 0.0; Lc[3] = 1.0;
+                for (int row = 2; row < b; ++row)
+                    for (int a2 = 0; a2 < 2; ++a2) Lc[row * 2 + a2] = Rz(img[(size_t)(row >> 1) * Hn], row & 1, a2);
+                double* C0 = Lc + 2 * BWc;
+                C0[0] = img[0].real(); C0[1] = -img[0].imag(); C0[2] = img[0].imag(); C0[3] = img[0].real();
+            }
             const int pk = pard[k];                                   // dense parent, directly or through a contracted chain
             const bool direct = chain_of[k] < 0;
             if (lazy_on && (direct || lazy_mode >= 2) && pk >= (d->c > 1 ? d->c : 1) && (int)lazy_of[pk].size() < LZ_MAX) {
@@ -1671,6 +1693,13 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
             std::stable_partition(dchild.begin() + dchild_ptr[pk], dchild.begin() + dchild_ptr[pk + 1], [&](int ch) { return !is_lazy[ch]; });
         }
     }
+    // elimination level 0: lazy leaves first (k_leaf_batch takes them 16 scenarios at a time), the other leaves behind them
+    T.n_lazy_level0 = 0;
+    if (T.n_levels > 0) {
+        auto first = T.lvl_nodes.begin() + T.lvl_ptr[0], last = T.lvl_nodes.begin() + T.lvl_ptr[1];
+        auto mid = std::stable_partition(first, last, [&](int k2) { return is_lazy[k2] != 0; });
+        T.n_lazy_level0 = (int)(mid - first);
+    }
     const long long sl_base = (long long)lzimg.size();          // super-leaf constants ride behind the lazy images
     lzimg.insert(lzimg.end(), slimg.begin(), slimg.end());
     T.lvl_all_leaf.assign(T.n_levels > 0 ? T.n_levels : 1, 1);
@@ -1793,6 +1822,7 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
     if ((r = upload(h, &T.d_Minv, minv))) return r;
     if ((r = upload(h, &T.d_lzrec, lzrec))) return r;
     if ((r = upload(h, &T.d_lzimg, lzimg))) return r;
+    if ((r = upload(h, &T.d_lbimg, lbimg))) return r;
     if ((r = upload(h, &T.d_lrec, lrec))) return r;
     if ((r = upload(h, &T.d_crec, crec))) return r;
     if ((r = upload(h, &T.d_cnode, cnode))) return r;
@@ -1815,7 +1845,7 @@ static void tree_free_one(Tree& T) {
     void* ptrs[] = {T.d_parent, T.d_lvl_nodes, T.d_dep_nodes, T.d_child_ptr, T.d_child, T.d_e_up, T.d_e_dn,
                     T.d_child_mid, T.d_lin, T.d_lin_ptr, T.d_lin_post, T.d_all_ptr, T.d_all_post, T.d_fdesc, T.d_child3,
                     T.d_bdesc, T.d_dchild, T.d_chain_ptr, T.d_chain_nodes, T.d_chain_ch, T.d_Minv, T.d_lrec, T.d_crec, T.d_cnode, T.d_arec,
-                    T.d_lzrec, T.d_lzimg};
+                    T.d_lzrec, T.d_lzimg, T.d_lbimg};
     for (void* p : ptrs)
         if (p) hipFree(p);
 }
@@ -1951,10 +1981,19 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
             if (cnt == 0) continue;
             const int* nodes = T.d_lvl_nodes + T.lvl_ptr[l];
             int r;
+            // level 0 of the contracted tree: its lazy leaves come first and go 16 scenarios per workgroup (k_leaf_batch)
+            static const int leafbatch = [] { const char* e = getenv("HPF_LEAFBATCH"); return e ? atoi(e) : 1; }();   // 0: one workgroup per (leaf, scenario)
+            const int nbatch = (l == 0 && leafbatch && h->has_ctree && T.lvl_all_leaf[0]) ? T.n_lazy_level0 : 0;
             ScopedTimer t(h, T_SOLVE);          // one span per k_factor_w launch (what rocprofv3 --stats averages)
             switch (BW) {
 #define HPF_FACTOR_CASE(BB_)                                                                                  \
     case BB_:                                                                                                 \
+        if (h->gj_mode == 1 && nbatch > 0) {                                                                  \
+            r = launch_leaf_batch<BB_>(h, td, T.d_fdesc + FDESC * (size_t)T.lvl_ptr[l], nbatch, active);      \
+            if (!r && cnt > nbatch)                                                                           \
+                r = launch_factor_q<BB_>(h, td, T.d_fdesc + FDESC * (size_t)(T.lvl_ptr[l] + nbatch), cnt - nbatch, active, true); \
+            break;                                                                                            \
+        }                                                                                                     \
         r = h->gj_mode == 1 ? launch_factor_q<BB_>(h, td, T.d_fdesc + FDESC * (size_t)T.lvl_ptr[l], cnt, active, \
                                                   T.lvl_all_leaf[l] != 0)                                       \
             : (h->gj_mode == 2 ? launch_factor_w<BB_, 1>(h, td, nodes, cnt, active)                           \

@@ -83,6 +83,8 @@ struct Tree {
     // lazy leaves: constant-inverse leaves directly under their dense parent never write their Schur complement; the parent
     // rebuilds the sum from per-model images and the leaves' 2x2 cores (k_factor_q, "lazy" phase)
     int n_lazy_parents = 0, n_lazy_leaves = 0;
+    int n_lazy_level0 = 0;            // the first n_lazy_level0 buses of elimination level 0 are lazy leaves (k_leaf_batch)
+    double* d_lbimg = nullptr;        // [leaf slot][LeafBatchImg::SZ]: the leaf images in MFMA A-operand layout (16 scenarios per workgroup)
     int* d_lzrec = nullptr;           // [n_lazy_parents][8]: image offset (doubles), L, leaf ids[4] (-1: none), 0, 0
     double* d_lzimg = nullptr;        // per parent: sum of constant parts (tile layout) | A operands [pair][tr][64] | row factors [pair][tc][2][64]
     double flops_per_solve = 0.0;     // factor sweep + back sweep

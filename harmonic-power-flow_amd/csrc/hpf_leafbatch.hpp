@@ -1,0 +1,227 @@
+// Lazy leaves, 16 scenarios per workgroup (included by hpf_block.hip after hpf_quad.hpp).
+//
+// A lazy constant-inverse leaf owes the factor sweep only vectors: w = D^-1 y, G w for its parent, its 2x2 core K
+// with the position-0 borders, S^-1 and A(k,parent) for the back sweep.  The one O(b^2) piece, Drect^-1 y, multiplies a PER-MODEL
+// matrix with a per-scenario vector -- across scenarios that is a GEMM:
+//     Drect^-1 y = [u; Vh + Lc u],   V = [0 Lr; 0 Ahh^-1] y,   u = K (y0 + V0),   K = (c0 + Delta_polar S_0^-1)^-1.
+// One workgroup takes one leaf and SB = 16 scenarios: V for all 16 is b/4 rank-4 MFMAs per 16-row tile (A operand = the image in
+// operand layout, read ONCE per 16 scenarios instead of once per scenario; B operand = the 16 right-hand sides from LDS), the
+// roles of k_factor_q (right-hand side with the 2x2-algebra children folded in, S^-1, coupling blocks) run per (scenario, row) /
+// (scenario, harmonic) thread.  Results are the same quantities k_factor_q<B, true> leaves for a lazy leaf.
+#pragma once
+
+constexpr int LB_SB = 16;      // scenarios per workgroup
+
+// per-leaf constants (Tree::d_lbimg): A-operand image [NTR][KS][64] | Lc as real b x 2 | c0 2x2
+template <int B>
+struct LeafBatchImg {
+    static constexpr int NTR = (B + 15) / 16, KS = (B + 3) / 4;
+    static constexpr int SZ = NTR * KS * 64 + 2 * B + 4;
+};
+
+template <int B>
+__global__ __launch_bounds__(256) void k_leaf_batch(
+    Model M, TreeDev T, const int* __restrict__ nodes, int b, const int* __restrict__ active, int S_cnt,
+    const cplx* __restrict__ Uall, const cplx* __restrict__ Eall, const double* __restrict__ fall, double* __restrict__ wall,
+    const double* __restrict__ linAall, double* __restrict__ Call, double* __restrict__ Hall, const double* __restrict__ chG,
+    const double* __restrict__ chH, const double* __restrict__ chD, const double* __restrict__ chy,
+    const double* __restrict__ lbimg, double* __restrict__ lfK, double* __restrict__ lfS, int s0) {
+    constexpr int NT = (B + 16) / 16;                       // tile columns of the block kernels (slot stride of C)
+    constexpr size_t CT = (size_t)NT * NT * 256;
+    constexpr int NTR = LeafBatchImg<B>::NTR, KS = LeafBatchImg<B>::KS, H2 = B / 2;
+    const int4* nd = reinterpret_cast<const int4*>(nodes) + (FDESC / 4) * (size_t)blockIdx.x;
+    const int4 nd0 = nd[0], nd1 = nd[1], nd3 = nd[3];
+    const int k = nd0.x, par = nd0.y;
+    const int e_dn_k = nd1.x, e_up_k = nd1.y, lin_beg = nd1.z, lin_end = nd1.z + nd1.w;
+    const bool via_chain = (nd3.z & 1) != 0;
+    const int slot = nd3.w - 1;                              // leaf slot (Tree::d_Minv numbering)
+    const int tid = threadIdx.x, lane = tid & 63, lg = lane >> 4, jj = lane & 15;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = M.n, c = M.c, Hn = M.Hn;
+    const int sc = tid >> 4, l16 = tid & 15;                 // role mapping: 16 threads per scenario
+    const int sl = blockIdx.y * LB_SB + sc;                  // scenario inside the launch
+    const int s = sl + s0;
+    const bool live = sl < S_cnt && !(active && !active[s]);
+    const size_t so = (size_t)s * n * Hn;
+    const cplx* U = Uall + so;
+    const cplx* E = Eall + so;
+    const double* img = lbimg + (size_t)slot * LeafBatchImg<B>::SZ;
+    const double* lcimg = img + NTR * KS * 64;               // R(Lc): [row][2] (rows 0, 1: identity)
+    const double* c0img = lcimg + 2 * B;
+
+    __shared__ double Y[64 * LB_SB];                         // right-hand sides [row][scenario]
+    __shared__ double V[64 * LB_SB];                         // [0 Lr; 0 Ahh^-1] y
+    __shared__ double DL[LB_SB * 4];                         // Delta_polar per scenario
+    __shared__ double SI[LB_SB * H2 * 4];                    // S_q^-1 per scenario
+    __shared__ double GL[LB_SB * H2 * 4];                    // A(parent, k) per scenario
+    __shared__ double UK[LB_SB * 2];                         // u = K (y0 + V0)
+
+    // ---- R1. rows: right-hand side and the 2x2 term of the fundamental, the 2x2-algebra children folded in (k_factor_q, wave 0
+    //      role + children, here one thread per (scenario, row) and every child of the bus in list order) -------------------------
+    for (int row = l16; row < 64; row += 16) {
+        double y = 0.0, d0 = 0.0, d1 = 0.0;
+        if (live && row < b && loc_valid(n, c, k, row)) {
+            const int q = row >> 1, tr_ = row & 1;
+            const size_t kq = (size_t)k * Hn + q;
+            double a0 = 0.0, a1 = 0.0, ay = 0.0;
+            if (via_chain) {
+                const size_t o = so + kq;
+                a0 = chD[o * 4 + 2 * tr_];
+                a1 = chD[o * 4 + 2 * tr_ + 1];
+                ay = chy[o * 2 + tr_];
+            }
+            double e0 = 0.0, e1 = 0.0, ey = 0.0;
+            if (lin_beg < lin_end) {
+                const double* ws = wall + (size_t)s * n * B;
+                const double* linA = linAall + so * 4;
+                const int4* c3 = reinterpret_cast<const int4*>(T.child3);
+                const cplx uk = U[kq], ek = E[kq];
+                for (int cp = lin_beg; cp < lin_end; ++cp) {
+                    const int4 cr = c3[cp];
+                    const int ch = cr.x;
+                    const cplx ydn = M.Y[(size_t)cr.y * Hn + q], yup = M.Y[(size_t)cr.z * Hn + q];
+                    const cplx uc = U[(size_t)ch * Hn + q], ec = E[(size_t)ch * Hn + q];
+                    const double2* pic = reinterpret_cast<const double2*>(linA + ((size_t)ch * Hn + q) * 4);
+                    const double2 ic01 = pic[0], ic23 = pic[1];
+                    const double2 wc = *reinterpret_cast<const double2*>(ws + (size_t)ch * B + 2 * q);
+                    const Blk2 g = (q == 0 && k < M.m) ? blk_power_off(ydn, uk, uc, ec) : blk_current(ydn, uc, ec);   // A(k, child)
+                    const Blk2 hb = (q == 0 && ch < M.m) ? blk_power_off(yup, uc, uk, ek) : blk_current(yup, uk, ek);  // A(child, k)
+                    const double g0 = pick(g, tr_, 0);
+                    const double g1 = loc_valid(n, c, ch, 2 * q + 1) ? pick(g, tr_, 1) : 0.0;
+                    double h4[4];
+                    mask_block(n, c, q, ch, k, hb, h4);
+                    const double v0 = fma(g1, ic23.x, g0 * ic01.x), v1 = fma(g1, ic23.y, g0 * ic01.y);
+                    e0 += fma(v1, h4[2], v0 * h4[0]);
+                    e1 += fma(v1, h4[3], v0 * h4[1]);
+                    ey = fma(g0, wc.x, ey);
+                    ey = fma(g1, wc.y, ey);
+                }
+            }
+            d0 = a0 - e0;
+            d1 = a1 - e1;
+            y = fall[((size_t)s * n + k) * B + row] + ay - ey;
+        }
+        Y[row * LB_SB + sc] = y;
+        if (row < 2) {
+            DL[sc * 4 + row * 2] = d0;
+            DL[sc * 4 + row * 2 + 1] = d1;
+        }
+    }
+    // ---- R2. harmonics: S_q^-1, the coupling blocks with the parent (H is kept for the back sweep), the position-0 borders ----
+    for (int q = l16; q < H2; q += 16) {
+        double si[4] = {1.0, 0.0, 0.0, 1.0}, g4[4] = {0.0, 0.0, 0.0, 0.0}, h4[4] = {0.0, 0.0, 0.0, 0.0};
+        if (live && q < Hn) {
+            const cplx uk = U[(size_t)k * Hn + q], ek = E[(size_t)k * Hn + q];
+            const double idet = 1.0 / (-(uk.im * ek.im) - ek.re * uk.re);      // S = [-ui er; ur ei]
+            si[0] = ek.im * idet;   si[1] = -ek.re * idet;
+            si[2] = -uk.re * idet;  si[3] = -uk.im * idet;
+            cplx up = {0.0, -1.0}, ep = {0.0, 1.0};
+            if (!via_chain || q == 0) {
+                up = U[(size_t)par * Hn + q];
+                ep = E[(size_t)par * Hn + q];
+            }
+            if (via_chain) {
+                const double2* pg = reinterpret_cast<const double2*>(chG + (so + (size_t)k * Hn + q) * 4);
+                const double2* ph = reinterpret_cast<const double2*>(chH + (so + (size_t)k * Hn + q) * 4);
+                const double2 ga = pg[0], gb = pg[1], ha = ph[0], hb = ph[1];
+                g4[0] = ga.x; g4[1] = ga.y; g4[2] = gb.x; g4[3] = gb.y;
+                h4[0] = ha.x; h4[1] = ha.y; h4[2] = hb.x; h4[3] = hb.y;
+            } else {
+                const cplx ydn = M.Y[(size_t)e_dn_k * Hn + q], yup = M.Y[(size_t)e_up_k * Hn + q];
+                const Blk2 g = (q == 0 && par < M.m) ? blk_power_off(ydn, up, uk, ek) : blk_current(ydn, uk, ek);   // row par, col k
+                const Blk2 hh = (q == 0 && k < M.m) ? blk_power_off(yup, uk, up, ep) : blk_current(yup, up, ep);     // row k, col par
+                mask_block(n, c, q, par, k, g, g4);
+                mask_block(n, c, q, k, par, hh, h4);
+            }
+            double* Hk = Hall + ((size_t)s * n + k) * Hn * 4 + q * 4;
+            double* Sk = lfS + (so + (size_t)k * Hn + q) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                Hk[e] = h4[e];
+                Sk[e] = si[e];
+            }
+            if (q == 0) {                                    // G0 S_c^-1, H0 S_p^-1 for the parent's rebuild
+                const double ip = 1.0 / (-(up.im * ep.im) - ep.re * up.re);
+                const double sp0 = ep.im * ip, sp1 = -ep.re * ip, sp2 = -up.re * ip, sp3 = -up.im * ip;
+                double* kk = lfK + ((size_t)s * n + k) * 12 + 4;
+                kk[0] = fma(g4[1], si[2], g4[0] * si[0]);  kk[1] = fma(g4[1], si[3], g4[0] * si[1]);
+                kk[2] = fma(g4[3], si[2], g4[2] * si[0]);  kk[3] = fma(g4[3], si[3], g4[2] * si[1]);
+                kk[4] = fma(h4[1], sp2, h4[0] * sp0);  kk[5] = fma(h4[1], sp3, h4[0] * sp1);
+                kk[6] = fma(h4[3], sp2, h4[2] * sp0);  kk[7] = fma(h4[3], sp3, h4[2] * sp1);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            SI[(sc * H2 + q) * 4 + e] = si[e];
+            GL[(sc * H2 + q) * 4 + e] = g4[e];
+        }
+    }
+    __syncthreads();
+    // ---- M. V = [0 Lr; 0 Ahh^-1] Y for the 16 scenarios: wave w owns rows 16 w .. 16 w + 15 ---------------------------------------
+    if (wv < NTR) {
+        d4_t acc = {0.0, 0.0, 0.0, 0.0};
+        const double* ia = img + (size_t)wv * KS * 64 + lane;
+#pragma unroll 4
+        for (int ks = 0; ks < KS; ++ks) {
+            const double a = ia[(size_t)ks * 64];
+            const double bop = Y[(4 * ks + lg) * LB_SB + jj];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bop, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) V[(16 * wv + 4 * reg + lg) * LB_SB + jj] = acc[reg];
+    }
+    __syncthreads();
+    // ---- K. per scenario: K = (c0 + Delta_polar S_0^-1)^-1, u = K (y0 + V0) --------------------------------------------------------
+    if (l16 == 0) {
+        const double* si = SI + (sc * H2) * 4;
+        const double* dl = DL + sc * 4;
+        const double q00 = c0img[0] + fma(dl[1], si[2], dl[0] * si[0]), q01 = c0img[1] + fma(dl[1], si[3], dl[0] * si[1]);
+        const double q10 = c0img[2] + fma(dl[3], si[2], dl[2] * si[0]), q11 = c0img[3] + fma(dl[3], si[3], dl[2] * si[1]);
+        double k00, k01, k10, k11;
+        inv2(q00, q01, q10, q11, k00, k01, k10, k11);
+        const double r0 = Y[sc] + V[sc], r1 = Y[LB_SB + sc] + V[LB_SB + sc];
+        UK[sc * 2] = fma(k01, r1, k00 * r0);
+        UK[sc * 2 + 1] = fma(k11, r1, k10 * r0);
+        if (live) {
+            double* kk = lfK + ((size_t)s * n + k) * 12;
+            kk[0] = k00; kk[1] = k01; kk[2] = k10; kk[3] = k11;
+        }
+    }
+    __syncthreads();
+    // ---- F. per (scenario, harmonic): x_rect = [u; Vh + Lc u], w = S_q^-1 x_rect, G w for the parent -----------------------------
+    if (live) {
+        const double u0 = UK[sc * 2], u1 = UK[sc * 2 + 1];
+        double* wk = wall + ((size_t)s * n + k) * B;
+        double* Ck = Call + ((size_t)s * n + k) * CT;
+        for (int q = l16; q < H2; q += 16) {
+            double x0 = u0, x1 = u1;
+            if (q > 0) {
+                const double* lc = lcimg + (2 * q) * 2;
+                x0 = V[(2 * q) * LB_SB + sc] + fma(lc[1], u1, lc[0] * u0);
+                x1 = V[(2 * q + 1) * LB_SB + sc] + fma(lc[3], u1, lc[2] * u0);
+            }
+            const double* si = SI + (sc * H2 + q) * 4;
+            const bool in = 2 * q < b;
+            const double w0 = in ? fma(si[1], x1, si[0] * x0) : 0.0, w1 = in ? fma(si[3], x1, si[2] * x0) : 0.0;
+            const double* g = GL + (sc * H2 + q) * 4;
+            wk[2 * q] = w0;
+            wk[2 * q + 1] = w1;
+            Ck[2 * q] = fma(g[1], w1, g[0] * w0);
+            Ck[2 * q + 1] = fma(g[3], w1, g[2] * w0);
+        }
+    }
+}
+
+template <int B>
+int launch_leaf_batch(hpf_handle* h, const TreeDev& T, const int* nodes, int count, const int* active) {
+    const dim3 grid((unsigned)count, (unsigned)((h->cur_S + LB_SB - 1) / LB_SB));
+    hipLaunchKernelGGL((k_leaf_batch<B>), grid, dim3(256), 0, h->cur_stream, h->M, T, nodes, 2 * h->Hn, active, h->cur_S, h->d_U,
+                       h->d_E, h->d_fb, h->d_w, h->d_linA, h->d_C, h->d_H, h->d_chG, h->d_chH, h->d_chD, h->d_chy,
+                       active_tree(h).d_lbimg, h->d_lfK, h->d_lfS, h->cur_s0);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        h->last_detail = (int)e;
+        return HPF_E_HIP;
+    }
+    return HPF_OK;
+}
