@@ -1700,6 +1700,12 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
         auto mid = std::stable_partition(first, last, [&](int k2) { return is_lazy[k2] != 0; });
         T.n_lazy_level0 = (int)(mid - first);
     }
+    T.dep_nleaf.assign(T.n_depths > 0 ? T.n_depths : 1, 0);      // back sweep: the leaves of a depth first
+    for (int dl = 0; dl < T.n_depths; ++dl) {
+        auto first = T.dep_nodes.begin() + T.dep_ptr[dl], last = T.dep_nodes.begin() + T.dep_ptr[dl + 1];
+        auto mid = std::stable_partition(first, last, [&](int k2) { return cleaf_of[k2] >= 0; });
+        T.dep_nleaf[dl] = (int)(mid - first);
+    }
     const long long sl_base = (long long)lzimg.size();          // super-leaf constants ride behind the lazy images
     lzimg.insert(lzimg.end(), slimg.begin(), slimg.end());
     T.lvl_all_leaf.assign(T.n_levels > 0 ? T.n_levels : 1, 1);
@@ -1815,6 +1821,13 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
     if ((r = upload(h, &T.d_fdesc, fdesc))) return r;
     if ((r = upload(h, &T.d_child3, child3))) return r;
     if ((r = upload(h, &T.d_bdesc, bdesc))) return r;
+    {
+        std::vector<int> bleaf;
+        for (int pos = 0; pos < T.n_dense; ++pos)
+            if (bdesc[(size_t)pos * 4 + 2] > 0 && bdesc[(size_t)pos * 4 + 1] >= 0) bleaf.insert(bleaf.end(), &bdesc[(size_t)pos * 4], &bdesc[(size_t)pos * 4] + 4);
+        T.n_bleaf = (int)bleaf.size() / 4;
+        if ((r = upload(h, &T.d_bleaf, bleaf))) return r;
+    }
     if ((r = upload(h, &T.d_dchild, dchild))) return r;
     if ((r = upload(h, &T.d_chain_ptr, T.chain_ptr))) return r;
     if ((r = upload(h, &T.d_chain_nodes, T.chain_nodes))) return r;
@@ -1845,7 +1858,7 @@ static void tree_free_one(Tree& T) {
     void* ptrs[] = {T.d_parent, T.d_lvl_nodes, T.d_dep_nodes, T.d_child_ptr, T.d_child, T.d_e_up, T.d_e_dn,
                     T.d_child_mid, T.d_lin, T.d_lin_ptr, T.d_lin_post, T.d_all_ptr, T.d_all_post, T.d_fdesc, T.d_child3,
                     T.d_bdesc, T.d_dchild, T.d_chain_ptr, T.d_chain_nodes, T.d_chain_ch, T.d_Minv, T.d_lrec, T.d_crec, T.d_cnode, T.d_arec,
-                    T.d_lzrec, T.d_lzimg, T.d_lbimg};
+                    T.d_lzrec, T.d_lzimg, T.d_lbimg, T.d_bleaf};
     for (void* p : ptrs)
         if (p) hipFree(p);
 }
@@ -2021,10 +2034,30 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
         if (cnt == 0) continue;
         const int* nodes = T.d_dep_nodes + T.dep_ptr[dl];
         int r = HPF_OK;
+        static const int leafbatch_b = [] { const char* e = getenv("HPF_LEAFBATCH"); return e ? atoi(e) : 1; }();
+        const int nlb = (leafbatch_b && h->has_ctree && dl > 0 && dl < (int)T.dep_nleaf.size()) ? T.dep_nleaf[dl] : 0;
         switch (BW) {
-            case 12: r = h->gj_mode == 1 ? launch_back_q<12>(h, td, T.d_bdesc + 4 * (size_t)T.dep_ptr[dl], cnt, active) : launch_back_w<12>(h, td, nodes, cnt, active); break;
-            case 28: r = h->gj_mode == 1 ? launch_back_q<28>(h, td, T.d_bdesc + 4 * (size_t)T.dep_ptr[dl], cnt, active) : launch_back_w<28>(h, td, nodes, cnt, active); break;
-            case 52: r = h->gj_mode == 1 ? launch_back_q<52>(h, td, T.d_bdesc + 4 * (size_t)T.dep_ptr[dl], cnt, active) : launch_back_w<52>(h, td, nodes, cnt, active); break;
+            case 12:
+                if (h->gj_mode == 1 && nlb > 0) {                    // (the leaves of this depth wait for the one batched launch below)
+                    if (cnt > nlb) r = launch_back_q<12>(h, td, T.d_bdesc + 4 * (size_t)(T.dep_ptr[dl] + nlb), cnt - nlb, active);
+                    break;
+                }
+                r = h->gj_mode == 1 ? launch_back_q<12>(h, td, T.d_bdesc + 4 * (size_t)T.dep_ptr[dl], cnt, active) : launch_back_w<12>(h, td, nodes, cnt, active);
+                break;
+            case 28:
+                if (h->gj_mode == 1 && nlb > 0) {                    // (the leaves of this depth wait for the one batched launch below)
+                    if (cnt > nlb) r = launch_back_q<28>(h, td, T.d_bdesc + 4 * (size_t)(T.dep_ptr[dl] + nlb), cnt - nlb, active);
+                    break;
+                }
+                r = h->gj_mode == 1 ? launch_back_q<28>(h, td, T.d_bdesc + 4 * (size_t)T.dep_ptr[dl], cnt, active) : launch_back_w<28>(h, td, nodes, cnt, active);
+                break;
+            case 52:
+                if (h->gj_mode == 1 && nlb > 0) {                    // (the leaves of this depth wait for the one batched launch below)
+                    if (cnt > nlb) r = launch_back_q<52>(h, td, T.d_bdesc + 4 * (size_t)(T.dep_ptr[dl] + nlb), cnt - nlb, active);
+                    break;
+                }
+                r = h->gj_mode == 1 ? launch_back_q<52>(h, td, T.d_bdesc + 4 * (size_t)T.dep_ptr[dl], cnt, active) : launch_back_w<52>(h, td, nodes, cnt, active);
+                break;
             default: {
                 hipLaunchKernelGGL(k_tree_back, dim3((unsigned)cnt, (unsigned)h->cur_S), dim3(256), 0, h->cur_stream, h->n, h->c,
                                    h->Hn, td, nodes, b, h->N, h->Nc, active, h->d_Z, h->d_w, h->d_x, h->d_f, h->cur_s0);
@@ -2036,6 +2069,21 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
             }
         }
         if (r) return r;
+    }
+    {
+        // every constant-inverse leaf at once, 16 scenarios per workgroup: a leaf's x needs its parent's only, and nothing of the
+        // dense tree hangs below a leaf (the 2x2 kernels that do come next)
+        static const int leafbatch_e = [] { const char* e = getenv("HPF_LEAFBATCH"); return e ? atoi(e) : 1; }();
+        if (leafbatch_e && h->has_ctree && h->gj_mode == 1 && T.n_bleaf > 0) {
+            int r = HPF_OK;
+            switch (BW) {
+                case 12: r = launch_leaf_back_batch<12>(h, T.d_bleaf, T.n_bleaf, active); break;
+                case 28: r = launch_leaf_back_batch<28>(h, T.d_bleaf, T.n_bleaf, active); break;
+                case 52: r = launch_leaf_back_batch<52>(h, T.d_bleaf, T.n_bleaf, active); break;
+                default: break;
+            }
+            if (r) return r;
+        }
     }
     const bool lvl2x2b = h->has_ctree && h->gj_mode == 1;
     if (lvl2x2b) {

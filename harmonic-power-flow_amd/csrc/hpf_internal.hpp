@@ -84,6 +84,9 @@ struct Tree {
     // rebuilds the sum from per-model images and the leaves' 2x2 cores (k_factor_q, "lazy" phase)
     int n_lazy_parents = 0, n_lazy_leaves = 0;
     int n_lazy_level0 = 0;            // the first n_lazy_level0 buses of elimination level 0 are lazy leaves (k_leaf_batch)
+    std::vector<int> dep_nleaf;       // [n_depths] constant-inverse leaves of a back-sweep depth (they come first in the depth's records)
+    int n_bleaf = 0;
+    int* d_bleaf = nullptr;           // [n_bleaf][4] back-sweep records of ALL constant-inverse leaves: one k_leaf_back_batch launch after the last depth
     double* d_lbimg = nullptr;        // [leaf slot][LeafBatchImg::SZ]: the leaf images in MFMA A-operand layout (16 scenarios per workgroup)
     int* d_lzrec = nullptr;           // [n_lazy_parents][8]: image offset (doubles), L, leaf ids[4] (-1: none), 0, 0
     double* d_lzimg = nullptr;        // per parent: sum of constant parts (tile layout) | A operands [pair][tr][64] | row factors [pair][tc][2][64]

@@ -225,3 +225,100 @@ int launch_leaf_batch(hpf_handle* h, const TreeDev& T, const int* nodes, int cou
     }
     return HPF_OK;
 }
+
+// Back sweep of the constant-inverse leaves, 16 scenarios per workgroup:  x_k = w_k - S^-1 Drect^-1 t,  t = A(k,parent) x_parent,
+// Drect^-1 t = [u; Vh + Lc u],  V = [0 Lr; 0 Ahh^-1] t  (the same per-model image on the matrix cores),  u = K (t0 + V0).
+// nodes: Tree::d_bdesc records (bus, parent, leaf slot + 1, 0) of leaves only.
+template <int B>
+__global__ __launch_bounds__(256) void k_leaf_back_batch(
+    Model M, const int* __restrict__ nodes, int b, const int* __restrict__ active, int S_cnt, const double* __restrict__ wall,
+    double* __restrict__ xall, const double* __restrict__ Hall, const double* __restrict__ lbimg, const double* __restrict__ lfK,
+    const double* __restrict__ lfS, int s0) {
+    constexpr int NTR = LeafBatchImg<B>::NTR, KS = LeafBatchImg<B>::KS, H2 = B / 2;
+    const int4 kp = reinterpret_cast<const int4*>(nodes)[blockIdx.x];
+    const int k = kp.x, par = kp.y, slot = kp.z - 1;
+    const int tid = threadIdx.x, lane = tid & 63, lg = lane >> 4, jj = lane & 15;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = M.n, Hn = M.Hn;
+    const int sc = tid >> 4, l16 = tid & 15;
+    const int sl = blockIdx.y * LB_SB + sc;
+    const int s = sl + s0;
+    const bool live = sl < S_cnt && !(active && !active[s]);
+    double* xs = xall + (size_t)s * n * B;
+    const double* img = lbimg + (size_t)slot * LeafBatchImg<B>::SZ;
+    const double* lcimg = img + NTR * KS * 64;
+
+    __shared__ double TT[64 * LB_SB];                        // t = A(k,parent) x_parent, [row][scenario]
+    __shared__ double V[64 * LB_SB];
+    __shared__ double UK[LB_SB * 2];
+
+    for (int q = l16; q < 32; q += 16) {
+        double t0 = 0.0, t1 = 0.0;
+        if (live && q < Hn) {
+            const double* hk = Hall + (((size_t)s * n + k) * Hn + q) * 4;
+            const double2 xp = *reinterpret_cast<const double2*>(xs + (size_t)par * B + 2 * q);
+            t0 = fma(hk[1], xp.y, hk[0] * xp.x);
+            t1 = fma(hk[3], xp.y, hk[2] * xp.x);
+        }
+        TT[(2 * q) * LB_SB + sc] = t0;
+        TT[(2 * q + 1) * LB_SB + sc] = t1;
+    }
+    __syncthreads();
+    if (wv < NTR) {
+        d4_t acc = {0.0, 0.0, 0.0, 0.0};
+        const double* ia = img + (size_t)wv * KS * 64 + lane;
+#pragma unroll 4
+        for (int ks = 0; ks < KS; ++ks) {
+            const double a = ia[(size_t)ks * 64];
+            const double bop = TT[(4 * ks + lg) * LB_SB + jj];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bop, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) V[(16 * wv + 4 * reg + lg) * LB_SB + jj] = acc[reg];
+    }
+    __syncthreads();
+    if (l16 == 0) {
+        double k00 = 0.0, k01 = 0.0, k10 = 0.0, k11 = 0.0;
+        if (live) {
+            const double* kk = lfK + ((size_t)s * n + k) * 12;
+            k00 = kk[0]; k01 = kk[1]; k10 = kk[2]; k11 = kk[3];
+        }
+        const double r0 = TT[sc] + V[sc], r1 = TT[LB_SB + sc] + V[LB_SB + sc];                      // [I Lr] t
+        UK[sc * 2] = fma(k01, r1, k00 * r0);
+        UK[sc * 2 + 1] = fma(k11, r1, k10 * r0);
+    }
+    __syncthreads();
+    if (live) {
+        const double u0 = UK[sc * 2], u1 = UK[sc * 2 + 1];
+        const double* wk = wall + ((size_t)s * n + k) * B;
+        for (int q = l16; q < H2; q += 16) {
+            double x0 = u0, x1 = u1;
+            if (q > 0) {
+                const double* lc = lcimg + (2 * q) * 2;
+                x0 = V[(2 * q) * LB_SB + sc] + fma(lc[1], u1, lc[0] * u0);
+                x1 = V[(2 * q + 1) * LB_SB + sc] + fma(lc[3], u1, lc[2] * u0);
+            }
+            double d0 = x0, d1 = x1;
+            if (q < Hn) {
+                const double* si = lfS + (((size_t)s * n + k) * Hn + q) * 4;
+                d0 = fma(si[1], x1, si[0] * x0);
+                d1 = fma(si[3], x1, si[2] * x0);
+            }
+            const double2 w2 = *reinterpret_cast<const double2*>(wk + 2 * q);
+            *reinterpret_cast<double2*>(xs + (size_t)k * B + 2 * q) = double2{w2.x - d0, w2.y - d1};
+        }
+    }
+}
+
+template <int B>
+int launch_leaf_back_batch(hpf_handle* h, const int* nodes, int count, const int* active) {
+    const dim3 grid((unsigned)count, (unsigned)((h->cur_S + LB_SB - 1) / LB_SB));
+    hipLaunchKernelGGL((k_leaf_back_batch<B>), grid, dim3(256), 0, h->cur_stream, h->M, nodes, 2 * h->Hn, active, h->cur_S, h->d_w,
+                       h->d_x, h->d_H, active_tree(h).d_lbimg, h->d_lfK, h->d_lfS, h->cur_s0);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        h->last_detail = (int)e;
+        return HPF_E_HIP;
+    }
+    return HPF_OK;
+}
