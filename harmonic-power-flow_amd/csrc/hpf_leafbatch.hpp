@@ -52,8 +52,8 @@ __global__ __launch_bounds__(256) void k_leaf_batch(
     __shared__ double Y[64 * LB_SB];                         // right-hand sides [row][scenario]
     __shared__ double V[64 * LB_SB];                         // [0 Lr; 0 Ahh^-1] y
     __shared__ double DL[LB_SB * 4];                         // Delta_polar per scenario
-    __shared__ double SI[LB_SB * H2 * 4];                    // S_q^-1 per scenario
-    __shared__ double GL[LB_SB * H2 * 4];                    // A(parent, k) per scenario
+    constexpr int QI = (H2 + 15) / 16;                       // harmonics per thread of a scenario's 16
+    double sir[QI][4], glr[QI][4];                           // S_q^-1 and A(parent, k) of the thread's harmonics (same mapping in R2, K, F)
     __shared__ double UK[LB_SB * 2];                         // u = K (y0 + V0)
 
     // ---- R1. rows: right-hand side and the 2x2 term of the fundamental, the 2x2-algebra children folded in (k_factor_q, wave 0
@@ -108,7 +108,9 @@ __global__ __launch_bounds__(256) void k_leaf_batch(
         }
     }
     // ---- R2. harmonics: S_q^-1, the coupling blocks with the parent (H is kept for the back sweep), the position-0 borders ----
-    for (int q = l16; q < H2; q += 16) {
+#pragma unroll
+    for (int it = 0; it < QI; ++it) {
+        const int q = l16 + 16 * it;
         double si[4] = {1.0, 0.0, 0.0, 1.0}, g4[4] = {0.0, 0.0, 0.0, 0.0}, h4[4] = {0.0, 0.0, 0.0, 0.0};
         if (live && q < Hn) {
             const cplx uk = U[(size_t)k * Hn + q], ek = E[(size_t)k * Hn + q];
@@ -152,8 +154,8 @@ __global__ __launch_bounds__(256) void k_leaf_batch(
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            SI[(sc * H2 + q) * 4 + e] = si[e];
-            GL[(sc * H2 + q) * 4 + e] = g4[e];
+            sir[it][e] = si[e];
+            glr[it][e] = g4[e];
         }
     }
     __syncthreads();
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(256) void k_leaf_batch(
     __syncthreads();
     // ---- K. per scenario: K = (c0 + Delta_polar S_0^-1)^-1, u = K (y0 + V0) --------------------------------------------------------
     if (l16 == 0) {
-        const double* si = SI + (sc * H2) * 4;
+        const double* si = sir[0];                           // (q = 0 belongs to this thread)
         const double* dl = DL + sc * 4;
         const double q00 = c0img[0] + fma(dl[1], si[2], dl[0] * si[0]), q01 = c0img[1] + fma(dl[1], si[3], dl[0] * si[1]);
         const double q10 = c0img[2] + fma(dl[3], si[2], dl[2] * si[0]), q11 = c0img[3] + fma(dl[3], si[3], dl[2] * si[1]);
@@ -193,17 +195,20 @@ __global__ __launch_bounds__(256) void k_leaf_batch(
         const double u0 = UK[sc * 2], u1 = UK[sc * 2 + 1];
         double* wk = wall + ((size_t)s * n + k) * B;
         double* Ck = Call + ((size_t)s * n + k) * CT;
-        for (int q = l16; q < H2; q += 16) {
+#pragma unroll
+        for (int it = 0; it < QI; ++it) {
+            const int q = l16 + 16 * it;
+            if (q >= H2) continue;
             double x0 = u0, x1 = u1;
             if (q > 0) {
                 const double* lc = lcimg + (2 * q) * 2;
                 x0 = V[(2 * q) * LB_SB + sc] + fma(lc[1], u1, lc[0] * u0);
                 x1 = V[(2 * q + 1) * LB_SB + sc] + fma(lc[3], u1, lc[2] * u0);
             }
-            const double* si = SI + (sc * H2 + q) * 4;
+            const double* si = sir[it];
             const bool in = 2 * q < b;
             const double w0 = in ? fma(si[1], x1, si[0] * x0) : 0.0, w1 = in ? fma(si[3], x1, si[2] * x0) : 0.0;
-            const double* g = GL + (sc * H2 + q) * 4;
+            const double* g = glr[it];
             wk[2 * q] = w0;
             wk[2 * q + 1] = w1;
             Ck[2 * q] = fma(g[1], w1, g[0] * w0);
