@@ -212,7 +212,7 @@ def main():
         "ms_per_iter_per_scenario": ms_step / S,
         "roofline": {"bound": "hbm",
                      "kernel": "k_factor_q<%d> (multi-wave block-tree factor kernel; one sweep = %d launches per scenario "
-                               "group, one per tree level)" % (52 if b > 28 else (28 if b > 12 else 12), dm.n_levels),
+                               "group, one per tree level; level 0 is k_leaf_batch: the lazy leaves, 16 scenarios per workgroup)" % (52 if b > 28 else (28 if b > 12 else 12), dm.n_levels),
                      "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS if achieved_gbs else None,
                      "traffic": traffic / max(launches_per_step, 1) if traffic else None, "traffic_note": traffic_note,
@@ -260,10 +260,15 @@ def pmc_traffic(args, S):
     path = os.path.join(REPO, "profiles", "pmc_traffic_latest.json")
     if not os.path.exists(path) or (args.buses, args.hmax, S, args.solver) != (1000, 51, 128, "block_tree"):
         return None, "no PMC pass for this workload"
-    d = json.load(open(path))["per_step_bytes"].get("k_factor_q")
+    per = json.load(open(path))["per_step_bytes"]
+    d = per.get("k_factor_q")
     if not d:
         return None, "no PMC pass for this kernel"
-    return d["fetch_raw"] + d.get("write_calibrated", d["write"]), ("per launch: (FETCH_SIZE*1024 raw + WRITE_SIZE*1024 x store calibration) of a factor sweep / launches; "
+    tot = d["fetch_raw"] + d.get("write_calibrated", d["write"])
+    lb = per.get("k_leaf_batch")                      # level 0 of the sweep: the lazy leaves' own kernel, same timing span
+    if lb:
+        tot += lb["fetch_raw"] + lb.get("write_calibrated", lb["write"])
+    return tot, ("per launch: (FETCH_SIZE*1024 raw + WRITE_SIZE*1024 x store calibration) of a factor sweep / launches; "
                                          "tile-image loads calibrate at 1.0 (k_back_q, known bytes), stores at ~0.55 (k_update, known "
                                          "bytes); includes the shared leaf images served by the Infinity Cache; separate "
                                          "rocprofv3 --pmc passes, see profiles/pmc_traffic_latest.json")
