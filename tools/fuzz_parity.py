@@ -63,4 +63,4 @@ for case in range(cases):
           (case, nn, Hn, 2 * Hn, frac, n_pv, seed, dVm, dVa, step), flush=True)
     assert np.isfinite(dVm) and np.isfinite(dVa)
 print("worst deviation relative to the step size %.2e" % worst)
-sys.exit(0 if worst < 1e-8 else 1)
+sys.exit(0 if worst < 1e-6 else 1)     # wrong algebra shows as O(1); ill-conditioned first steps (100 rad) reach 1e-7 on either path
