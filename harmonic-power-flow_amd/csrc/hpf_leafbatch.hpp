@@ -20,7 +20,7 @@ struct LeafBatchImg {
 };
 
 template <int B>
-__global__ __launch_bounds__(256) void k_leaf_batch(
+__global__ __launch_bounds__(256, 4) void k_leaf_batch(
     Model M, TreeDev T, const int* __restrict__ nodes, int b, const int* __restrict__ active, int S_cnt,
     const cplx* __restrict__ Uall, const cplx* __restrict__ Eall, const double* __restrict__ fall, double* __restrict__ wall,
     const double* __restrict__ linAall, double* __restrict__ Call, double* __restrict__ Hall, const double* __restrict__ chG,
@@ -58,53 +58,70 @@ __global__ __launch_bounds__(256) void k_leaf_batch(
 
     // ---- R1. rows: right-hand side and the 2x2 term of the fundamental, the 2x2-algebra children folded in (k_factor_q, wave 0
     //      role + children, here one thread per (scenario, row) and every child of the bus in list order) -------------------------
-    for (int row = l16; row < 64; row += 16) {
-        double y = 0.0, d0 = 0.0, d1 = 0.0;
-        if (live && row < b && loc_valid(n, c, k, row)) {
-            const int q = row >> 1, tr_ = row & 1;
-            const size_t kq = (size_t)k * Hn + q;
-            double a0 = 0.0, a1 = 0.0, ay = 0.0;
-            if (via_chain) {
-                const size_t o = so + kq;
-                a0 = chD[o * 4 + 2 * tr_];
-                a1 = chD[o * 4 + 2 * tr_ + 1];
-                ay = chy[o * 2 + tr_];
-            }
-            double e0 = 0.0, e1 = 0.0, ey = 0.0;
-            if (lin_beg < lin_end) {
-                const double* ws = wall + (size_t)s * n * B;
-                const double* linA = linAall + so * 4;
-                const int4* c3 = reinterpret_cast<const int4*>(T.child3);
-                const cplx uk = U[kq], ek = E[kq];
-                for (int cp = lin_beg; cp < lin_end; ++cp) {
-                    const int4 cr = c3[cp];
-                    const int ch = cr.x;
-                    const cplx ydn = M.Y[(size_t)cr.y * Hn + q], yup = M.Y[(size_t)cr.z * Hn + q];
-                    const cplx uc = U[(size_t)ch * Hn + q], ec = E[(size_t)ch * Hn + q];
-                    const double2* pic = reinterpret_cast<const double2*>(linA + ((size_t)ch * Hn + q) * 4);
-                    const double2 ic01 = pic[0], ic23 = pic[1];
-                    const double2 wc = *reinterpret_cast<const double2*>(ws + (size_t)ch * B + 2 * q);
-                    const Blk2 g = (q == 0 && k < M.m) ? blk_power_off(ydn, uk, uc, ec) : blk_current(ydn, uc, ec);   // A(k, child)
-                    const Blk2 hb = (q == 0 && ch < M.m) ? blk_power_off(yup, uc, uk, ek) : blk_current(yup, uk, ek);  // A(child, k)
-                    const double g0 = pick(g, tr_, 0);
-                    const double g1 = loc_valid(n, c, ch, 2 * q + 1) ? pick(g, tr_, 1) : 0.0;
-                    double h4[4];
-                    mask_block(n, c, q, ch, k, hb, h4);
-                    const double v0 = fma(g1, ic23.x, g0 * ic01.x), v1 = fma(g1, ic23.y, g0 * ic01.y);
-                    e0 += fma(v1, h4[2], v0 * h4[0]);
-                    e1 += fma(v1, h4[3], v0 * h4[1]);
-                    ey = fma(g0, wc.x, ey);
-                    ey = fma(g1, wc.y, ey);
+    {
+        // (the thread's four rows side by side: the children loop runs once, with the loads of all four rows in flight)
+        double e0[4] = {0.0, 0.0, 0.0, 0.0}, e1[4] = {0.0, 0.0, 0.0, 0.0}, ey[4] = {0.0, 0.0, 0.0, 0.0};
+        double a0[4] = {0.0, 0.0, 0.0, 0.0}, a1[4] = {0.0, 0.0, 0.0, 0.0}, ay[4] = {0.0, 0.0, 0.0, 0.0}, fy[4] = {0.0, 0.0, 0.0, 0.0};
+        bool ok[4];
+        cplx ukr[4], ekr[4];
+#pragma unroll
+        for (int pz = 0; pz < 4; ++pz) {
+            const int row = l16 + 16 * pz, q = row >> 1, tr_ = row & 1;
+            ok[pz] = live && row < b && loc_valid(n, c, k, row);
+            ukr[pz] = cplx{0.0, 0.0};
+            ekr[pz] = cplx{0.0, 0.0};
+            if (ok[pz]) {
+                const size_t kq = (size_t)k * Hn + q;
+                fy[pz] = fall[((size_t)s * n + k) * B + row];
+                if (via_chain) {
+                    const size_t o = so + kq;
+                    a0[pz] = chD[o * 4 + 2 * tr_];
+                    a1[pz] = chD[o * 4 + 2 * tr_ + 1];
+                    ay[pz] = chy[o * 2 + tr_];
+                }
+                if (lin_beg < lin_end) {
+                    ukr[pz] = U[kq];
+                    ekr[pz] = E[kq];
                 }
             }
-            d0 = a0 - e0;
-            d1 = a1 - e1;
-            y = fall[((size_t)s * n + k) * B + row] + ay - ey;
         }
-        Y[row * LB_SB + sc] = y;
-        if (row < 2) {
-            DL[sc * 4 + row * 2] = d0;
-            DL[sc * 4 + row * 2 + 1] = d1;
+        const double* ws = wall + (size_t)s * n * B;
+        const double* linA = linAall + so * 4;
+        const int4* c3 = reinterpret_cast<const int4*>(T.child3);
+        for (int cp = lin_beg; cp < lin_end; ++cp) {
+            const int4 cr = c3[cp];
+            const int ch = cr.x;
+#pragma unroll
+            for (int pz = 0; pz < 4; ++pz) {
+                if (!ok[pz]) continue;
+                const int row = l16 + 16 * pz, q = row >> 1, tr_ = row & 1;
+                const cplx uk = ukr[pz], ek = ekr[pz];
+                const cplx ydn = M.Y[(size_t)cr.y * Hn + q], yup = M.Y[(size_t)cr.z * Hn + q];
+                const cplx uc = U[(size_t)ch * Hn + q], ec = E[(size_t)ch * Hn + q];
+                const double2* pic = reinterpret_cast<const double2*>(linA + ((size_t)ch * Hn + q) * 4);
+                const double2 ic01 = pic[0], ic23 = pic[1];
+                const double2 wc = *reinterpret_cast<const double2*>(ws + (size_t)ch * B + 2 * q);
+                const Blk2 g = (q == 0 && k < M.m) ? blk_power_off(ydn, uk, uc, ec) : blk_current(ydn, uc, ec);   // A(k, child)
+                const Blk2 hb = (q == 0 && ch < M.m) ? blk_power_off(yup, uc, uk, ek) : blk_current(yup, uk, ek);  // A(child, k)
+                const double g0 = pick(g, tr_, 0);
+                const double g1 = loc_valid(n, c, ch, 2 * q + 1) ? pick(g, tr_, 1) : 0.0;
+                double h4[4];
+                mask_block(n, c, q, ch, k, hb, h4);
+                const double v0 = fma(g1, ic23.x, g0 * ic01.x), v1 = fma(g1, ic23.y, g0 * ic01.y);
+                e0[pz] += fma(v1, h4[2], v0 * h4[0]);
+                e1[pz] += fma(v1, h4[3], v0 * h4[1]);
+                ey[pz] = fma(g0, wc.x, ey[pz]);
+                ey[pz] = fma(g1, wc.y, ey[pz]);
+            }
+        }
+#pragma unroll
+        for (int pz = 0; pz < 4; ++pz) {
+            const int row = l16 + 16 * pz;
+            Y[row * LB_SB + sc] = ok[pz] ? fy[pz] + ay[pz] - ey[pz] : 0.0;
+            if (row < 2) {
+                DL[sc * 4 + row * 2] = ok[pz] ? a0[pz] - e0[pz] : 0.0;
+                DL[sc * 4 + row * 2 + 1] = ok[pz] ? a1[pz] - e1[pz] : 0.0;
+            }
         }
     }
     // ---- R2. harmonics: S_q^-1, the coupling blocks with the parent (H is kept for the back sweep), the position-0 borders ----
