@@ -1349,6 +1349,12 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
     const bool sleaf_on = !(sl_env && atoi(sl_env) == 0);      // HPF_SLEAF=0: every bus with dense children takes the Gauss-Jordan path
     const int sleaf_mode = sl_env ? atoi(sl_env) : 2;          // 1: nonlinear buses only
     int n_sleaf = 0;
+    const char* sb_env = getenv("HPF_SLBACK");
+    const char* lb_env = getenv("HPF_LEAFBATCH");
+    const bool slback_on = !(sb_env && atoi(sb_env) == 0) && !(lb_env && atoi(lb_env) == 0);   // super-leaves keep T^-1 only; k_sleaf_back_batch
+                                                                                             // rebuilds D^-1 t (needs the batched back sweep)
+    std::vector<int> sb_ord(n, -1), sb_m(n, 0);
+    std::vector<double> sbimg;
     std::vector<std::vector<int>> lazy_of(n);
     std::vector<int> is_lazy(n, 0);
     const char* lz_env = getenv("HPF_LAZY");
@@ -1638,6 +1644,21 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
                 for (int c2 = 0; c2 < mr; ++c2) slimg.push_back(R(Pb[(size_t)(row >> 1) * m1 + (c2 >> 1)], row & 1, c2 & 1));
             for (int r2 = 0; r2 < mr; ++r2)
                 for (int col = 0; col < b; ++col) slimg.push_back(R(Qb[(size_t)(r2 >> 1) * Hn + (col >> 1)], r2 & 1, col & 1));
+            if (slback_on) {                                                               // [0 0; 0 Ahh^-1] in MFMA A-operand layout
+                const int NTR = (BWc + 15) / 16, KS = (BWc + 3) / 4;
+                sb_ord[k] = n_sleaf;
+                sb_m[k] = mr;
+                const size_t o0 = sbimg.size();
+                sbimg.resize(o0 + (size_t)NTR * KS * 64, 0.0);
+                for (int w2 = 0; w2 < NTR; ++w2)
+                    for (int ks = 0; ks < KS; ++ks)
+                        for (int lg = 0; lg < 4; ++lg)
+                            for (int jj = 0; jj < 16; ++jj) {
+                                const int row = 16 * w2 + jj, col = 4 * ks + lg;
+                                if (row >= 2 && col >= 2 && row < b && col < b)
+                                    sbimg[o0 + ((size_t)w2 * KS + ks) * 64 + lg * 16 + jj] = R(Ainv(row >> 1, col >> 1), row & 1, col & 1);
+                            }
+            }
             ++n_sleaf;
         }
     }
@@ -1704,7 +1725,8 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
     for (int dl = 0; dl < T.n_depths; ++dl) {
         auto first = T.dep_nodes.begin() + T.dep_ptr[dl], last = T.dep_nodes.begin() + T.dep_ptr[dl + 1];
         auto mid = std::stable_partition(first, last, [&](int k2) { return cleaf_of[k2] >= 0; });
-        T.dep_nleaf[dl] = (int)(mid - first);
+        auto mid2 = std::stable_partition(mid, last, [&](int k2) { return sb_ord[k2] >= 0; });   // batched super-leaves next
+        T.dep_nleaf[dl] = (int)(mid2 - first);
     }
     const long long sl_base = (long long)lzimg.size();          // super-leaf constants ride behind the lazy images
     lzimg.insert(lzimg.end(), slimg.begin(), slimg.end());
@@ -1742,6 +1764,7 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
             for (int i = 0; i < 6; ++i) r[28 + i] = lzrec[(size_t)lz_idx[k] * 8 + i];
         if (sl_off[k] >= 0 && lz_idx[k] >= 0) {                    // super-leaf: Z0 image slot, offset of [Tc | Pb | Qb]
             r[14] |= 4;
+            if (sb_ord[k] >= 0) r[14] |= 8;                        // its back sweep is k_sleaf_back_batch's: T^-1 instead of the inverse
             r[34] = sl_slot[k];
             r[35] = (int)(sl_base + sl_off[k]);
         }
@@ -1822,6 +1845,18 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
     if ((r = upload(h, &T.d_child3, child3))) return r;
     if ((r = upload(h, &T.d_bdesc, bdesc))) return r;
     {
+        std::vector<int> bsleaf;
+        for (int pos = 0; pos < T.n_dense; ++pos) {
+            const int kb = T.dep_nodes[pos];
+            if (sb_ord[kb] < 0 || sl_off[kb] < 0 || lz_idx[kb] < 0) continue;
+            const int rec[8] = {kb, pard[kb], sb_ord[kb], (int)(sl_base + sl_off[kb]), sb_m[kb], 0, 0, 0};
+            bsleaf.insert(bsleaf.end(), rec, rec + 8);
+        }
+        T.n_bsleaf = (int)bsleaf.size() / 8;
+        if ((r = upload(h, &T.d_bsleaf, bsleaf))) return r;
+        if ((r = upload(h, &T.d_sbimg, sbimg))) return r;
+    }
+    {
         std::vector<int> bleaf;
         for (int pos = 0; pos < T.n_dense; ++pos)
             if (bdesc[(size_t)pos * 4 + 2] > 0 && bdesc[(size_t)pos * 4 + 1] >= 0) bleaf.insert(bleaf.end(), &bdesc[(size_t)pos * 4], &bdesc[(size_t)pos * 4] + 4);
@@ -1858,7 +1893,7 @@ static void tree_free_one(Tree& T) {
     void* ptrs[] = {T.d_parent, T.d_lvl_nodes, T.d_dep_nodes, T.d_child_ptr, T.d_child, T.d_e_up, T.d_e_dn,
                     T.d_child_mid, T.d_lin, T.d_lin_ptr, T.d_lin_post, T.d_all_ptr, T.d_all_post, T.d_fdesc, T.d_child3,
                     T.d_bdesc, T.d_dchild, T.d_chain_ptr, T.d_chain_nodes, T.d_chain_ch, T.d_Minv, T.d_lrec, T.d_crec, T.d_cnode, T.d_arec,
-                    T.d_lzrec, T.d_lzimg, T.d_lbimg, T.d_bleaf};
+                    T.d_lzrec, T.d_lzimg, T.d_lbimg, T.d_bleaf, T.d_bsleaf, T.d_sbimg};
     for (void* p : ptrs)
         if (p) hipFree(p);
 }
@@ -2074,6 +2109,16 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
         // every constant-inverse leaf at once, 16 scenarios per workgroup: a leaf's x needs its parent's only, and nothing of the
         // dense tree hangs below a leaf (the 2x2 kernels that do come next)
         static const int leafbatch_e = [] { const char* e = getenv("HPF_LEAFBATCH"); return e ? atoi(e) : 1; }();
+        if (leafbatch_e && h->has_ctree && h->gj_mode == 1 && T.n_bsleaf > 0) {    // super-leaves first: leaves hang below them
+            int r = HPF_OK;
+            switch (BW) {
+                case 12: r = launch_sleaf_back_batch<12>(h, T.d_bsleaf, T.n_bsleaf, active); break;
+                case 28: r = launch_sleaf_back_batch<28>(h, T.d_bsleaf, T.n_bsleaf, active); break;
+                case 52: r = launch_sleaf_back_batch<52>(h, T.d_bsleaf, T.n_bsleaf, active); break;
+                default: break;
+            }
+            if (r) return r;
+        }
         if (leafbatch_e && h->has_ctree && h->gj_mode == 1 && T.n_bleaf > 0) {
             int r = HPF_OK;
             switch (BW) {

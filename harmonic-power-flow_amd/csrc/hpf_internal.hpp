@@ -85,6 +85,10 @@ struct Tree {
     int n_lazy_parents = 0, n_lazy_leaves = 0;
     int n_lazy_level0 = 0;            // the first n_lazy_level0 buses of elimination level 0 are lazy leaves (k_leaf_batch)
     std::vector<int> dep_nleaf;       // [n_depths] constant-inverse leaves of a back-sweep depth (they come first in the depth's records)
+    std::vector<int> dep_nskip;       // [n_depths] leaves + batched super-leaves of a depth: k_back_q starts behind them
+    int n_bsleaf = 0;
+    int* d_bsleaf = nullptr;          // [n_bsleaf][8] back-sweep records of the super-leaves (k_sleaf_back_batch)
+    double* d_sbimg = nullptr;        // [n_bsleaf][NTR*KS*64] their [0 0; 0 Ahh^-1] images in MFMA A-operand layout
     int n_bleaf = 0;
     int* d_bleaf = nullptr;           // [n_bleaf][4] back-sweep records of ALL constant-inverse leaves: one k_leaf_back_batch launch after the last depth
     double* d_lbimg = nullptr;        // [leaf slot][LeafBatchImg::SZ]: the leaf images in MFMA A-operand layout (16 scenarios per workgroup)

@@ -344,3 +344,122 @@ int launch_leaf_back_batch(hpf_handle* h, const int* nodes, int count, const int
     }
     return HPF_OK;
 }
+
+// Back sweep of the super-leaves, 16 scenarios per workgroup:  x_k = w_k - S_k^-1 M_k^-1 (Wd^-1 t),  t = A(k,parent) x_parent,
+//     M_k^-1 v = [0 0; 0 Ahh_k^-1] v + Pb (T^-1 (Qb v)),
+// the Ahh_k^-1 part on the matrix cores (per-model image in A-operand layout), the m <= 10 border unknowns per thread; T^-1 and
+// W_k^-1 were left by the factor kernel at the head of the bus's (otherwise unused) inverse slot.
+// nodes: records of 8 ints (bus, parent, slot in Tree::d_sbimg, offset of [Tc | Pb | Qb] in Tree::d_lzimg, m, 0, 0, 0).
+template <int B>
+__global__ __launch_bounds__(256) void k_sleaf_back_batch(
+    Model M, const int* __restrict__ nodes, int b, const int* __restrict__ active, int S_cnt, const double* __restrict__ wall,
+    double* __restrict__ xall, const double* __restrict__ Hall, const double* __restrict__ sbimg, const double* __restrict__ lzimg,
+    const double* __restrict__ Zall, const double* __restrict__ lfS, int s0) {
+    constexpr int NT = (B + 16) / 16;
+    constexpr size_t CT = (size_t)NT * NT * 256;
+    constexpr int NTR = LeafBatchImg<B>::NTR, KS = LeafBatchImg<B>::KS, H2 = B / 2;
+    const int4* rec = reinterpret_cast<const int4*>(nodes) + 2 * (size_t)blockIdx.x;
+    const int4 r0 = rec[0], r1 = rec[1];
+    const int k = r0.x, par = r0.y, m = r1.x;
+    const double* img = sbimg + (size_t)r0.z * NTR * KS * 64;
+    const double* pbm = lzimg + (size_t)r0.w + m * m;           // Pb [b][m]
+    const double* qbm = pbm + (size_t)b * m;                    // Qb [m][b]
+    const int tid = threadIdx.x, lane = tid & 63, lg = lane >> 4, jj = lane & 15;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = M.n, Hn = M.Hn;
+    const int sc = tid >> 4, l16 = tid & 15;
+    const int sl = blockIdx.y * LB_SB + sc;
+    const int s = sl + s0;
+    const bool live = sl < S_cnt && !(active && !active[s]);
+    double* xs = xall + (size_t)s * n * B;
+    const double* tk = Zall + ((size_t)s * n + k) * CT;         // T^-1 [10][10] | W_k^-1 [4]
+
+    __shared__ double TT[64 * LB_SB];                           // v = Wd^-1 t, [row][scenario]
+    __shared__ double V[64 * LB_SB];
+    __shared__ double RR[16 * LB_SB];                           // r = Qb v, then y = T^-1 r, [border unknown][scenario]
+    __shared__ double YY[16 * LB_SB];
+
+    for (int q = l16; q < 32; q += 16) {
+        double t0 = 0.0, t1 = 0.0;
+        if (live && q < Hn) {
+            const double* hk = Hall + (((size_t)s * n + k) * Hn + q) * 4;
+            const double2 xp = *reinterpret_cast<const double2*>(xs + (size_t)par * B + 2 * q);
+            t0 = fma(hk[1], xp.y, hk[0] * xp.x);
+            t1 = fma(hk[3], xp.y, hk[2] * xp.x);
+            if (q == 0) {                                       // power rows of a linear bus arrive in polar form: W_k^-1 (identity otherwise)
+                const double a = t0, c2 = t1;
+                t0 = fma(tk[101], c2, tk[100] * a);
+                t1 = fma(tk[103], c2, tk[102] * a);
+            }
+        }
+        TT[(2 * q) * LB_SB + sc] = t0;
+        TT[(2 * q + 1) * LB_SB + sc] = t1;
+    }
+    __syncthreads();
+    if (wv < NTR) {
+        d4_t acc = {0.0, 0.0, 0.0, 0.0};
+        const double* ia = img + (size_t)wv * KS * 64 + lane;
+#pragma unroll 4
+        for (int ks = 0; ks < KS; ++ks) {
+            const double a = ia[(size_t)ks * 64];
+            const double bop = TT[(4 * ks + lg) * LB_SB + jj];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bop, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) V[(16 * wv + 4 * reg + lg) * LB_SB + jj] = acc[reg];
+    }
+    {
+        double r = 0.0;                                         // r_j = Qb[j][:] v   (thread (scenario, j))
+        if (l16 < m) {
+            const double* qr = qbm + (size_t)l16 * b;
+            for (int col = 0; col < b; ++col) r = fma(qr[col], TT[col * LB_SB + sc], r);
+        }
+        RR[l16 * LB_SB + sc] = r;
+    }
+    __syncthreads();
+    {
+        double y = 0.0;                                         // y_i = T^-1[i][:] r
+        if (live && l16 < m) {
+            const double* tr = tk + l16 * 10;
+            for (int j = 0; j < m; ++j) y = fma(tr[j], RR[j * LB_SB + sc], y);
+        }
+        YY[l16 * LB_SB + sc] = y;
+    }
+    __syncthreads();
+    if (live) {
+        const double* wk = wall + ((size_t)s * n + k) * B;
+        for (int q = l16; q < H2; q += 16) {
+            double x0 = V[(2 * q) * LB_SB + sc], x1 = V[(2 * q + 1) * LB_SB + sc];
+            if (2 * q < b) {
+                const double* p0 = pbm + (size_t)(2 * q) * m;
+                const double* p1 = p0 + m;
+                for (int i = 0; i < m; ++i) {
+                    const double yi = YY[i * LB_SB + sc];
+                    x0 = fma(p0[i], yi, x0);
+                    x1 = fma(p1[i], yi, x1);
+                }
+            }
+            double d0 = x0, d1 = x1;
+            if (q < Hn) {
+                const double* si = lfS + (((size_t)s * n + k) * Hn + q) * 4;
+                d0 = fma(si[1], x1, si[0] * x0);
+                d1 = fma(si[3], x1, si[2] * x0);
+            }
+            const double2 w2 = *reinterpret_cast<const double2*>(wk + 2 * q);
+            *reinterpret_cast<double2*>(xs + (size_t)k * B + 2 * q) = double2{w2.x - d0, w2.y - d1};
+        }
+    }
+}
+
+template <int B>
+int launch_sleaf_back_batch(hpf_handle* h, const int* nodes, int count, const int* active) {
+    const dim3 grid((unsigned)count, (unsigned)((h->cur_S + LB_SB - 1) / LB_SB));
+    hipLaunchKernelGGL((k_sleaf_back_batch<B>), grid, dim3(256), 0, h->cur_stream, h->M, nodes, 2 * h->Hn, active, h->cur_S, h->d_w,
+                       h->d_x, h->d_H, active_tree(h).d_sbimg, active_tree(h).d_lzimg, h->d_Z, h->d_lfS, h->cur_s0);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        h->last_detail = (int)e;
+        return HPF_E_HIP;
+    }
+    return HPF_OK;
+}

@@ -173,6 +173,7 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
     const int cleafv = nd3.w;                // constant-inverse leaf: 1 + slot in Minv (0: general path; < 0: lazy-leaf record)
     const bool cleaf = LEAF || cleafv > 0;
     const bool sleaf = !LEAF && (nd3.z & 4) != 0;   // super-leaf: every dense child is a lazy leaf -> bordered low-rank inverse, no Gauss-Jordan
+    const bool slback = !LEAF && (nd3.z & 8) != 0;  // ... whose back sweep rebuilds D^-1 t from T^-1 (k_sleaf_back_batch): no inverse goes to HBM
     const bool lazy = !LEAF && cleafv < 0;   // this bus has lazy leaves below it
     const bool cleafr = cleaf || sleaf;      // roles of a constant-part bus: S^-1 staged, network diagonal lives in the images
     // lazy-leaf record (Tree::d_lzrec, 8 ints: image offset, L, leaf ids[4])
@@ -705,7 +706,17 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
                 for (int c2 = 0; c2 < 10; ++c2)
                     if (c2 < m) aug[mycol * 20 + m + pcol[c2]] = row[c2];
             }
+            if (slback) {                                                // T^-1 [m][m] and W_k^-1 at the head of the (unused) inverse slot
+                double* tk = Zall + ((size_t)s * n + k) * CT;
+                if (lane < m) {
+#pragma unroll
+                    for (int c2 = 0; c2 < 10; ++c2)
+                        if (c2 < m) tk[mycol * 10 + pcol[c2]] = row[c2];
+                }
+                if (lane < 4) tk[100 + lane] = aug[10 * 20 + lane];
+            }
         }
+        if (slback && tid < Hn * 4) lfS[(so + (size_t)k * Hn) * 4 + tid] = tab[tid];
         __syncthreads();
         // [0 0; 0 Ahh^-1] + Pb (T^-1 Qb) on the matrix cores: per chunk of four border unknowns one rank-4 MFMA per tile
         // (A operand = rows of Pb, B operand = the own column of T^-1 Qb: 10 FMAs per chunk and lane).  The image is fetched
@@ -909,7 +920,7 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
     // ---- D. inverse (tile layout) and w = A^-1 y ------------------------------------------------------------------------
     {
         double* Zk = Zall + ((size_t)s * n + k) * CT;
-        if (!cleaf) {
+        if (!cleaf && !slback) {
             double zv[NT * 4];
 #pragma unroll
             for (int e = 0; e < NT * 4; ++e) zv[e] = ct[e >> 2][e & 3];

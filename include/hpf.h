@@ -145,7 +145,7 @@ int  hpf_debug_stamps(hpf_handle* h, long long* out, int count);
  * leaf writes its Schur complement; 1: only leaves directly under their dense parent), HPF_SLEAF=0 sends the nonlinear buses
  * whose dense children are all lazy leaves (super-leaves: bordered low-rank inverse) through Gauss-Jordan like every other bus,
  * HPF_LEAFBATCH=0 runs the lazy leaves one workgroup per (leaf, scenario) instead of 16 scenarios per workgroup on the matrix
- * cores, HPF_TREE_INFO=1 prints the tree statistics to stderr, HPF_GROUPS=n presets "scenario_groups". */
+ * cores, HPF_SLBACK=0 lets the super-leaves store their inverse for the per-scenario back sweep instead of keeping T^-1 only, HPF_TREE_INFO=1 prints the tree statistics to stderr, HPF_GROUPS=n presets "scenario_groups". */
 int  hpf_set_option(hpf_handle* h, const char* name, int value);
 
 /* Stream plumbing: run on a caller stream (e.g. torch's current stream) instead of the handle's own; NULL restores. */
