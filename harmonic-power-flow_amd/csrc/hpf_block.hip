@@ -1802,14 +1802,16 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
         else
             T.flops_factor += leaf ? 10.0 * bd * bd : 2.0 * bd * bd * bd + 2.0 * bd * bd + bd * bd * (nch - nlz);
         if (nlz && !sl) T.flops_factor += 4.0 * bd * bd * nlz + 4.0 * bd * bd;
-        T.bytes_factor += TB * (nch - nlz) + nlz * (32.0 + 8.0 * bd) + (leaf ? 0.0 : TB) + 8.0 * (4.0 * bd + bd + bd + 2.0 * bd) +
+        const bool slb = sl && sb_ord[i] >= 0;                        // super-leaf that keeps T^-1 (+ W^-1, S^-1) instead of its inverse
+        T.bytes_factor += TB * (nch - nlz) + nlz * (32.0 + 8.0 * bd) + (leaf ? 0.0 : (slb ? 8.0 * 104 + 32.0 * d->Hn : TB)) +
+                          8.0 * (4.0 * bd + bd + bd + 2.0 * bd) +
                           48.0 * d->Hn * (T.child_mid[i] - T.child_ptr[i]);
         if (i > 0) {
             T.flops_factor += is_lazy[i] ? 8.0 * bd : 8.0 * bd * bd;
             T.bytes_factor += is_lazy[i] ? 8.0 * bd : TB;
             // back sweep: inverse of a Gauss-Jordan bus in (leaves rebuild it from the shared image), w, A(k,parent), x of the
             // parent in, x out; leaves also their 2x2 core and S^-1
-            T.bytes_back += (leaf ? 32.0 + 32.0 * d->Hn : TB) + 8.0 * (bd + 2.0 * bd + bd + bd);
+            T.bytes_back += (leaf ? 32.0 + 32.0 * d->Hn : (slb ? 8.0 * 104 + 32.0 * d->Hn : TB)) + 8.0 * (bd + 2.0 * bd + bd + bd);
             ++n_dense_nonroot;
         }
     }
