@@ -37,7 +37,7 @@ using namespace hpf;
 
 namespace {
 
-constexpr int FDESC = 36;   // ints per node record of the multi-wave factor kernel (Tree::d_fdesc)
+constexpr int FDESC = 40;   // ints per node record of the multi-wave factor kernel (Tree::d_fdesc)
 
 struct TreeDev {
     const int* parent;
@@ -1354,6 +1354,16 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
     const bool slback_on = !(sb_env && atoi(sb_env) == 0) && !(lb_env && atoi(lb_env) == 0);   // super-leaves keep T^-1 only; k_sleaf_back_batch
                                                                                              // rebuilds D^-1 t (needs the batched back sweep)
     std::vector<int> sb_ord(n, -1), sb_m(n, 0);
+    // super-leaves whose parent rebuilds their Schur complement itself (like a lazy leaf's, with the m x m core T^-1): constants
+    //   C0 = g Ahh^-1 h,  GP = g Pb (rows q >= 1),  QH = Qb h (columns q >= 1)
+    struct LazySuper {
+        int k, m1;
+        std::vector<std::complex<double>> C0, GP, QH;
+    };
+    std::vector<LazySuper> slzs;
+    std::vector<std::vector<int>> slz_of(n);
+    const char* sz_env = getenv("HPF_SLLAZY");
+    const bool sllazy_on = sz_env && atoi(sz_env) != 0;
     std::vector<double> sbimg;
     std::vector<std::vector<int>> lazy_of(n);
     std::vector<int> is_lazy(n, 0);
@@ -1644,6 +1654,25 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
                 for (int c2 = 0; c2 < mr; ++c2) slimg.push_back(R(Pb[(size_t)(row >> 1) * m1 + (c2 >> 1)], row & 1, c2 & 1));
             for (int r2 = 0; r2 < mr; ++r2)
                 for (int col = 0; col < b; ++col) slimg.push_back(R(Qb[(size_t)(r2 >> 1) * Hn + (col >> 1)], r2 & 1, col & 1));
+            const int pks = pard[k];
+            if (slback_on && sllazy_on && mr <= 10 && pks >= (d->c > 1 ? d->c : 1) && (int)slz_of[pks].size() < 2) {
+                LazySuper z;
+                z.k = k;
+                z.m1 = m1;
+                z.C0.assign((size_t)Hn * Hn, cd(0.0, 0.0));
+                z.GP.assign((size_t)Hn * m1, cd(0.0, 0.0));
+                z.QH.assign((size_t)m1 * Hn, cd(0.0, 0.0));
+                for (int q = 1; q < Hn; ++q) {
+                    for (int p2 = 1; p2 < Hn; ++p2) z.C0[(size_t)q * Hn + p2] = geff[q] * Ainv(q, p2) * heff[p2];
+                    for (int i = 0; i < m1; ++i) {
+                        z.GP[(size_t)q * m1 + i] = geff[q] * Pb[(size_t)q * m1 + i];
+                        z.QH[(size_t)i * Hn + q] = Qb[(size_t)i * Hn + q] * heff[q];
+                    }
+                }
+                slz_of[pks].push_back((int)slzs.size());
+                slzs.push_back(std::move(z));
+                is_lazy[k] = 1;
+            }
             if (slback_on) {                                                               // [0 0; 0 Ahh^-1] in MFMA A-operand layout
                 const int NTR = (BWc + 15) / 16, KS = (BWc + 3) / 4;
                 sb_ord[k] = n_sleaf;
@@ -1663,11 +1692,11 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
         }
     }
     // per-parent lazy records and images; the parent's dense-child list keeps its non-lazy children first
-    std::vector<int> lzrec, lz_idx(n, -1), n_lazy(n, 0);
+    std::vector<int> lzrec, lz_idx(n, -1), n_lazy(n, 0), n_slz(n, 0);
     std::vector<double> lzimg;
     T.n_lazy_parents = 0;
     T.n_lazy_leaves = (int)lazies.size();
-    if (!lazies.empty()) {
+    if (!lazies.empty() || !slzs.empty()) {
         typedef std::complex<double> cd;
         const int Hn = d->Hn;
         const int NTc = (BWc + 16) / 16;
@@ -1675,12 +1704,15 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
         auto R = [](cd z, int t, int t2) { return (t == t2) ? z.real() : (t ? z.imag() : -z.imag()); };   // R(z) = [re -im; im re]
         for (int pk = 0; pk < n; ++pk) {
             const int L = (int)lazy_of[pk].size();
-            if (L == 0) continue;
+            const int LS = (int)slz_of[pk].size();
+            if (L == 0 && LS == 0) continue;
             n_lazy[pk] = L;
+            n_slz[pk] = LS;
             lz_idx[pk] = T.n_lazy_parents++;
             const int np = (L + 1) / 2;
             const size_t off = lzimg.size();
-            lzimg.resize(off + CTc + (size_t)np * NTc * 64 + (size_t)np * NTc * 2 * 64, 0.0);
+            const size_t sl_img = (size_t)3 * 64 * NTc + (size_t)10 * BWc;      // per lazy super-leaf: A operands [3][64][NT] | QH [10][B]
+            lzimg.resize(off + CTc + (size_t)np * NTc * 64 + (size_t)np * NTc * 2 * 64 + (size_t)LS * sl_img, 0.0);
             double* I0 = &lzimg[off];
             double* IA = I0 + CTc;
             double* IH = IA + (size_t)np * NTc * 64;
@@ -1688,6 +1720,7 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
                 for (int col = 0; col < b; ++col) {
                     double v = 0.0;
                     for (int li : lazy_of[pk]) v += R(lazies[li].C0[(size_t)(row >> 1) * Hn + (col >> 1)], row & 1, col & 1);
+                    for (int zi : slz_of[pk]) v += R(slzs[zi].C0[(size_t)(row >> 1) * Hn + (col >> 1)], row & 1, col & 1);
                     const long long o = tile_off(row, col);
                     if (o >= 0) I0[o] = v;
                 }
@@ -1708,6 +1741,27 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
                                 if (col < b) IH[(((size_t)pr * NTc + tc) * 64 + lg * 16 + jj) * 2 + a2] = R(ll.H[col >> 1], a2, col & 1);
                             }
                 }
+            {   // lazy super-leaves: A operands (rows >= 2 of g Pb; rows 0 / 1 come per scenario) and Qb h (columns >= 2)
+                double* IS = IH + (size_t)np * NTc * 2 * 64;
+                for (int zc = 0; zc < LS; ++zc) {
+                    const LazySuper& z = slzs[slz_of[pk][zc]];
+                    const int mz = 2 * z.m1;
+                    double* ZA = IS + (size_t)zc * sl_img;
+                    double* ZQ = ZA + (size_t)3 * 64 * NTc;
+                    for (int ch = 0; ch < 3; ++ch)
+                        for (int lg = 0; lg < 4; ++lg) {
+                            const int i = 4 * ch + lg;
+                            if (i >= mz) continue;
+                            for (int tr = 0; tr < NTc; ++tr)
+                                for (int jj = 0; jj < 16; ++jj) {
+                                    const int row = 16 * tr + jj;
+                                    if (row >= 2 && row < b) ZA[((size_t)ch * 64 + lg * 16 + jj) * NTc + tr] = R(z.GP[(size_t)(row >> 1) * z.m1 + (i >> 1)], row & 1, i & 1);
+                                }
+                        }
+                    for (int j = 0; j < mz; ++j)
+                        for (int col = 2; col < b; ++col) ZQ[(size_t)j * BWc + col] = R(z.QH[(size_t)(j >> 1) * Hn + (col >> 1)], j & 1, col & 1);
+                }
+            }
             int rec[8] = {(int)off, L, -1, -1, -1, -1, 0, 0};
             for (int i = 0; i < L; ++i) rec[2 + i] = lazies[lazy_of[pk][i]].k;
             lzrec.insert(lzrec.end(), rec, rec + 8);
@@ -1747,7 +1801,7 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
         r[6] = T.child_ptr[k];
         r[7] = T.child_mid[k] - T.child_ptr[k];
         r[8] = dchild_ptr[k];
-        r[9] = dchild_ptr[k + 1] - dchild_ptr[k] - n_lazy[k];      // children whose Schur complement is read from HBM
+        r[9] = dchild_ptr[k + 1] - dchild_ptr[k] - n_lazy[k] - n_slz[k];      // children whose Schur complement is read from HBM
         for (int i = 0; i < 4 && i < r[9]; ++i) r[10 + i] = dchild[dchild_ptr[k] + i];
         r[14] = ((k > 0 && pass[T.parent[k]]) ? 1 : 0) | (is_lazy[k] ? 2 : 0);   // bit 0: linked to its dense parent through a contracted chain; bit 1: lazy leaf
         r[15] = lz_idx[k] >= 0 ? -(lz_idx[k] + 1) : cleaf_of[k] + 1;     // > 0: constant-inverse leaf, 1 + slot in Tree::d_Minv; < 0: -(1 + lazy record)
@@ -1762,6 +1816,13 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
         for (int i = 28; i < 36; ++i) r[i] = (i >= 30 && i < 34) ? -1 : 0;
         if (lz_idx[k] >= 0)                                        // lazy-leaf record inline: image offset, L, leaf ids[4]
             for (int i = 0; i < 6; ++i) r[28 + i] = lzrec[(size_t)lz_idx[k] * 8 + i];
+        r[36] = r[37] = -1;
+        r[38] = r[39] = 0;
+        for (int zc = 0; zc < n_slz[k]; ++zc) {                    // lazy super-leaf children: bus, border unknowns
+            const LazySuper& z = slzs[slz_of[k][zc]];
+            r[36 + zc] = z.k;
+            r[38] |= (2 * z.m1) << (8 * zc);
+        }
         if (sl_off[k] >= 0 && lz_idx[k] >= 0) {                    // super-leaf: Z0 image slot, offset of [Tc | Pb | Qb]
             r[14] |= 4;
             if (sb_ord[k] >= 0) r[14] |= 8;                        // its back sweep is k_sleaf_back_batch's: T^-1 instead of the inverse

@@ -177,10 +177,11 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
     const bool lazy = !LEAF && cleafv < 0;   // this bus has lazy leaves below it
     const bool cleafr = cleaf || sleaf;      // roles of a constant-part bus: S^-1 staged, network diagonal lives in the images
     // lazy-leaf record (Tree::d_lzrec, 8 ints: image offset, L, leaf ids[4])
-    int4 lzA = {0, 0, -1, -1}, lzB = {-1, -1, 0, 0};
-    if (lazy) {                               // (inline copy of the record: ints 28..35 of the node record, same scalar round trip)
+    int4 lzA = {0, 0, -1, -1}, lzB = {-1, -1, 0, 0}, lzC = {-1, -1, 0, 0};
+    if (lazy) {                               // (inline copy of the record: ints 28..39 of the node record, same scalar round trip)
         lzA = nd[7];
         lzB = nd[8];
+        lzC = nd[9];                          // lazy super-leaf children: buses, their numbers of border unknowns (8 bits each)
     }
 #ifdef HPF_FACTOR_STAMPS
     long long sd1 = 0, sd2 = 0, sd3 = 0;
@@ -332,7 +333,9 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
                     const double g1 = lzA.w >= 0 ? Cs[(size_t)lzA.w * CT + lane] : 0.0;
                     const double g2 = lzB.x >= 0 ? Cs[(size_t)lzB.x * CT + lane] : 0.0;
                     const double g3 = lzB.y >= 0 ? Cs[(size_t)lzB.y * CT + lane] : 0.0;
-                    ay = -((g0 + g1) + (g2 + g3));
+                    const double g4s = lzC.x >= 0 ? Cs[(size_t)lzC.x * CT + lane] : 0.0;
+                    const double g5s = lzC.y >= 0 ? Cs[(size_t)lzC.y * CT + lane] : 0.0;
+                    ay = -(((g0 + g1) + (g2 + g3)) + (g4s + g5s));
                 }
                 if (via_chain) {                                         // what the elimination of the chain above left here
                     const size_t o = so + (size_t)k * Hn + q;
@@ -470,6 +473,44 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
         if (np > 1) {
 #pragma unroll
             for (int tr = 0; tr < NT; ++tr) xt[tr] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[tr], b1, xt[tr], 0, 0, 0);
+        }
+        // lazy super-leaf children (at most two): the same rebuild with the m x m core T^-1 the child left at the head of its
+        // inverse slot, m <= 10 border unknowns in chunks of four; position 0 of the borders from the child's record
+        // (G0 S_c^-1 on rows 0 / 1 of the first two unknowns, W_c^-1 H0 S_k^-1 on columns 0 / 1)
+        const double* simgs = himg + (size_t)np * NT * 2 * 64;
+        for (int zc = 0; zc < 2; ++zc) {
+            const int child = zc == 0 ? lzC.x : lzC.y;
+            if (child < 0) break;
+            const int mz = (lzC.z >> (8 * zc)) & 0xff;
+            const double* za = simgs + (size_t)zc * (3 * 64 * NT + 10 * B);
+            const double* zq = za + 3 * 64 * NT;
+            const double* tk = Zall + ((size_t)s * n + child) * CT;                 // T^-1 [10][10] | W^-1 [4]
+            const double* kc = lfK + ((size_t)s * n + child) * 12;
+            double qh[10];
+#pragma unroll
+            for (int j = 0; j < 10; ++j) qh[j] = (j < mz && col < b) ? zq[(size_t)j * B + col] : 0.0;
+            if (col < 2) {                                               // (W^-1 H0 S_k^-1)[j][col], j < 2
+                const double h0 = kc[8 + col], h1 = kc[10 + col];
+                qh[0] = fma(tk[101], h1, tk[100] * h0);
+                qh[1] = fma(tk[103], h1, tk[102] * h0);
+            }
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                if (4 * ch < mz) {
+                    const int i = 4 * ch + lg;
+                    const double* tr_ = tk + (i < mz ? i : 0) * 10;
+                    double bop = 0.0;
+#pragma unroll
+                    for (int j = 0; j < 10; ++j)
+                        if (j < mz) bop = fma(tr_[j], qh[j], bop);
+                    bop = i < mz ? bop : 0.0;
+                    double az[NT];
+                    lz_aop<NT>(za + ((size_t)ch * 64 + lane) * NT, az);
+                    if (jj < 2) az[0] = i < 2 ? kc[4 + jj * 2 + i] : 0.0;                  // rows 0 / 1: (G0 S_c^-1)[jj][i]
+#pragma unroll
+                    for (int tr = 0; tr < NT; ++tr) xt[tr] = __builtin_amdgcn_mfma_f64_16x16x4f64(az[tr], bop, xt[tr], 0, 0, 0);
+                }
+            }
         }
     }
     // super-leaf: stage the per-model constants and everything of T that does not depend on this bus's own roles (all of it but
