@@ -1363,7 +1363,7 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
     std::vector<LazySuper> slzs;
     std::vector<std::vector<int>> slz_of(n);
     const char* sz_env = getenv("HPF_SLLAZY");
-    const bool sllazy_on = sz_env && atoi(sz_env) != 0;
+    const bool sllazy_on = !(sz_env && atoi(sz_env) == 0);     // HPF_SLLAZY=0: every super-leaf pushes its Schur complement itself
     std::vector<double> sbimg;
     std::vector<std::vector<int>> lazy_of(n);
     std::vector<int> is_lazy(n, 0);
@@ -1775,6 +1775,14 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
         auto mid = std::stable_partition(first, last, [&](int k2) { return is_lazy[k2] != 0; });
         T.n_lazy_level0 = (int)(mid - first);
     }
+    T.lvl_nbatch.assign(T.n_levels > 0 ? T.n_levels : 1, 0);     // factor sweep: vector-only super-leaves of a level first
+    std::vector<int> is_slz(n, 0);
+    for (const LazySuper& z : slzs) is_slz[z.k] = 1;
+    for (int l = 1; l < T.n_levels; ++l) {
+        auto first = T.lvl_nodes.begin() + T.lvl_ptr[l], last = T.lvl_nodes.begin() + T.lvl_ptr[l + 1];
+        auto mid = std::stable_partition(first, last, [&](int k2) { return is_slz[k2] != 0 && sb_ord[k2] >= 0; });
+        T.lvl_nbatch[l] = (int)(mid - first);
+    }
     T.dep_nleaf.assign(T.n_depths > 0 ? T.n_depths : 1, 0);      // back sweep: the leaves of a depth first
     for (int dl = 0; dl < T.n_depths; ++dl) {
         auto first = T.dep_nodes.begin() + T.dep_ptr[dl], last = T.dep_nodes.begin() + T.dep_ptr[dl + 1];
@@ -1828,6 +1836,7 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
             if (sb_ord[k] >= 0) r[14] |= 8;                        // its back sweep is k_sleaf_back_batch's: T^-1 instead of the inverse
             r[34] = sl_slot[k];
             r[35] = (int)(sl_base + sl_off[k]);
+            r[39] = sb_ord[k] >= 0 ? sb_ord[k] : 0;                // its image in Tree::d_sbimg (k_sleaf_batch)
         }
         const int kb = T.dep_nodes[pos];
         bdesc[(size_t)pos * 4 + 0] = kb;
@@ -1861,10 +1870,13 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
             T.flops_factor += 2.0 * msl * msl * msl + 2.0 * bd * bd * 4.0 * (double)((2 + 2 * nlz + 3) / 4) + 2.0 * bd * msl * 3.0 +
                               4.0 * bd * bd + 2.0 * bd * bd;
         else
-            T.flops_factor += leaf ? 10.0 * bd * bd : 2.0 * bd * bd * bd + 2.0 * bd * bd + bd * bd * (nch - nlz);
+            T.flops_factor += leaf ? 10.0 * bd * bd : 2.0 * bd * bd * bd + 2.0 * bd * bd + bd * bd * (nch - nlz - n_slz[i]);
         if (nlz && !sl) T.flops_factor += 4.0 * bd * bd * nlz + 4.0 * bd * bd;
         const bool slb = sl && sb_ord[i] >= 0;                        // super-leaf that keeps T^-1 (+ W^-1, S^-1) instead of its inverse
-        T.bytes_factor += TB * (nch - nlz) + nlz * (32.0 + 8.0 * bd) + (leaf ? 0.0 : (slb ? 8.0 * 104 + 32.0 * d->Hn : TB)) +
+        const int nsz = n_slz[i];                                     // lazy super-leaf children: T^-1, borders, G w in; rank-m rebuild
+        if (nsz) T.flops_factor += nsz * (2.0 * bd * bd * 12.0 + 2.0 * bd * 30.0);
+        T.bytes_factor += TB * (nch - nlz - nsz) + nlz * (32.0 + 8.0 * bd) + nsz * (8.0 * 104 + 64.0 + 8.0 * bd) +
+                          (leaf ? 0.0 : (slb ? 8.0 * 104 + 32.0 * d->Hn : TB)) +
                           8.0 * (4.0 * bd + bd + bd + 2.0 * bd) +
                           48.0 * d->Hn * (T.child_mid[i] - T.child_ptr[i]);
         if (i > 0) {
@@ -2094,15 +2106,18 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
             int r;
             // level 0 of the contracted tree: its lazy leaves come first and go 16 scenarios per workgroup (k_leaf_batch)
             static const int leafbatch = [] { const char* e = getenv("HPF_LEAFBATCH"); return e ? atoi(e) : 1; }();   // 0: one workgroup per (leaf, scenario)
-            const int nbatch = (l == 0 && leafbatch && h->has_ctree && T.lvl_all_leaf[0]) ? T.n_lazy_level0 : 0;
+            int nbatch = (l == 0 && leafbatch && h->has_ctree && T.lvl_all_leaf[0]) ? T.n_lazy_level0 : 0;
+            const bool slbatch = l > 0 && leafbatch && h->has_ctree && l < (int)T.lvl_nbatch.size() && T.lvl_nbatch[l] > 0;
+            if (slbatch) nbatch = T.lvl_nbatch[l];
             ScopedTimer t(h, T_SOLVE);          // one span per k_factor_w launch (what rocprofv3 --stats averages)
             switch (BW) {
 #define HPF_FACTOR_CASE(BB_)                                                                                  \
     case BB_:                                                                                                 \
         if (h->gj_mode == 1 && nbatch > 0) {                                                                  \
-            r = launch_leaf_batch<BB_>(h, td, T.d_fdesc + FDESC * (size_t)T.lvl_ptr[l], nbatch, active);      \
+            r = slbatch ? launch_sleaf_batch<BB_>(h, td, T.d_fdesc + FDESC * (size_t)T.lvl_ptr[l], nbatch, active) \
+                        : launch_leaf_batch<BB_>(h, td, T.d_fdesc + FDESC * (size_t)T.lvl_ptr[l], nbatch, active); \
             if (!r && cnt > nbatch)                                                                           \
-                r = launch_factor_q<BB_>(h, td, T.d_fdesc + FDESC * (size_t)(T.lvl_ptr[l] + nbatch), cnt - nbatch, active, true); \
+                r = launch_factor_q<BB_>(h, td, T.d_fdesc + FDESC * (size_t)(T.lvl_ptr[l] + nbatch), cnt - nbatch, active, !slbatch); \
             break;                                                                                            \
         }                                                                                                     \
         r = h->gj_mode == 1 ? launch_factor_q<BB_>(h, td, T.d_fdesc + FDESC * (size_t)T.lvl_ptr[l], cnt, active, \

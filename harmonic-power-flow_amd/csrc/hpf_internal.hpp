@@ -84,6 +84,8 @@ struct Tree {
     // rebuilds the sum from per-model images and the leaves' 2x2 cores (k_factor_q, "lazy" phase)
     int n_lazy_parents = 0, n_lazy_leaves = 0;
     int n_lazy_level0 = 0;            // the first n_lazy_level0 buses of elimination level 0 are lazy leaves (k_leaf_batch)
+    std::vector<int> lvl_nbatch;      // [n_levels] super-leaves of a level whose parent rebuilds their Schur complement: they come first
+                                      // in the level's records and go through k_sleaf_batch (16 scenarios per workgroup)
     std::vector<int> dep_nleaf;       // [n_depths] constant-inverse leaves of a back-sweep depth (they come first in the depth's records)
     std::vector<int> dep_nskip;       // [n_depths] leaves + batched super-leaves of a depth: k_back_q starts behind them
     int n_bsleaf = 0;

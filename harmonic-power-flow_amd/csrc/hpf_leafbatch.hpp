@@ -463,3 +463,357 @@ int launch_sleaf_back_batch(hpf_handle* h, const int* nodes, int count, const in
     }
     return HPF_OK;
 }
+
+// Factor sweep of the super-leaves whose parent rebuilds their Schur complement (HPF_SLLAZY), 16 scenarios per workgroup: such a
+// bus owes the sweep vectors only -- w = S^-1 M^-1 Wd^-1 y, G w, T^-1 (+ W^-1), S^-1, A(k,parent), its position-0 borders.
+// Roles as in k_leaf_batch (plus the power-row diagonal of a linear bus and the G w of its lazy leaves), T assembled and inverted
+// per scenario by the scenario's 16 threads (thread r owns row r; the pivot row goes through LDS), the Ahh^-1 part on the matrix
+// cores.  nodes: Tree::d_fdesc records (int 39: slot of the bus's image in Tree::d_sbimg).
+template <int B>
+__global__ __launch_bounds__(256, 4) void k_sleaf_batch(
+    Model M, TreeDev T, const int* __restrict__ nodes, int b, const int* __restrict__ active, int S_cnt,
+    const cplx* __restrict__ Uall, const cplx* __restrict__ Eall, const double* __restrict__ fall, double* __restrict__ wall,
+    const double* __restrict__ linAall, double* __restrict__ Call, double* __restrict__ Hall, const cplx* __restrict__ I0all,
+    const double* __restrict__ chG, const double* __restrict__ chH, const double* __restrict__ chD, const double* __restrict__ chy,
+    const double* __restrict__ sbimg, double* __restrict__ Zall, double* __restrict__ lfK, double* __restrict__ lfS, int s0) {
+    constexpr int NT = (B + 16) / 16;
+    constexpr size_t CT = (size_t)NT * NT * 256;
+    constexpr int NTR = LeafBatchImg<B>::NTR, KS = LeafBatchImg<B>::KS, H2 = B / 2, QI = (H2 + 15) / 16;
+    const int4* nd = reinterpret_cast<const int4*>(nodes) + (FDESC / 4) * (size_t)blockIdx.x;
+    const int4 nd0 = nd[0], nd1 = nd[1], nd3 = nd[3], lzA = nd[7], lzB = nd[8], lzC = nd[9];
+    const int k = nd0.x, par = nd0.y, diag_e = nd0.z;
+    const int e_dn_k = nd1.x, e_up_k = nd1.y, lin_beg = nd1.z, lin_end = nd1.z + nd1.w;
+    const bool via_chain = (nd3.z & 1) != 0;
+    const int L = lzA.y, m = 2 + 2 * L;
+    const double* simg = T.lzimg + (size_t)lzB.w;                // Tc [m][m] | Pb [b][m] | Qb [m][b]
+    const double* pbm = simg + m * m;
+    const double* qbm = pbm + (size_t)b * m;
+    const double* img = sbimg + (size_t)lzC.w * NTR * KS * 64;   // [0 0; 0 Ahh^-1], A-operand layout
+    const int tid = threadIdx.x, lane = tid & 63, lg = lane >> 4, jj = lane & 15;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = M.n, c = M.c, Hn = M.Hn;
+    const int sc = tid >> 4, l16 = tid & 15;
+    const int sl = blockIdx.y * LB_SB + sc;
+    const int s = sl + s0;
+    const bool live = sl < S_cnt && !(active && !active[s]);
+    const size_t so = (size_t)s * n * Hn;
+    const cplx* U = Uall + so;
+    const cplx* E = Eall + so;
+    const double* Cs = Call + (size_t)s * n * CT;
+    const bool linear_k = k < M.m;
+
+    __shared__ double Y[64 * LB_SB];                             // v = Wd^-1 y, [row][scenario]
+    __shared__ double V[64 * LB_SB];
+    __shared__ double AUG[LB_SB * 100];                          // T, then T^-1, per scenario [10][10]
+    __shared__ double PR[LB_SB * 10];                            // pivot row of the step
+    __shared__ double DL[LB_SB * 4], S0[LB_SB * 4], WI[LB_SB * 4];
+    __shared__ double RR[16 * LB_SB], YY[16 * LB_SB];
+
+    // ---- R1. rows --------------------------------------------------------------------------------------------------------------
+    {
+        double e0[4] = {0.0, 0.0, 0.0, 0.0}, e1[4] = {0.0, 0.0, 0.0, 0.0}, ey[4] = {0.0, 0.0, 0.0, 0.0};
+        double a0[4] = {0.0, 0.0, 0.0, 0.0}, a1[4] = {0.0, 0.0, 0.0, 0.0}, ay[4] = {0.0, 0.0, 0.0, 0.0}, fy[4] = {0.0, 0.0, 0.0, 0.0};
+        bool ok[4];
+        cplx ukr[4], ekr[4];
+#pragma unroll
+        for (int pz = 0; pz < 4; ++pz) {
+            const int row = l16 + 16 * pz, q = row >> 1, tr_ = row & 1;
+            ok[pz] = live && row < b && loc_valid(n, c, k, row);
+            ukr[pz] = cplx{0.0, 0.0};
+            ekr[pz] = cplx{0.0, 0.0};
+            if (ok[pz]) {
+                const size_t kq = (size_t)k * Hn + q;
+                fy[pz] = fall[((size_t)s * n + k) * B + row];
+                if (via_chain) {
+                    const size_t o = so + kq;
+                    a0[pz] = chD[o * 4 + 2 * tr_];
+                    a1[pz] = chD[o * 4 + 2 * tr_ + 1];
+                    ay[pz] = chy[o * 2 + tr_];
+                }
+                ukr[pz] = U[kq];
+                ekr[pz] = E[kq];
+                // G w of the lazy leaves: y -= sum
+                const double g0 = lzA.z >= 0 ? Cs[(size_t)lzA.z * CT + row] : 0.0, g1 = lzA.w >= 0 ? Cs[(size_t)lzA.w * CT + row] : 0.0;
+                const double g2 = lzB.x >= 0 ? Cs[(size_t)lzB.x * CT + row] : 0.0, g3 = lzB.y >= 0 ? Cs[(size_t)lzB.y * CT + row] : 0.0;
+                ay[pz] -= (g0 + g1) + (g2 + g3);
+                if (row < 2 && linear_k) {                           // power rows: the state-dependent diagonal of the fundamental
+                    const Blk2 blk = blk_power_diag(M.Y[(size_t)diag_e * Hn], ukr[pz], ekr[pz], I0all[(size_t)s * n + k]);
+                    a0[pz] += pick(blk, tr_, 0);
+                    a1[pz] += pick(blk, tr_, 1);
+                }
+            }
+        }
+        const double* ws = wall + (size_t)s * n * B;
+        const double* linA = linAall + so * 4;
+        const int4* c3 = reinterpret_cast<const int4*>(T.child3);
+        for (int cp = lin_beg; cp < lin_end; ++cp) {
+            const int4 cr = c3[cp];
+            const int ch = cr.x;
+#pragma unroll
+            for (int pz = 0; pz < 4; ++pz) {
+                if (!ok[pz]) continue;
+                const int row = l16 + 16 * pz, q = row >> 1, tr_ = row & 1;
+                const cplx uk = ukr[pz], ek = ekr[pz];
+                const cplx ydn = M.Y[(size_t)cr.y * Hn + q], yup = M.Y[(size_t)cr.z * Hn + q];
+                const cplx uc = U[(size_t)ch * Hn + q], ec = E[(size_t)ch * Hn + q];
+                const double2* pic = reinterpret_cast<const double2*>(linA + ((size_t)ch * Hn + q) * 4);
+                const double2 ic01 = pic[0], ic23 = pic[1];
+                const double2 wc = *reinterpret_cast<const double2*>(ws + (size_t)ch * B + 2 * q);
+                const Blk2 g = (q == 0 && k < M.m) ? blk_power_off(ydn, uk, uc, ec) : blk_current(ydn, uc, ec);
+                const Blk2 hb = (q == 0 && ch < M.m) ? blk_power_off(yup, uc, uk, ek) : blk_current(yup, uk, ek);
+                const double g0 = pick(g, tr_, 0);
+                const double g1 = loc_valid(n, c, ch, 2 * q + 1) ? pick(g, tr_, 1) : 0.0;
+                double h4[4];
+                mask_block(n, c, q, ch, k, hb, h4);
+                const double v0 = fma(g1, ic23.x, g0 * ic01.x), v1 = fma(g1, ic23.y, g0 * ic01.y);
+                e0[pz] += fma(v1, h4[2], v0 * h4[0]);
+                e1[pz] += fma(v1, h4[3], v0 * h4[1]);
+                ey[pz] = fma(g0, wc.x, ey[pz]);
+                ey[pz] = fma(g1, wc.y, ey[pz]);
+            }
+        }
+#pragma unroll
+        for (int pz = 0; pz < 4; ++pz) {
+            const int row = l16 + 16 * pz;
+            Y[row * LB_SB + sc] = ok[pz] ? fy[pz] + ay[pz] - ey[pz] : 0.0;
+            if (row < 2) {
+                DL[sc * 4 + row * 2] = ok[pz] ? a0[pz] - e0[pz] : 0.0;
+                DL[sc * 4 + row * 2 + 1] = ok[pz] ? a1[pz] - e1[pz] : 0.0;
+            }
+        }
+    }
+    // ---- R2. harmonics ---------------------------------------------------------------------------------------------------------
+    double sir[QI][4], glr[QI][4];
+#pragma unroll
+    for (int it = 0; it < QI; ++it) {
+        const int q = l16 + 16 * it;
+        double si[4] = {1.0, 0.0, 0.0, 1.0}, g4[4] = {0.0, 0.0, 0.0, 0.0}, h4[4] = {0.0, 0.0, 0.0, 0.0};
+        if (live && q < Hn) {
+            const cplx uk = U[(size_t)k * Hn + q], ek = E[(size_t)k * Hn + q];
+            const double idet = 1.0 / (-(uk.im * ek.im) - ek.re * uk.re);
+            si[0] = ek.im * idet;   si[1] = -ek.re * idet;
+            si[2] = -uk.re * idet;  si[3] = -uk.im * idet;
+            cplx up = {0.0, -1.0}, ep = {0.0, 1.0};
+            if (!via_chain || q == 0) {
+                up = U[(size_t)par * Hn + q];
+                ep = E[(size_t)par * Hn + q];
+            }
+            if (via_chain) {
+                const double2* pg = reinterpret_cast<const double2*>(chG + (so + (size_t)k * Hn + q) * 4);
+                const double2* ph = reinterpret_cast<const double2*>(chH + (so + (size_t)k * Hn + q) * 4);
+                const double2 ga = pg[0], gb = pg[1], ha = ph[0], hb = ph[1];
+                g4[0] = ga.x; g4[1] = ga.y; g4[2] = gb.x; g4[3] = gb.y;
+                h4[0] = ha.x; h4[1] = ha.y; h4[2] = hb.x; h4[3] = hb.y;
+            } else {
+                const cplx ydn = M.Y[(size_t)e_dn_k * Hn + q], yup = M.Y[(size_t)e_up_k * Hn + q];
+                const Blk2 g = (q == 0 && par < M.m) ? blk_power_off(ydn, up, uk, ek) : blk_current(ydn, uk, ek);
+                const Blk2 hh = (q == 0 && k < M.m) ? blk_power_off(yup, uk, up, ep) : blk_current(yup, up, ep);
+                mask_block(n, c, q, par, k, g, g4);
+                mask_block(n, c, q, k, par, hh, h4);
+            }
+            double* Hk = Hall + ((size_t)s * n + k) * Hn * 4 + q * 4;
+            double* Sk = lfS + (so + (size_t)k * Hn + q) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                Hk[e] = h4[e];
+                Sk[e] = si[e];
+            }
+            if (q == 0) {
+                const double ip = 1.0 / (-(up.im * ep.im) - ep.re * up.re);
+                const double sp0 = ep.im * ip, sp1 = -ep.re * ip, sp2 = -up.re * ip, sp3 = -up.im * ip;
+                double* kk = lfK + ((size_t)s * n + k) * 12 + 4;
+                kk[0] = fma(g4[1], si[2], g4[0] * si[0]);  kk[1] = fma(g4[1], si[3], g4[0] * si[1]);
+                kk[2] = fma(g4[3], si[2], g4[2] * si[0]);  kk[3] = fma(g4[3], si[3], g4[2] * si[1]);
+                kk[4] = fma(h4[1], sp2, h4[0] * sp0);  kk[5] = fma(h4[1], sp3, h4[0] * sp1);
+                kk[6] = fma(h4[3], sp2, h4[2] * sp0);  kk[7] = fma(h4[3], sp3, h4[2] * sp1);
+                double w00 = 1.0, w01 = 0.0, w10 = 0.0, w11 = 1.0;      // W_k^-1 = W_k / |U|^2 for a linear bus
+                if (linear_k) {
+                    const double iu = 1.0 / fma(uk.re, uk.re, uk.im * uk.im);
+                    w00 = uk.re * iu; w01 = uk.im * iu; w10 = w01; w11 = -w00;
+                }
+                WI[sc * 4] = w00; WI[sc * 4 + 1] = w01; WI[sc * 4 + 2] = w10; WI[sc * 4 + 3] = w11;
+                double* tk = Zall + ((size_t)s * n + k) * CT + 100;
+                tk[0] = w00; tk[1] = w01; tk[2] = w10; tk[3] = w11;
+            }
+        }
+        if (q == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) S0[sc * 4 + e] = si[e];
+            if (!(live && q < Hn)) { WI[sc * 4] = 1.0; WI[sc * 4 + 1] = 0.0; WI[sc * 4 + 2] = 0.0; WI[sc * 4 + 3] = 1.0; }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            sir[it][e] = si[e];
+            glr[it][e] = g4[e];
+        }
+    }
+    // T <- Tc (per scenario copy), rows by the scenario's threads
+    if (l16 < m)
+        for (int c2 = 0; c2 < m; ++c2) AUG[sc * 100 + l16 * 10 + c2] = simg[l16 * m + c2];
+    __syncthreads();
+    // ---- T. per-scenario parts of T (as in k_factor_q's super-leaf branch), v = Wd^-1 y -----------------------------------------
+    {
+        double* aug = AUG + sc * 100;
+        const double* wi = WI + sc * 4;
+        if (l16 == 0) {
+            const double* si = S0 + sc * 4;
+            const double* dl = DL + sc * 4;
+            const double e00 = fma(dl[1], si[2], dl[0] * si[0]), e01 = fma(dl[1], si[3], dl[0] * si[1]);
+            const double e10 = fma(dl[3], si[2], dl[2] * si[0]), e11 = fma(dl[3], si[3], dl[2] * si[1]);
+            aug[0] += fma(wi[1], e10, wi[0] * e00);
+            aug[1] += fma(wi[1], e11, wi[0] * e01);
+            aug[10] += fma(wi[3], e10, wi[2] * e00);
+            aug[11] += fma(wi[3], e11, wi[2] * e01);
+            const double y0 = Y[sc], y1 = Y[LB_SB + sc];                  // right-hand side rows 0 / 1: W_k^-1
+            Y[sc] = fma(wi[1], y1, wi[0] * y0);
+            Y[LB_SB + sc] = fma(wi[3], y1, wi[2] * y0);
+        } else if (l16 <= L && live) {
+            const int i = l16 - 1, bc = 2 + 2 * i;
+            const int leaf = i == 0 ? lzA.z : (i == 1 ? lzA.w : (i == 2 ? lzB.x : lzB.y));
+            const double* kk = lfK + ((size_t)s * n + leaf) * 12;
+            double q00, q01, q10, q11;
+            inv2(kk[0], kk[1], kk[2], kk[3], q00, q01, q10, q11);
+            aug[bc * 10 + bc] += q00;
+            aug[bc * 10 + bc + 1] += q01;
+            aug[(bc + 1) * 10 + bc] += q10;
+            aug[(bc + 1) * 10 + bc + 1] += q11;
+            aug[bc] -= fma(wi[1], kk[6], wi[0] * kk[4]);
+            aug[bc + 1] -= fma(wi[1], kk[7], wi[0] * kk[5]);
+            aug[10 + bc] -= fma(wi[3], kk[6], wi[2] * kk[4]);
+            aug[10 + bc + 1] -= fma(wi[3], kk[7], wi[2] * kk[5]);
+            aug[bc * 10] -= kk[8];
+            aug[bc * 10 + 1] -= kk[9];
+            aug[(bc + 1) * 10] -= kk[10];
+            aug[(bc + 1) * 10 + 1] -= kk[11];
+        }
+    }
+    __syncthreads();
+    // ---- I. in-place inversion with partial pivoting, one scenario per 16 threads (thread r = row r; pivot row through LDS) -----
+    {
+        double* aug = AUG + sc * 100;
+        double* pr = PR + sc * 10;
+        double row[10];
+#pragma unroll
+        for (int c2 = 0; c2 < 10; ++c2) row[c2] = (l16 < m && c2 < m) ? aug[l16 * 10 + c2] : 0.0;
+        bool used = l16 >= m;
+        int mycol = 0, pcol[10];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+            pcol[j] = 0;
+            if (j < m) {
+                const double cand = used ? -1.0 : fabs(row[j]);
+                double mx = cand;
+                mx = fmax(mx, dpp_f64<0xB1>(mx));
+                mx = fmax(mx, dpp_f64<0x4E>(mx));
+                mx = fmax(mx, dpp_f64<0x141>(mx));
+                mx = fmax(mx, dpp_f64<0x140>(mx));
+                const unsigned long long bal = __builtin_amdgcn_ballot_w64(!used && cand == mx);
+                const unsigned grp = (unsigned)((bal >> (16 * lg)) & 0xffffull);
+                const int pi = __builtin_ctz(grp | 0x8000u);
+                const bool me = l16 == pi;
+                if (me) {
+#pragma unroll
+                    for (int c2 = 0; c2 < 10; ++c2) pr[c2] = row[c2];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                double prow[10];
+#pragma unroll
+                for (int c2 = 0; c2 < 10; ++c2) prow[c2] = pr[c2];
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const double ipv = 1.0 / prow[j];
+                const double f = me ? 0.0 : row[j] * ipv;
+#pragma unroll
+                for (int c2 = 0; c2 < 10; ++c2)
+                    row[c2] = c2 == j ? (me ? ipv : -f) : (me ? prow[c2] * ipv : fma(-f, prow[c2], row[c2]));
+                used = used || me;
+                mycol = me ? j : mycol;
+                pcol[j] = pi;
+            }
+        }
+        if (l16 < m) {
+            double* tk = Zall + ((size_t)s * n + k) * CT;
+#pragma unroll
+            for (int c2 = 0; c2 < 10; ++c2)
+                if (c2 < m) {
+                    aug[mycol * 10 + pcol[c2]] = row[c2];
+                    if (live) tk[mycol * 10 + pcol[c2]] = row[c2];
+                }
+        }
+    }
+    __syncthreads();
+    // ---- M. V = [0 0; 0 Ahh^-1] v on the matrix cores; r = Qb v -----------------------------------------------------------------
+    if (wv < NTR) {
+        d4_t acc = {0.0, 0.0, 0.0, 0.0};
+        const double* ia = img + (size_t)wv * KS * 64 + lane;
+#pragma unroll 4
+        for (int ks = 0; ks < KS; ++ks) {
+            const double a = ia[(size_t)ks * 64];
+            const double bop = Y[(4 * ks + lg) * LB_SB + jj];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bop, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) V[(16 * wv + 4 * reg + lg) * LB_SB + jj] = acc[reg];
+    }
+    {
+        double r = 0.0;
+        if (l16 < m) {
+            const double* qr = qbm + (size_t)l16 * b;
+            for (int col = 0; col < b; ++col) r = fma(qr[col], Y[col * LB_SB + sc], r);
+        }
+        RR[l16 * LB_SB + sc] = r;
+    }
+    __syncthreads();
+    {
+        double y = 0.0;
+        if (l16 < m) {
+            const double* tr = AUG + sc * 100 + l16 * 10;
+            for (int j = 0; j < m; ++j) y = fma(tr[j], RR[j * LB_SB + sc], y);
+        }
+        YY[l16 * LB_SB + sc] = y;
+    }
+    __syncthreads();
+    // ---- F. x_rect = V + Pb y, w = S^-1 x_rect, G w --------------------------------------------------------------------------
+    if (live) {
+        double* wk = wall + ((size_t)s * n + k) * B;
+        double* Ck = Call + ((size_t)s * n + k) * CT;
+#pragma unroll
+        for (int it = 0; it < QI; ++it) {
+            const int q = l16 + 16 * it;
+            if (q >= H2) continue;
+            double x0 = V[(2 * q) * LB_SB + sc], x1 = V[(2 * q + 1) * LB_SB + sc];
+            if (2 * q < b) {
+                const double* p0 = pbm + (size_t)(2 * q) * m;
+                const double* p1 = p0 + m;
+                for (int i = 0; i < m; ++i) {
+                    const double yi = YY[i * LB_SB + sc];
+                    x0 = fma(p0[i], yi, x0);
+                    x1 = fma(p1[i], yi, x1);
+                }
+            }
+            const double* si = sir[it];
+            const bool in = 2 * q < b;
+            const double w0 = in ? fma(si[1], x1, si[0] * x0) : 0.0, w1 = in ? fma(si[3], x1, si[2] * x0) : 0.0;
+            const double* g = glr[it];
+            wk[2 * q] = w0;
+            wk[2 * q + 1] = w1;
+            Ck[2 * q] = fma(g[1], w1, g[0] * w0);
+            Ck[2 * q + 1] = fma(g[3], w1, g[2] * w0);
+        }
+    }
+}
+
+template <int B>
+int launch_sleaf_batch(hpf_handle* h, const TreeDev& T, const int* nodes, int count, const int* active) {
+    const dim3 grid((unsigned)count, (unsigned)((h->cur_S + LB_SB - 1) / LB_SB));
+    hipLaunchKernelGGL((k_sleaf_batch<B>), grid, dim3(256), 0, h->cur_stream, h->M, T, nodes, 2 * h->Hn, active, h->cur_S, h->d_U,
+                       h->d_E, h->d_fb, h->d_w, h->d_linA, h->d_C, h->d_H, h->d_I0, h->d_chG, h->d_chH, h->d_chD, h->d_chy,
+                       active_tree(h).d_sbimg, h->d_Z, h->d_lfK, h->d_lfS, h->cur_s0);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        h->last_detail = (int)e;
+        return HPF_E_HIP;
+    }
+    return HPF_OK;
+}
