@@ -212,7 +212,7 @@ def main():
         "ms_per_iter_per_scenario": ms_step / S,
         "roofline": {"bound": "hbm",
                      "kernel": "k_factor_q<%d> (multi-wave block-tree factor kernel; one sweep = %d launches per scenario "
-                               "group, one per tree level; level 0 is k_leaf_batch: the lazy leaves, 16 scenarios per workgroup)" % (52 if b > 28 else (28 if b > 12 else 12), dm.n_levels),
+                               "group, one per tree level; levels 0 / 1 are mostly k_leaf_batch / k_sleaf_batch: lazy leaves and super-leaves, 16 scenarios per workgroup)" % (52 if b > 28 else (28 if b > 12 else 12), dm.n_levels),
                      "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS if achieved_gbs else None,
                      "traffic": traffic / max(launches_per_step, 1) if traffic else None, "traffic_note": traffic_note,
@@ -265,9 +265,10 @@ def pmc_traffic(args, S):
     if not d:
         return None, "no PMC pass for this kernel"
     tot = d["fetch_raw"] + d.get("write_calibrated", d["write"])
-    lb = per.get("k_leaf_batch")                      # level 0 of the sweep: the lazy leaves' own kernel, same timing span
-    if lb:
-        tot += lb["fetch_raw"] + lb.get("write_calibrated", lb["write"])
+    for name in ("k_leaf_batch", "k_sleaf_batch"):    # levels 0 / 1 of the sweep: the scenario-batched kernels, same timing spans
+        lb = per.get(name)
+        if lb:
+            tot += lb["fetch_raw"] + lb.get("write_calibrated", lb["write"])
     return tot, ("per launch: (FETCH_SIZE*1024 raw + WRITE_SIZE*1024 x store calibration) of a factor sweep / launches; "
                                          "tile-image loads calibrate at 1.0 (k_back_q, known bytes), stores at ~0.55 (k_update, known "
                                          "bytes); includes the shared leaf images served by the Infinity Cache; separate "

@@ -15,7 +15,7 @@ import os
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KEYS = ("k_sleaf_back_batch", "k_leaf_back_batch", "k_leaf_batch", "k_factor_q", "k_back_q", "k_lin_level", "k_chain", "k_mismatch", "k_update", "k_factor_w", "k_back_w", "k_tree_factor",
+KEYS = ("k_sleaf_batch", "k_sleaf_back_batch", "k_leaf_back_batch", "k_leaf_batch", "k_factor_q", "k_back_q", "k_lin_level", "k_chain", "k_mismatch", "k_update", "k_factor_w", "k_back_w", "k_tree_factor",
         "k_tree_back")
 
 
