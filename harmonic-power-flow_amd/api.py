@@ -162,17 +162,13 @@ def hpf(buses, lines, coupled, thresh_h=1e-4, max_iter_h=50, plt_convergence=Fal
                 print("Fundamental power flow converged after " + str(int(nf[0])) + " iterations.")
             else:
                 print("Warning! Maximum of " + str(int(nf[0])) + " iterations reached.")
+        # (block-tree: hpf_solve itself watches the static pivot order and repeats a flagged scenario with partial pivoting)
         n_iter, err, hist = dm.solve(thresh_h, max_iter_h)                        # HG:530-542
-        if dm.solver == "block_tree" and not np.isfinite(err[0]) and 2 * dm.Hn <= 52:
-            # the default block-tree mode inverts the bus blocks with a STATIC pivot order; if that ever breaks down (a
-            # non-finite mismatch), repeat on the GPU with partial pivoting over the whole block before reporting failure
-            if verbose:
-                print("Warning! Static-pivot block elimination produced a non-finite mismatch; repeating with partial pivoting.")
-            dm.set_option("block_pivoting", 1)
-            dm.set_state(seed[0], seed[1])
-            n_iter, err, hist = dm.solve(thresh_h, max_iter_h)
-            if details is not None:
-                details["repeated_with_pivoting"] = True
+        stats = dm.stats()
+        if details is not None:
+            details["repeated_with_pivoting"] = bool(stats["flags"][0] & 16)
+        if verbose and (stats["flags"][0] & 16):
+            print("Warning! Static-pivot block elimination was flagged; the solve was repeated with partial pivoting.")
         Vm_raw, Va_raw = dm.get_state()
         n_iter_h = int(n_iter[0])
         J = None
@@ -185,7 +181,7 @@ def hpf(buses, lines, coupled, thresh_h=1e-4, max_iter_h=50, plt_convergence=Fal
         if details is not None:
             details.update(err_hist=hist[0, :n_iter_h + 1].copy(), seed=(seed[0][0].copy(), seed[1][0].copy()),
                            n_iter_f=int(nf[0]), err_f=hf[0, :int(nf[0])].copy(), solver=dm.solver,
-                           stats=dm.stats(), Vm_raw=Vm_raw[0].copy(), Va_raw=Va_raw[0].copy(), N=dm.N)
+                           stats=stats, Vm_raw=Vm_raw[0].copy(), Va_raw=Va_raw[0].copy(), N=dm.N)
     finally:
         dm.close()
     Vm, Va = _postprocess(Vm_raw[0], Va_raw[0])                                   # HG:545-549
@@ -287,5 +283,6 @@ def solve(filename_buses, filename_lines, coupled=True, settings=None, ne_dir=No
     details = {}
     V, err_h, n_iter_h, J = hpf(buses, lines, coupled, st.thresh_h, st.max_iter_h, settings=st, ne_dir=ne_dir,
                                 solver=solver, verbose=verbose, details=details)
+    # converged = the stop rule err_h <= thresh_h was met (flags bit 0) -- not "the loop ended": a NaN mismatch ends it too
     return {"V": V, "err_h": err_h, "n_iter_h": n_iter_h, "THD": get_THD(V), "details": details,
-            "converged": n_iter_h < st.max_iter_h}
+            "converged": bool(details["stats"]["flags"][0] & 1)}

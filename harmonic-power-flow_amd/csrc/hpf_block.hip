@@ -494,13 +494,14 @@ __device__ __forceinline__ void assemble_row(const Model& M, const TreeDev& T, c
     }
 }
 
-template <int B, int MODE>
-__global__ __launch_bounds__(64, MODE == 1 ? 2 : 1) void k_factor_w(Model M, TreeDev T, const int* __restrict__ nodes, int b, int N, int Nc,
+// One wave per (bus, scenario), lane = row: Gauss-Jordan with partial pivoting over the whole block on the uncontracted tree
+// ("block_pivoting" = 1; also the path a scenario is repeated on when the static-pivot MFMA kernels flag it, hpf.h).
+template <int B>
+__global__ __launch_bounds__(64, 1) void k_factor_w(Model M, TreeDev T, const int* __restrict__ nodes, int b, int N, int Nc,
                                                  const int* __restrict__ active, const cplx* __restrict__ Uall,
                                                  const cplx* __restrict__ Eall, const double* __restrict__ fall,
                                                  double* __restrict__ Aall, double* __restrict__ wall,
-                                                 const double* __restrict__ linAall, double* __restrict__ Call,
-                                                 double* __restrict__ Hall, long long* __restrict__ dbg, int ablate,
+                                                 const double* __restrict__ linAall, int* __restrict__ pivflag, int ablate,
                                                  int s0) {
     const int s = blockIdx.y + s0;
     if (active && !active[s]) return;
@@ -517,10 +518,6 @@ __global__ __launch_bounds__(64, MODE == 1 ? 2 : 1) void k_factor_w(Model M, Tre
 
     __shared__ double bup[(B / 2) * 8];
     __shared__ int rj[B];
-    // diagnostic stamps: compiled only into the -DHPF_FACTOR_STAMPS build (build.py --stamps -> libhpf_stamps.so); even
-    // disabled at run time they cost ~15 % through register allocation, so the product build has none
-    HPF_STAMP_DECL;
-    HPF_STAMP(st0);
 
     const int q = lane >> 1, t = lane & 1;
     const bool rowvalid = lane < b && loc_valid(n, c, k, lane);
@@ -529,11 +526,8 @@ __global__ __launch_bounds__(64, MODE == 1 ? 2 : 1) void k_factor_w(Model M, Tre
     double a[B], y;
     assemble_row<B>(M, T, U, E, f, ws, linAall + (size_t)s * n * Hn * 4, k, lane, b, Nc, ablate, bup, a, y);
 
-    // ---- B. dense children (fixed order).  MODE 1: every dense child has already formed its Schur complement
-    //      C = A(k,ch) D_ch^-1 A(ch,k) (+ the right-hand-side column) in its own wave (schur_tiles): just subtract. -------
-    // (MODE 1 subtracts the children's tile-layout Schur complements after the layout conversion, see C')
-    // MODE 0: pull from the children's transposed inverses
-    for (int cp = T.child_mid[k]; cp < ((MODE == 1 || (ablate & 2)) ? 0 : T.child_ptr[k + 1]); ++cp) {
+    // ---- B. dense children (fixed order): pull from the children's transposed inverses --------------------------------
+    for (int cp = T.child_mid[k]; cp < ((ablate & 2) ? 0 : T.child_ptr[k + 1]); ++cp) {
         const int ch = T.child[cp];
         __syncthreads();
         if (lane < Hn) {
@@ -569,108 +563,22 @@ __global__ __launch_bounds__(64, MODE == 1 ? 2 : 1) void k_factor_w(Model M, Tre
         y = fma(-g1, wc[2 * qq + 1], y);
     }
 
-    if constexpr (MODE == 1) {
-        // ---- C'. FP64 matrix cores: row-per-lane -> accumulator tiles (LDS), blocked Gauss-Jordan with static 4x4
-        //      pivot blocks (hpf_gj_mfma.hpp), tiles -> coalesced transposed inverse + w --------------------------------
-        constexpr int NT = (B + 16) / 16;
-        __shared__ double tbuf[64 * 17];
-        __shared__ double panel[NT * 64 + 16];
-        d4_t ct[NT][NT];
-        HPF_STAMP(st1);
-        rows_to_tiles<B, NT>(a, y, lane, ct, tbuf);
-        HPF_STAMP(st2);
-        {
-            // dense children: C = A(k,ch) D_ch^-1 A(ch,k) (+ right-hand-side column) was formed by the child's own wave
-            // (schur_tiles) and stored in accumulator layout: 64 coalesced 512-byte loads per child, fixed child order
-            constexpr size_t CT = (size_t)NT * NT * 4 * 64;
-            const double* Cs = Call + (size_t)s * n * CT;
-            for (int cp = T.child_mid[k]; cp < ((ablate & 2) ? 0 : T.child_ptr[k + 1]); ++cp) {
-                const double* Cc = Cs + (size_t)T.child[cp] * CT + lane;
-#pragma unroll
-                for (int tr = 0; tr < NT; ++tr) {
-                    double tmp[NT * 4];                      // one tile-row (<= 16 loads) in flight at a time
-#pragma unroll
-                    for (int e = 0; e < NT * 4; ++e)
-                        if (16 * tr + 4 * (e & 3) < B) tmp[e] = Cc[(size_t)(tr * NT * 4 + e) * 64];   // rows >= B: padding
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int tc = 0; tc < NT; ++tc)
-#pragma unroll
-                        for (int reg = 0; reg < 4; ++reg)
-                            if (16 * tr + 4 * reg < B) ct[tr][tc][reg] -= tmp[tc * 4 + reg];
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
-        HPF_STAMP(st3);
-        gauss_jordan_mfma<NT, B / 4>(ct, panel);
-        HPF_STAMP(st4);
-        tiles_to_global<B, NT>(ct, lane, tbuf, As + (size_t)k * BB, ws + (size_t)k * B);
-        HPF_STAMP(st5);
-        const int par = T.parent[k];
-        if (par >= 0) {
-            // ---- E. push: Schur complement of this bus for its parent ------------------------------------------
-            __shared__ double gl[NT * 8 * 4], hl[NT * 8 * 4];
-            __syncthreads();
-            if (lane < NT * 8) {
-                double g4[4] = {0.0, 0.0, 0.0, 0.0}, h4[4] = {0.0, 0.0, 0.0, 0.0};
-                if (lane < Hn) {
-                    coupling_block(M, U, E, lane, par, k, T.e_dn[k], g4);       // A(parent, k)
-                    coupling_block(M, U, E, lane, k, par, T.e_up[k], h4);       // A(k, parent)
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    gl[lane * 4 + e] = g4[e];
-                    hl[lane * 4 + e] = h4[e];
-                }
-                if (lane < Hn) {       // A(k, parent) is needed again by the back sweep: keep it (32 B per harmonic)
-                    double* Hk = Hall + ((size_t)s * n + k) * Hn * 4 + lane * 4;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) Hk[e] = h4[e];
-                }
-            }
-            __syncthreads();
-            schur_tiles<B, NT>(ct, lane, gl, hl);
-            constexpr size_t CT = (size_t)NT * NT * 4 * 64;
-            double* Ck = Call + ((size_t)s * n + k) * CT + lane;
-#pragma unroll
-            for (int tr = 0; tr < NT; ++tr)
-#pragma unroll
-                for (int tc = 0; tc < NT; ++tc)
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg)
-                        if (16 * tr + 4 * reg < B) Ck[(size_t)((tr * NT + tc) * 4 + reg) * 64] = ct[tr][tc][reg];
-        }
-#ifdef HPF_FACTOR_STAMPS
-        if ((ablate & 16) && lane == 0 && dbg) {
-            st6 = __builtin_amdgcn_s_memtime();
-            long long* o = dbg + ((size_t)s * n + k) * 8;
-            o[0] = st1 - st0;   // assembly (+ linear children)
-            o[1] = st2 - st1;   // rows -> tiles
-            o[2] = st3 - st2;   // dense children sums
-            o[3] = st4 - st3;   // MFMA Gauss-Jordan
-            o[4] = st5 - st4;   // tiles -> A^-T, w
-            o[5] = st6 - st5;   // Schur push
-            o[6] = T.child_ptr[k + 1] - T.child_mid[k];
-            o[7] = (k >= M.m) | ((T.child_mid[k] - T.child_ptr[k]) << 1);
-        }
-#endif
-    } else {
-        // ---- C. Gauss-Jordan with implicit partial pivoting, rotating registers (hpf_gj.hpp) ---------------------
-        int myj = 0;
-        double mypiv = 1.0;
-        if (ablate & 1) ablate |= 8;
-        gauss_jordan_wave_rl<B>(a, y, lane, (ablate & 1) ? 0 : B, rj, myj, mypiv);
+    // ---- C. Gauss-Jordan with implicit partial pivoting, rotating registers (hpf_gj.hpp) ---------------------
+    int myj = 0;
+    double mypiv = 1.0;
+    if (ablate & 1) ablate |= 8;
+    gauss_jordan_wave_rl<B>(a, y, lane, (ablate & 1) ? 0 : B, rj, myj, mypiv);
+    // an exactly zero pivot = a singular block (what rocSOLVER reports as info > 0 on the dense path): HPF_E_SINGULAR
+    if (lane < B && mypiv == 0.0) atomicOr(pivflag + s, 4);
 
-        // ---- D. store the transposed inverse and w -------------------------------------------------------------
-        __syncthreads();
-        if (lane < B && !(ablate & 8)) {
-            const double invp = 1.0 / mypiv;
-            double* Ak = As + (size_t)k * BB;
+    // ---- D. store the transposed inverse and w -------------------------------------------------------------
+    __syncthreads();
+    if (lane < B && !(ablate & 8)) {
+        const double invp = 1.0 / mypiv;
+        double* Ak = As + (size_t)k * BB;
 #pragma unroll
-            for (int j = 0; j < B; ++j) Ak[(size_t)rj[j] * B + myj] = a[j] * invp;
-            ws[(size_t)k * B + myj] = y * invp;
-        }
+        for (int j = 0; j < B; ++j) Ak[(size_t)rj[j] * B + myj] = a[j] * invp;
+        ws[(size_t)k * B + myj] = y * invp;
     }
 }
 
@@ -884,147 +792,10 @@ __device__ __forceinline__ void mul22(const double a[4], const double b[4], doub
     o[3] = fma(a[3], b[3], a[2] * b[1]);
 }
 
-__global__ __launch_bounds__(128) void k_chain_factor(Model M, TreeDev T, int nchains, int N, int Nc, int Bst,
-                                                      const int* __restrict__ active, const cplx* __restrict__ Uall,
-                                                      const cplx* __restrict__ Eall, const double* __restrict__ fall,
-                                                      double* __restrict__ linAall, double* __restrict__ wall,
-                                                      const cplx* __restrict__ I0all, double* __restrict__ chG,
-                                                      double* __restrict__ chH, double* __restrict__ chD, double* __restrict__ chy,
-                                                      double* __restrict__ chZ, int s0) {
-    const int s = blockIdx.y + s0;
-    if (active && !active[s]) return;
-    const int tix = blockIdx.x * 128 + threadIdx.x;
-    if (tix >= nchains * M.Hn) return;
-    const int q = tix % M.Hn, r = tix / M.Hn;
-    const int n = M.n, c = M.c, Hn = M.Hn;
-    const size_t so = (size_t)s * n * Hn;
-    const cplx* U = Uall + so;
-    const cplx* E = Eall + so;
-    const double* f = fall + (size_t)s * N;
-    double* linA = linAall + so * 4;
-    double* ws = wall + (size_t)s * n * Bst;
-    const int ch = T.chain_ch[r];
-    const int beg = T.chain_ptr[r], end = T.chain_ptr[r + 1];
-    double a_kc[4], a_ck[4];                       // A(k, ch), A(ch, k) for the current chain bus k (fill after the first)
-    {
-        const int k1 = T.chain_nodes[beg];
-        coupling_block(M, U, E, q, k1, ch, T.e_dn[ch], a_kc);
-        coupling_block(M, U, E, q, ch, k1, T.e_up[ch], a_ck);
-    }
-    double dD[4] = {0.0, 0.0, 0.0, 0.0}, dy[2] = {0.0, 0.0}, cD[4] = {0.0, 0.0, 0.0, 0.0}, cy[2] = {0.0, 0.0};
-    for (int idx = beg; idx < end; ++idx) {
-        const int k = T.chain_nodes[idx];
-        const int up = T.parent[k];
-        double m2[4];
-        diag2x2<false>(M, U, E, I0all + (size_t)s * n, q, k, m2);
-        const int kst = q * n + k;
-        double y0 = (kst >= 1 ? f[kst - 1] : 0.0) + cy[0];
-        double y1 = (kst >= c ? f[Nc + kst - c] : 0.0) + cy[1];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) m2[e] += cD[e];
-        for (int cp = T.child_ptr[k]; cp < T.child_mid[k]; ++cp) {          // the linear subtrees hanging off k
-            const int lc = T.child[cp];
-            double g4[4], h4[4], gi[4], gh[4];
-            coupling_block(M, U, E, q, k, lc, T.e_dn[lc], g4);
-            coupling_block(M, U, E, q, lc, k, T.e_up[lc], h4);
-            mul22(g4, linA + ((size_t)lc * Hn + q) * 4, gi);
-            mul22(gi, h4, gh);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) m2[e] -= gh[e];
-            const double* wc = ws + (size_t)lc * Bst + 2 * q;
-            y0 -= fma(g4[1], wc[1], g4[0] * wc[0]);
-            y1 -= fma(g4[3], wc[1], g4[2] * wc[0]);
-        }
-        double di[4];
-        inv2(m2[0], m2[1], m2[2], m2[3], di[0], di[1], di[2], di[3]);
-        double* ik = linA + ((size_t)k * Hn + q) * 4;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) ik[e] = di[e];
-        const double w0 = fma(di[1], y1, di[0] * y0), w1 = fma(di[3], y1, di[2] * y0);
-        double* wk = ws + (size_t)k * Bst + 2 * q;
-        wk[0] = w0;
-        wk[1] = w1;
-        double a_ku[4], a_uk[4], zc[4], zu[4], t4[4];
-        coupling_block(M, U, E, q, k, up, T.e_up[k], a_ku);              // A(k, up)
-        coupling_block(M, U, E, q, up, k, T.e_dn[k], a_uk);              // A(up, k)
-        mul22(di, a_kc, zc);                                             // D_k^-1 A(k, ch): kept for the back substitution
-        mul22(di, a_ku, zu);
-        double* zk = chZ + (so + (size_t)k * Hn + q) * 4;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) zk[e] = zc[e];
-        mul22(a_ck, zc, t4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) dD[e] -= t4[e];
-        dy[0] -= fma(a_ck[1], w1, a_ck[0] * w0);
-        dy[1] -= fma(a_ck[3], w1, a_ck[2] * w0);
-        double n_ck[4], n_kc[4];
-        mul22(a_ck, zu, n_ck);                                           // -A'(ch, up)
-        mul22(a_uk, zc, n_kc);                                           // -A'(up, ch)
-        mul22(a_uk, zu, t4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            cD[e] = -t4[e];
-            a_ck[e] = -n_ck[e];
-            a_kc[e] = -n_kc[e];
-        }
-        cy[0] = -fma(a_uk[1], w1, a_uk[0] * w0);
-        cy[1] = -fma(a_uk[3], w1, a_uk[2] * w0);
-    }
-    const size_t o = (so + (size_t)ch * Hn + q);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        chG[o * 4 + e] = a_kc[e];                  // A'(top parent, ch)
-        chH[o * 4 + e] = a_ck[e];                  // A'(ch, top parent)
-        chD[o * 4 + e] = dD[e];
-    }
-    chy[o * 2 + 0] = dy[0];
-    chy[o * 2 + 1] = dy[1];
-}
-
-// after the dense back sweep (x of the dense buses known): x_k = w_k - D_k^-1 A(k,up) x_up - D_k^-1 A'(k,ch) x_ch, top-down
-__global__ __launch_bounds__(128) void k_chain_back(Model M, TreeDev T, int nchains, int N, int Nc, int Bst,
-                                                    const int* __restrict__ active, const cplx* __restrict__ Uall,
-                                                    const cplx* __restrict__ Eall, const double* __restrict__ linAall,
-                                                    const double* __restrict__ wall, double* __restrict__ xall,
-                                                    double* __restrict__ step, const double* __restrict__ chZ, int s0) {
-    const int s = blockIdx.y + s0;
-    if (active && !active[s]) return;
-    const int tix = blockIdx.x * 128 + threadIdx.x;
-    if (tix >= nchains * M.Hn) return;
-    const int q = tix % M.Hn, r = tix / M.Hn;
-    const int n = M.n, c = M.c, Hn = M.Hn;
-    const size_t so = (size_t)s * n * Hn;
-    const double* linA = linAall + so * 4;
-    const double* ws = wall + (size_t)s * n * Bst;
-    double* xs = xall + (size_t)s * n * Bst;
-    double* st = step + (size_t)s * N;
-    const int ch = T.chain_ch[r];
-    const double xc0 = xs[(size_t)ch * Bst + 2 * q], xc1 = xs[(size_t)ch * Bst + 2 * q + 1];
-    for (int idx = T.chain_ptr[r + 1] - 1; idx >= T.chain_ptr[r]; --idx) {
-        const int k = T.chain_nodes[idx];
-        const int up = T.parent[k];
-        double h4[4];
-        coupling_block(M, Uall + so, Eall + so, q, k, up, T.e_up[k], h4);        // A(k, up)
-        const double* xp = xs + (size_t)up * Bst + 2 * q;
-        const double t0 = fma(h4[1], xp[1], h4[0] * xp[0]), t1 = fma(h4[3], xp[1], h4[2] * xp[0]);
-        const double* ik = linA + ((size_t)k * Hn + q) * 4;
-        const double* zk = chZ + (so + (size_t)k * Hn + q) * 4;
-        const double* wk = ws + (size_t)k * Bst + 2 * q;
-        const double x0 = wk[0] - fma(ik[1], t1, ik[0] * t0) - fma(zk[1], xc1, zk[0] * xc0);
-        const double x1 = wk[1] - fma(ik[3], t1, ik[2] * t0) - fma(zk[3], xc1, zk[2] * xc0);
-        double* xk = xs + (size_t)k * Bst + 2 * q;
-        xk[0] = x0;
-        xk[1] = x1;
-        const int kst = q * n + k;
-        if (kst >= 1) st[kst - 1] = x0;
-        if (kst >= c) st[Nc + kst - c] = x1;
-    }
-}
-
-template <int B, int MODE>
+template <int B>
 int launch_factor_w(hpf_handle* h, const TreeDev& T, const int* nodes, int count, const int* active) {
-    hipLaunchKernelGGL((k_factor_w<B, MODE>), dim3((unsigned)count, (unsigned)h->cur_S), dim3(64), 0, h->cur_stream, h->M, T, nodes,
-                       2 * h->Hn, h->N, h->Nc, active, h->d_U, h->d_E, h->d_f, h->d_Z, h->d_w, h->d_linA, h->d_C, h->d_H, h->d_dbg, h->debug_ablate, h->cur_s0);
+    hipLaunchKernelGGL((k_factor_w<B>), dim3((unsigned)count, (unsigned)h->cur_S), dim3(64), 0, h->cur_stream, h->M, T, nodes,
+                       2 * h->Hn, h->N, h->Nc, active, h->d_U, h->d_E, h->d_f, h->d_Z, h->d_w, h->d_linA, h->d_pivflag, h->debug_ablate, h->cur_s0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         h->last_detail = (int)e;
@@ -2089,23 +1860,13 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
                 return HPF_E_HIP;
             }
         }
-        if (!lvl2x2 && T.n_chains > 0) {
-            hipLaunchKernelGGL(k_chain_factor, dim3((unsigned)((T.n_chains * h->Hn + 127) / 128), (unsigned)h->cur_S), dim3(128), 0,
-                               h->cur_stream, h->M, td, T.n_chains, h->N, h->Nc, Bst, active, h->d_U, h->d_E, h->d_f, h->d_linA,
-                               h->d_w, h->d_I0, h->d_chG, h->d_chH, h->d_chD, h->d_chy, h->d_chZ, h->cur_s0);
-            hipError_t e = hipGetLastError();
-            if (e != hipSuccess) {
-                h->last_detail = (int)e;
-                return HPF_E_HIP;
-            }
-        }
         for (int l = 0; l < T.n_levels; ++l) {
             const int cnt = T.lvl_ptr[l + 1] - T.lvl_ptr[l];
             if (cnt == 0) continue;
             const int* nodes = T.d_lvl_nodes + T.lvl_ptr[l];
             int r;
             // level 0 of the contracted tree: its lazy leaves come first and go 16 scenarios per workgroup (k_leaf_batch)
-            static const int leafbatch = [] { const char* e = getenv("HPF_LEAFBATCH"); return e ? atoi(e) : 1; }();   // 0: one workgroup per (leaf, scenario)
+            const int leafbatch = h->leafbatch;                 // 0: one workgroup per (leaf, scenario)
             int nbatch = (l == 0 && leafbatch && h->has_ctree && T.lvl_all_leaf[0]) ? T.n_lazy_level0 : 0;
             const bool slbatch = l > 0 && leafbatch && h->has_ctree && l < (int)T.lvl_nbatch.size() && T.lvl_nbatch[l] > 0;
             if (slbatch) nbatch = T.lvl_nbatch[l];
@@ -2122,8 +1883,7 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
         }                                                                                                     \
         r = h->gj_mode == 1 ? launch_factor_q<BB_>(h, td, T.d_fdesc + FDESC * (size_t)T.lvl_ptr[l], cnt, active, \
                                                   T.lvl_all_leaf[l] != 0)                                       \
-            : (h->gj_mode == 2 ? launch_factor_w<BB_, 1>(h, td, nodes, cnt, active)                           \
-                               : launch_factor_w<BB_, 0>(h, td, nodes, cnt, active));                         \
+                            : launch_factor_w<BB_>(h, td, nodes, cnt, active);                               \
         break
                 HPF_FACTOR_CASE(12);
                 HPF_FACTOR_CASE(28);
@@ -2147,7 +1907,7 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
         if (cnt == 0) continue;
         const int* nodes = T.d_dep_nodes + T.dep_ptr[dl];
         int r = HPF_OK;
-        static const int leafbatch_b = [] { const char* e = getenv("HPF_LEAFBATCH"); return e ? atoi(e) : 1; }();
+        const int leafbatch_b = h->leafbatch;
         const int nlb = (leafbatch_b && h->has_ctree && dl > 0 && dl < (int)T.dep_nleaf.size()) ? T.dep_nleaf[dl] : 0;
         switch (BW) {
             case 12:
@@ -2186,7 +1946,7 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
     {
         // every constant-inverse leaf at once, 16 scenarios per workgroup: a leaf's x needs its parent's only, and nothing of the
         // dense tree hangs below a leaf (the 2x2 kernels that do come next)
-        static const int leafbatch_e = [] { const char* e = getenv("HPF_LEAFBATCH"); return e ? atoi(e) : 1; }();
+        const int leafbatch_e = h->leafbatch;
         if (leafbatch_e && h->has_ctree && h->gj_mode == 1 && T.n_bsleaf > 0) {    // super-leaves first: leaves hang below them
             int r = HPF_OK;
             switch (BW) {
@@ -2227,16 +1987,6 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
             return HPF_E_HIP;
         }
         return HPF_OK;
-    }
-    if (T.n_chains > 0) {
-        hipLaunchKernelGGL(k_chain_back, dim3((unsigned)((T.n_chains * h->Hn + 127) / 128), (unsigned)h->cur_S), dim3(128), 0,
-                           h->cur_stream, h->M, td, T.n_chains, h->N, h->Nc, Bst, active, h->d_U, h->d_E, h->d_linA, h->d_w, h->d_x,
-                           h->d_f, h->d_chZ, h->cur_s0);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) {
-            h->last_detail = (int)e;
-            return HPF_E_HIP;
-        }
     }
     if (lin_threads > 0) {
         hipLaunchKernelGGL((k_lin_back<false>), dim3((unsigned)((lin_threads + 127) / 128), (unsigned)h->cur_S), dim3(128), 0, h->cur_stream,

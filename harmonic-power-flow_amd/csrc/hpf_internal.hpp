@@ -111,7 +111,9 @@ struct hpf_handle {
     int N = 0, Nc = 0, Nf = 0;
     bool loads_set = false, state_set = false, mismatch_valid = false;
     int last_detail = 0;
-    int gj_mode = 1;                  // BLOCK_TREE block inversion: 0 pivoted wave Gauss-Jordan (VALU), 1 MFMA static 4x4 blocks, NT waves per bus (hpf_quad.hpp), 2 same, one wave per bus
+    int gj_mode = 1;                  // BLOCK_TREE block inversion: 0 pivoted wave Gauss-Jordan (VALU, uncontracted tree), 1 MFMA static 4x4 blocks, NT waves per bus (hpf_quad.hpp)
+    double piv_limit = 1e10;          // static pivot order: amplification of a 4x4 pivot block's inverse beyond which a scenario is repeated with partial pivoting
+    int leafbatch = 1;                // HPF_LEAFBATCH (read by hpf_create): 0 = one workgroup per (leaf, scenario) instead of 16 scenarios per workgroup
     int debug_ablate = 0;             // HPF_DEBUG_ABLATE: timing-only ablation of factor-kernel phases (results invalid)
 
     // model (device)
@@ -127,6 +129,10 @@ struct hpf_handle {
     int* d_niter = nullptr;           // [S]
     int* d_active = nullptr;          // [S]
     int* d_nactive = nullptr;         // [1]
+    int* d_pivflag = nullptr;         // [S] bit0: a static 4x4 pivot block exceeded piv_limit (k_factor_q), bit1: repeated with partial pivoting,
+                                      //     bit2: exactly zero pivot met by the pivoted wave Gauss-Jordan (k_factor_w)
+    int* d_mask = nullptr;            // [S] scenarios of a repeat pass
+    double *d_Vm0 = nullptr, *d_Va0 = nullptr;   // [S][Hn*n] state at the entry of hpf_solve (repeat with partial pivoting starts from it)
     double* d_hist = nullptr;         // [S][hist_cap]
     int hist_cap = 0;
     hpf_stat* d_stats = nullptr;      // [S]
@@ -140,9 +146,11 @@ struct hpf_handle {
     hpf::Tree tree;                   // elimination tree as the network gives it (single-wave / generic kernels, pf)
     hpf::Tree ctree;                  // the same with pass-through buses contracted (multi-wave kernels, gj_mode 1)
     bool has_ctree = false;
-    // one captured NR iteration per scenario group (hpf_iterate): replayed on the group's stream, no per-kernel launch cost
-    hipGraphExec_t step_graph[8] = {};
-    int graph_key = -1;               // (S, groups, mode) the graphs were captured for
+    int auto_repivot = 1;             // hpf_solve repeats scenarios flagged by the static-pivot monitor with partial pivoting
+    int* h_act[2] = {nullptr, nullptr};          // pinned copies of d_active (hpf_solve looks at chunk c - 1 while chunk c runs)
+    hipEvent_t poll_ev[2] = {nullptr, nullptr};
+    double *trace_Vm = nullptr, *trace_Va = nullptr;   // hpf_set_trace: caller's [S][trace_cap][Hn*n] arrays (per-iteration states)
+    int trace_cap = 0;
     double* d_Z = nullptr;            // [S][n][b*b]
     double* d_w = nullptr;            // [S][n][b]
     double* d_x = nullptr;            // [S][n][b]  Newton step, bus-major

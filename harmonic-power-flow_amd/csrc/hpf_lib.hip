@@ -197,11 +197,15 @@ __global__ void k_update(int n, int Hn, int c, int count, int stride, int N, int
 __global__ void k_finalize(int S, int first, double thresh, int max_iter, int hist_cap, int hist_off,
                            const unsigned long long* __restrict__ errbits, double* __restrict__ err,
                            int* __restrict__ niter, int* __restrict__ active, int* __restrict__ nactive,
-                           double* __restrict__ hist, int s0) {
+                           double* __restrict__ hist, int s0, const int* __restrict__ mask) {
     const int sl = blockIdx.x * blockDim.x + threadIdx.x;
     if (sl >= S) return;
     const int s = sl + s0;
     if (first) {
+        if (mask && !mask[s]) {           // repeat pass: the other scenarios keep their result and stay frozen
+            active[s] = 0;
+            return;
+        }
         const double e = __longlong_as_double((long long)errbits[s]);
         err[s] = e;
         niter[s] = 0;
@@ -232,6 +236,34 @@ __global__ void k_set_int(int* p, int count, int v) {
     if (i < count) p[i] = v;
 }
 
+// scenarios that need the repeat pass with partial pivoting: a static pivot block went over the limit (pivflag bit 0) or the
+// mismatch became non-finite.  mask[s] = 1, pivflag[s] |= 2 ("repeated"); k_restore_masked then resets their state.
+__global__ void k_mark_repeat(int S, const double* __restrict__ err, int* __restrict__ pivflag, int* __restrict__ mask,
+                              int* __restrict__ count) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const double e = err[s];
+    const int m = ((pivflag[s] & 1) || e != e || isinf(e)) ? 1 : 0;
+    mask[s] = m;
+    if (m) {
+        pivflag[s] = (pivflag[s] & 1) | 2;      // bit 1: repeated (bit 0 stays: why)
+        atomicAdd(count, 1);
+    }
+}
+
+__global__ void k_restore_masked(int count, const int* __restrict__ mask, const double* __restrict__ Vm0,
+                                 const double* __restrict__ Va0, double* __restrict__ Vm, double* __restrict__ Va,
+                                 double* __restrict__ hist, int hist_cap) {
+    const int s = blockIdx.y;
+    if (!mask[s]) return;
+    const int k = blockIdx.x * TPB + threadIdx.x;
+    if (k < count) {
+        Vm[(size_t)s * count + k] = Vm0[(size_t)s * count + k];
+        Va[(size_t)s * count + k] = Va0[(size_t)s * count + k];
+    }
+    if (hist && k < hist_cap) hist[(size_t)s * hist_cap + k] = NAN;
+}
+
 __global__ void k_init_voltages(int Hn, int count, double* Vm, double* Va) {
     const int k = blockIdx.x * TPB + threadIdx.x;
     if (k >= count) return;
@@ -242,7 +274,8 @@ __global__ void k_init_voltages(int Hn, int count, double* Vm, double* Va) {
 
 // get_THD (HG:563-572) THD_F per bus, max over buses, plus the result flags; one block per scenario.
 __global__ void k_stats(int n, int Hn, double thresh, int max_iter, const double* __restrict__ Vm,
-                        const double* __restrict__ err, const int* __restrict__ niter, hpf_stat* __restrict__ out) {
+                        const double* __restrict__ err, const int* __restrict__ niter, const int* __restrict__ pivflag,
+                        hpf_stat* __restrict__ out) {
     const int s = blockIdx.x;
     const double* V = Vm + (size_t)s * n * Hn;
     double best = 0.0;
@@ -266,7 +299,9 @@ __global__ void k_stats(int n, int Hn, double thresh, int max_iter, const double
         st.n_iter = niter[s];
         const double e = err[s];
         st.err = e;
-        st.flags = (e <= thresh ? 1 : 0) | ((niter[s] >= max_iter && !(e <= thresh)) ? 2 : 0) | ((e != e || isinf(e)) ? 4 : 0);
+        const int pf = pivflag ? pivflag[s] : 0;
+        st.flags = (e <= thresh ? 1 : 0) | ((niter[s] >= max_iter && !(e <= thresh)) ? 2 : 0) | ((e != e || isinf(e)) ? 4 : 0) |
+                   ((pf & 1) ? 8 : 0) | ((pf & 2) ? 16 : 0) | ((pf & 4) ? 32 : 0);
         st.thd_max = __longlong_as_double((long long)r);
         out[s] = st;
     }
@@ -486,13 +521,121 @@ int check_info(hpf_handle* h, const std::vector<int>& was_active) {
     return HPF_OK;
 }
 
+// state of every scenario after iteration `it` -> the caller's trace arrays (hpf_set_trace), ABI order q*n + i
+int trace_record(hpf_handle* h, int it) {
+    if (!h->trace_Vm || it >= h->trace_cap) return HPF_OK;
+    const size_t count = (size_t)h->n * h->Hn, cnt = (size_t)h->S * count;
+    std::vector<double> tm(cnt), ta(cnt);
+    HIPCHK(hipMemcpyAsync(tm.data(), h->d_Vm, sizeof(double) * cnt, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(ta.data(), h->d_Va, sizeof(double) * cnt, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int sc = 0; sc < h->S; ++sc) {
+        double* om = h->trace_Vm + ((size_t)sc * h->trace_cap + it) * count;
+        double* oa = h->trace_Va + ((size_t)sc * h->trace_cap + it) * count;
+        for (int i = 0; i < h->n; ++i)
+            for (int q = 0; q < h->Hn; ++q) {
+                om[(size_t)q * h->n + i] = tm[(size_t)sc * count + (size_t)i * h->Hn + q];
+                oa[(size_t)q * h->n + i] = ta[(size_t)sc * count + (size_t)i * h->Hn + q];
+            }
+    }
+    return HPF_OK;
+}
+
+// One pass of the NR loop (HG:530-542 / HG:257-265) from the current state over the scenarios selected by `mask` (nullptr: all).
+template <bool FUND>
+int nr_pass(hpf_handle* h, double thresh, int max_iter, const int* mask) {
+    int r;
+    const int S = h->S;
+    const int hist_off = FUND ? 1 : 0;                // pf records only post-update errors (HG:264)
+    if ((r = launch_polar<FUND>(h))) return r;
+    HIPCHK(hipMemsetAsync(h->d_errbits, 0, sizeof(unsigned long long) * S, h->stream));
+    if ((r = launch_mismatch<FUND>(h, mask, false))) return r;
+    HIPCHK(hipMemsetAsync(h->d_nactive, 0, sizeof(int), h->stream));
+    hipLaunchKernelGGL(k_finalize, dim3((S + 63) / 64), dim3(64), 0, h->stream, S, 1, thresh, max_iter, h->hist_cap,
+                       hist_off, h->d_errbits, h->d_err, h->d_niter, h->d_active, h->d_nactive, h->d_hist, 0, mask);
+    const bool trace = !FUND && h->trace_Vm != nullptr;
+    if (trace && !mask && (r = trace_record(h, 0))) return r;
+    // The per-scenario stop rule lives on the device (k_finalize after every iteration, in the scenario group's own pipeline):
+    // frozen scenarios are skipped by every kernel, so the host only has to notice when NO scenario is active any more, and
+    // noticing late changes nothing in the results.  BLOCK_TREE: the host looks every `chunk` iterations, and it looks at chunk
+    // c - 1 while chunk c is already queued (pinned double buffer + events), so the device never drains between chunks.
+    const bool pipelined = !FUND && h->solver == HPF_SOLVER_BLOCK_TREE && !trace;
+    const int chunk = pipelined ? (S >= 8 ? 4 : 2) : 1;
+    auto enqueue = [&](int todo) -> int {
+        auto body = [&]() -> int {
+            int rr;
+            for (int j = 0; j < todo; ++j) {
+                if ((rr = newton_step<FUND>(h, h->d_active))) return rr;
+                if ((rr = launch_update<FUND>(h, h->d_active))) return rr;
+                if ((rr = launch_mismatch<FUND>(h, h->d_active, false))) return rr;
+                hipLaunchKernelGGL(k_finalize, dim3((h->cur_S + 63) / 64), dim3(64), 0, h->cur_stream, h->cur_S, 0, thresh,
+                                   max_iter, h->hist_cap, hist_off, h->d_errbits, h->d_err, h->d_niter, h->d_active,
+                                   h->d_nactive, h->d_hist, h->cur_s0, (const int*)nullptr);
+            }
+            return HPF_OK;
+        };
+        if (FUND) {
+            full_ctx(h);
+            return body();
+        }
+        return for_groups(h, body);
+    };
+    auto count_active = [&](const int* a) {
+        int c = 0;
+        for (int s = 0; s < S; ++s) c += a[s] != 0;
+        return c;
+    };
+    if (pipelined) {
+        if (!h->h_act[0]) {
+            for (int i = 0; i < 2; ++i) {
+                HIPCHK(hipHostMalloc((void**)&h->h_act[i], sizeof(int) * h->S_max, hipHostMallocDefault));
+                HIPCHK(hipEventCreateWithFlags(&h->poll_ev[i], hipEventDisableTiming));
+            }
+        }
+        int it = 0, c = 0;
+        HIPCHK(hipMemcpyAsync(h->h_act[0], h->d_active, sizeof(int) * S, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipEventRecord(h->poll_ev[0], h->stream));
+        for (;;) {
+            // queue chunk c + 1 (iterations it .. it + todo) before looking at the flags chunk c left
+            const int todo = (max_iter - it) < chunk ? (max_iter - it) : chunk;
+            if (todo > 0) {
+                if ((r = enqueue(todo))) return r;
+                HIPCHK(hipMemcpyAsync(h->h_act[(c + 1) & 1], h->d_active, sizeof(int) * S, hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(hipEventRecord(h->poll_ev[(c + 1) & 1], h->stream));
+                it += todo;
+            }
+            HIPCHK(hipEventSynchronize(h->poll_ev[c & 1]));
+            if (count_active(h->h_act[c & 1]) == 0 || todo == 0) break;
+            ++c;
+        }
+        HIPCHK(hipStreamSynchronize(h->stream));
+        return HPF_OK;
+    }
+    std::vector<int> act(S), was(S);
+    HIPCHK(hipMemcpyAsync(act.data(), h->d_active, sizeof(int) * S, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    int nactive = count_active(act.data());
+    int it = 0;
+    while (nactive > 0 && it < max_iter) {
+        was = act;
+        if ((r = enqueue(1))) return r;
+        HIPCHK(hipMemcpyAsync(act.data(), h->d_active, sizeof(int) * S, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        nactive = count_active(act.data());
+        if (h->solver == HPF_SOLVER_DENSE)
+            if ((r = check_info(h, was))) return r;
+        ++it;
+        if (trace && (r = trace_record(h, it))) return r;
+    }
+    return HPF_OK;
+}
+
 template <bool FUND>
 int nr_loop(hpf_handle* h, double thresh, int max_iter, int* n_iter, double* err, double* err_hist) {
     if (!h->loads_set || !h->state_set) return HPF_E_STATE;
     if (max_iter < 0) return HPF_E_ARG;
     int r;
     const int S = h->S;
-    const int hist_off = FUND ? 1 : 0;                // pf records only post-update errors (HG:264)
     const int cap = max_iter + 1;
     if (h->hist_cap < cap) {
         if (h->d_hist) hipFree(h->d_hist);
@@ -504,54 +647,39 @@ int nr_loop(hpf_handle* h, double thresh, int max_iter, int* n_iter, double* err
         hipLaunchKernelGGL(k_fill, dim3((unsigned)((cnt + TPB - 1) / TPB)), dim3(TPB), 0, h->stream, h->d_hist, cnt,
                            (double)NAN);
     }
-    if ((r = launch_polar<FUND>(h))) return r;
-    HIPCHK(hipMemsetAsync(h->d_errbits, 0, sizeof(unsigned long long) * S, h->stream));
-    if ((r = launch_mismatch<FUND>(h, nullptr, false))) return r;
-    HIPCHK(hipMemsetAsync(h->d_nactive, 0, sizeof(int), h->stream));
-    hipLaunchKernelGGL(k_finalize, dim3((S + 63) / 64), dim3(64), 0, h->stream, S, 1, thresh, max_iter, h->hist_cap,
-                       hist_off, h->d_errbits, h->d_err, h->d_niter, h->d_active, h->d_nactive, h->d_hist, 0);
-    std::vector<int> act(S), was(S);
-    auto count_active = [&]() {
-        int c = 0;
-        for (int s = 0; s < S; ++s) c += act[s] != 0;
-        return c;
-    };
-    HIPCHK(hipMemcpyAsync(act.data(), h->d_active, sizeof(int) * S, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    int nactive = count_active();
-    int it = 0;
-    // The per-scenario stop rule lives on the device (k_finalize after every iteration, in the scenario group's own pipeline), so
-    // the host only has to notice when NO scenario is active any more: it looks every `chunk` iterations.  Frozen scenarios are
-    // skipped by every kernel, so looking late changes nothing in the results.
-    const int chunk = (!FUND && h->solver == HPF_SOLVER_BLOCK_TREE) ? 4 : 1;
-    while (nactive > 0 && it < max_iter) {
-        was = act;
-        const int todo = (max_iter - it) < chunk ? (max_iter - it) : chunk;
-        auto body = [&]() -> int {
-            int rr;
-            for (int j = 0; j < todo; ++j) {
-                if ((rr = newton_step<FUND>(h, h->d_active))) return rr;
-                if ((rr = launch_update<FUND>(h, h->d_active))) return rr;
-                if ((rr = launch_mismatch<FUND>(h, h->d_active, false))) return rr;
-                hipLaunchKernelGGL(k_finalize, dim3((h->cur_S + 63) / 64), dim3(64), 0, h->cur_stream, h->cur_S, 0, thresh,
-                                   max_iter, h->hist_cap, hist_off, h->d_errbits, h->d_err, h->d_niter, h->d_active,
-                                   h->d_nactive, h->d_hist, h->cur_s0);
-            }
-            return HPF_OK;
-        };
-        if (FUND) {
-            full_ctx(h);
-            r = body();
-        } else {
-            r = for_groups(h, body);
+    // BLOCK_TREE inverts the bus blocks with a STATIC pivot order (4x4 blocks on the matrix cores).  Every pivot block is watched
+    // (inv4_cofactor_lane): a scenario in which one amplifies by more than piv_limit, or whose mismatch becomes non-finite, is
+    // repeated from the state this call was entered with, with partial pivoting over the whole block (pivoted wave Gauss-Jordan
+    // on the uncontracted tree).  hpf_stat.flags bit 3 / bit 4 report it.
+    const bool can_repeat = !FUND && h->solver == HPF_SOLVER_BLOCK_TREE && h->has_ctree && h->gj_mode == 1 && h->auto_repivot;
+    const size_t count = (size_t)h->n * h->Hn;
+    if (!FUND) HIPCHK(hipMemsetAsync(h->d_pivflag, 0, sizeof(int) * S, h->stream));
+    if (can_repeat) {
+        if (!h->d_Vm0) {
+            if ((r = dev_alloc(h, &h->d_Vm0, (size_t)h->S_max * count))) return r;
+            if ((r = dev_alloc(h, &h->d_Va0, (size_t)h->S_max * count))) return r;
+            if ((r = dev_alloc(h, &h->d_mask, (size_t)h->S_max))) return r;
         }
-        if (r) return r;
-        HIPCHK(hipMemcpyAsync(act.data(), h->d_active, sizeof(int) * S, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(h->d_Vm0, h->d_Vm, sizeof(double) * S * count, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->d_Va0, h->d_Va, sizeof(double) * S * count, hipMemcpyDeviceToDevice, h->stream));
+    }
+    if ((r = nr_pass<FUND>(h, thresh, max_iter, nullptr))) return r;
+    if (can_repeat) {
+        int nrep = 0;
+        HIPCHK(hipMemsetAsync(h->d_nactive, 0, sizeof(int), h->stream));
+        hipLaunchKernelGGL(k_mark_repeat, dim3((S + 63) / 64), dim3(64), 0, h->stream, S, h->d_err, h->d_pivflag, h->d_mask,
+                           h->d_nactive);
+        HIPCHK(hipMemcpyAsync(&nrep, h->d_nactive, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
-        nactive = count_active();
-        if (h->solver == HPF_SOLVER_DENSE)
-            if ((r = check_info(h, was))) return r;
-        it += todo;
+        if (nrep > 0) {
+            const unsigned gx = (unsigned)(((count > (size_t)h->hist_cap ? count : (size_t)h->hist_cap) + TPB - 1) / TPB);
+            hipLaunchKernelGGL(k_restore_masked, dim3(gx, (unsigned)S), dim3(TPB), 0, h->stream, (int)count, h->d_mask, h->d_Vm0,
+                               h->d_Va0, h->d_Vm, h->d_Va, h->d_hist, h->hist_cap);
+            h->gj_mode = 0;
+            r = nr_pass<FUND>(h, thresh, max_iter, h->d_mask);
+            h->gj_mode = 1;
+            if (r) return r;
+        }
     }
     h->mismatch_valid = false;   // frozen scenarios leave stale rows in d_f: hpf_mismatch before hpf_iterate
     if (n_iter) HIPCHK(hipMemcpy(n_iter, h->d_niter, sizeof(int) * S, hipMemcpyDeviceToHost));
@@ -563,8 +691,15 @@ int nr_loop(hpf_handle* h, double thresh, int max_iter, int* n_iter, double* err
     }
     if (!FUND) {
         hipLaunchKernelGGL(k_stats, dim3(S), dim3(TPB), 0, h->stream, h->n, h->Hn, thresh, max_iter, h->d_Vm, h->d_err,
-                           h->d_niter, h->d_stats);
+                           h->d_niter, h->d_pivflag, h->d_stats);
+        std::vector<int> pf(S);
+        HIPCHK(hipMemcpyAsync(pf.data(), h->d_pivflag, sizeof(int) * S, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
+        for (int s = 0; s < S; ++s)
+            if (pf[s] & 4) {               // the pivoted Gauss-Jordan met an exactly zero pivot: singular Jacobian block
+                h->last_detail = s;
+                return HPF_E_SINGULAR;
+            }
     }
     return HPF_OK;
 }
@@ -572,7 +707,7 @@ int nr_loop(hpf_handle* h, double thresh, int max_iter, int* n_iter, double* err
 void free_all(hpf_handle* h) {
     void* ptrs[] = {h->d_rowptr, h->d_col, h->d_diag, h->d_erow, h->d_dev, h->d_Y, h->d_YN, h->d_YNt, h->d_IN, h->d_P, h->d_Q,
                     h->d_Vm, h->d_Va, h->d_U, h->d_E, h->d_I0, h->d_f, h->d_errbits, h->d_err, h->d_niter, h->d_active,
-                    h->d_nactive, h->d_hist, h->d_stats, h->d_J, h->d_ipiv, h->d_info, h->d_Z, h->d_w, h->d_x, h->d_linA, h->d_C, h->d_dbg, h->d_H, h->d_chG, h->d_chH, h->d_chD, h->d_chy, h->d_chZ, h->d_lfK, h->d_lfS, h->d_fb};
+                    h->d_nactive, h->d_pivflag, h->d_mask, h->d_Vm0, h->d_Va0, h->d_hist, h->d_stats, h->d_J, h->d_ipiv, h->d_info, h->d_Z, h->d_w, h->d_x, h->d_linA, h->d_C, h->d_dbg, h->d_H, h->d_chG, h->d_chH, h->d_chD, h->d_chy, h->d_chZ, h->d_lfK, h->d_lfS, h->d_fb};
     for (void* p : ptrs)
         if (p) hipFree(p);
     tree_free(h);
@@ -585,6 +720,10 @@ void free_all(hpf_handle* h) {
         if (h->join_ev[g]) hipEventDestroy(h->join_ev[g]);
     }
     if (h->fork_ev) hipEventDestroy(h->fork_ev);
+    for (int i = 0; i < 2; ++i) {
+        if (h->h_act[i]) hipHostFree(h->h_act[i]);
+        if (h->poll_ev[i]) hipEventDestroy(h->poll_ev[i]);
+    }
     if (h->blas) rocblas_destroy_handle(h->blas);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
 }
@@ -658,7 +797,8 @@ int hpf_create(hpf_handle** out, const hpf_desc* d) {
         return HPF_E_ARG;
     }
     if (const char* ab = getenv("HPF_DEBUG_ABLATE")) h->debug_ablate = atoi(ab);
-    if (const char* gm = getenv("HPF_GJ_MODE")) h->gj_mode = atoi(gm);
+    if (const char* gm = getenv("HPF_GJ_MODE")) h->gj_mode = atoi(gm) ? 1 : 0;
+    if (const char* lb = getenv("HPF_LEAFBATCH")) h->leafbatch = atoi(lb) ? 1 : 0;
     if (hipSetDevice(d->device) != hipSuccess) return fail(HPF_E_HIP);
     if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) return fail(HPF_E_HIP);
     h->stream = h->own_stream;
@@ -708,6 +848,8 @@ int hpf_create(hpf_handle** out, const hpf_desc* d) {
     if ((r = dev_alloc(h, &h->d_niter, S))) return fail(r);
     if ((r = dev_alloc(h, &h->d_active, S))) return fail(r);
     if ((r = dev_alloc(h, &h->d_nactive, (size_t)1))) return fail(r);
+    if ((r = dev_alloc(h, &h->d_pivflag, S))) return fail(r);
+    if (hipMemset(h->d_pivflag, 0, sizeof(int) * S) != hipSuccess) return fail(HPF_E_HIP);
     if ((r = dev_alloc(h, &h->d_stats, S))) return fail(r);
     Model& M = h->M;
     M.n = d->n; M.m = d->m; M.c = d->c; M.Hn = d->Hn; M.nnz = d->nnz; M.n_dev = d->n_dev; M.coupled = h->coupled; M.bus_major = 1;
@@ -761,8 +903,10 @@ int hpf_set_state(hpf_handle* h, int n_scen, const double* Vm, const double* Va)
                     tm[(size_t)sc * count + (size_t)i * h->Hn + q] = Vm[(size_t)sc * count + (size_t)q * h->n + i];
                     ta[(size_t)sc * count + (size_t)i * h->Hn + q] = Va[(size_t)sc * count + (size_t)q * h->n + i];
                 }
-        HIPCHK(hipMemcpy(h->d_Vm, tm.data(), sizeof(double) * tm.size(), hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(h->d_Va, ta.data(), sizeof(double) * ta.size(), hipMemcpyHostToDevice));
+        // on the handle's stream: ordered behind whatever hpf_iterate left in flight (the group streams join h->stream)
+        HIPCHK(hipMemcpyAsync(h->d_Vm, tm.data(), sizeof(double) * tm.size(), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->d_Va, ta.data(), sizeof(double) * ta.size(), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
     } else {
         hipLaunchKernelGGL(k_init_voltages, grid2(count, n_scen), dim3(TPB), 0, h->stream, h->Hn, count, h->d_Vm, h->d_Va);
         HIPCHK(hipGetLastError());
@@ -777,10 +921,10 @@ int hpf_get_state(hpf_handle* h, double* Vm, double* Va) {
     if (!h || !Vm || !Va) return HPF_E_ARG;
     if (!h->state_set) return HPF_E_STATE;
     const size_t count = (size_t)h->n * h->Hn, cnt = (size_t)h->S * count;
-    HIPCHK(hipStreamSynchronize(h->stream));
     std::vector<double> tm(cnt), ta(cnt);
-    HIPCHK(hipMemcpy(tm.data(), h->d_Vm, sizeof(double) * cnt, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(ta.data(), h->d_Va, sizeof(double) * cnt, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpyAsync(tm.data(), h->d_Vm, sizeof(double) * cnt, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(ta.data(), h->d_Va, sizeof(double) * cnt, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
     for (int sc = 0; sc < h->S; ++sc)                                   // device bus-major -> ABI stacked order
         for (int q = 0; q < h->Hn; ++q)
             for (int i = 0; i < h->n; ++i) {
@@ -841,53 +985,6 @@ int hpf_iterate(hpf_handle* h, int iters) {
     // iteration-major enqueue order (all groups' step i before any group's step i+1) keeps the group pipelines in phase
     const int G = groups_for(h);
     int r = HPF_OK;
-    static const int use_graph = getenv("HPF_GRAPH") ? atoi(getenv("HPF_GRAPH")) : 0;
-    if (use_graph && !h->timing && G <= 8) {
-        const int key = h->S * 64 + G * 8 + h->gj_mode;
-        if (h->graph_key != key) {
-            for (int g = 0; g < 8; ++g)
-                if (h->step_graph[g]) {
-                    hipGraphExecDestroy(h->step_graph[g]);
-                    h->step_graph[g] = nullptr;
-                }
-            for (int g = 0; g < G; ++g) {
-                hipStream_t st = G > 1 ? h->gstream[g] : h->stream;
-                HIPCHK(hipStreamSynchronize(st));
-                HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-                if (G > 1)
-                    set_ctx(h, st, (int)((long long)h->S * g / G), (int)((long long)h->S * (g + 1) / G) - (int)((long long)h->S * g / G));
-                else
-                    full_ctx(h);
-                r = newton_step<false>(h, nullptr);
-                if (!r) r = launch_update<false>(h, nullptr);
-                if (!r) r = launch_mismatch<false>(h, nullptr, false);
-                hipGraph_t gr = nullptr;
-                const hipError_t ee = hipStreamEndCapture(st, &gr);
-                if (r || ee != hipSuccess) {
-                    full_ctx(h);
-                    h->last_detail = (int)ee;
-                    return r ? r : HPF_E_HIP;
-                }
-                HIPCHK(hipGraphInstantiate(&h->step_graph[g], gr, nullptr, nullptr, 0));
-                hipGraphDestroy(gr);
-            }
-            h->graph_key = key;
-        }
-        if (G > 1) {
-            HIPCHK(hipEventRecord(h->fork_ev, h->stream));
-            for (int g = 0; g < G; ++g) HIPCHK(hipStreamWaitEvent(h->gstream[g], h->fork_ev, 0));
-        }
-        for (int it = 0; it < iters; ++it)
-            for (int g = 0; g < G; ++g) HIPCHK(hipGraphLaunch(h->step_graph[g], G > 1 ? h->gstream[g] : h->stream));
-        if (G > 1) {
-            for (int g = 0; g < G; ++g) {
-                HIPCHK(hipEventRecord(h->join_ev[g], h->gstream[g]));
-                HIPCHK(hipStreamWaitEvent(h->stream, h->join_ev[g], 0));
-            }
-        }
-        full_ctx(h);
-        return HPF_OK;
-    }
     if (G > 1) {
         HIPCHK(hipEventRecord(h->fork_ev, h->stream));
         for (int g = 0; g < G; ++g) HIPCHK(hipStreamWaitEvent(h->gstream[g], h->fork_ev, 0));
@@ -946,7 +1043,24 @@ int hpf_set_option(hpf_handle* h, const char* name, int value) {
         h->gj_mode = value ? 0 : 1;
         return HPF_OK;
     }
+    if (!strcmp(name, "pivot_growth_limit_log10")) { // static pivot order: amplification limit of a 4x4 pivot block, 10^value
+        if (value < 0 || value > 300) return HPF_E_ARG;
+        h->piv_limit = pow(10.0, (double)value);
+        return HPF_OK;
+    }
+    if (!strcmp(name, "auto_repivot")) {            // 0: flagged scenarios are only reported (flags bit 3), not repeated
+        h->auto_repivot = value ? 1 : 0;
+        return HPF_OK;
+    }
     return HPF_E_ARG;
+}
+
+int hpf_set_trace(hpf_handle* h, double* Vm_traj, double* Va_traj, int cap) {
+    if (!h || (Vm_traj == nullptr) != (Va_traj == nullptr) || (Vm_traj && cap < 1)) return HPF_E_ARG;
+    h->trace_Vm = Vm_traj;
+    h->trace_Va = Va_traj;
+    h->trace_cap = Vm_traj ? cap : 0;
+    return HPF_OK;
 }
 
 int hpf_set_stream(hpf_handle* h, void* s) {

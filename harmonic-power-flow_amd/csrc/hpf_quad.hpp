@@ -151,7 +151,8 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
     double* __restrict__ wall, const double* __restrict__ linAall, double* __restrict__ Call, double* __restrict__ Hall,
     const cplx* __restrict__ I0all, const double* __restrict__ chG, const double* __restrict__ chH,
     const double* __restrict__ chD, const double* __restrict__ chy, const double* __restrict__ Minv,
-    double* __restrict__ lfK, double* __restrict__ lfS, long long* __restrict__ dbg, int ablate, int s0) {
+    double* __restrict__ lfK, double* __restrict__ lfS, long long* __restrict__ dbg, int ablate, int s0,
+    int* __restrict__ pivflag, double piv_limit) {
     constexpr int NT = (B + 16) / 16;
     constexpr size_t CT = (size_t)NT * NT * 256;
     constexpr int tcB = B >> 4, jjB = B & 15;
@@ -909,13 +910,17 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
                 // pivot block -> LDS scratch (the 16 lanes that hold it), lane-parallel cofactor inverse, W -> LDS; the pivot
                 // columns (64 x 4 panel) follow while the inverse's LDS reads are in flight
                 if (incol) pv[buf][lg * 4 + (jj - j0)] = ct[tP][rg];
-                const double wji = inv4_cofactor_lane(pv[buf], lane);
+                bool weak;
+                const double wji = inv4_cofactor_lane(pv[buf], lane, piv_limit, weak);
                 if (incol) {
 #pragma unroll
                     for (int tr = 0; tr < NT; ++tr)
 #pragma unroll
                         for (int reg = 0; reg < 4; ++reg) panel[buf][(16 * tr + lg + 4 * reg) * 4 + (jj - j0)] = ct[tr][reg];
                 }
+                // static pivot order under watch: a pivot block whose inverse amplifies by more than piv_limit (or is singular)
+                // marks the scenario; hpf_solve repeats marked scenarios with partial pivoting (hpf.h, hpf_stat.flags bit 3)
+                if (weak && lane < 16) atomicOr(pivflag + s, 1);
                 if (lane < 16) wl[buf][(lane & 3) * 4 + (lane >> 2)] = wji;        // lane (i, j) holds W[j][i]
             }
 #ifdef HPF_FACTOR_STAMPS
@@ -1137,7 +1142,8 @@ int launch_factor_q2(hpf_handle* h, const TreeDev& T, const int* nodes, int coun
     const dim3 grid((unsigned)count, (unsigned)h->cur_S);
     hipLaunchKernelGGL((k_factor_q<B, LEAF>), grid, dim3(64 * NT), 0, h->cur_stream, h->M, T, nodes,
                        2 * h->Hn, h->N, h->Nc, active, h->d_U, h->d_E, h->d_fb, h->d_Z, h->d_w, h->d_linA, h->d_C, h->d_H,
-                       h->d_I0, h->d_chG, h->d_chH, h->d_chD, h->d_chy, active_tree(h).d_Minv, h->d_lfK, h->d_lfS, h->d_dbg, h->debug_ablate, h->cur_s0);
+                       h->d_I0, h->d_chG, h->d_chH, h->d_chD, h->d_chy, active_tree(h).d_Minv, h->d_lfK, h->d_lfS, h->d_dbg, h->debug_ablate, h->cur_s0,
+                       h->d_pivflag, h->piv_limit);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         h->last_detail = (int)e;

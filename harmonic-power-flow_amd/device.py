@@ -145,12 +145,24 @@ class DeviceModel:
                   "hpf_fund_pf")
         return n_iter, err, hist[:, :max_iter]
 
-    def solve(self, thresh=1e-4, max_iter=50):
+    def solve(self, thresh=1e-4, max_iter=50, trace=False):
+        """hpf_solve -> (n_iter [S], err [S], err_hist [S][max_iter+1]); with trace=True additionally the per-iteration states
+        (Vm_traj, Va_traj) [S][max_iter+1][Hn*n] (entry k = state after iteration k; frozen scenarios repeat their last state)."""
         n_iter = np.zeros(self.S, dtype=np.int32)
         err = np.empty(self.S)
         hist = np.empty((self.S, max_iter + 1))
-        self._chk(self.lib.hpf_solve(self._h, float(thresh), int(max_iter), _ip(n_iter), _dp(err), _dp(hist)),
-                  "hpf_solve")
+        if trace:
+            Vt = np.full((self.S, max_iter + 1, self.n * self.Hn), np.nan)
+            At = np.full_like(Vt, np.nan)
+            self._chk(self.lib.hpf_set_trace(self._h, _dp(Vt), _dp(At), max_iter + 1), "hpf_set_trace")
+        try:
+            self._chk(self.lib.hpf_solve(self._h, float(thresh), int(max_iter), _ip(n_iter), _dp(err), _dp(hist)),
+                      "hpf_solve")
+        finally:
+            if trace:
+                self.lib.hpf_set_trace(self._h, None, None, 0)
+        if trace:
+            return n_iter, err, hist, Vt, At
         return n_iter, err, hist
 
     def iterate(self, iters):

@@ -92,23 +92,30 @@ def import_Norton_Equivalents(buses, coupled, settings=None, ne_dir=None):
     """HG:278-310 -> {device: [I_N, Y_N]} as DataFrames in p.u., exactly the reference's objects."""
     st = settings or Settings()
     ne_dir = ne_dir or default_ne_dir()
-    freqs = st.HARMONICS_FREQ
+    want = [int(f) for f in st.HARMONICS_FREQ]
+    types = buses["type"].to_numpy()
+    comps = buses["component"].to_numpy()
     NE = {}
-    for device in buses.component[buses.type == "nonlinear"].unique():
-        NE_device = pd.read_csv(_find_ne_file(ne_dir, device), index_col=["Parameter", "Frequency"])
-        NE_device.columns = NE_device.columns.astype(int)
-        missing = [f for f in freqs if f not in NE_device.columns]
+    for device in dict.fromkeys(comps[types == "nonlinear"]):            # unique device names, first-seen order (HG:285)
+        have, Ycc, Ic, Yuc, Iuc = read_Norton_file(_find_ne_file(ne_dir, device))
+        pos = {f: j for j, f in enumerate(have)}
+        missing = [f for f in want if f not in pos]
         if missing:
             raise KeyError("Norton file of %r lacks harmonics at %s Hz" % (device, missing))
-        NE_device = NE_device[freqs]
-        NE_device = NE_device.apply(lambda col: col.apply(lambda val: complex(val.strip("()"))))
+        sel = np.array([pos[f] for f in want])
+        # SI -> p.u. (HG:298-308); the reference hands out pandas objects labelled by frequency in Hz, and its callers
+        # index them positionally (HG:320, 432) or by that label (HG:322): keep both ways working
         if coupled:
-            I_N = NE_device.loc["I_N_c"] / st.base_current
-            Y_N = NE_device.loc[("Y_N_c", freqs), freqs] / st.base_admittance
+            i_n = pd.DataFrame((Ic[sel] / st.base_current)[None, :], columns=want,
+                               index=pd.Index([0], name="Frequency"))
+            y_n = pd.DataFrame(Ycc[np.ix_(sel, sel)] / st.base_admittance, columns=want,
+                               index=pd.MultiIndex.from_product([["Y_N_c"], want], names=["Parameter", "Frequency"]))
         else:
-            I_N = NE_device.loc["I_N_uc"] / st.base_current
-            Y_N = NE_device.loc["Y_N_uc"] / st.base_admittance
-        NE[device] = [I_N, Y_N]
+            i_n = pd.DataFrame((Iuc[sel] / st.base_current)[None, :], columns=want,
+                               index=pd.Index([0], name="Frequency"))
+            y_n = pd.DataFrame((Yuc[sel] / st.base_admittance)[None, :], columns=want,
+                               index=pd.Index([0], name="Frequency"))
+        NE[device] = [i_n, y_n]
     return NE
 
 

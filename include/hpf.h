@@ -71,7 +71,10 @@ typedef struct hpf_desc {
 /* Per-scenario result record, also the payload of the multi-GPU statistics gather (24 bytes). */
 typedef struct hpf_stat {
     int32_t n_iter;            /* harmonic NR iterations performed                       HG:542 */
-    int32_t flags;             /* bit0 converged (err <= thresh), bit1 hit max_iter, bit2 non-finite mismatch */
+    int32_t flags;             /* bit0 converged (err <= thresh), bit1 hit max_iter, bit2 non-finite mismatch,
+                                  bit3 BLOCK_TREE: a static 4x4 pivot block amplified beyond the limit during the solve,
+                                  bit4 the scenario was repeated with partial pivoting (its result is the repeat's),
+                                  bit5 the pivoted elimination met an exactly zero pivot (hpf_solve returns HPF_E_SINGULAR) */
     double  err;               /* final ||f||_inf                                        HG:389 */
     double  thd_max;           /* max over buses of THD_F                                HG:566-568 */
 } hpf_stat;
@@ -113,8 +116,20 @@ int  hpf_fund_pf(hpf_handle* h, double thresh, int max_iter, int* n_iter, double
 
 /* The NR loop of hpf (HG:530-542) from the current state: initial mismatch, then while err > thresh and
  * n_iter < max_iter: Jacobian -> solve -> update -> mismatch.  Scenarios that satisfy the stop rule freeze.
- * n_iter [S], err [S], err_hist [S][max_iter+1] (initial + one per iteration; unused tail = NaN) may be NULL. */
+ * n_iter [S], err [S], err_hist [S][max_iter+1] (initial + one per iteration; unused tail = NaN) may be NULL.
+ * BLOCK_TREE (static pivot order on the matrix cores): every 4x4 pivot block is watched; a scenario in which one amplifies
+ * rounding errors by more than the limit (option "pivot_growth_limit_log10", default 10), or whose mismatch turns non-finite,
+ * is repeated from the state the call was entered with, with partial pivoting over the whole bus block (flags bit3 / bit4).
+ * Returns HPF_E_SINGULAR (detail = scenario; outputs are still written) if a pivoted elimination met an exactly zero pivot --
+ * DENSE: rocSOLVER info > 0, BLOCK_TREE: the pivoted wave Gauss-Jordan. */
 int  hpf_solve(hpf_handle* h, double thresh, int max_iter, int* n_iter, double* err, double* err_hist);
+
+/* Per-iteration state dump for trajectory diffing against the oracle / the reference (the reference's analogue is the JSON log of
+ * every iterate, hcne_based_on_fuchs.py:186,370-372): while set, hpf_solve writes the voltages after iteration k (k = 0: the
+ * state it was entered with) of every scenario to Vm_traj / Va_traj [S][cap][Hn*n] (caller-owned host arrays, stacked order
+ * q*n + i; frozen scenarios repeat their last state; iterations >= cap are not recorded).  The solve then synchronises with the
+ * host after every iteration.  NULL, NULL, 0 switches it off. */
+int  hpf_set_trace(hpf_handle* h, double* Vm_traj, double* Va_traj, int cap);
 
 /* One unconditional NR iteration (Jacobian -> solve -> update -> mismatch) for all S scenarios, repeated `iters`
  * times, no host synchronisation inside (throughput measurement; update_harmonic_state_vec HG:476-479 +
@@ -139,7 +154,10 @@ int  hpf_debug_stamps(hpf_handle* h, long long* out, int count);
  * a static pivot order (4x4 blocks = two harmonics, lane-parallel cofactor inverse), after contracting pass-through buses and
  * with per-model constant inverses for nonlinear leaf buses; 1 uses wave-level Gauss-Jordan with partial pivoting over the
  * whole block on the uncontracted tree (slower, for networks whose bus blocks are not block-diagonally dominant).  Env
- * HPF_GJ_MODE=0 selects the pivoted variant process-wide (2: the one-wave-per-bus MFMA variant).
+ * HPF_GJ_MODE=0 selects the pivoted variant process-wide.
+ * "pivot_growth_limit_log10" (0..300, default 10): the static-pivot monitor flags a scenario when |a_ij W_ji| of a pivot block
+ * (a lower bound of its condition number) exceeds 10^value; "auto_repivot" (default 1): hpf_solve repeats flagged scenarios
+ * with partial pivoting (0: they are only reported in hpf_stat.flags).
  * "scenario_groups" (1..8, default 3): independent scenario pipelines on separate HIP streams.
  * Environment read by hpf_create (diagnostics, A/B runs): HPF_LAZY=0 builds the elimination tree without lazy leaves (every
  * leaf writes its Schur complement; 1: only leaves directly under their dense parent), HPF_SLEAF=0 sends the nonlinear buses

@@ -1,0 +1,108 @@
+"""The Python face of the drop-in boundary, called the way INTEGRATION.md §1 promises (run with -m gpu):
+reference-style objects in -- the dense `Y_all` DataFrame of HG:139-143,170, the `V` DataFrame of HG:174-184, the Norton dict
+of HG:278-310 -- and the reference's return objects out, against the goldens captured from the unmodified reference
+(`pf` HG:244, `harmonic_mismatch` HG:360, `build_harmonic_jacobian` HG:401), plus the known-answer test of
+`hcne_based_on_fuchs.py` (HF:79-131; the reference's only committed golden, V_log.json iteration 0)."""
+import json
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from conftest import GOLD, INPUTS
+
+pytestmark = pytest.mark.gpu
+CASES = ["net2_H11_c", "net1_H11_uc", "net3_H51_c", "net1_H51_c"]
+
+
+def _hp():
+    import harmonic_power_flow_amd as hp
+    return hp
+
+
+def _setup(hp, name):
+    net_name, hs, cs = name.split("_")
+    st = hp.Settings(H_MAX=int(hs[1:]))
+    buses, lines, m, n, c = hp.init_network(os.path.join(INPUTS, net_name + "_buses.csv"),
+                                            os.path.join(INPUTS, net_name + "_lines.csv"), settings=st)
+    g = np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=True)
+    idx = pd.MultiIndex.from_product([st.HARMONICS, list(range(n))], names=["harmonic", "bus"])
+    Y_all = pd.DataFrame(g["Y_all"], index=idx, columns=[np.arange(n)])          # the reference's object (HG:139-143)
+    return st, buses, g, Y_all, idx, cs == "c"
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_pf_with_reference_style_admittance_frame(name):
+    """pf(Y, buses) (HG:244-275) with the reference's own `Y_all` frame -> (V, err_t, n_iter_f)."""
+    hp = _hp()
+    st, buses, g, Y_all, idx, coupled = _setup(hp, name)
+    V, err_t, n_iter_f = hp.pf(Y_all, buses, settings=st, verbose=False)
+    assert n_iter_f == int(g["n_iter_f"])
+    assert list(V.columns) == ["V_m", "V_a"] and V.index.equals(idx)
+    np.testing.assert_allclose(V.to_numpy(), g["V_pf"], rtol=0, atol=1e-13)
+    assert sorted(err_t) == list(range(n_iter_f))
+    np.testing.assert_allclose([err_t[i] for i in range(n_iter_f)], g["err_f"], rtol=1e-6, atol=1e-15)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_harmonic_mismatch_with_reference_style_objects(name):
+    """harmonic_mismatch(V, Y, buses, NE) (HG:360-390) -> (f, err_h): the reference's f0 at the pf seed, and the err_h of every
+    iterate of the reference's trajectory."""
+    hp = _hp()
+    st, buses, g, Y_all, idx, coupled = _setup(hp, name)
+    NE = hp.import_Norton_Equivalents(buses, coupled, st, INPUTS)
+    traj = g["V_traj"]
+    V0 = pd.DataFrame(traj[0], index=idx, columns=["V_m", "V_a"])
+    f, err_h = hp.harmonic_mismatch(V0, Y_all, buses, NE, settings=st)
+    fs = max(1.0, np.abs(g["f0"]).max())
+    assert f.shape == g["f0"].shape
+    assert np.abs(f - g["f0"]).max() <= 1e-12 * fs
+    assert abs(err_h - g["err_hist"][0]) <= 1e-12 * fs
+    for it in (1, len(traj) - 1):
+        Vi = pd.DataFrame(traj[it], index=idx, columns=["V_m", "V_a"])
+        _, e = hp.harmonic_mismatch(Vi, Y_all, buses, NE, settings=st)
+        assert abs(e - g["err_hist"][it]) <= 1e-9 * max(g["err_hist"][it], 1e-3)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_build_harmonic_jacobian_with_reference_style_objects(name):
+    """build_harmonic_jacobian(V, Y, NE, coupled) (HG:401-473) -> scipy CSR in the reference's row / column order = J0."""
+    import scipy.sparse as sp
+    hp = _hp()
+    st, buses, g, Y_all, idx, coupled = _setup(hp, name)
+    NE = hp.import_Norton_Equivalents(buses, coupled, st, INPUTS)
+    V0 = pd.DataFrame(g["V_traj"][0], index=idx, columns=["V_m", "V_a"])
+    J = hp.build_harmonic_jacobian(V0, Y_all, NE, coupled, buses=buses)
+    assert sp.issparse(J) and J.format == "csr" and J.shape == tuple(g["J0_shape"])
+    Jg = sp.csr_matrix((g["J0_data"], (g["J0_row"], g["J0_col"])), shape=tuple(g["J0_shape"]))
+    assert abs(J - Jg).max() <= 1e-12 * abs(Jg).max()
+    # one reference-style Newton step from these pieces (HG:537-539): x - J^-1 f lands on the reference's next iterate
+    f, _ = hp.harmonic_mismatch(V0, Y_all, buses, NE, settings=st)
+    c = int(g["c"])
+    x0 = hp.harmonic_state_vector(V0, c=c)
+    x1 = hp.update_harmonic_state_vec(J, x0, f)
+    V1 = g["V_traj"][1]
+    ref = np.append(V1[1:, 1], V1[c:, 0])
+    assert np.abs(x1 - ref).max() < 1e-9 * max(1.0, np.abs(ref).max())
+
+
+def test_fuchs_4bus_known_answer():
+    """hcne_based_on_fuchs.py:36-131 = example_hpf_fuchs.py:77-130: the 4-bus ring (p.u. data of HF:44-54 written as SI values
+    in the reference's CSV dialect: tests/golden/inputs/fuchs4_*.csv), fundamental Newton-Raphson.  The product's `pf` must land
+    on the reference's committed golden, V_log.json iteration 0 (10 decimals), and on the captured HF run."""
+    hp = _hp()
+    st = hp.Settings(H_MAX=5)
+    buses, lines, m, n, c = hp.init_network(os.path.join(INPUTS, "fuchs4_buses.csv"), os.path.join(INPUTS, "fuchs4_lines.csv"),
+                                            settings=st)
+    assert (m, n, c) == (3, 4, 1)
+    Y = hp.build_admittance_matrices(buses, lines, st.HARMONICS)
+    V, err_t, n_iter_f = hp.pf(Y, buses, settings=st, verbose=False)
+    with open(os.path.join(GOLD, "v_log_iter0.json")) as fh:
+        rows = [r for r in json.load(fh)["rows"] if r["harmonic"] == 1]
+    Vf = V.loc[1].to_numpy()
+    for k, r in enumerate(rows):
+        assert abs(Vf[k, 0] - r["V_m"]) < 1e-9 and abs(Vf[k, 1] - r["V_a"]) < 1e-9, (k, Vf[k], r)
+    with open(os.path.join(GOLD, "hf_fuchs.json")) as fh:
+        hf = np.array(json.load(fh)["V_final"])
+    np.testing.assert_allclose(Vf, hf[:4], rtol=0, atol=1e-9)

@@ -1,0 +1,193 @@
+"""Robustness of the block-tree path (run with -m gpu): the static-pivot monitor and the automatic repeat with partial
+pivoting, the per-iteration state dump, the tree-build variants behind the diagnostic environment switches, and a randomised
+feeder sweep with the north-star criterion (converged voltages within 1e-8 p.u. of the dense rocSOLVER path / the oracle)."""
+import os
+
+import numpy as np
+import pytest
+
+import hpf_oracle as o
+from conftest import GOLD, INPUTS
+
+pytestmark = pytest.mark.gpu
+TOL_V = 1e-8
+
+
+def _hp():
+    import harmonic_power_flow_amd as hp
+    return hp
+
+
+def _feeder(hp, n, hmax, tmp_path, seed=0, frac_nl=0.35, n_pv=0):
+    from harmonic_power_flow_amd import synth
+    fb, fl = synth.gen(n, seed=seed, frac_nl=frac_nl, outdir=str(tmp_path))
+    if n_pv:
+        rows = open(fb).read().splitlines()
+        for bid in range(2, 2 + n_pv):
+            cols = rows[bid].split(";")
+            cols[1], cols[2], cols[4], cols[5] = "PV", "gen_%d" % bid, "-120", "0"
+            rows[bid] = ";".join(cols)
+        open(fb, "w").write("\n".join(rows) + "\n")
+    st = hp.Settings(H_MAX=hmax)
+    buses, lines, m, nn, c = hp.init_network(fb, fl, settings=st)
+    Y = hp.build_admittance_matrices(buses, lines, st.HARMONICS)
+    NE = hp.import_Norton_Equivalents(buses, True, st, INPUTS)
+    return st, buses, Y, NE, (fb, fl)
+
+
+def _solve(hp, st, buses, Y, NE, solver="block_tree", S=1, options=(), seed_state=None, polish=0, thresh=1e-4):
+    from harmonic_power_flow_amd import api, synth
+    n = len(buses)
+    dm = api._device_model(buses, Y, NE, True, st.HARMONICS, solver=solver, max_scenarios=S)
+    try:
+        for k, v in options:
+            dm.set_option(k, v)
+        P0, Q0 = buses["P"].to_numpy(float), buses["Q"].to_numpy(float)
+        scale = np.stack([np.ones(n)] + [synth.scenario_scale(n, s) for s in range(1, S)])
+        dm.set_loads(P0 * scale, Q0 * scale)
+        dm.set_state(None, None, n_scen=S)
+        dm.fund_pf(1e-6, 30)
+        if seed_state is not None:
+            dm.set_state(*seed_state)
+        seed = dm.get_state()
+        it, err, hist = dm.solve(thresh, 50)
+        st_ = dm.stats()
+        if polish:
+            dm.mismatch(want_f=False)
+            dm.iterate(polish)
+            dm.sync()
+        Vm, Va = dm.get_state()
+    finally:
+        dm.close()
+    return dict(it=it, err=err, Vm=Vm, Va=Va, seed=seed, stats=st_, hist=hist)
+
+
+def test_static_pivot_monitor_and_repeat_with_partial_pivoting(tmp_path):
+    """With the growth limit at 10^0 every pivot block counts as weak: every scenario is flagged (flags bit 3) and repeated with
+    partial pivoting (bit 4) inside hpf_solve; the result must be bit-identical to an explicit block_pivoting = 1 solve.  With
+    auto_repivot = 0 the flag is only reported.  At the default limit (10^10) nothing is flagged on this feeder."""
+    hp = _hp()
+    st, buses, Y, NE, _ = _feeder(hp, 100, 27, tmp_path)                      # b = 28 blocks
+    S = 3
+    ref = _solve(hp, st, buses, Y, NE, S=S, options=[("block_pivoting", 1)])
+    dflt = _solve(hp, st, buses, Y, NE, S=S)
+    forced = _solve(hp, st, buses, Y, NE, S=S, options=[("pivot_growth_limit_log10", 0)])
+    only_flag = _solve(hp, st, buses, Y, NE, S=S, options=[("pivot_growth_limit_log10", 0), ("auto_repivot", 0)])
+    assert ((dflt["stats"]["flags"] & (8 | 16)) == 0).all() and ((dflt["stats"]["flags"] & 1) == 1).all()
+    assert ((forced["stats"]["flags"] & (8 | 16)) == (8 | 16)).all()
+    assert ((forced["stats"]["flags"] & 1) == 1).all()
+    assert np.array_equal(forced["it"], ref["it"])
+    assert np.array_equal(forced["Vm"], ref["Vm"]) and np.array_equal(forced["Va"], ref["Va"])
+    np.testing.assert_array_equal(forced["hist"], ref["hist"])                # NaN tail included
+    assert ((only_flag["stats"]["flags"] & 8) == 8).all() and ((only_flag["stats"]["flags"] & 16) == 0).all()
+    assert np.array_equal(only_flag["Vm"], dflt["Vm"])                        # reported, not repeated: the static result
+    # both pivot orders end at the same voltages
+    U0 = dflt["Vm"] * np.exp(1j * dflt["Va"])
+    U1 = ref["Vm"] * np.exp(1j * ref["Va"])
+    assert np.array_equal(dflt["it"], ref["it"]) and np.abs(U0 - U1).max() < 1e-9
+
+
+def test_converged_flag_and_api_details(tmp_path):
+    """solve()['converged'] follows the stop rule (flags bit 0), not 'the loop ended'."""
+    hp = _hp()
+    from harmonic_power_flow_amd import synth
+    fb, fl = synth.gen(50, seed=0, outdir=str(tmp_path))
+    st = hp.Settings(H_MAX=11)
+    res = hp.solve(fb, fl, coupled=True, settings=st, ne_dir=INPUTS)
+    assert res["converged"] and res["details"]["stats"]["flags"][0] & 1 and not res["details"]["repeated_with_pivoting"]
+    assert res["details"]["stats"]["n_iter"][0] == res["n_iter_h"]            # the record of THIS solve (not of a replay)
+    assert res["details"]["stats"]["err"][0] == res["err_h"]
+    st2 = hp.Settings(H_MAX=11, max_iter_h=3)
+    res2 = hp.solve(fb, fl, coupled=True, settings=st2, ne_dir=INPUTS)
+    assert not res2["converged"] and res2["n_iter_h"] == 3 and (res2["details"]["stats"]["flags"][0] & 2)
+
+
+@pytest.mark.parametrize("name,solver", [("net2_H11_c", "dense"), ("net1_H11_c", "dense"), ("syn100_H11_c", "block_tree")])
+def test_per_iteration_state_dump_follows_the_reference_trajectory(name, solver, tmp_path):
+    """hpf_set_trace: the voltages after every Newton iteration, against the reference's own iterates (golden V_traj) on the
+    robust K = 5 cases -- every iterate, not only the last."""
+    hp = _hp()
+    from harmonic_power_flow_amd import api, synth
+    g = np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=True)
+    st = hp.Settings(H_MAX=11)
+    if name.startswith("syn"):
+        fb, fl = synth.gen(100, seed=0, outdir=str(tmp_path))
+    else:
+        fb, fl = (os.path.join(INPUTS, name.split("_")[0] + s) for s in ("_buses.csv", "_lines.csv"))
+    buses, lines, m, n, c = hp.init_network(fb, fl, settings=st)
+    Y = hp.build_admittance_matrices(buses, lines, st.HARMONICS)
+    NE = hp.import_Norton_Equivalents(buses, True, st, INPUTS)
+    dm = api._device_model(buses, Y, NE, True, st.HARMONICS, solver=solver)
+    try:
+        dm.set_loads(buses["P"].to_numpy(float), buses["Q"].to_numpy(float))
+        dm.set_state(None, None, n_scen=1)
+        dm.fund_pf(1e-6, 30)
+        it, err, hist, Vt, At = dm.solve(1e-4, 50, trace=True)
+        Vm, Va = dm.get_state()
+    finally:
+        dm.close()
+    n_it = int(it[0])
+    assert n_it == int(g["n_iter_h"])
+    if "V_traj" in g.files:
+        traj = g["V_traj"]
+        assert len(traj) == n_it + 1
+        worst = 0.0
+        for k in range(n_it + 1):
+            Ud = Vt[0, k] * np.exp(1j * At[0, k])
+            Ug = traj[k][:, 0] * np.exp(1j * traj[k][:, 1])
+            scale = max(1.0, np.abs(Ug).max())
+            worst = max(worst, np.abs(Ud - Ug).max() / scale)
+        print("\n%s: %d iterates, worst relative deviation from the reference's trajectory %.2e" % (name, n_it + 1, worst))
+        assert worst < 1e-7
+    assert np.array_equal(Vt[0, n_it], Vm[0]) and np.array_equal(At[0, n_it], Va[0])      # last recorded iterate = final state
+    assert np.isnan(Vt[0, n_it + 1:]).all()
+
+
+@pytest.mark.parametrize("env", [{"HPF_LAZY": "0"}, {"HPF_LAZY": "1"}, {"HPF_SLEAF": "0"}, {"HPF_SLEAF": "1"},
+                                 {"HPF_SLLAZY": "0"}, {"HPF_SLBACK": "0"}, {"HPF_LEAFBATCH": "0"}, {"HPF_GROUPS": "2"}])
+def test_tree_build_variants_take_the_same_newton_steps(env, tmp_path, monkeypatch):
+    """Every diagnostic switch of hpf_create (hpf.h) selects a more general path for some class of buses (no lazy leaves, no
+    super-leaves, super-leaves that push their Schur complement / store their inverse, leaves one workgroup per scenario): the
+    first Newton steps and the converged voltages must agree with the default build at rounding level."""
+    hp = _hp()
+    st, buses, Y, NE, _ = _feeder(hp, 300, 51, tmp_path, seed=2)
+    S = 17
+    base = _solve(hp, st, buses, Y, NE, S=S, polish=1)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    var = _solve(hp, st, buses, Y, NE, S=S, polish=1)
+    if "HPF_GROUPS" in env:
+        assert np.array_equal(var["Vm"], base["Vm"]) and np.array_equal(var["Va"], base["Va"])
+    Ub, Uv = base["Vm"] * np.exp(1j * base["Va"]), var["Vm"] * np.exp(1j * var["Va"])
+    print("\n%s: iterations %s vs %s, max|dU| after one more iteration %.2e" % (env, var["it"][:4], base["it"][:4], np.abs(Ub - Uv).max()))
+    assert (var["err"] <= 1e-4).all()
+    assert np.abs(Ub - Uv).max() < TOL_V
+
+
+FUZZ = [(347, 35, 0.85, 0, 880227), (377, 51, 0.60, 2, 318146), (118, 27, 0.85, 2, 867892), (384, 59, 0.15, 0, 569402),
+        (200, 35, 0.60, 2, 422784), (262, 25, 0.85, 0, 438186), (54, 27, 0.15, 0, 657433), (403, 11, 0.35, 2, 522250),
+        (296, 25, 0.85, 1, 644436), (161, 19, 0.35, 1, 692459)]
+
+
+@pytest.mark.parametrize("n,hmax,frac,n_pv,seed", FUZZ)
+def test_fuzz_feeders_converged_voltages_block_tree_vs_dense(n, hmax, frac, n_pv, seed, tmp_path):
+    """The cases of the round-1 fuzz sweep (tools/fuzz_parity.py; seed 880227 was its worst first-step deviation, 5e-8 rad on a
+    step of tens of radians) with the north-star criterion: the CONVERGED voltages (fixed point: two Newton iterations past the
+    stop rule on both sides) of the block-tree path and of the dense rocSOLVER path agree within 1e-8 p.u.; no scenario is
+    flagged by the pivot monitor."""
+    hp = _hp()
+    st, buses, Y, NE, _ = _feeder(hp, n, hmax, tmp_path, seed=seed, frac_nl=frac, n_pv=n_pv)
+    Hn = len(st.HARMONICS)
+    dense_ok = (2 * n * Hn) ** 2 < 2 ** 31
+    bt = _solve(hp, st, buses, Y, NE, S=1, polish=2)
+    assert (bt["err"] <= 1e-4).all() and ((bt["stats"]["flags"] & 1) == 1).all()
+    assert ((bt["stats"]["flags"] & (8 | 16 | 32)) == 0).all()
+    if not dense_ok:
+        pytest.skip("dense comparator exceeds rocSOLVER's 32-bit addressing")
+    de = _solve(hp, st, buses, Y, NE, solver="dense", S=1, seed_state=bt["seed"], polish=2)
+    Ub, Ud = bt["Vm"] * np.exp(1j * bt["Va"]), de["Vm"] * np.exp(1j * de["Va"])
+    step = max(np.abs(bt["seed"][0] - bt["Vm"]).max(), 1.0)
+    print("\nn=%d Hn=%d nl=%.2f pv=%d seed=%d: block-tree %s it, dense %s it, fixed points differ by %.2e"
+          % (n, Hn, frac, n_pv, seed, bt["it"], de["it"], np.abs(Ub - Ud).max()))
+    assert (de["err"] <= 1e-4).all()
+    assert np.abs(Ub - Ud).max() < TOL_V

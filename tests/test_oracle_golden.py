@@ -116,6 +116,24 @@ def test_reference_committed_golden_fundamental_4bus():
         assert abs(V[k, 0] - r["V_m"]) < 1e-9 and abs(V[k, 1] - r["V_a"]) < 1e-9
 
 
+def test_oracle_pf_lands_on_the_reference_committed_fuchs_golden():
+    """Known-answer test on the reference's ONLY committed numeric golden: the 4-bus ring of hcne_based_on_fuchs.py:36-54 (written
+    as SI values in the reference's CSV dialect, tests/golden/inputs/fuchs4_*.csv) through the oracle's ingest, admittance build
+    and fundamental NR (HG:244-275 = HF:79-131 in the PyPSA formulation) must give V_log.json iteration 0 (10 decimals)."""
+    net = o.init_network(os.path.join(INPUTS, "fuchs4_buses.csv"), os.path.join(INPUTS, "fuchs4_lines.csv"))
+    assert (net.m, net.n, net.c) == (3, 4, 1)
+    H = o.harmonics_upto(5)
+    rowptr, col, Yval = o.build_admittance_matrices(net, H)
+    # the admittances are the p.u. values of HF:44-54
+    Y1 = o.y_csr(rowptr, col, Yval[0], 4).toarray()
+    assert Y1[0, 1] == -1 / (0.01 + 0.01j) and Y1[1, 2] == -1 / (0.02 + 0.08j) and Y1[3, 0] == -1 / (0.01 + 0.02j)
+    Vm, Va, err_t, n_iter_f = o.pf(net, rowptr, col, Yval)
+    with open(os.path.join(GOLD, "v_log_iter0.json")) as f:
+        rows = [r for r in json.load(f)["rows"] if r["harmonic"] == 1]
+    for k, r in enumerate(rows):
+        assert abs(Vm[k] - r["V_m"]) < 1e-9 and abs(Va[k] - r["V_a"]) < 1e-9
+
+
 def test_oracle_syn1000_headline_shape(tmp_path):
     """The north-star shape (1 000 buses x 25 harmonics, coupled): 27 iterations, err 7.047e-10."""
     import importlib.util

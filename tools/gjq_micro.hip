@@ -29,6 +29,7 @@ __global__ __launch_bounds__(256, 4) void k_gj(long long* out, double* sink) {
     if (tid < 32) { wl[tid >> 4][tid & 15] = ((tid & 15) % 5 == 0) ? 1.0 : 0.0; }
     __syncthreads();
     const long long t0 = __builtin_amdgcn_s_memtime();
+    bool weak_ = false;
 #pragma unroll
     for (int st = 0; st < B / 4; ++st) {
         const int tP = st >> 2, rg = st & 3, j0 = 4 * (st & 3), buf = st & 1;
@@ -42,11 +43,11 @@ __global__ __launch_bounds__(256, 4) void k_gj(long long* out, double* sink) {
 #pragma unroll
                         for (int reg = 0; reg < 4; ++reg) panel[buf][(16 * tr + lg + 4 * reg) * 4 + (jj - j0)] = ct[tr][reg];
                 }
-                const double wji = inv4_cofactor_lane(pv[buf], lane);
+                const double wji = inv4_cofactor_lane(pv[buf], lane, 1e10, weak_);
                 if (lane < 16) wl[buf][(lane & 3) * 4 + (lane >> 2)] = wji;
             } else if (!(ABL & 1)) {
                 if (incol) pv[buf][lg * 4 + (jj - j0)] = ct[tP][rg];
-                const double wji = inv4_cofactor_lane(pv[buf], lane);
+                const double wji = inv4_cofactor_lane(pv[buf], lane, 1e10, weak_);
                 if (lane < 16) wl[buf][(lane & 3) * 4 + (lane >> 2)] = wji;
             }
             if (!(ABL & 16) && !(ABL & 32) && incol) {
@@ -171,13 +172,14 @@ __global__ __launch_bounds__(256, 4) void k_gj_ref(double* sink) {    // referen
             ct[tr][reg] = (row == col) ? 40.0 + 0.01 * hsh : 0.001 * hsh - 0.5;
         }
     __syncthreads();
+    bool weak_ = false;
 #pragma unroll
     for (int st = 0; st < B / 4; ++st) {
         const int tP = st >> 2, rg = st & 3, j0 = 4 * (st & 3), buf = st & 1;
         const bool incol = jj >= j0 && jj < j0 + 4;
         if (wv == tP) {
             if (incol) pv[buf][lg * 4 + (jj - j0)] = ct[tP][rg];
-            const double wji = inv4_cofactor_lane(pv[buf], lane);
+            const double wji = inv4_cofactor_lane(pv[buf], lane, 1e10, weak_);
             if (lane < 16) wl[buf][(lane & 3) * 4 + (lane >> 2)] = wji;
             if (incol) {
 #pragma unroll
