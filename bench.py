@@ -15,12 +15,20 @@ back-substitution, state update, mismatch + inf-norm (HG:537-540).  The W+K time
 of the real solves from the reference's start point (no scenario has converged yet: the reference needs 27), run
 with `hpf_iterate`, i.e. without host synchronisation.  value = scenarios_total * K / t  [NR iterations / s].
 
-After the timed region every rank finishes its solves with the reference's stop rule (`hpf_solve`), the per-scenario
-records (n_iter, flags, err, thd_max; 24 B) are all-gathered with RCCL and rank 0 prints ONE JSON line.
+Untimed legs after the timed region (rank 0 prints ONE JSON line with all of them):
+  roofline        the dominant kernel k_factor_q<52,false> ALONE: HIP-event span of every one of its launches over K more steps
+                  against its own algorithmic bytes (hpf_kernel_model) — compare profiles/*kernel_stats.csv of the same command;
+  sweep           every rank finishes its solves with the reference's stop rule (`hpf_solve`: per-scenario freeze, compaction
+                  of the running scenarios, pipelined polling); per-scenario records (24 B) all-gathered with RCCL;
+  sweep_1gpu      (N = 1 only) the whole 1 024-scenario sweep of BASELINE config 4 on ONE GPU, all scenarios live (74 GB of
+                  the 288 GB): lock-step rate and solve-to-convergence rate;
+  single_scenario BASELINE config 3 latency;
+  cpu_baseline    the oracle (CPU restatement of the reference) on one core and on all host cores (one scenario per core).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import tempfile
 import time
@@ -45,7 +53,9 @@ def parse():
     ap.add_argument("--hmax", type=int, default=51)
     ap.add_argument("--solver", default="block_tree", choices=["block_tree", "dense"])
     ap.add_argument("--cpu-iters", type=int, default=12, help="NR iterations of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-workers", type=int, default=0, help="worker processes of the all-cores CPU leg (0 = host cores, at most 16)")
     ap.add_argument("--no-finish", action="store_true", help="skip the untimed solve-to-convergence + stats gather")
+    ap.add_argument("--sweep-1gpu", type=int, default=1024, help="(N = 1) scenarios of the single-GPU sweep leg (0 = skip)")
     ap.add_argument("--single", action="store_true", help="(default on rank 0 at N=1) also time a single-scenario solve: BASELINE config 3")
     ap.add_argument("--no-single", action="store_true", help="skip the single-scenario latency leg")
     return ap.parse_args()
@@ -63,25 +73,51 @@ def build_inputs(args, hp):
     return dict(st=st, buses=buses, n=n, m=m, c=c, Y=Y, dev=dev, Y_N=Y_N, I_N=I_N, n_dev=n_dev, files=(fb, fl))
 
 
-def cpu_baseline(inp, iters):
-    """The oracle (CPU restatement, bit-identical to the reference on the golden cases) on the same feeder, ONE scenario,
-    `iters` NR iterations from the same start; timer placed like the reference's (HG:535,543)."""
-    sys.path.insert(0, os.path.join(REPO, "oracle"))
-    import hpf_oracle as o
-    fb, fl = inp["files"]
-    net = o.init_network(fb, fl)
-    H = inp["st"].HARMONICS
-    rowptr, col, Yval = o.build_admittance_matrices(net, H)
-    Vm, Va, _, _ = o.pf(net, rowptr, col, Yval)
-    NE = o.import_Norton_Equivalents(net, H, True, INPUTS)
-    mdl = o.Model(net, H, rowptr, col, Yval, NE, True)
-    r = o.hpf_from_model(mdl, Vm, Va, thresh_h=0.0, max_iter_h=iters)
-    return {"value": r["n_iter_h"] / r["loop_s"], "unit": "NR iterations/s", "cores": 1, "kind": "port",
-            "sample": "%d NR iterations of one scenario of the same %d-bus x %d-harmonic feeder (oracle: NumPy/SciPy "
-                      "SuperLU restatement, bit-identical to the reference on its golden cases); the reference itself "
-                      "measured 0.0257 it/s (38.9 s/it) on this feeder in the build container"
-                      % (r["n_iter_h"], inp["n"], len(H) - 1),
-            "ms_per_iter": 1e3 * r["loop_s"] / max(r["n_iter_h"], 1)}
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline_start(args):
+    """Start the CPU legs as child processes BEFORE this process touches the GPU (oracle/cpu_worker.py: the oracle on the same
+    feeder, `cpu-iters` NR iterations per scenario from the reference's start, timer placed like the reference's HG:535,543):
+    first one worker alone (1 core), then one worker per host core at once (the natural CPU parallelisation of the scenario
+    sweep: one scenario per core)."""
+    if args.cpu_iters <= 0:
+        return None
+    worker = os.path.join(REPO, "oracle", "cpu_worker.py")
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    nw = args.cpu_workers or min(cores, 16)
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+
+    def run(ids):
+        t0 = time.perf_counter()
+        ps = [subprocess.Popen([sys.executable, worker, str(args.buses), str(args.hmax), str(s), str(args.cpu_iters)],
+                               stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True) for s in ids]
+        outs = [json.loads(p.communicate()[0].strip().splitlines()[-1]) for p in ps]
+        return outs, time.perf_counter() - t0
+    one, _ = run([0])
+    many, wall = run(list(range(nw)))
+    it1 = one[0]["n_iter"] / one[0]["loop_s"]
+    loop_max = max(o["loop_s"] for o in many)
+    itn = sum(o["n_iter"] for o in many) / loop_max
+    return {"value": itn, "unit": "NR iterations/s", "cores": nw, "kind": "port",
+            "sample": "%d NR iterations of each of %d Monte-Carlo scenarios of the same %d-bus x %d-harmonic feeder, one oracle process "
+                      "per core (NumPy/SciPy SuperLU restatement, bit-identical to the reference on its golden cases; BLAS pinned to 1 "
+                      "thread per process); the reference itself measured 0.0257 it/s (38.9 s/it) on this feeder in the build container"
+                      % (args.cpu_iters, nw, args.buses, (args.hmax + 1) // 2 - 1),
+            "ms_per_iter_per_core": 1e3 * loop_max / max(many[0]["n_iter"], 1),
+            "single_core": {"value": it1, "cores": 1, "ms_per_iter": 1e3 / it1},
+            "host_cores": cores, "cpu_model": cpu_model()}
 
 
 def main():
@@ -89,6 +125,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    cpu = cpu_baseline_start(args) if (rank == 0 and world == 1) else None      # child processes: before any GPU initialisation
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -139,8 +176,8 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    # per-phase HIP-event timing (on the streams the kernels run on) over the same K steps, continued from the state the
-    # timed region left; kept out of the headline region because every span costs two event records on the host
+    # per-kernel HIP-event timing (on the streams the kernels run on) over K more steps of the same configuration, continued
+    # from the state the timed region left; kept out of the headline region because every span costs two event records
     dm.timing(True)
     dm.timing_reset()
     dm.iterate(args.steps)
@@ -151,6 +188,8 @@ def main():
     # ---- untimed: finish the solves with the reference's stop rule, gather convergence statistics (RCCL) ----------
     sweep = None
     if not args.no_finish:
+        dm.set_state(seed[0], seed[1])
+        dm.solve(inp["st"].thresh_h, inp["st"].max_iter_h)                   # warm (pinned buffers, repeat-pass state)
         dm.set_state(seed[0], seed[1])
         torch.cuda.synchronize()
         t_sw = time.perf_counter()
@@ -173,23 +212,21 @@ def main():
     total_scen = S * world
     value = total_scen * K / elapsed
     ms_step = 1e3 * elapsed / K
-    solve_ms, solve_n = tim["solve"]
-    # One HIP-event span per k_factor_w launch (tree level x scenario group), on the stream it runs on.  Scenario groups are
-    # independent pipelines on separate streams, so launches of different groups overlap; like rocprofv3 --stats, `avg_ms`
-    # averages the launch durations as if they were alone.  achieved = algorithmic flops of all launches / sum of their
-    # durations = (flops per launch) / (average launch duration).
-    flops_step = dm.solve_flops() * S                  # all factor launches of one NR step on this GPU
-    bytes_sweep = dm.solve_bytes() * S                 # algorithmic HBM bytes of the same launches (hpf_solve_bytes)
-    launches_per_step = solve_n / max(K, 1)
-    achieved_tf = flops_step * K / (solve_ms * 1e-3) / 1e12 if solve_ms > 0 else None
-    achieved_gbs = bytes_sweep * K / (solve_ms * 1e-3) / 1e9 if solve_ms > 0 else None
-    G = max(1, round(launches_per_step / max(dm.n_levels, 1)))
     b = 2 * Hn
+    bt = args.solver == "block_tree"
+    G = 3 if S >= 24 else (2 if S >= 16 else 1)
+    # ---- roofline of the dominant kernel, alone: k_factor_q<B,false> (block_tree) / the rocSOLVER LU (dense) ----------------------
+    gj_ms, gj_n = tim["gj"] if bt else tim["solve"]
+    by_gj, fl_gj, ln_gj = dm.kernel_model("gj") if bt else dm.kernel_model("solve")
+    launches_per_step = gj_n / max(K, 1)                                     # all scenario groups
+    bytes_per_launch = by_gj * S / max(launches_per_step, 1)                 # average over its launches (tree levels x groups)
+    flops_per_launch = fl_gj * S / max(launches_per_step, 1)
+    avg_ms = gj_ms / max(gj_n, 1)
+    achieved_gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else None
+    achieved_tf = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else None
+    # the whole factor sweep (all factor kernels) and the whole step, algorithmic bytes over wall time
+    sweep_bytes = dm.solve_bytes() * S
     nnz = len(inp["Y"].col)
-    # algorithmic HBM bytes of the other kernels of a step, one scenario (per-scenario arrays only; Y, Y_N, the tree records and
-    # the leaf images are shared by all scenarios and served by L2 / Infinity Cache):
-    #   mismatch: U in, f out;  back sweep: the inverses of the Gauss-Jordan buses in, w and A(k,parent) in, x out;
-    #   2x2 kernels: per bus and harmonic 2x2 inverse + w out and in, voltages in;  update: x, Vm, Va in, Vm, Va, U, E out
     bytes_mismatch = 16 * Hn * n + 8 * dm.N
     bytes_back = dm.back_bytes()
     bytes_2x2 = (32 + 16) * 2 * Hn * n + 2 * 16 * Hn * n
@@ -197,6 +234,7 @@ def main():
     step_bytes = S * (dm.solve_bytes() + bytes_mismatch + bytes_back + bytes_2x2 + bytes_update)
     traffic, traffic_note = pmc_traffic(args, S)
     step_traffic = pmc_step_traffic(args, S)
+    kname = "k_factor_q<%d,false>" % (52 if b > 28 else (28 if b > 12 else 12)) if bt and b <= 52 else ("k_tree_factor (generic)" if bt else "rocsolver_dgetrf/dgetrs")
     out = {
         "metric": "NR iterations/sec + ms/iter, 1 000-bus x 25-harmonic feeder; |dV| vs reference",
         "value": value, "unit": "NR iterations/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
@@ -204,31 +242,33 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "syn%d radial feeder (gen seed 0), harmonics 1..%d odd (K=%d), coupled Norton (smps), "
                                "%d Monte-Carlo load scenarios per GPU (%d total), block-tree Newton step"
-                               % (n, args.hmax, Hn - 1, S, total_scen) if args.solver == "block_tree" else
+                               % (n, args.hmax, Hn - 1, S, total_scen) if bt else
                                "syn%d, K=%d, coupled, %d scenarios per GPU, dense rocSOLVER" % (n, Hn - 1, S),
                    "buses": n, "harmonics": Hn - 1, "unknowns_per_scenario": dm.N, "scenarios_per_gpu": S,
                    "solver": dm.solver, "step": "one NR iteration of every scenario (HG:537-540)",
                    "pf_iterations": int(nf.max())},
         "ms_per_iter_per_scenario": ms_step / S,
         "roofline": {"bound": "hbm",
-                     "kernel": "k_factor_q<%d> (multi-wave block-tree factor kernel; one sweep = %d launches per scenario "
-                               "group, one per tree level; levels 0 / 1 are mostly k_leaf_batch / k_sleaf_batch: lazy leaves and super-leaves, 16 scenarios per workgroup)" % (52 if b > 28 else (28 if b > 12 else 12), dm.n_levels),
+                     "kernel": kname + " alone (general multi-wave block-tree factor kernel: Gauss-Jordan buses and non-batched "
+                               "super-leaves; %d launches per Newton step and scenario group, one per tree level)" % ln_gj,
                      "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS if achieved_gbs else None,
-                     "traffic": traffic / max(launches_per_step, 1) if traffic else None, "traffic_note": traffic_note,
-                     "bytes_per_launch": bytes_sweep / max(launches_per_step, 1),
-                     "avg_ms": solve_ms / max(solve_n, 1), "launches_per_step": launches_per_step,
+                     "traffic": traffic, "traffic_note": traffic_note,
+                     "bytes_per_launch": bytes_per_launch, "flop_per_launch": flops_per_launch,
+                     "avg_ms": avg_ms, "launches_timed": gj_n, "launches_per_step": launches_per_step,
                      "concurrent_groups": G,
-                     "aggregate_over_step_wall": bytes_sweep / (ms_step * 1e-3) / 1e9,
-                     "note": "launches of the %d scenario groups overlap on separate streams, so a launch's duration includes the "
-                             "share of the GPU the other groups take; aggregate_over_step_wall = algorithmic bytes of all factor "
-                             "launches of a step / step wall time (GB/s). " % G +
-                             "arithmetic intensity of the sweep %.2f flop/B < ridge %.1f: HBM-bound by the roofline; achieved = "
-                             "algorithmic bytes per launch / average launch duration (HIP events on the launch streams)"
-                             % (flops_step / bytes_sweep, FP64_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS)},
-        "roofline_mfma": {"bound": "mfma", "kernel": "same launches", "achieved": achieved_tf, "peak": FP64_PEAK_TFLOPS,
-                          "unit": "TFLOP/s", "frac": achieved_tf / FP64_PEAK_TFLOPS if achieved_tf else None,
-                          "flop_per_launch": flops_step / max(launches_per_step, 1)},
+                     "mfma": {"achieved": achieved_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": achieved_tf / FP64_PEAK_TFLOPS if achieved_tf else None},
+                     "note": "achieved = algorithmic bytes of this kernel's buses (hpf_kernel_model: Schur complements in and out, "
+                             "inverses out, per-scenario bus operands) per launch / average launch duration (one HIP-event span per "
+                             "launch on the stream it runs on, %d spans); the launches of the %d scenario groups overlap on separate "
+                             "streams, so a launch shares the chip with the other groups' kernels.  arithmetic intensity %.2f flop/B "
+                             "< ridge %.1f: HBM-bound by the roofline, in practice bound by workgroup latency (DESIGN.md §5)"
+                             % (gj_n, G, fl_gj / max(by_gj, 1.0), FP64_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS)},
+        "roofline_factor_sweep": {"bound": "hbm", "kernels": "all factor kernels of a step (k_leaf_batch, k_sleaf_batch, k_factor_q)",
+                                  "achieved": sweep_bytes / (ms_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": sweep_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_step": sweep_bytes,
+                                  "note": "algorithmic bytes of the factor sweep of all scenarios / step wall time"},
         "roofline_hbm_step": {"bound": "hbm", "achieved": step_bytes / (ms_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                               "unit": "GB/s", "frac": step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                               "bytes_per_step": step_bytes,
@@ -236,60 +276,101 @@ def main():
                               "traffic_gbs_over_step_wall": step_traffic / (ms_step * 1e-3) / 1e9 if step_traffic else None,
                               "note": "algorithmic bytes of a whole NR step (factor sweep + back sweep + 2x2 kernels + mismatch "
                                       "+ update) over the step wall time"},
-        "phase_ms_per_step": {k: (v[0] / max(v[1], 1)) for k, v in tim.items() if v[1]},
-        "phase_note": "solve: per k_factor_w launch; others: per scenario group and step (%d groups overlap on separate "
-                      "streams)" % G,
+        "phase_ms_per_launch": {k: (v[0] / max(v[1], 1)) for k, v in tim.items() if v[1]},
+        "phase_launches_per_step": {k: v[1] / max(K, 1) for k, v in tim.items() if v[1]},
+        "phase_note": "HIP-event spans: gj = one per k_factor_q<B,false> launch; solve = one per launch of the other factor kernels "
+                      "(k_leaf_batch, k_sleaf_batch, leaf-only k_factor_q); mismatch / update: per launch; back: per scenario "
+                      "group and step (%d groups overlap on separate streams)" % G,
         "vs_reference_measured": value / 0.0257,
     }
     if sweep is not None:
         out["sweep"] = sweep
+        out["sweep_iters_per_s"] = sweep["iters_per_s_rank0"] * world
+    if world == 1 and args.sweep_1gpu > 0 and bt:
+        dm.close()
+        dm = None
+        out["sweep_1gpu"] = sweep_one_gpu(hp, inp, args, dev_index)
     if (args.single or world == 1) and not args.no_single:
         out["single_scenario"] = single_scenario(hp, inp, args)
-    if args.cpu_iters > 0 and world == 1:
-        out["cpu_baseline"] = cpu_baseline(inp, args.cpu_iters)
-    else:
-        out["cpu_baseline"] = None
+    out["cpu_baseline"] = cpu
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
 
 
 def pmc_traffic(args, S):
-    """HBM bytes of one factor sweep from the committed PMC passes (tools/pmc_traffic.py); only valid for the default
-    workload they were collected on."""
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/pmc_traffic.py); only valid for the
+    default workload they were collected on."""
     path = os.path.join(REPO, "profiles", "pmc_traffic_latest.json")
     if not os.path.exists(path) or (args.buses, args.hmax, S, args.solver) != (1000, 51, 128, "block_tree"):
         return None, "no PMC pass for this workload"
-    per = json.load(open(path))["per_step_bytes"]
-    d = per.get("k_factor_q")
+    j = json.load(open(path))
+    if j.get("format") != 2:
+        return None, "no PMC pass in the current format"
+    d = j.get("per_launch_bytes", {}).get("k_factor_q_general")
     if not d:
         return None, "no PMC pass for this kernel"
-    tot = d["fetch_raw"] + d.get("write_calibrated", d["write"])
-    for name in ("k_leaf_batch", "k_sleaf_batch"):    # levels 0 / 1 of the sweep: the scenario-batched kernels, same timing spans
-        lb = per.get(name)
-        if lb:
-            tot += lb["fetch_raw"] + lb.get("write_calibrated", lb["write"])
-    return tot, ("per launch: (FETCH_SIZE*1024 raw + WRITE_SIZE*1024 x store calibration) of a factor sweep / launches; "
-                                         "tile-image loads calibrate at 1.0 (k_back_q, known bytes), stores at ~0.55 (k_update, known "
-                                         "bytes); includes the shared leaf images served by the Infinity Cache; separate "
-                                         "rocprofv3 --pmc passes, see profiles/pmc_traffic_latest.json")
+    return d["fetch"] + d["write"], j.get("note", "")
 
 
 def pmc_step_traffic(args, S):
-    """Counter bytes of a whole NR step (all kernels, fetch raw + calibrated stores) from the committed PMC passes."""
+    """Counter bytes of a whole NR step (all kernels) from the committed PMC passes."""
     path = os.path.join(REPO, "profiles", "pmc_traffic_latest.json")
     if not os.path.exists(path) or (args.buses, args.hmax, S, args.solver) != (1000, 51, 128, "block_tree"):
         return None
-    t = json.load(open(path))["per_step_bytes"]
-    return sum(v["fetch_raw"] + v.get("write_calibrated", v["write"]) for v in t.values())
+    j = json.load(open(path))
+    t = j.get("per_step_bytes") if j.get("format") == 2 else None
+    if not t:
+        return None
+    return sum(v["fetch"] + v["write"] for v in t.values())
 
 
-def K_steps(args):
-    return args.steps
-
-
-def dm_levels(dm):
-    return getattr(dm, "n_levels", 0) or 0
+def sweep_one_gpu(hp, inp, args, dev_index):
+    """BASELINE config 4 on ONE GPU: all `--sweep-1gpu` (1 024) Monte-Carlo scenarios live at once (72 MB of solver state per
+    scenario): lock-step rate over `steps` iterations, then the solve with the reference's stop rule from the pf seed."""
+    import torch
+    from harmonic_power_flow_amd import synth
+    from harmonic_power_flow_amd.sweep import summarize
+    n, S = inp["n"], args.sweep_1gpu
+    P0 = inp["buses"]["P"].to_numpy(float)
+    Q0 = inp["buses"]["Q"].to_numpy(float)
+    scale = np.stack([synth.scenario_scale(n, s) for s in range(S)])
+    dm = hp.DeviceModel(n, inp["m"], inp["c"], inp["st"].HARMONICS, inp["Y"].rowptr, inp["Y"].col, inp["Y"].Yval,
+                        inp["dev"], inp["Y_N"], inp["I_N"], inp["n_dev"], True, solver=args.solver,
+                        device=dev_index, max_scenarios=S)
+    try:
+        dm.set_loads(P0 * scale, Q0 * scale)
+        dm.set_state(None, None, n_scen=S)
+        t0 = time.perf_counter()
+        dm.fund_pf(inp["st"].thresh_f, inp["st"].max_iter_f)
+        t_pf = time.perf_counter() - t0
+        seed = dm.get_state()
+        dm.mismatch(want_f=False)
+        dm.iterate(2)
+        dm.sync()
+        Kl = max(4, args.steps // 2)
+        t0 = time.perf_counter()
+        dm.iterate(Kl)
+        dm.sync()
+        t_lock = time.perf_counter() - t0
+        dm.set_state(seed[0], seed[1])
+        dm.solve(inp["st"].thresh_h, 2)                                       # warm the solve path (pinned buffers)
+        dm.set_state(seed[0], seed[1])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_iter, err, _ = dm.solve(inp["st"].thresh_h, inp["st"].max_iter_h)
+        t_solve = time.perf_counter() - t0
+        st = dm.stats()
+        rec = np.zeros((S, 24), dtype=np.uint8)
+        rec.view([("n_iter", "<i4"), ("flags", "<i4"), ("err", "<f8"), ("thd_max", "<f8")])[:, 0] = st
+        out = summarize(rec)
+    finally:
+        dm.close()
+    out.update({"scenarios": S, "lockstep_ms_per_step": 1e3 * t_lock / Kl, "lockstep_iters_per_s": S * Kl / t_lock,
+                "solve_wall_s": t_solve, "iters_per_s": float(n_iter.sum()) / t_solve, "pf_wall_s": t_pf,
+                "note": "one GPU, all scenarios live; solve = hpf_solve with the reference's stop rule (per-scenario freeze, "
+                        "compaction of the running scenarios between chunks of 4 iterations, pipelined polling)"})
+    return out
 
 
 def single_scenario(hp, inp, args):

@@ -79,8 +79,8 @@ __global__ __launch_bounds__(256) void k_tree_factor(Model M, TreeDev T, const i
                                                      const cplx* __restrict__ Uall, const cplx* __restrict__ Eall,
                                                      const double* __restrict__ fall, double* __restrict__ Zall,
                                                      double* __restrict__ wall, int s0) {
-    const int s = blockIdx.y + s0;
-    if (active && !active[s]) return;
+    const int s = active ? active[blockIdx.y + s0] : (int)blockIdx.y + s0;   // slot -> scenario (active list; -1: frozen / empty slot)
+    if (s < 0) return;
     const int k = nodes[blockIdx.x];
     const int tid = threadIdx.x, tr = tid >> 4, tc = tid & 15;
     const int n = M.n, c = M.c;
@@ -321,8 +321,8 @@ __global__ __launch_bounds__(256) void k_tree_back(int n, int c, int Hn, TreeDev
                                                    int N, int Nc, const int* __restrict__ active,
                                                    const double* __restrict__ Zall, const double* __restrict__ wall,
                                                    double* __restrict__ xall, double* __restrict__ step, int s0) {
-    const int s = blockIdx.y + s0;
-    if (active && !active[s]) return;
+    const int s = active ? active[blockIdx.y + s0] : (int)blockIdx.y + s0;   // slot -> scenario (active list; -1: frozen / empty slot)
+    if (s < 0) return;
     const int k = nodes[blockIdx.x];
     const size_t bb = (size_t)b * b;
     const double* Zk = Zall + ((size_t)s * n + k) * bb;
@@ -503,8 +503,8 @@ __global__ __launch_bounds__(64, 1) void k_factor_w(Model M, TreeDev T, const in
                                                  double* __restrict__ Aall, double* __restrict__ wall,
                                                  const double* __restrict__ linAall, int* __restrict__ pivflag, int ablate,
                                                  int s0) {
-    const int s = blockIdx.y + s0;
-    if (active && !active[s]) return;
+    const int s = active ? active[blockIdx.y + s0] : (int)blockIdx.y + s0;   // slot -> scenario (active list; -1: frozen / empty slot)
+    if (s < 0) return;
     const int k = nodes[blockIdx.x];
     const int lane = threadIdx.x;
     const int n = M.n, c = M.c, Hn = M.Hn;
@@ -589,8 +589,8 @@ __global__ __launch_bounds__(64) void k_back_w(Model M, TreeDev T, const int* __
                                                const cplx* __restrict__ Eall, const double* __restrict__ Aall,
                                                const double* __restrict__ wall, double* __restrict__ xall,
                                                double* __restrict__ step, const double* __restrict__ Hall, int s0) {
-    const int s = blockIdx.y + s0;
-    if (active && !active[s]) return;
+    const int s = active ? active[blockIdx.y + s0] : (int)blockIdx.y + s0;   // slot -> scenario (active list; -1: frozen / empty slot)
+    if (s < 0) return;
     const int k = nodes[blockIdx.x];
     const int lane = threadIdx.x;
     const int n = M.n, c = M.c, Hn = M.Hn;
@@ -677,8 +677,8 @@ __global__ __launch_bounds__(128) void k_lin_factor(Model M, TreeDev T, int nroo
                                                     const cplx* __restrict__ Eall, const double* __restrict__ fall,
                                                     double* __restrict__ linAall, double* __restrict__ wall,
                                                     const cplx* __restrict__ I0all, int s0) {
-    const int s = blockIdx.y + s0;
-    if (active && !active[s]) return;
+    const int s = active ? active[blockIdx.y + s0] : (int)blockIdx.y + s0;   // slot -> scenario (active list; -1: frozen / empty slot)
+    if (s < 0) return;
     const int tix = blockIdx.x * 128 + threadIdx.x;
     const int HnE = FUND ? 1 : M.Hn;                               // FUND: harmonic position 0 only
     if (tix >= nroots * HnE) return;
@@ -737,8 +737,8 @@ __global__ __launch_bounds__(128) void k_lin_back(Model M, TreeDev T, int nroots
                                                   const cplx* __restrict__ Eall, const double* __restrict__ linAall,
                                                   const double* __restrict__ wall, double* __restrict__ xall,
                                                   double* __restrict__ step, int s0) {
-    const int s = blockIdx.y + s0;
-    if (active && !active[s]) return;
+    const int s = active ? active[blockIdx.y + s0] : (int)blockIdx.y + s0;   // slot -> scenario (active list; -1: frozen / empty slot)
+    if (s < 0) return;
     const int tix = blockIdx.x * 128 + threadIdx.x;
     const int HnE = FUND ? 1 : M.Hn;
     if (tix >= nroots * HnE) return;
@@ -794,6 +794,7 @@ __device__ __forceinline__ void mul22(const double a[4], const double b[4], doub
 
 template <int B>
 int launch_factor_w(hpf_handle* h, const TreeDev& T, const int* nodes, int count, const int* active) {
+    ScopedTimer t(h, T_SOLVE);
     hipLaunchKernelGGL((k_factor_w<B>), dim3((unsigned)count, (unsigned)h->cur_S), dim3(64), 0, h->cur_stream, h->M, T, nodes,
                        2 * h->Hn, h->N, h->Nc, active, h->d_U, h->d_E, h->d_f, h->d_Z, h->d_w, h->d_linA, h->d_pivflag, h->debug_ablate, h->cur_s0);
     hipError_t e = hipGetLastError();
@@ -848,6 +849,7 @@ size_t factor_lds_bytes(int b) {
 
 template <int R>
 int launch_factor(hpf_handle* h, const TreeDev& T, const int* nodes, int count, const int* active) {
+    ScopedTimer t(h, T_SOLVE);
     const int b = 2 * h->Hn;
     const size_t lds = factor_lds_bytes(b);
     static bool attr_set = false;
@@ -1630,6 +1632,15 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
     // bytes of a block's tile image (TileIO: the last tile column is stored 8 wide when it holds at most 8 columns)
     const int NTf = (BWf + 16) / 16, LWf = (BWf + 1 - 16 * (NTf - 1)) <= 8 ? 8 : 16;
     const double TB = BWf ? (double)((BWf + 3) / 4) * ((NTf - 1) * 64 + 4 * LWf) * 8.0 : 8.0 * bd * bd;
+    T.flops_gj = 0.0;
+    T.bytes_gj = 0.0;
+    T.n_gj_launches = 0;
+    for (int l = 0; l < T.n_levels; ++l) {         // launches of the general kernel k_factor_q<B, false> per sweep (default switches)
+        const int cntl = T.lvl_ptr[l + 1] - T.lvl_ptr[l];
+        const int nb = (l == 0) ? (T.lvl_all_leaf[0] ? T.n_lazy_level0 : 0) : T.lvl_nbatch[l];
+        const bool leafk = (l == 0 && nb > 0) || (nb == 0 && T.lvl_all_leaf[l]);
+        if (cntl - nb > 0 && !leafk) ++T.n_gj_launches;
+    }
     for (int i = 0; i < n; ++i) {
         if (!kept(i)) continue;
         const int nch = dchild_ptr[i + 1] - dchild_ptr[i];
@@ -1637,26 +1648,36 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
         const int nlz = n_lazy[i];                                   // lazy leaves: 2x2 core + G w column in, rank-2 MFMA update
         const bool sl = nlz > 0 && sl_off[i] >= 0;                    // super-leaf: m x m inversion, rank-4 MFMAs per 4 border unknowns, S^-1, w
         const double msl = 2.0 + 2.0 * nlz;
+        double fl = 0.0, by = 0.0;
         if (sl)
-            T.flops_factor += 2.0 * msl * msl * msl + 2.0 * bd * bd * 4.0 * (double)((2 + 2 * nlz + 3) / 4) + 2.0 * bd * msl * 3.0 +
-                              4.0 * bd * bd + 2.0 * bd * bd;
+            fl += 2.0 * msl * msl * msl + 2.0 * bd * bd * 4.0 * (double)((2 + 2 * nlz + 3) / 4) + 2.0 * bd * msl * 3.0 +
+                  4.0 * bd * bd + 2.0 * bd * bd;
         else
-            T.flops_factor += leaf ? 10.0 * bd * bd : 2.0 * bd * bd * bd + 2.0 * bd * bd + bd * bd * (nch - nlz - n_slz[i]);
-        if (nlz && !sl) T.flops_factor += 4.0 * bd * bd * nlz + 4.0 * bd * bd;
+            fl += leaf ? 10.0 * bd * bd : 2.0 * bd * bd * bd + 2.0 * bd * bd + bd * bd * (nch - nlz - n_slz[i]);
+        if (nlz && !sl) fl += 4.0 * bd * bd * nlz + 4.0 * bd * bd;
         const bool slb = sl && sb_ord[i] >= 0;                        // super-leaf that keeps T^-1 (+ W^-1, S^-1) instead of its inverse
         const int nsz = n_slz[i];                                     // lazy super-leaf children: T^-1, borders, G w in; rank-m rebuild
-        if (nsz) T.flops_factor += nsz * (2.0 * bd * bd * 12.0 + 2.0 * bd * 30.0);
-        T.bytes_factor += TB * (nch - nlz - nsz) + nlz * (32.0 + 8.0 * bd) + nsz * (8.0 * 104 + 64.0 + 8.0 * bd) +
-                          (leaf ? 0.0 : (slb ? 8.0 * 104 + 32.0 * d->Hn : TB)) +
-                          8.0 * (4.0 * bd + bd + bd + 2.0 * bd) +
-                          48.0 * d->Hn * (T.child_mid[i] - T.child_ptr[i]);
+        if (nsz) fl += nsz * (2.0 * bd * bd * 12.0 + 2.0 * bd * 30.0);
+        by += TB * (nch - nlz - nsz) + nlz * (32.0 + 8.0 * bd) + nsz * (8.0 * 104 + 64.0 + 8.0 * bd) +
+              (leaf ? 0.0 : (slb ? 8.0 * 104 + 32.0 * d->Hn : TB)) +
+              8.0 * (4.0 * bd + bd + bd + 2.0 * bd) +
+              48.0 * d->Hn * (T.child_mid[i] - T.child_ptr[i]);
         if (i > 0) {
-            T.flops_factor += is_lazy[i] ? 8.0 * bd : 8.0 * bd * bd;
-            T.bytes_factor += is_lazy[i] ? 8.0 * bd : TB;
+            fl += is_lazy[i] ? 8.0 * bd : 8.0 * bd * bd;
+            by += is_lazy[i] ? 8.0 * bd : TB;
             // back sweep: inverse of a Gauss-Jordan bus in (leaves rebuild it from the shared image), w, A(k,parent), x of the
             // parent in, x out; leaves also their 2x2 core and S^-1
             T.bytes_back += (leaf ? 32.0 + 32.0 * d->Hn : (slb ? 8.0 * 104 + 32.0 * d->Hn : TB)) + 8.0 * (bd + 2.0 * bd + bd + bd);
             ++n_dense_nonroot;
+        }
+        T.flops_factor += fl;
+        T.bytes_factor += by;
+        const int hl2 = height[i];
+        const bool batched = hl2 == 0 ? (T.lvl_all_leaf[0] != 0) : (is_slz[i] != 0 && sb_ord[i] >= 0);
+        const bool leafkern = hl2 > 0 && !batched && T.lvl_nbatch[hl2] == 0 && T.lvl_all_leaf[hl2];
+        if (!batched && !leafkern) {                                   // goes through k_factor_q<B, false>
+            T.flops_gj += fl;
+            T.bytes_gj += by;
         }
     }
     T.flops_per_solve = T.flops_factor + 2.0 * bd * bd * n_dense_nonroot;
@@ -1870,8 +1891,7 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
             int nbatch = (l == 0 && leafbatch && h->has_ctree && T.lvl_all_leaf[0]) ? T.n_lazy_level0 : 0;
             const bool slbatch = l > 0 && leafbatch && h->has_ctree && l < (int)T.lvl_nbatch.size() && T.lvl_nbatch[l] > 0;
             if (slbatch) nbatch = T.lvl_nbatch[l];
-            ScopedTimer t(h, T_SOLVE);          // one span per k_factor_w launch (what rocprofv3 --stats averages)
-            switch (BW) {
+            switch (BW) {                       // (timing spans: one per kernel launch, inside the launch helpers)
 #define HPF_FACTOR_CASE(BB_)                                                                                  \
     case BB_:                                                                                                 \
         if (h->gj_mode == 1 && nbatch > 0) {                                                                  \

@@ -11,7 +11,7 @@
 
 namespace hpf {
 
-enum { T_MISMATCH = 0, T_JACOBIAN = 1, T_SOLVE = 2, T_UPDATE = 3, T_BACK = 4, T_COUNT = 5 };
+enum { T_MISMATCH = 0, T_JACOBIAN = 1, T_SOLVE = 2, T_UPDATE = 3, T_BACK = 4, T_GJ = 5, T_COUNT = 6 };
 
 struct TimedSpan {
     int which;
@@ -100,6 +100,8 @@ struct Tree {
     double flops_factor = 0.0;        // factor sweep only (k_tree_factor, all levels)
     double bytes_back = 0.0;          // algorithmic HBM bytes of the dense back sweep, one scenario and step
     double bytes_factor = 0.0;        // algorithmic HBM bytes of the factor sweep, one scenario and step (see hpf_solve_bytes)
+    double flops_gj = 0.0, bytes_gj = 0.0;   // the share of the buses that go through the general kernel k_factor_q<B, false>
+    int n_gj_launches = 0;            // launches of that kernel per sweep (and scenario group)
 };
 
 }  // namespace hpf
@@ -178,8 +180,8 @@ struct hpf_handle {
     rocblas_handle blas = nullptr;
     bool timing = false;
     std::vector<hpf::TimedSpan> spans;
-    double t_ms[hpf::T_COUNT] = {0, 0, 0, 0, 0};
-    int64_t t_n[hpf::T_COUNT] = {0, 0, 0, 0, 0};
+    double t_ms[hpf::T_COUNT] = {0, 0, 0, 0, 0, 0};
+    int64_t t_n[hpf::T_COUNT] = {0, 0, 0, 0, 0, 0};
 };
 
 namespace hpf {

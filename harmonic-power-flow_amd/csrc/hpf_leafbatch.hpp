@@ -40,8 +40,9 @@ __global__ __launch_bounds__(256, 4) void k_leaf_batch(
     const int n = M.n, c = M.c, Hn = M.Hn;
     const int sc = tid >> 4, l16 = tid & 15;                 // role mapping: 16 threads per scenario
     const int sl = blockIdx.y * LB_SB + sc;                  // scenario inside the launch
-    const int s = sl + s0;
-    const bool live = sl < S_cnt && !(active && !active[s]);
+    const int ss = sl < S_cnt ? (active ? active[sl + s0] : sl + s0) : -1;      // slot -> scenario (active list; -1: frozen / empty slot)
+    const bool live = ss >= 0;
+    const int s = live ? ss : 0;
     const size_t so = (size_t)s * n * Hn;
     const cplx* U = Uall + so;
     const cplx* E = Eall + so;
@@ -236,6 +237,7 @@ __global__ __launch_bounds__(256, 4) void k_leaf_batch(
 
 template <int B>
 int launch_leaf_batch(hpf_handle* h, const TreeDev& T, const int* nodes, int count, const int* active) {
+    ScopedTimer t(h, T_SOLVE);
     const dim3 grid((unsigned)count, (unsigned)((h->cur_S + LB_SB - 1) / LB_SB));
     hipLaunchKernelGGL((k_leaf_batch<B>), grid, dim3(256), 0, h->cur_stream, h->M, T, nodes, 2 * h->Hn, active, h->cur_S, h->d_U,
                        h->d_E, h->d_fb, h->d_w, h->d_linA, h->d_C, h->d_H, h->d_chG, h->d_chH, h->d_chD, h->d_chy,
@@ -264,8 +266,9 @@ __global__ __launch_bounds__(256) void k_leaf_back_batch(
     const int n = M.n, Hn = M.Hn;
     const int sc = tid >> 4, l16 = tid & 15;
     const int sl = blockIdx.y * LB_SB + sc;
-    const int s = sl + s0;
-    const bool live = sl < S_cnt && !(active && !active[s]);
+    const int ss = sl < S_cnt ? (active ? active[sl + s0] : sl + s0) : -1;      // slot -> scenario (active list; -1: frozen / empty slot)
+    const bool live = ss >= 0;
+    const int s = live ? ss : 0;
     double* xs = xall + (size_t)s * n * B;
     const double* img = lbimg + (size_t)slot * LeafBatchImg<B>::SZ;
     const double* lcimg = img + NTR * KS * 64;
@@ -369,8 +372,9 @@ __global__ __launch_bounds__(256) void k_sleaf_back_batch(
     const int n = M.n, Hn = M.Hn;
     const int sc = tid >> 4, l16 = tid & 15;
     const int sl = blockIdx.y * LB_SB + sc;
-    const int s = sl + s0;
-    const bool live = sl < S_cnt && !(active && !active[s]);
+    const int ss = sl < S_cnt ? (active ? active[sl + s0] : sl + s0) : -1;      // slot -> scenario (active list; -1: frozen / empty slot)
+    const bool live = ss >= 0;
+    const int s = live ? ss : 0;
     double* xs = xall + (size_t)s * n * B;
     const double* tk = Zall + ((size_t)s * n + k) * CT;         // T^-1 [10][10] | W_k^-1 [4]
 
@@ -494,8 +498,9 @@ __global__ __launch_bounds__(256, 4) void k_sleaf_batch(
     const int n = M.n, c = M.c, Hn = M.Hn;
     const int sc = tid >> 4, l16 = tid & 15;
     const int sl = blockIdx.y * LB_SB + sc;
-    const int s = sl + s0;
-    const bool live = sl < S_cnt && !(active && !active[s]);
+    const int ss = sl < S_cnt ? (active ? active[sl + s0] : sl + s0) : -1;      // slot -> scenario (active list; -1: frozen / empty slot)
+    const bool live = ss >= 0;
+    const int s = live ? ss : 0;
     const size_t so = (size_t)s * n * Hn;
     const cplx* U = Uall + so;
     const cplx* E = Eall + so;
@@ -806,6 +811,7 @@ __global__ __launch_bounds__(256, 4) void k_sleaf_batch(
 
 template <int B>
 int launch_sleaf_batch(hpf_handle* h, const TreeDev& T, const int* nodes, int count, const int* active) {
+    ScopedTimer t(h, T_SOLVE);
     const dim3 grid((unsigned)count, (unsigned)((h->cur_S + LB_SB - 1) / LB_SB));
     hipLaunchKernelGGL((k_sleaf_batch<B>), grid, dim3(256), 0, h->cur_stream, h->M, T, nodes, 2 * h->Hn, active, h->cur_S, h->d_U,
                        h->d_E, h->d_fb, h->d_w, h->d_linA, h->d_C, h->d_H, h->d_I0, h->d_chG, h->d_chH, h->d_chD, h->d_chy,

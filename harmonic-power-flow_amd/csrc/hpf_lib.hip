@@ -86,8 +86,8 @@ __global__ void k_mismatch(Model M, int count, int N, int Nc, const int* __restr
                            const double* __restrict__ P, const double* __restrict__ Q, double* __restrict__ f,
                            unsigned long long* __restrict__ errbits, cplx* __restrict__ I0, double* __restrict__ fb, int Bst,
                            int s0) {
-    const int s = blockIdx.y + s0;
-    if (active && !active[s]) return;
+    const int s = active ? active[blockIdx.y + s0] : (int)blockIdx.y + s0;   // slot -> scenario (active list; -1: frozen / empty slot)
+    if (s < 0) return;
     const int t = blockIdx.x * TPB + threadIdx.x;
     unsigned long long b = 0;
     if (t < count) {
@@ -127,8 +127,8 @@ template <bool FUND>
 __global__ void k_jac_dense(Model M, int total, int N, int Nc, size_t J_stride, const int* __restrict__ active,
                             const int* __restrict__ erow, const cplx* __restrict__ U, const cplx* __restrict__ E,
                             double* __restrict__ J) {
-    const int s = blockIdx.y;
-    if (active && !active[s]) return;
+    const int s = active ? active[blockIdx.y] : (int)blockIdx.y;
+    if (s < 0) return;
     const int t = blockIdx.x * TPB + threadIdx.x;
     if (t >= total) return;
     const int q = t / M.nnz, e = t - q * M.nnz;
@@ -144,8 +144,8 @@ __global__ void k_jac_dense(Model M, int total, int N, int Nc, size_t J_stride, 
 // Dense Jacobian, coupled Norton cross terms q != p at nonlinear buses (HG:425-435).
 __global__ void k_jac_cross_dense(Model M, int total, int N, int Nc, size_t J_stride, const int* __restrict__ active,
                                   const cplx* __restrict__ U, const cplx* __restrict__ E, double* __restrict__ J) {
-    const int s = blockIdx.y;
-    if (active && !active[s]) return;
+    const int s = active ? active[blockIdx.y] : (int)blockIdx.y;
+    if (s < 0) return;
     const int t = blockIdx.x * TPB + threadIdx.x;
     if (t >= total) return;
     // consecutive threads -> consecutive buses (coalesced U/E reads for a fixed column harmonic p)
@@ -165,8 +165,8 @@ __global__ void k_update(int n, int Hn, int c, int count, int stride, int N, int
                          const double* __restrict__ step, double* __restrict__ Vm, double* __restrict__ Va,
                          cplx* __restrict__ U, cplx* __restrict__ E, unsigned long long* __restrict__ errbits,
                          const double* __restrict__ xbus, int Bst, int s0) {
-    const int s = blockIdx.y + s0;
-    if (active && !active[s]) return;
+    const int s = active ? active[blockIdx.y + s0] : (int)blockIdx.y + s0;   // slot -> scenario (active list; -1: frozen / empty slot)
+    if (s < 0) return;
     const int t = blockIdx.x * TPB + threadIdx.x;
     if (t >= count) return;
     const int i = FUND ? t : t / Hn, q = FUND ? 0 : t - i * Hn;          // thread t = i*Hn + q: bus-major state arrays
@@ -193,17 +193,21 @@ __global__ void k_update(int n, int Hn, int c, int count, int stride, int N, int
     if (k == 0) errbits[s] = 0ull;
 }
 
-// Per-scenario bookkeeping of the NR loop (HG:536-542 / HG:259-265).  first: record the initial mismatch.
+// Per-scenario bookkeeping of the NR loop (HG:536-542 / HG:259-265).  The set of running scenarios is a SLOT LIST: active[i] =
+// scenario id that slot i runs, or -1 (frozen scenario / empty slot); every kernel of the loop maps its blockIdx.y through it.
+// first: slot i <- scenario i, record the initial mismatch, apply the stop rule (mask: a repeat pass starts masked scenarios only).
+// else: one thread per slot; a scenario that meets the stop rule freezes (its slot becomes -1).
 __global__ void k_finalize(int S, int first, double thresh, int max_iter, int hist_cap, int hist_off,
                            const unsigned long long* __restrict__ errbits, double* __restrict__ err,
                            int* __restrict__ niter, int* __restrict__ active, int* __restrict__ nactive,
                            double* __restrict__ hist, int s0, const int* __restrict__ mask) {
     const int sl = blockIdx.x * blockDim.x + threadIdx.x;
     if (sl >= S) return;
-    const int s = sl + s0;
+    const int slot = sl + s0;
     if (first) {
+        const int s = slot;
         if (mask && !mask[s]) {           // repeat pass: the other scenarios keep their result and stay frozen
-            active[s] = 0;
+            active[slot] = -1;
             return;
         }
         const double e = __longlong_as_double((long long)errbits[s]);
@@ -211,19 +215,48 @@ __global__ void k_finalize(int S, int first, double thresh, int max_iter, int hi
         niter[s] = 0;
         if (hist && hist_off == 0) hist[(size_t)s * hist_cap] = e;
         const int a = (e > thresh) && (0 < max_iter);
-        active[s] = a;
+        active[slot] = a ? s : -1;
         if (a) atomicAdd(nactive, 1);
         return;
     }
-    if (!active[s]) return;
+    const int s = active[slot];
+    if (s < 0) return;
     const double e = __longlong_as_double((long long)errbits[s]);
     const int it = niter[s] + 1;
     err[s] = e;
     niter[s] = it;
     if (hist) hist[(size_t)s * hist_cap + it - 1 + (hist_off == 0 ? 1 : 0)] = e;
     const int a = (e > thresh) && (it < max_iter);
-    active[s] = a;
-    if (a) atomicAdd(nactive, 1);
+    if (!a) active[slot] = -1;
+}
+
+// Stable compaction of the slot list (running scenarios to the front, -1 behind them) and their count -> *count.  One workgroup;
+// runs between two chunks of iterations, so that the next chunk launches grids over the running scenarios only and the
+// 16-scenario tiles of the leaf kernels stay full.
+__global__ __launch_bounds__(1024) void k_compact(int S, int* __restrict__ active, int* __restrict__ count) {
+    __shared__ int wsum[16];
+    __shared__ int base;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < S; i0 += 1024) {
+        const int i = i0 + tid;
+        const int v = i < S ? active[i] : -1;
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(v >= 0);
+        const int before = __builtin_popcountll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wv] = __builtin_popcountll(bal);
+        __syncthreads();                  // (also: every read of active[i0 .. i0+1023] precedes the writes below)
+        int off = base;
+        for (int w = 0; w < wv; ++w) off += wsum[w];
+        int tot = 0;
+        for (int w = 0; w < 16; ++w) tot += wsum[w];
+        if (v >= 0) active[off + before] = v;        // off + before <= i: never overtakes an unread entry of a later tile
+        __syncthreads();
+        if (tid == 0) base += tot;
+        __syncthreads();
+    }
+    for (int i = base + tid; i < S; i += 1024) active[i] = -1;
+    if (tid == 0) *count = base;
 }
 
 __global__ void k_fill(double* p, size_t count, double v) {
@@ -249,6 +282,12 @@ __global__ void k_mark_repeat(int S, const double* __restrict__ err, int* __rest
         pivflag[s] = (pivflag[s] & 1) | 2;      // bit 1: repeated (bit 0 stays: why)
         atomicAdd(count, 1);
     }
+}
+
+// mask (per scenario, 0 / 1) -> slot list of a repeat pass: slot s runs scenario s or nothing
+__global__ void k_mask_to_list(int S, const int* __restrict__ mask, int* __restrict__ list) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < S) list[s] = mask[s] ? s : -1;
 }
 
 __global__ void k_restore_masked(int count, const int* __restrict__ mask, const double* __restrict__ Vm0,
@@ -383,25 +422,29 @@ inline void set_ctx(hpf_handle* h, hipStream_t st, int s0, int cnt) {
 }
 inline void full_ctx(hpf_handle* h) { set_ctx(h, h->stream, 0, h->S); }
 
-inline int groups_for(const hpf_handle* h) {
+inline int groups_for(const hpf_handle* h, int count) {
     if (h->solver != HPF_SOLVER_BLOCK_TREE) return 1;
     int g = h->n_groups;
-    while (g > 1 && h->S < 8 * g) --g;         // at least 8 scenarios per group
+    while (g > 1 && count < 8 * g) --g;        // at least 8 scenarios per group
     return g < 1 ? 1 : g;
 }
+inline int groups_for(const hpf_handle* h) { return groups_for(h, h->S); }
 
-// Run body() once per scenario group, each group on its own stream between a fork and a join with the main stream.
+// Run body() once per scenario group (slots [0, count) of the active list / scenarios [0, S) split evenly), each group on its
+// own stream between a fork and a join with the main stream.
 template <class F>
-int for_groups(hpf_handle* h, F body) {
-    const int G = groups_for(h);
+int for_groups(hpf_handle* h, int count, F body) {
+    const int G = groups_for(h, count);
     if (G == 1) {
+        set_ctx(h, h->stream, 0, count);
+        const int rc1 = body();
         full_ctx(h);
-        return body();
+        return rc1;
     }
     HIPCHK(hipEventRecord(h->fork_ev, h->stream));
     int rc = HPF_OK;
     for (int g = 0; g < G && rc == HPF_OK; ++g) {
-        const int s0 = (int)((long long)h->S * g / G), s1 = (int)((long long)h->S * (g + 1) / G);
+        const int s0 = (int)((long long)count * g / G), s1 = (int)((long long)count * (g + 1) / G);
         HIPCHK(hipStreamWaitEvent(h->gstream[g], h->fork_ev, 0));
         set_ctx(h, h->gstream[g], s0, s1 - s0);
         rc = body();
@@ -514,7 +557,7 @@ int check_info(hpf_handle* h, const std::vector<int>& was_active) {
     HIPCHK(hipMemcpyAsync(info.data(), h->d_info, sizeof(int) * h->S, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     for (int s = 0; s < h->S; ++s)
-        if (was_active[s] && info[s] != 0) {
+        if (was_active[s] >= 0 && info[s] != 0) {
             h->last_detail = info[s];
             return HPF_E_SINGULAR;
         }
@@ -549,7 +592,8 @@ int nr_pass(hpf_handle* h, double thresh, int max_iter, const int* mask) {
     const int hist_off = FUND ? 1 : 0;                // pf records only post-update errors (HG:264)
     if ((r = launch_polar<FUND>(h))) return r;
     HIPCHK(hipMemsetAsync(h->d_errbits, 0, sizeof(unsigned long long) * S, h->stream));
-    if ((r = launch_mismatch<FUND>(h, mask, false))) return r;
+    if (mask) hipLaunchKernelGGL(k_mask_to_list, dim3((S + 63) / 64), dim3(64), 0, h->stream, S, mask, h->d_active);
+    if ((r = launch_mismatch<FUND>(h, mask ? h->d_active : nullptr, false))) return r;
     HIPCHK(hipMemsetAsync(h->d_nactive, 0, sizeof(int), h->stream));
     hipLaunchKernelGGL(k_finalize, dim3((S + 63) / 64), dim3(64), 0, h->stream, S, 1, thresh, max_iter, h->hist_cap,
                        hist_off, h->d_errbits, h->d_err, h->d_niter, h->d_active, h->d_nactive, h->d_hist, 0, mask);
@@ -561,7 +605,7 @@ int nr_pass(hpf_handle* h, double thresh, int max_iter, const int* mask) {
     // c - 1 while chunk c is already queued (pinned double buffer + events), so the device never drains between chunks.
     const bool pipelined = !FUND && h->solver == HPF_SOLVER_BLOCK_TREE && !trace;
     const int chunk = pipelined ? (S >= 8 ? 4 : 2) : 1;
-    auto enqueue = [&](int todo) -> int {
+    auto enqueue = [&](int todo, int slots) -> int {
         auto body = [&]() -> int {
             int rr;
             for (int j = 0; j < todo; ++j) {
@@ -578,47 +622,56 @@ int nr_pass(hpf_handle* h, double thresh, int max_iter, const int* mask) {
             full_ctx(h);
             return body();
         }
-        return for_groups(h, body);
-    };
-    auto count_active = [&](const int* a) {
-        int c = 0;
-        for (int s = 0; s < S; ++s) c += a[s] != 0;
-        return c;
+        return for_groups(h, slots, body);
     };
     if (pipelined) {
         if (!h->h_act[0]) {
             for (int i = 0; i < 2; ++i) {
-                HIPCHK(hipHostMalloc((void**)&h->h_act[i], sizeof(int) * h->S_max, hipHostMallocDefault));
+                HIPCHK(hipHostMalloc((void**)&h->h_act[i], sizeof(int) * 4, hipHostMallocDefault));
                 HIPCHK(hipEventCreateWithFlags(&h->poll_ev[i], hipEventDisableTiming));
             }
         }
-        int it = 0, c = 0;
-        HIPCHK(hipMemcpyAsync(h->h_act[0], h->d_active, sizeof(int) * S, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipEventRecord(h->poll_ev[0], h->stream));
+        // Between two chunks the slot list is compacted on the device (running scenarios first) and their count goes to the
+        // host; the count the host knows is one chunk old, i.e. an upper bound (the count only falls): it sizes the grids and
+        // the scenario groups of the next chunk.  Slots behind the true count hold -1 and their workgroups exit at once.
+        auto compact_and_post = [&](int buf) -> int {
+            hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, h->stream, S, h->d_active, h->d_nactive);
+            HIPCHK(hipMemcpyAsync(h->h_act[buf], h->d_nactive, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipEventRecord(h->poll_ev[buf], h->stream));
+            return HPF_OK;
+        };
+        int it = 0, c = 0, n_ub = S;
+        if ((r = compact_and_post(0))) return r;
         for (;;) {
-            // queue chunk c + 1 (iterations it .. it + todo) before looking at the flags chunk c left
+            // queue chunk c + 1 (iterations it .. it + todo) before looking at the count chunk c left
             const int todo = (max_iter - it) < chunk ? (max_iter - it) : chunk;
             if (todo > 0) {
-                if ((r = enqueue(todo))) return r;
-                HIPCHK(hipMemcpyAsync(h->h_act[(c + 1) & 1], h->d_active, sizeof(int) * S, hipMemcpyDeviceToHost, h->stream));
-                HIPCHK(hipEventRecord(h->poll_ev[(c + 1) & 1], h->stream));
+                if ((r = enqueue(todo, n_ub))) return r;
+                if ((r = compact_and_post((c + 1) & 1))) return r;
                 it += todo;
             }
             HIPCHK(hipEventSynchronize(h->poll_ev[c & 1]));
-            if (count_active(h->h_act[c & 1]) == 0 || todo == 0) break;
+            const int cnt = h->h_act[c & 1][0];
+            if (cnt == 0 || todo == 0) break;
+            n_ub = cnt;
             ++c;
         }
         HIPCHK(hipStreamSynchronize(h->stream));
         return HPF_OK;
     }
+    auto count_active = [&](const int* a) {
+        int c = 0;
+        for (int s = 0; s < S; ++s) c += a[s] >= 0;
+        return c;
+    };
     std::vector<int> act(S), was(S);
     HIPCHK(hipMemcpyAsync(act.data(), h->d_active, sizeof(int) * S, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     int nactive = count_active(act.data());
     int it = 0;
     while (nactive > 0 && it < max_iter) {
-        was = act;
-        if ((r = enqueue(1))) return r;
+        was = act;                        // (no compaction on this path: slot i runs scenario i)
+        if ((r = enqueue(1, S))) return r;
         HIPCHK(hipMemcpyAsync(act.data(), h->d_active, sizeof(int) * S, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         nactive = count_active(act.data());
@@ -1145,6 +1198,32 @@ double hpf_solve_bytes(const hpf_handle* h) {
     if (h->solver == HPF_SOLVER_BLOCK_TREE) return active_tree(const_cast<hpf_handle*>(h)).bytes_factor;
     const double N = h->N;
     return 8.0 * (2.0 * N * N + 2.0 * N);           // Jacobian written by the assembly, read and written back by getrf
+}
+
+int hpf_kernel_model(const hpf_handle* h, int which, double* bytes, double* flops, int* launches) {
+    if (!h) return HPF_E_ARG;
+    double by = 0.0, fl = 0.0;
+    int ln = 0;
+    if (h->solver == HPF_SOLVER_BLOCK_TREE) {
+        const Tree& T = active_tree(const_cast<hpf_handle*>(h));
+        if (which == T_GJ) {
+            by = T.bytes_gj; fl = T.flops_gj; ln = T.n_gj_launches;
+        } else if (which == T_SOLVE) {
+            by = T.bytes_factor; fl = T.flops_factor; ln = T.n_levels;
+        } else if (which == T_BACK) {
+            by = T.bytes_back; fl = T.flops_per_solve - T.flops_factor; ln = T.n_depths;
+        } else {
+            return HPF_E_ARG;
+        }
+    } else if (which == T_SOLVE) {
+        by = hpf_solve_bytes(h); fl = hpf_solve_flops(h); ln = 1;
+    } else {
+        return HPF_E_ARG;
+    }
+    if (bytes) *bytes = by;
+    if (flops) *flops = fl;
+    if (launches) *launches = ln;
+    return HPF_OK;
 }
 
 double hpf_back_bytes(const hpf_handle* h) {

@@ -161,8 +161,8 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
     long long sa = 0, sc = 0, gown = 0, gwait = 0, gmf = 0;
 #endif
     HPF_STAMP(st0);
-    const int s = blockIdx.y + s0;
-    if (active && !active[s]) return;
+    const int s = active ? active[blockIdx.y + s0] : (int)blockIdx.y + s0;   // slot -> scenario (active list; -1: frozen / empty slot)
+    if (s < 0) return;
     // node record: everything the block needs to form its addresses, behind one scalar load (Tree::d_fdesc)
     const int4* nd = reinterpret_cast<const int4*>(nodes) + (FDESC / 4) * (size_t)blockIdx.x;
     const int4 nd0 = nd[0], nd1 = nd[1], nd2 = nd[2], nd3 = nd[3];
@@ -1052,8 +1052,8 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16)) void k_back_q(
     const double* __restrict__ lfS, int s0) {
     constexpr int NT = (B + 16) / 16;
     constexpr size_t CT = (size_t)NT * NT * 256;
-    const int s = blockIdx.y + s0;
-    if (active && !active[s]) return;
+    const int s = active ? active[blockIdx.y + s0] : (int)blockIdx.y + s0;   // slot -> scenario (active list; -1: frozen / empty slot)
+    if (s < 0) return;
     const int4 kp = reinterpret_cast<const int4*>(nodes)[blockIdx.x];          // Tree::d_bdesc: (bus, parent, leaf slot + 1, 0)
     const int k = kp.x, par = kp.y, cleaf = kp.z;
     const int tid = threadIdx.x, lane = tid & 63, lg = lane >> 4, jj = lane & 15;
@@ -1138,6 +1138,7 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16)) void k_back_q(
 
 template <int B, bool LEAF>
 int launch_factor_q2(hpf_handle* h, const TreeDev& T, const int* nodes, int count, const int* active) {
+    ScopedTimer t(h, LEAF ? T_SOLVE : T_GJ);            // T_GJ: the general kernel k_factor_q<B, false> alone (roofline numerator: hpf_kernel_model)
     constexpr int NT = (B + 16) / 16;
     const dim3 grid((unsigned)count, (unsigned)h->cur_S);
     hipLaunchKernelGGL((k_factor_q<B, LEAF>), grid, dim3(64 * NT), 0, h->cur_stream, h->M, T, nodes,
@@ -1234,8 +1235,8 @@ __global__ __launch_bounds__(128) void k_lin_level_factor(Model M, TreeDev T, co
                                                           const cplx* __restrict__ I0all, int fund, int s0) {
     // fund: fundamental power flow (HG:205-223) -- harmonic position 0 only, every bus a power row (m_eff = n), mismatch in
     // the stacked order of `pf`; the records then cover the whole tree
-    const int s = blockIdx.y + s0;
-    if (active && !active[s]) return;
+    const int s = active ? active[blockIdx.y + s0] : (int)blockIdx.y + s0;   // slot -> scenario (active list; -1: frozen / empty slot)
+    if (s < 0) return;
     const int tix = blockIdx.x * 128 + threadIdx.x;
     const int HnE = fund ? 1 : M.Hn;
     if (tix >= count * HnE) return;
@@ -1283,8 +1284,8 @@ __global__ __launch_bounds__(128) void k_lin_level_back(Model M, TreeDev T, cons
                                                         const cplx* __restrict__ Eall, const double* __restrict__ linAall,
                                                         const double* __restrict__ wall, double* __restrict__ xall,
                                                         double* __restrict__ step, int fund, int s0) {
-    const int s = blockIdx.y + s0;
-    if (active && !active[s]) return;
+    const int s = active ? active[blockIdx.y + s0] : (int)blockIdx.y + s0;   // slot -> scenario (active list; -1: frozen / empty slot)
+    if (s < 0) return;
     const int tix = blockIdx.x * 128 + threadIdx.x;
     const int HnE = fund ? 1 : M.Hn;
     if (tix >= count * HnE) return;
@@ -1335,8 +1336,8 @@ __global__ __launch_bounds__(128) void k_chain_factor2(Model M, TreeDev T, const
                                                        double* __restrict__ wall, const cplx* __restrict__ I0all,
                                                        double* __restrict__ chG, double* __restrict__ chH, double* __restrict__ chD,
                                                        double* __restrict__ chy, double* __restrict__ chZ, int s0) {
-    const int s = blockIdx.y + s0;
-    if (active && !active[s]) return;
+    const int s = active ? active[blockIdx.y + s0] : (int)blockIdx.y + s0;   // slot -> scenario (active list; -1: frozen / empty slot)
+    if (s < 0) return;
     const int tix = blockIdx.x * 128 + threadIdx.x;
     if (tix >= nchains * M.Hn) return;
     const int q = tix % M.Hn, r = tix / M.Hn;
@@ -1426,8 +1427,8 @@ __global__ __launch_bounds__(128) void k_chain_back2(Model M, TreeDev T, const i
                                                      const double* __restrict__ linAall, const double* __restrict__ wall,
                                                      double* __restrict__ xall, double* __restrict__ step,
                                                      const double* __restrict__ chZ, int s0) {
-    const int s = blockIdx.y + s0;
-    if (active && !active[s]) return;
+    const int s = active ? active[blockIdx.y + s0] : (int)blockIdx.y + s0;   // slot -> scenario (active list; -1: frozen / empty slot)
+    if (s < 0) return;
     const int tix = blockIdx.x * 128 + threadIdx.x;
     if (tix >= nchains * M.Hn) return;
     const int q = tix % M.Hn, r = tix / M.Hn;

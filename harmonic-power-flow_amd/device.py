@@ -195,7 +195,7 @@ class DeviceModel:
 
     def timing_get(self):
         out = {}
-        for which, name in enumerate(("mismatch", "jacobian", "solve", "update", "back")):
+        for which, name in enumerate(("mismatch", "jacobian", "solve", "update", "back", "gj")):
             ms = C.c_double()
             cnt = C.c_int64()
             self._chk(self.lib.hpf_timing_get(self._h, which, C.byref(ms), C.byref(cnt)), "hpf_timing_get")
@@ -211,3 +211,11 @@ class DeviceModel:
 
     def back_bytes(self):
         return float(self.lib.hpf_back_bytes(self._h))
+
+    def kernel_model(self, which):
+        """(algorithmic bytes, flops) of one kernel class per scenario and Newton step, launches per step and scenario group
+        (hpf_kernel_model; which: "gj" = the general factor kernel k_factor_q<B,false>, "solve" = whole factor sweep, "back")."""
+        by, fl, ln = C.c_double(), C.c_double(), C.c_int32()
+        idx = {"solve": 2, "back": 4, "gj": 5}[which]
+        self._chk(self.lib.hpf_kernel_model(self._h, idx, C.byref(by), C.byref(fl), C.byref(ln)), "hpf_kernel_model")
+        return by.value, fl.value, ln.value

@@ -172,9 +172,10 @@ int  hpf_sync(hpf_handle* h);
 
 /* Kernel timing with HIP events on the handle's stream, accumulated since the last reset.
  * which: 0 mismatch kernel, 1 Jacobian assembly kernels (DENSE only; BLOCK_TREE assembles inside the factor kernel),
- * 2 linear solve (DENSE: getrf+getrs, one span per step; BLOCK_TREE: one span per factor-kernel launch, i.e. per tree level
- *   and scenario group),
- * 3 state update, 4 back-substitution sweep (BLOCK_TREE only; one span per Newton step and scenario group).
+ * 2 linear solve (DENSE: getrf+getrs, one span per step; BLOCK_TREE: one span per launch of a factor kernel OTHER than the
+ *   general one: k_leaf_batch, k_sleaf_batch, the leaf-only k_factor_q<B,true>, the pivoted / generic kernels),
+ * 3 state update, 4 back-substitution sweep (BLOCK_TREE only; one span per Newton step and scenario group),
+ * 5 BLOCK_TREE: one span per launch of the general factor kernel k_factor_q<B,false> (the dominant kernel of a step).
  * Returns total milliseconds in *ms and the number of timed spans in *launches. */
 int  hpf_timing_enable(hpf_handle* h, int on);
 int  hpf_timing_get(hpf_handle* h, int which, double* ms, int64_t* launches);
@@ -190,6 +191,12 @@ double hpf_solve_flops(const hpf_handle* h);
 double hpf_solve_bytes(const hpf_handle* h);
 /* ... and of the span `which == 4` (BLOCK_TREE back sweep: Gauss-Jordan inverses in, w, A(k,parent), x in / out); 0 for DENSE. */
 double hpf_back_bytes(const hpf_handle* h);
+/* Roofline model of ONE kernel class (timing span `which`, see hpf_timing_get): algorithmic HBM bytes and FP64 flops of all its
+ * launches of one Newton step for ONE scenario, and the number of launches per step and scenario group.  which == 5: the
+ * general multi-wave factor kernel k_factor_q<B,false> alone (Gauss-Jordan buses, non-batched super-leaves; the buses of the
+ * scenario-batched kernels k_leaf_batch / k_sleaf_batch and of the leaf-only instantiation are NOT in it); which == 2: the
+ * whole factor sweep (= hpf_solve_bytes / hpf_solve_flops); which == 4: the back sweep.  Other classes: HPF_E_ARG. */
+int  hpf_kernel_model(const hpf_handle* h, int which, double* bytes, double* flops, int* launches);
 
 #ifdef __cplusplus
 }

@@ -13,6 +13,15 @@ for p in (REPO, os.path.join(REPO, "oracle")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # On a GPU box PyTorch must initialise ITS HIP runtime before libhpf.so brings in /opt/rocm's: the other way round
+    # torch.cuda.is_available() turns False for the rest of the process (the product does not need torch; the tests that check
+    # "a GPU is present" and the RCCL gather do).
+    if os.path.exists("/dev/kfd"):
+        try:
+            import torch
+            torch.cuda.is_available()
+        except Exception:
+            pass
 
 
 @pytest.fixture(scope="session")

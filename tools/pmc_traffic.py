@@ -1,63 +1,74 @@
 #!/usr/bin/env python3
-"""HBM traffic of the bench kernels from rocprofv3 PMC passes.
+"""HBM-side traffic of the bench kernels from rocprofv3 PMC passes (tools/measure.sh <tag> pmc: FETCH_SIZE and WRITE_SIZE in two
+separate --pmc passes with --kernel-trace only), corrected as MI355X_MICROARCH.md (HBM) prescribes and as the known-bytes
+calibration of THIS access pattern confirms (tools/pmc_calib.hip -> profiles/r02/pmc_calib.json: FETCH_SIZE reads 0.500 of the bytes
+of 16 B/lane, 8 B/lane and tile-image streaming loads alike; WRITE_SIZE reads 1.000 of the stores of all three patterns):
+    bytes fetched = FETCH_SIZE [KB] x 1024 x 2,    bytes written = WRITE_SIZE [KB] x 1024.
+Infinity-Cache hits are counted (fabric-side requests of the L2), so per-model images served on-die are in `fetch` too.
 
-On the GPU box (two separate passes, counters only with --kernel-trace, as MI355X_MICROARCH.md / the pool rules require):
-    cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-    for c in FETCH_SIZE WRITE_SIZE; do rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_$c -- \
-        python3 bench.py --steps 3 --warmup 1 --cpu-iters 0 --no-finish; done
-Then here:  python tools/pmc_traffic.py profiles/r01/pmc_traffic.json [steps_profiled=4]
+    python tools/pmc_traffic.py profiles/r02/pmc_traffic_<tag>.json [steps_profiled=7] [calib.json]
 """
 import collections
 import csv
 import glob
 import json
 import os
+import re
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KEYS = ("k_sleaf_batch", "k_sleaf_back_batch", "k_leaf_back_batch", "k_leaf_batch", "k_factor_q", "k_back_q", "k_lin_level", "k_chain", "k_mismatch", "k_update", "k_factor_w", "k_back_w", "k_tree_factor",
-        "k_tree_back")
+
+
+def short(name):
+    m = re.search(r"(k_\w+)(<[^>]*>)?", name)
+    if not m:
+        return None
+    return m.group(1) + (m.group(2) or "").replace(" ", "")
 
 
 def main():
     out_path = sys.argv[1]
-    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 7
+    calib = sys.argv[3] if len(sys.argv) > 3 else os.path.join(REPO, "profiles", "r02", "pmc_calib.json")
+    ff, wf = 2.0, 1.0
+    if os.path.exists(calib):
+        ck = json.load(open(calib))["kernels"]
+        ff = 1.0 / ck["k_tile_load"]["FETCH_SIZE_over_known"]
+        wf = 1.0 / ck["k_tile_store"]["WRITE_SIZE_over_known"]
     res = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
-        f = max(glob.glob(os.path.join(REPO, "gpurun_out", f"pmc_{c}", "*", "*counter_collection.csv")), key=os.path.getmtime)
+        f = max(glob.glob(os.path.join(REPO, "gpurun_out", f"pmc_{c}", "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
         agg = collections.defaultdict(lambda: [0, 0.0])
         for r in csv.DictReader(open(f)):
-            for key in KEYS:
-                if key in r["Kernel_Name"]:
-                    agg[key][0] += 1
-                    agg[key][1] += float(r["Counter_Value"])
-        res[c] = {k: {"dispatches": v[0], "sum_counter_KB": v[1]} for k, v in agg.items()}
-    out = {"command": "rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-trace -- python3 bench.py --steps 3 --warmup 1 "
-                      "--cpu-iters 0 --no-finish (two separate passes)",
-           "steps_profiled": steps, "raw": res, "per_step_bytes": {}}
-    for k in res["FETCH_SIZE"]:
-        fe = res["FETCH_SIZE"][k]["sum_counter_KB"] / steps * 1024
-        wr = res["WRITE_SIZE"].get(k, {"sum_counter_KB": 0.0})["sum_counter_KB"] / steps * 1024
-        out["per_step_bytes"][k] = {"fetch_raw": fe, "fetch_x2_gfx950_wide_stream_correction": 2 * fe, "write": wr}
-    # calibration of the store counter on THIS access pattern (MI355X_MICROARCH.md: widths other than 16 B/lane are
-    # uncalibrated): k_update writes exactly Vm, Va (8 B/lane) and U, E (16 B/lane) of every (bus, harmonic, scenario)
-    n_b, n_h, n_s = (int(a) for a in (sys.argv[3:6] if len(sys.argv) >= 6 else (1000, 26, 128)))
-    known = 48.0 * n_b * n_h * n_s
-    upd = out["per_step_bytes"].get("k_update")
-    if upd and upd["write"] > 0:
-        cal = known / upd["write"]
-        out["write_calibration"] = {"kernel": "k_update", "known_bytes": known, "counter_bytes": upd["write"], "factor": cal,
-                                    "note": "WRITE_SIZE over-counts the stores of these kernels; the tile-image LOADS calibrate at 1.0 "
-                                            "on k_back_q (raw FETCH_SIZE = inverse tiles + operands), with 8-byte accesses per "
-                                            "lane (up to v14) and with 16-byte accesses (v15: 0.83 -> 0.81 GB) alike"}
-        for k in out["per_step_bytes"]:
-            out["per_step_bytes"][k]["write_calibrated"] = out["per_step_bytes"][k]["write"] * cal
-    out["note"] = ("FETCH_SIZE/WRITE_SIZE are KB. MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reads exactly 1/2 of the bytes of a "
-                   "wide coalesced 16 B/lane stream and other widths are uncalibrated; on the tile images of the factor / back kernels "
-                   "(16 B/lane pairs + one 8 B/lane row group per lane, 1 KB / 512 B rows) the RAW value matches the known bytes "
-                   "(see write_calibration.note), so raw and doubled values are both given and the raw one is used.")
+            k = short(r["Kernel_Name"])
+            if k:
+                agg[k][0] += 1
+                agg[k][1] += float(r["Counter_Value"])
+        res[c] = agg
+    out = {"format": 2,
+           "command": "rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-trace --output-format csv -- python3 bench.py --steps 5 --warmup 2 "
+                      "--cpu-iters 0 --no-finish --no-single --sweep-1gpu 0 (two separate passes; tools/measure.sh <tag> pmc)",
+           "steps_profiled": steps, "fetch_factor": ff, "write_factor": wf, "calibration": os.path.relpath(calib, REPO),
+           "per_step_bytes": {}, "per_launch_bytes": {}}
+    for k, (nd, kb) in sorted(res["FETCH_SIZE"].items()):
+        wkb = res["WRITE_SIZE"].get(k, [0, 0.0])[1]
+        fe, wr = kb * 1024 * ff, wkb * 1024 * wf
+        if "<true>" in k or k in ("k_polar<false>", "k_polar<true>", "k_init_voltages", "k_fill", "k_finalize", "k_compact"):
+            continue                                            # set-up kernels (pf, initial state), not part of a timed step
+        out["per_step_bytes"][k] = {"fetch": fe / steps, "write": wr / steps, "dispatches_per_step": nd / steps}
+        out["per_launch_bytes"][k] = {"fetch": fe / nd, "write": wr / nd}
+    g = [k for k in out["per_launch_bytes"] if k.startswith("k_factor_q<") and k.endswith("false>")]
+    if g:
+        out["per_launch_bytes"]["k_factor_q_general"] = out["per_launch_bytes"][g[0]]
+    tot = sum(v["fetch"] + v["write"] for v in out["per_step_bytes"].values())
+    out["step_total_bytes"] = tot
+    out["note"] = ("per launch / per step: FETCH_SIZE x 1024 x %.3f + WRITE_SIZE x 1024 x %.3f (factors from the known-bytes calibration, = the "
+                   "guide's gfx950 correction); fabric-side counters: reads served by the Infinity Cache are included" % (ff, wf))
+    os.makedirs(os.path.dirname(out_path), exist_ok=True)
     json.dump(out, open(out_path, "w"), indent=1)
-    print(json.dumps(out["per_step_bytes"], indent=1))
+    for k, v in sorted(out["per_step_bytes"].items(), key=lambda kv: -(kv[1]["fetch"] + kv[1]["write"])):
+        print("%-28s fetch %8.1f MB  write %8.1f MB  per step (%5.1f launches)" % (k, v["fetch"] / 1e6, v["write"] / 1e6, v["dispatches_per_step"]))
+    print("step total %.2f GB" % (tot / 1e9))
 
 
 if __name__ == "__main__":
