@@ -184,6 +184,14 @@ def main():
     dm.sync()
     tim = dm.timing_get()
     dm.timing(False)
+    # ... and the dominant kernel's own duration on the device clock over K more steps WITHOUT event packets between the kernels
+    # (a HIP event record is a barrier packet with cache maintenance: it perturbs the ~25 us kernels it brackets)
+    dm.timing(2)
+    dm.timing_reset()
+    dm.iterate(args.steps)
+    dm.sync()
+    tim["gj_dev"] = dm.timing_get()["gj_dev"]
+    dm.timing(False)
 
     # ---- untimed: finish the solves with the reference's stop rule, gather convergence statistics (RCCL) ----------
     sweep = None
@@ -216,7 +224,8 @@ def main():
     bt = args.solver == "block_tree"
     G = 3 if S >= 24 else (2 if S >= 16 else 1)
     # ---- roofline of the dominant kernel, alone: k_factor_q<B,false> (block_tree) / the rocSOLVER LU (dense) ----------------------
-    gj_ms, gj_n = tim["gj"] if bt else tim["solve"]
+    gj_ms, gj_n = tim["gj_dev"] if (bt and tim.get("gj_dev", (0, 0))[1]) else (tim["gj"] if bt else tim["solve"])
+    ev_ms, ev_n = tim["gj"] if bt else tim["solve"]
     by_gj, fl_gj, ln_gj = dm.kernel_model("gj") if bt else dm.kernel_model("solve")
     launches_per_step = gj_n / max(K, 1)                                     # all scenario groups
     bytes_per_launch = by_gj * S / max(launches_per_step, 1)                 # average over its launches (tree levels x groups)
@@ -255,14 +264,18 @@ def main():
                      "frac": achieved_gbs / HBM_PEAK_GBS if achieved_gbs else None,
                      "traffic": traffic, "traffic_note": traffic_note,
                      "bytes_per_launch": bytes_per_launch, "flop_per_launch": flops_per_launch,
-                     "avg_ms": avg_ms, "launches_timed": gj_n, "launches_per_step": launches_per_step,
+                     "avg_ms": avg_ms, "avg_ms_hip_event_spans": ev_ms / max(ev_n, 1), "launches_timed": gj_n,
+                     "launches_per_step": launches_per_step,
                      "concurrent_groups": G,
                      "mfma": {"achieved": achieved_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": achieved_tf / FP64_PEAK_TFLOPS if achieved_tf else None},
                      "note": "achieved = algorithmic bytes of this kernel's buses (hpf_kernel_model: Schur complements in and out, "
-                             "inverses out, per-scenario bus operands) per launch / average launch duration (one HIP-event span per "
-                             "launch on the stream it runs on, %d spans); the launches of the %d scenario groups overlap on separate "
-                             "streams, so a launch shares the chip with the other groups' kernels.  arithmetic intensity %.2f flop/B "
+                             "inverses out, per-scenario bus operands) per launch / average launch duration.  Duration of a launch = last "
+                             "workgroup end - first workgroup start on the device's constant-rate clock (wall_clock64 stamps written by "
+                             "the kernel during the timing leg, %d launches) = what rocprofv3 --kernel-trace --stats averages for this "
+                             "kernel (profiles/); avg_ms_hip_event_spans is the same launches bracketed by HIP events on their streams, "
+                             "which adds the event packets and queue gaps around a ~25 us kernel.  The launches of the %d scenario groups "
+                             "overlap on separate streams, so a launch shares the chip with the other groups' kernels.  arithmetic intensity %.2f flop/B "
                              "< ridge %.1f: HBM-bound by the roofline, in practice bound by workgroup latency (DESIGN.md §5)"
                              % (gj_n, G, fl_gj / max(by_gj, 1.0), FP64_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS)},
         "roofline_factor_sweep": {"bound": "hbm", "kernels": "all factor kernels of a step (k_leaf_batch, k_sleaf_batch, k_factor_q)",

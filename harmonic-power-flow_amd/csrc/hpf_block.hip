@@ -821,8 +821,9 @@ int launch_back_w(hpf_handle* h, const TreeDev& T, const int* nodes, int count, 
 #include "hpf_quad.hpp"
 #include "hpf_leafbatch.hpp"
 
-// padded block size of the wave-per-bus path (0: use the 256-thread generic kernels)
-int wave_block_size(int b) { return b <= 12 ? 12 : (b <= 28 ? 28 : (b <= 52 ? 52 : 0)); }
+// padded block size of the multi-wave MFMA path: 12 / 28 / 52, and 100 for 52 < b <= 100 (K <= 49: BASELINE config 5; the general
+// Gauss-Jordan kernel only -- no constant-inverse leaves / lazy leaves / super-leaves there yet); 0: the 256-thread generic kernels
+int wave_block_size(int b) { return b <= 12 ? 12 : (b <= 28 ? 28 : (b <= 52 ? 52 : (b <= 100 ? 100 : 0))); }
 
 template <class T>
 int upload(hpf_handle* h, T** dst, const std::vector<T>& v) {
@@ -901,8 +902,9 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
             if (d->col[e] == p) e_up[i] = e;
         if (e_up[i] < 0 || e_dn[i] < 0) return HPF_E_TOPOLOGY;  // pattern not symmetric
     }
-    // buses whose whole subtree is linear: 2x2-per-harmonic algebra (wave-per-bus path only)
-    const bool use_lin = wave_block_size(b) != 0;
+    // buses whose whole subtree is linear: 2x2-per-harmonic algebra (multi-wave / wave-per-bus kernels only: the plain tree of a
+    // b > 52 model is the one the generic pivoted kernels run on, which eliminate every bus as a full block)
+    const bool use_lin = wave_block_size(b) != 0 && (contract || wave_block_size(b) <= 52);
     T.lin.assign(n, 0);
     if (use_lin) {
         for (int i = 0; i < n; ++i) T.lin[i] = (i < d->m || !d->coupled) ? 1 : 0;
@@ -1155,7 +1157,7 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
             return (long long)(e >> 1) * 2 * RG + (wv < NTq - 1 ? wv * 128 + (lg * 16 + jj) * 2 : (NTq - 1) * 128 + (lg * LW + jj) * 2) + (e & 1);
         return (long long)NP * 2 * RG + (wv < NTq - 1 ? wv * 64 + lg * 16 + jj : (NTq - 1) * 64 + lg * LW + jj);
     };
-    if (contract && d->coupled && BWc) {
+    if (contract && d->coupled && BWc && BWc <= 52) {
         typedef std::complex<double> cd;
         const int Hn = d->Hn, nnz = d->nnz;
         auto yv = [&](int q, int e) { return cd(d->Yval[((size_t)q * nnz + e) * 2], d->Yval[((size_t)q * nnz + e) * 2 + 1]); };
@@ -1909,6 +1911,12 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
                 HPF_FACTOR_CASE(28);
                 HPF_FACTOR_CASE(52);
 #undef HPF_FACTOR_CASE
+                case 100:       // 52 < b <= 100: general multi-wave kernel for every dense bus; pivoted mode = generic kernels below
+                    if (h->gj_mode == 1) {
+                        r = launch_factor_q2<100, false>(h, td, T.d_fdesc + FDESC * (size_t)T.lvl_ptr[l], cnt, active);
+                        break;
+                    }
+                    [[fallthrough]];
                 default:
                     switch (R) {
                         case 4: r = launch_factor<4>(h, td, nodes, cnt, active); break;
@@ -1951,6 +1959,12 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
                 }
                 r = h->gj_mode == 1 ? launch_back_q<52>(h, td, T.d_bdesc + 4 * (size_t)T.dep_ptr[dl], cnt, active) : launch_back_w<52>(h, td, nodes, cnt, active);
                 break;
+            case 100:
+                if (h->gj_mode == 1) {
+                    r = launch_back_q<100>(h, td, T.d_bdesc + 4 * (size_t)T.dep_ptr[dl], cnt, active);
+                    break;
+                }
+                [[fallthrough]];
             default: {
                 hipLaunchKernelGGL(k_tree_back, dim3((unsigned)cnt, (unsigned)h->cur_S), dim3(256), 0, h->cur_stream, h->n, h->c,
                                    h->Hn, td, nodes, b, h->N, h->Nc, active, h->d_Z, h->d_w, h->d_x, h->d_f, h->cur_s0);

@@ -11,7 +11,7 @@
 
 namespace hpf {
 
-enum { T_MISMATCH = 0, T_JACOBIAN = 1, T_SOLVE = 2, T_UPDATE = 3, T_BACK = 4, T_GJ = 5, T_COUNT = 6 };
+enum { T_MISMATCH = 0, T_JACOBIAN = 1, T_SOLVE = 2, T_UPDATE = 3, T_BACK = 4, T_GJ = 5, T_GJ_DEV = 6, T_COUNT = 7 };
 
 struct TimedSpan {
     int which;
@@ -178,10 +178,13 @@ struct hpf_handle {
     hipStream_t gstream[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t fork_ev = nullptr, join_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     rocblas_handle blas = nullptr;
-    bool timing = false;
+    int timing = 0;                   // hpf_timing_enable: 1 HIP-event spans + device stamps, 2 device stamps only (no event packets between kernels)
     std::vector<hpf::TimedSpan> spans;
-    double t_ms[hpf::T_COUNT] = {0, 0, 0, 0, 0, 0};
-    int64_t t_n[hpf::T_COUNT] = {0, 0, 0, 0, 0, 0};
+    double t_ms[hpf::T_COUNT] = {0, 0, 0, 0, 0, 0, 0};
+    int64_t t_n[hpf::T_COUNT] = {0, 0, 0, 0, 0, 0, 0};
+    static constexpr int TS_CAP = 16384;         // launches of the general factor kernel a timing leg can stamp
+    unsigned long long* d_tstamp = nullptr;      // [TS_CAP][2] first workgroup start / last workgroup end (wall_clock64) per launch
+    int ts_next = 0;
 };
 
 namespace hpf {
@@ -191,14 +194,14 @@ struct ScopedTimer {
     int which;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     ScopedTimer(hpf_handle* h_, int w) : h(h_), which(w) {
-        if (h->timing) {
+        if (h->timing == 1) {
             hipEventCreate(&e0);
             hipEventCreate(&e1);
             hipEventRecord(e0, h->cur_stream);
         }
     }
     ~ScopedTimer() {
-        if (h->timing) {
+        if (h->timing == 1) {
             hipEventRecord(e1, h->cur_stream);
             h->spans.push_back({which, e0, e1});
         }

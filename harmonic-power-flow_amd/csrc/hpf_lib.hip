@@ -399,7 +399,7 @@ int ensure_dense(hpf_handle* h, int Nsys) {
 }
 
 int resolve_spans(hpf_handle* h) {
-    if (h->spans.empty()) return HPF_OK;
+    if (h->spans.empty() && h->ts_next == 0) return HPF_OK;
     HIPCHK(hipStreamSynchronize(h->stream));
     for (auto& sp : h->spans) {
         float ms = 0.f;
@@ -410,6 +410,24 @@ int resolve_spans(hpf_handle* h) {
         hipEventDestroy(sp.e1);
     }
     h->spans.clear();
+    if (h->d_tstamp && h->ts_next > 0) {              // device-clock durations of the stamped general-factor-kernel launches
+        std::vector<unsigned long long> ts(2 * (size_t)h->ts_next);
+        HIPCHK(hipMemcpy(ts.data(), h->d_tstamp, sizeof(unsigned long long) * ts.size(), hipMemcpyDeviceToHost));
+        int khz = 100000;
+        hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->device);
+        for (int i = 0; i < h->ts_next; ++i)
+            if (ts[2 * i + 1] > ts[2 * i] && ts[2 * i] != ~0ull) {
+                h->t_ms[T_GJ_DEV] += (double)(ts[2 * i + 1] - ts[2 * i]) / (double)khz;
+                h->t_n[T_GJ_DEV] += 1;
+            }
+        h->ts_next = 0;
+        std::vector<unsigned long long> init(2 * (size_t)hpf_handle::TS_CAP);
+        for (size_t i = 0; i < init.size(); i += 2) {
+            init[i] = ~0ull;
+            init[i + 1] = 0ull;
+        }
+        HIPCHK(hipMemcpy(h->d_tstamp, init.data(), sizeof(unsigned long long) * init.size(), hipMemcpyHostToDevice));
+    }
     return HPF_OK;
 }
 
@@ -468,7 +486,7 @@ int launch_polar(hpf_handle* h) {
 
 // the Newton step of the multi-wave block-tree sweep works on bus-major images of the mismatch and of the step
 static bool bus_images(const hpf_handle* h) { return h->solver == HPF_SOLVER_BLOCK_TREE && h->has_ctree && h->gj_mode == 1; }
-static int tree_bst(const hpf_handle* h) { return 2 * h->Hn <= 12 ? 12 : (2 * h->Hn <= 28 ? 28 : (2 * h->Hn <= 52 ? 52 : 2 * h->Hn)); }
+static int tree_bst(const hpf_handle* h) { const int b = 2 * h->Hn; return b <= 12 ? 12 : (b <= 28 ? 28 : (b <= 52 ? 52 : (b <= 100 ? 100 : b))); }   // = wave_block_size, or b
 
 // stacked: also write the mismatch in the reference's stacked order (C ABI, dense solver, single-wave / generic tree kernels)
 template <bool FUND>
@@ -760,7 +778,7 @@ int nr_loop(hpf_handle* h, double thresh, int max_iter, int* n_iter, double* err
 void free_all(hpf_handle* h) {
     void* ptrs[] = {h->d_rowptr, h->d_col, h->d_diag, h->d_erow, h->d_dev, h->d_Y, h->d_YN, h->d_YNt, h->d_IN, h->d_P, h->d_Q,
                     h->d_Vm, h->d_Va, h->d_U, h->d_E, h->d_I0, h->d_f, h->d_errbits, h->d_err, h->d_niter, h->d_active,
-                    h->d_nactive, h->d_pivflag, h->d_mask, h->d_Vm0, h->d_Va0, h->d_hist, h->d_stats, h->d_J, h->d_ipiv, h->d_info, h->d_Z, h->d_w, h->d_x, h->d_linA, h->d_C, h->d_dbg, h->d_H, h->d_chG, h->d_chH, h->d_chD, h->d_chy, h->d_chZ, h->d_lfK, h->d_lfS, h->d_fb};
+                    h->d_nactive, h->d_pivflag, h->d_mask, h->d_Vm0, h->d_Va0, h->d_tstamp, h->d_hist, h->d_stats, h->d_J, h->d_ipiv, h->d_info, h->d_Z, h->d_w, h->d_x, h->d_linA, h->d_C, h->d_dbg, h->d_H, h->d_chG, h->d_chH, h->d_chD, h->d_chy, h->d_chZ, h->d_lfK, h->d_lfS, h->d_fb};
     for (void* p : ptrs)
         if (p) hipFree(p);
     tree_free(h);
@@ -1132,8 +1150,17 @@ int hpf_sync(hpf_handle* h) {
 
 int hpf_timing_enable(hpf_handle* h, int on) {
     if (!h) return HPF_E_ARG;
+    if (on && !h->d_tstamp && h->solver == HPF_SOLVER_BLOCK_TREE) {
+        std::vector<unsigned long long> init(2 * (size_t)hpf_handle::TS_CAP);
+        for (size_t i = 0; i < init.size(); i += 2) {
+            init[i] = ~0ull;
+            init[i + 1] = 0ull;
+        }
+        int rr = dev_upload(h, &h->d_tstamp, init.data(), init.size());
+        if (rr) return rr;
+    }
     int r = resolve_spans(h);
-    h->timing = on != 0;
+    h->timing = on == 2 ? 2 : (on != 0 ? 1 : 0);
     return r;
 }
 

@@ -145,17 +145,19 @@ __device__ __forceinline__ void lz_aop(const double* p, double (&a)[NT]) {
 // LEAF: every bus of the launch is a constant-inverse leaf (elimination level 0 of the contracted tree): the general path
 // (assembly, child sums, Gauss-Jordan) is compiled out and with it most of the register budget -> more workgroups per CU.
 template <int B, bool LEAF>
-__global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_OCC) : 5)) void k_factor_q(
+__global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 52 ? 2 : (B > 28 ? (LEAF ? 6 : HPF_Q_OCC) : 5))) void k_factor_q(
     Model M, TreeDev T, const int* __restrict__ nodes, int b, int N, int Nc, const int* __restrict__ active,
     const cplx* __restrict__ Uall, const cplx* __restrict__ Eall, const double* __restrict__ fall, double* __restrict__ Zall,
     double* __restrict__ wall, const double* __restrict__ linAall, double* __restrict__ Call, double* __restrict__ Hall,
     const cplx* __restrict__ I0all, const double* __restrict__ chG, const double* __restrict__ chH,
     const double* __restrict__ chD, const double* __restrict__ chy, const double* __restrict__ Minv,
     double* __restrict__ lfK, double* __restrict__ lfS, long long* __restrict__ dbg, int ablate, int s0,
-    int* __restrict__ pivflag, double piv_limit) {
+    int* __restrict__ pivflag, double piv_limit, unsigned long long* __restrict__ tstamp) {
     constexpr int NT = (B + 16) / 16;
     constexpr size_t CT = (size_t)NT * NT * 256;
     constexpr int tcB = B >> 4, jjB = B & 15;
+    constexpr int RP = 16 * NT > 64 ? 16 * NT : 64;     // rows the per-row roles cover (one lane per row, 64 per wave: B > 64 takes two waves)
+    constexpr bool SPECIAL = B <= 52;                   // constant-inverse leaves, lazy leaves, super-leaves exist (tree_build: b <= 52 only)
     HPF_STAMP_DECL;      // cycle stamps of wave 0: -DHPF_FACTOR_STAMPS build only
 #ifdef HPF_FACTOR_STAMPS
     long long sa = 0, sc = 0, gown = 0, gwait = 0, gmf = 0;
@@ -163,6 +165,8 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
     HPF_STAMP(st0);
     const int s = active ? active[blockIdx.y + s0] : (int)blockIdx.y + s0;   // slot -> scenario (active list; -1: frozen / empty slot)
     if (s < 0) return;
+    // timing leg only (hpf_timing_enable): first start / last end of the launch's workgroups on the device's constant-rate clock
+    if (tstamp && threadIdx.x == 0) atomicMin(tstamp, (unsigned long long)wall_clock64());
     // node record: everything the block needs to form its addresses, behind one scalar load (Tree::d_fdesc)
     const int4* nd = reinterpret_cast<const int4*>(nodes) + (FDESC / 4) * (size_t)blockIdx.x;
     const int4 nd0 = nd[0], nd1 = nd[1], nd2 = nd[2], nd3 = nd[3];
@@ -170,12 +174,12 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
     const int e_dn_k = nd1.x, e_up_k = nd1.y, lin_beg = nd1.z, lin_end = nd1.z + nd1.w;
     const int den_beg = nd2.x, n_den = nd2.y;
     const bool via_chain = (nd3.z & 1) != 0; // linked to the dense parent through a contracted chain (k_chain_factor)
-    const bool lazy_leaf = (nd3.z & 2) != 0; // the parent rebuilds this leaf's Schur complement itself: only G w goes to HBM
+    const bool lazy_leaf = SPECIAL && (nd3.z & 2) != 0; // the parent rebuilds this leaf's Schur complement itself: only G w goes to HBM
     const int cleafv = nd3.w;                // constant-inverse leaf: 1 + slot in Minv (0: general path; < 0: lazy-leaf record)
-    const bool cleaf = LEAF || cleafv > 0;
-    const bool sleaf = !LEAF && (nd3.z & 4) != 0;   // super-leaf: every dense child is a lazy leaf -> bordered low-rank inverse, no Gauss-Jordan
-    const bool slback = !LEAF && (nd3.z & 8) != 0;  // ... whose back sweep rebuilds D^-1 t from T^-1 (k_sleaf_back_batch): no inverse goes to HBM
-    const bool lazy = !LEAF && cleafv < 0;   // this bus has lazy leaves below it
+    const bool cleaf = SPECIAL && (LEAF || cleafv > 0);
+    const bool sleaf = SPECIAL && !LEAF && (nd3.z & 4) != 0;   // super-leaf: every dense child is a lazy leaf -> bordered low-rank inverse, no Gauss-Jordan
+    const bool slback = SPECIAL && !LEAF && (nd3.z & 8) != 0;  // ... whose back sweep rebuilds D^-1 t from T^-1 (k_sleaf_back_batch): no inverse goes to HBM
+    const bool lazy = SPECIAL && !LEAF && cleafv < 0;   // this bus has lazy leaves below it
     const bool cleafr = cleaf || sleaf;      // roles of a constant-part bus: S^-1 staged, network diagonal lives in the images
     // lazy-leaf record (Tree::d_lzrec, 8 ints: image offset, L, leaf ids[4])
     int4 lzA = {0, 0, -1, -1}, lzB = {-1, -1, 0, 0}, lzC = {-1, -1, 0, 0};
@@ -201,8 +205,8 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
     const double* Cs = Call + (size_t)s * n * CT;
 
     __shared__ double tab[(B / 2) * 8];
-    __shared__ double dgb[64 * 3];          // per row: harmonic-diagonal 2x2 part (d0, d1) and right-hand side y
-    __shared__ double cc[NT][64 * 3];       // the linear children's contributions to (d0, d1, y), one slot per wave
+    __shared__ double dgb[RP * 3];          // per row: harmonic-diagonal 2x2 part (d0, d1) and right-hand side y
+    __shared__ double cc[NT][RP * 3];       // the linear children's contributions to (d0, d1, y), one slot per wave
     __shared__ double panel[2][NT * 64];
     __shared__ double wl[2][16], pv[2][16];
     __shared__ double gl[NT * 32], hl[NT * 32];
@@ -221,21 +225,24 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
         const double2* ynd = reinterpret_cast<const double2*>(M.YN + (size_t)devk * Hn * Hn);
         double2* yl = reinterpret_cast<double2*>(ynl);
         const int t0 = tid - 64 * (NT / 2);
-        double2 y0 = {0.0, 0.0}, y1 = y0, y2 = y0, y3 = y0, y4 = y0, y5 = y0;      // (named scalars: an array here goes to scratch)
-        static_assert(YNL <= 6, "staging registers");
-        if (YNL > 0 && t0 < Hn * Hn) y0 = ynd[t0];
-        if (YNL > 1 && t0 + YT < Hn * Hn) y1 = ynd[t0 + YT];
-        if (YNL > 2 && t0 + 2 * YT < Hn * Hn) y2 = ynd[t0 + 2 * YT];
-        if (YNL > 3 && t0 + 3 * YT < Hn * Hn) y3 = ynd[t0 + 3 * YT];
-        if (YNL > 4 && t0 + 4 * YT < Hn * Hn) y4 = ynd[t0 + 4 * YT];
-        if (YNL > 5 && t0 + 5 * YT < Hn * Hn) y5 = ynd[t0 + 5 * YT];
-        __builtin_amdgcn_sched_barrier(0);
-        if (YNL > 0 && t0 < Hn * Hn) yl[t0] = y0;
-        if (YNL > 1 && t0 + YT < Hn * Hn) yl[t0 + YT] = y1;
-        if (YNL > 2 && t0 + 2 * YT < Hn * Hn) yl[t0 + 2 * YT] = y2;
-        if (YNL > 3 && t0 + 3 * YT < Hn * Hn) yl[t0 + 3 * YT] = y3;
-        if (YNL > 4 && t0 + 4 * YT < Hn * Hn) yl[t0 + 4 * YT] = y4;
-        if (YNL > 5 && t0 + 5 * YT < Hn * Hn) yl[t0 + 5 * YT] = y5;
+        if constexpr (YNL <= 6) {
+            double2 y0 = {0.0, 0.0}, y1 = y0, y2 = y0, y3 = y0, y4 = y0, y5 = y0;      // (named scalars: an array here goes to scratch)
+            if (YNL > 0 && t0 < Hn * Hn) y0 = ynd[t0];
+            if (YNL > 1 && t0 + YT < Hn * Hn) y1 = ynd[t0 + YT];
+            if (YNL > 2 && t0 + 2 * YT < Hn * Hn) y2 = ynd[t0 + 2 * YT];
+            if (YNL > 3 && t0 + 3 * YT < Hn * Hn) y3 = ynd[t0 + 3 * YT];
+            if (YNL > 4 && t0 + 4 * YT < Hn * Hn) y4 = ynd[t0 + 4 * YT];
+            if (YNL > 5 && t0 + 5 * YT < Hn * Hn) y5 = ynd[t0 + 5 * YT];
+            __builtin_amdgcn_sched_barrier(0);
+            if (YNL > 0 && t0 < Hn * Hn) yl[t0] = y0;
+            if (YNL > 1 && t0 + YT < Hn * Hn) yl[t0 + YT] = y1;
+            if (YNL > 2 && t0 + 2 * YT < Hn * Hn) yl[t0 + 2 * YT] = y2;
+            if (YNL > 3 && t0 + 3 * YT < Hn * Hn) yl[t0 + 3 * YT] = y3;
+            if (YNL > 4 && t0 + 4 * YT < Hn * Hn) yl[t0 + 4 * YT] = y4;
+            if (YNL > 5 && t0 + 5 * YT < Hn * Hn) yl[t0 + 5 * YT] = y5;
+        } else {
+            for (int i = t0; i < Hn * Hn; i += YT) yl[i] = ynd[i];
+        }
     }
     // ---- A1. roles before the first barrier.  Every role FIRST issues all its loads (addresses come from the node record
     //      alone), then computes from registers with the value forms of the per-entry formulas (blk_current / blk_power_off /
@@ -315,14 +322,18 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
     {
         // lane = row 2q+tr_: wave 0 forms the network part of the harmonic-diagonal 2x2 and the right-hand side; the children
         // folded in 2x2-per-harmonic algebra (linear subtrees, contracted chains) are dealt to the waves, lightest roles first
-        const int q = lane >> 1, tr_ = lane & 1;
-        const bool rowvalid = lane < b && loc_valid(n, c, k, lane);
+        // (B > 64: rows 64.. are formed by wave 1 and the children loop takes a second slice of rows)
+#pragma unroll
+        for (int rb = 0; rb < RP; rb += 64) {
+        const int rw = rb + lane;
+        const int q = rw >> 1, tr_ = rw & 1;
+        const bool rowvalid = rw < b && loc_valid(n, c, k, rw);
         const size_t kq = (size_t)k * Hn + (q < Hn ? q : 0);
-        if (wv == 0) {
+        if (wv == rb / 64) {
             double y = 0.0, d0 = 0.0, d1 = 0.0;
             if (rowvalid) {
                 const bool prow = q == 0 && k < M.m;                     // power row (HG:451-459)
-                const double fy = fall[((size_t)s * n + k) * B + lane];  // bus-major mismatch image (k_mismatch)
+                const double fy = fall[((size_t)s * n + k) * B + rw];  // bus-major mismatch image (k_mismatch)
                 const cplx yd = M.Y[(size_t)diag_e * Hn + q];
                 const cplx uk = U[kq], ek = E[kq];
                 cplx yn = {0.0, 0.0}, I0v = {0.0, 0.0};
@@ -356,9 +367,11 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
             asm volatile("" : "+v"(d0), "+v"(d1), "+v"(y));
             sd2 = __builtin_amdgcn_s_memtime();
 #endif
-            dgb[lane * 3 + 0] = d0;
-            dgb[lane * 3 + 1] = d1;
-            dgb[lane * 3 + 2] = y;
+            if (rw < RP) {                                  // (RP = 112 at B = 100: the second slice is 48 rows)
+                dgb[rw * 3 + 0] = d0;
+                dgb[rw * 3 + 1] = d1;
+                dgb[rw * 3 + 2] = y;
+            }
         }
         const int slot = (wv + NT - (2 % NT)) % NT;          // waves 2, 3 have the lightest roles: they take the first children
         if (lin_beg + slot < lin_end) {
@@ -394,10 +407,13 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
                     ey = fma(g1, wc.y, ey);
                 }
             }
-            cc[slot][lane * 3 + 0] = e0;
-            cc[slot][lane * 3 + 1] = e1;
-            cc[slot][lane * 3 + 2] = ey;
+            if (rw < RP) {
+                cc[slot][rw * 3 + 0] = e0;
+                cc[slot][rw * 3 + 1] = e1;
+                cc[slot][rw * 3 + 2] = ey;
+            }
         }
+    }
     }
     // ---- B0. Schur complement of the FIRST dense child (accumulator layout, own tile column): the loads are issued here, after
     //      the role loads (loads return in order: a role must not wait behind them), and first touched after the assembly ----------
@@ -516,7 +532,7 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
     }
     // super-leaf: stage the per-model constants and everything of T that does not depend on this bus's own roles (all of it but
     // the 2x2 term of the fundamental) while the roles' loads are in flight
-    __shared__ double slb[2 * B * 10 + 200 + 4];
+    __shared__ double slb[SPECIAL ? 2 * B * 10 + 200 + 4 : 1];
     if (sleaf) {
         const int L = lzA.y, m = 2 + 2 * L, m2 = 2 * m;
         const double* simg = T.lzimg + (size_t)lzB.w;                    // Tc [m][m] | Pb [b][m] | Qb [m][b]
@@ -584,7 +600,7 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
     HPF_STAMP(sa);
     {
         const int nw = (lin_end - lin_beg) < NT ? (lin_end - lin_beg) : NT;
-        for (int idx = tid; idx < 64 * 3; idx += 64 * NT) {
+        for (int idx = tid; idx < RP * 3; idx += 64 * NT) {
             double v = dgb[idx];
             for (int w2 = 0; w2 < nw; ++w2) v -= cc[w2][idx];       // fixed order
             dgb[idx] = v;
@@ -1022,6 +1038,10 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 28 ? (LEAF ? 6 : HPF_Q_O
                 if (16 * (e >> 2) + 4 * (e & 3) < B) Ck[16 * (e >> 2) + 4 * (e & 3) + lg] = cv[e];
         }
     }
+    if (tstamp) {
+        __syncthreads();
+        if (threadIdx.x == 0) atomicMax(tstamp + 1, (unsigned long long)wall_clock64());
+    }
 #ifdef HPF_FACTOR_STAMPS
     if ((ablate & 16) && tid == 0 && dbg) {
         st6 = __builtin_amdgcn_s_memtime();
@@ -1060,8 +1080,9 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16)) void k_back_q(
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = M.n, c = M.c, Hn = M.Hn;
     double* xs = xall + (size_t)s * n * B;
-    __shared__ double part[NT][64];
-    __shared__ double mcl[64 * 2], zl[64];
+    constexpr int RP = 16 * NT > 64 ? 16 * NT : 64;
+    __shared__ double part[NT][RP];
+    __shared__ double mcl[RP * 2], zl[RP];
     double x = 0.0;
     if (tid < B) x = wall[((size_t)s * n + k) * B + tid];
     if (par >= 0) {
@@ -1139,12 +1160,14 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16)) void k_back_q(
 template <int B, bool LEAF>
 int launch_factor_q2(hpf_handle* h, const TreeDev& T, const int* nodes, int count, const int* active) {
     ScopedTimer t(h, LEAF ? T_SOLVE : T_GJ);            // T_GJ: the general kernel k_factor_q<B, false> alone (roofline numerator: hpf_kernel_model)
+    unsigned long long* ts = nullptr;                   // device-clock stamps of this launch (timing leg, general kernel only)
+    if (!LEAF && h->timing && h->d_tstamp && h->ts_next < hpf_handle::TS_CAP) ts = h->d_tstamp + 2 * (size_t)(h->ts_next++);
     constexpr int NT = (B + 16) / 16;
     const dim3 grid((unsigned)count, (unsigned)h->cur_S);
     hipLaunchKernelGGL((k_factor_q<B, LEAF>), grid, dim3(64 * NT), 0, h->cur_stream, h->M, T, nodes,
                        2 * h->Hn, h->N, h->Nc, active, h->d_U, h->d_E, h->d_fb, h->d_Z, h->d_w, h->d_linA, h->d_C, h->d_H,
                        h->d_I0, h->d_chG, h->d_chH, h->d_chD, h->d_chy, active_tree(h).d_Minv, h->d_lfK, h->d_lfS, h->d_dbg, h->debug_ablate, h->cur_s0,
-                       h->d_pivflag, h->piv_limit);
+                       h->d_pivflag, h->piv_limit, ts);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         h->last_detail = (int)e;

@@ -195,7 +195,7 @@ class DeviceModel:
 
     def timing_get(self):
         out = {}
-        for which, name in enumerate(("mismatch", "jacobian", "solve", "update", "back", "gj")):
+        for which, name in enumerate(("mismatch", "jacobian", "solve", "update", "back", "gj", "gj_dev")):
             ms = C.c_double()
             cnt = C.c_int64()
             self._chk(self.lib.hpf_timing_get(self._h, which, C.byref(ms), C.byref(cnt)), "hpf_timing_get")

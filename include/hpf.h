@@ -175,9 +175,13 @@ int  hpf_sync(hpf_handle* h);
  * 2 linear solve (DENSE: getrf+getrs, one span per step; BLOCK_TREE: one span per launch of a factor kernel OTHER than the
  *   general one: k_leaf_batch, k_sleaf_batch, the leaf-only k_factor_q<B,true>, the pivoted / generic kernels),
  * 3 state update, 4 back-substitution sweep (BLOCK_TREE only; one span per Newton step and scenario group),
- * 5 BLOCK_TREE: one span per launch of the general factor kernel k_factor_q<B,false> (the dominant kernel of a step).
+ * 5 BLOCK_TREE: one span per launch of the general factor kernel k_factor_q<B,false> (the dominant kernel of a step),
+ * 6 the same launches on the DEVICE clock: last workgroup end - first workgroup start (wall_clock64 stamps written by the kernel
+ *   while timing is enabled) -- what rocprofv3 --kernel-trace reports as the kernel's duration; a HIP-event span additionally
+ *   holds the event packets and the queue gaps around a ~25 us kernel.
  * Returns total milliseconds in *ms and the number of timed spans in *launches. */
-int  hpf_timing_enable(hpf_handle* h, int on);
+int  hpf_timing_enable(hpf_handle* h, int on);   /* 1: HIP-event spans (classes 0..5) + device stamps (6); 2: device stamps only --
+                                                    no event packets between the kernels, the launches run exactly as untimed; 0: off */
 int  hpf_timing_get(hpf_handle* h, int which, double* ms, int64_t* launches);
 int  hpf_timing_reset(hpf_handle* h);
 /* FP64 flop count of the span `which == 2` for ONE scenario and ONE Newton step (roofline numerator):

@@ -418,30 +418,48 @@ def test_block_pivoting_option_gives_same_solution(tmp_path):
     assert np.abs(U0 - U1).max() < 1e-10
 
 
-def test_k49_generic_block_path_matches_dense(tmp_path):
-    """BASELINE config 5 shape in small: K = 49 harmonics (block size 100 > 52 -> generic 256-thread block kernels, no MFMA,
-    no linear-subtree shortcut) against the dense rocSOLVER step on a 60-bus feeder."""
+@pytest.mark.parametrize("hmax,pivoting", [(99, 0), (99, 1), (59, 0), (75, 0)])
+def test_large_blocks_k49_match_dense(tmp_path, hmax, pivoting):
+    """BASELINE config 5 shape in small: K = 49 harmonics (b = 100), and K = 29 / 37 (b = 60 / 76 padded to 100): the multi-wave
+    MFMA factor kernel k_factor_q<100> (7 wavefronts per bus, rows spread over two waves) + contracted tree + 2x2 kernels -- and,
+    with block_pivoting = 1, the generic 256-thread pivoted kernels on the plain tree -- against the dense rocSOLVER path on a
+    60-bus feeder: first Newton step and converged voltages."""
     hp = _hp()
     out = {}
     for solver in ("dense", "block_tree"):
-        st, buses, lines, dm, _ = _syn_model(hp, 60, 99, solver, tmp_path)
+        st, buses, lines, dm, _ = _syn_model(hp, 60, hmax, solver, tmp_path)
         try:
-            assert dm.Hn == 50
+            assert dm.Hn == (hmax + 1) // 2
+            if solver == "block_tree":
+                dm.set_option("block_pivoting", pivoting)
             dm.set_loads(buses["P"].to_numpy(float), buses["Q"].to_numpy(float))
             dm.set_state(None, None, n_scen=1)
             dm.fund_pf(1e-6, 30)
             v0 = dm.get_state()
+            if "dense" in out:
+                dm.set_state(*out["dense"][0])
             dm.mismatch()
             dm.iterate(1)
             dm.sync()
-            out[solver] = (v0, dm.get_state())
+            v1 = dm.get_state()
+            dm.set_state(*(out["dense"][0] if "dense" in out else v0))
+            n_iter, err, _ = dm.solve(1e-4, 50)
+            dm.mismatch(want_f=False)
+            dm.iterate(2)
+            dm.sync()
+            out[solver] = (v0, v1, dm.get_state(), int(n_iter[0]), float(err[0]), dm.stats())
         finally:
             dm.close()
-    (v0d, v1d), (v0b, v1b) = out["dense"], out["block_tree"]
+    (v0d, v1d, vfd, itd, ed, _), (v0b, v1b, vfb, itb, eb, stb) = out["dense"], out["block_tree"]
     step = np.abs(v1d[0] - v0d[0]).max()
     assert step > 1e-3
     assert np.abs(v1d[0] - v1b[0]).max() <= 1e-9 * max(1.0, step)
     assert np.abs(v1d[1] - v1b[1]).max() <= 1e-9 * max(1.0, np.abs(v1d[1] - v0d[1]).max())
+    assert ed <= 1e-4 and eb <= 1e-4 and (stb["flags"][0] & (8 | 16 | 32)) == 0
+    Ud = vfd[0][0] * np.exp(1j * vfd[1][0])
+    Ub = vfb[0][0] * np.exp(1j * vfb[1][0])
+    print(f"\nH_MAX={hmax} pivoting={pivoting}: dense {itd} it, block_tree {itb} it, fixed points differ by {np.abs(Ud - Ub).max():.2e}")
+    assert np.abs(Ud - Ub).max() < TOL_V
 
 
 @pytest.mark.gpu
