@@ -20,6 +20,8 @@
 #include <complex>
 #include <cstdio>
 #include <cstdlib>
+#include <rocsolver/rocsolver.h>
+
 #include "hpf_internal.hpp"
 #include "hpf_gj.hpp"
 #include "hpf_gj_mfma.hpp"
@@ -869,6 +871,79 @@ int launch_factor(hpf_handle* h, const TreeDev& T, const int* nodes, int count, 
     return HPF_OK;
 }
 
+
+// =============================================================================================================
+// Meshed networks on the block-tree path: "bordered Newton step".
+// The admittance pattern = BFS spanning tree + k loop-closing lines (ties).  With J_t = the Jacobian without the ties' off-
+// diagonal blocks (their admittances stay on the diagonals: J_t's bus blocks are J's), J = J_t + E_T Q^T, where T = the ties'
+// endpoint buses, E_T = identity columns of their equations (m = |T| 2Hn) and row (i, l) of Q^T = sum over ties (i,j) of
+// A(i,j)[l, :] E_j^T -- harmonic-diagonal 2x2 blocks like every off-diagonal block.  Then (Woodbury in its bordered form)
+//     y = J_t^-1 f,  Z = J_t^-1 E_T,  (I + Q^T Z) g = Q^T y,  x = y - Z g.
+// y and the m columns of Z are 1 + m right-hand sides of the SAME tree system: they run as 1 + m virtual scenarios (same
+// voltages, different mismatch images) through the unchanged block-tree kernels -- every kernel stays as tested; the m x m
+// border system goes to rocSOLVER.  Cost: (1 + m) x one scenario's step per real scenario (m <= 1024).
+// =============================================================================================================
+// virtual slot v0 + v <- state of real scenario r; mismatch image: v = 0 the scenario's own, v >= 1 the unit vector of border row v - 1
+__global__ __launch_bounds__(256) void k_border_prepare(int n, int Hn, int Bst, int b, int r, int v0, const int* __restrict__ tb_bus,
+                                                        cplx* __restrict__ U, cplx* __restrict__ E, cplx* __restrict__ I0,
+                                                        double* __restrict__ fb) {
+    const int v = blockIdx.y;
+    const size_t dst = (size_t)(v0 + v);
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < n * Hn) {
+        U[dst * n * Hn + t] = U[(size_t)r * n * Hn + t];
+        E[dst * n * Hn + t] = E[(size_t)r * n * Hn + t];
+    }
+    if (t < n) I0[dst * n + t] = I0[(size_t)r * n + t];
+    if (t < n * Bst) {
+        double val = 0.0;
+        if (v == 0) {
+            val = fb[(size_t)r * n * Bst + t];
+        } else {
+            const int a = (v - 1) / b, l = (v - 1) - a * b;
+            if (t == tb_bus[a] * Bst + l) val = 1.0;
+        }
+        fb[dst * n * Bst + t] = val;
+    }
+}
+
+// border system: M[row, col] = delta + (Q^T z_col)[row], rhs[row] = (Q^T y)[row]; row = (endpoint a, local row l), z_col = x of virtual
+// slot v0 + 1 + col, y = x of virtual slot v0
+__global__ __launch_bounds__(256) void k_border_build(Model M, int Bst, int b, int r, int v0, int m, const int* __restrict__ tb_bus,
+                                                      const int* __restrict__ tb_ptr, const int* __restrict__ tb_adj,
+                                                      const cplx* __restrict__ Uall, const cplx* __restrict__ Eall,
+                                                      const double* __restrict__ xall, double* __restrict__ bM, double* __restrict__ brhs) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    const int col = blockIdx.y;                        // 0: right-hand side, 1 + c: column c of the border matrix
+    if (row >= m) return;
+    const int a = row / b, l = row - a * b, q = l >> 1, t = l & 1;
+    const int i = tb_bus[a];
+    const size_t so = (size_t)r * M.n * M.Hn;
+    const double* x = xall + (size_t)(v0 + col) * M.n * Bst;
+    double acc = 0.0;
+    for (int e = tb_ptr[a]; e < tb_ptr[a + 1]; ++e) {
+        const int j = tb_adj[3 * e], ent = tb_adj[3 * e + 1];
+        double g4[4];
+        coupling_block(M, Uall + so, Eall + so, q, i, j, ent, g4);          // A(i, j) at harmonic position q, masked
+        acc = fma(g4[t * 2], x[(size_t)j * Bst + 2 * q], acc);
+        acc = fma(g4[t * 2 + 1], x[(size_t)j * Bst + 2 * q + 1], acc);
+    }
+    if (col == 0)
+        brhs[row] = acc;
+    else
+        bM[(size_t)(col - 1) * m + row] = acc + (row == col - 1 ? 1.0 : 0.0);
+}
+
+// x(real scenario r) = y - Z g
+__global__ __launch_bounds__(256) void k_border_apply(int count, int r, int v0, int m, const double* __restrict__ g,
+                                                      double* __restrict__ xall) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= count) return;
+    double acc = xall[(size_t)v0 * count + t];
+    for (int c2 = 0; c2 < m; ++c2) acc = fma(-g[c2], xall[(size_t)(v0 + 1 + c2) * count + t], acc);
+    xall[(size_t)r * count + t] = acc;
+}
+
 }  // namespace
 
 namespace hpf {
@@ -877,7 +952,7 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
     const int n = d->n;
     const int b = 2 * d->Hn;
     if (b > 16 * 7) return HPF_E_ARG;                          // register tile limit (K <= 55)
-    if (d->nnz != n + 2 * (n - 1)) return HPF_E_TOPOLOGY;
+    if (d->nnz != n + 2 * (n - 1) + 2 * h->n_ties) return HPF_E_TOPOLOGY;   // (tree_find_ties counted the loop-closing lines)
     T.parent.assign(n, -2);
     std::vector<int> order, depth(n, 0), height(n, 0), e_up(n, -1), e_dn(n, -1);
     order.reserve(n);
@@ -1770,11 +1845,14 @@ static void tree_free_one(Tree& T) {
 void tree_free(hpf_handle* h) {
     tree_free_one(h->tree);
     tree_free_one(h->ctree);
+    void* bp[] = {h->d_tb_bus, h->d_tb_ptr, h->d_tb_adj, h->d_bM, h->d_brhs, h->d_bipiv, h->d_binfo};
+    for (void* q2 : bp)
+        if (q2) hipFree(q2);
 }
 
 int tree_alloc_scenarios(hpf_handle* h) {
     const int bw = wave_block_size(2 * h->Hn);
-    const size_t b = bw ? (size_t)bw : 2 * (size_t)h->Hn, S = h->S_max, n = h->n;
+    const size_t b = bw ? (size_t)bw : 2 * (size_t)h->Hn, S = h->S_alloc, n = h->n;
     hipError_t e;
     const size_t ct = bw ? (size_t)(((bw + 16) / 16) * ((bw + 16) / 16) * 256) : 0;     // accumulator-tile image of a block
     if ((e = hipMalloc((void**)&h->d_Z, sizeof(double) * S * n * (b * b > ct ? b * b : ct))) != hipSuccess ||
@@ -2031,6 +2109,125 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
             h->last_detail = (int)e;
             return HPF_E_HIP;
         }
+    }
+    return HPF_OK;
+}
+
+// BFS spanning tree of the admittance pattern from bus 0 (the SAME visiting order as tree_build_into) and the entries that are
+// not tree edges: loop-closing lines.  Fills h->n_ties / n_tb / m_border and the device lists; radial networks: all zero.
+int tree_find_ties(hpf_handle* h, const hpf_desc* d) {
+    const int n = d->n;
+    std::vector<int> parent(n, -2), order;
+    order.reserve(n);
+    order.push_back(0);
+    parent[0] = -1;
+    for (size_t oi = 0; oi < order.size(); ++oi) {
+        const int i = order[oi];
+        for (int e = d->rowptr[i]; e < d->rowptr[i + 1]; ++e) {
+            const int j = d->col[e];
+            if (j != i && parent[j] == -2) {
+                parent[j] = i;
+                order.push_back(j);
+            }
+        }
+    }
+    if ((int)order.size() != n) return HPF_E_TOPOLOGY;               // not connected
+    std::vector<std::vector<std::pair<int, int>>> adj(n);           // per bus: (other endpoint, CSR entry (i, j)) of its ties
+    int n_entries = 0;
+    for (int i = 0; i < n; ++i)
+        for (int e = d->rowptr[i]; e < d->rowptr[i + 1]; ++e) {
+            const int j = d->col[e];
+            if (j == i || parent[i] == j || parent[j] == i) continue;
+            adj[i].push_back({j, e});
+            ++n_entries;
+        }
+    if (n_entries & 1) return HPF_E_TOPOLOGY;                       // pattern not symmetric
+    for (int i = 0; i < n; ++i)
+        for (auto& pr : adj[i]) {
+            bool back = false;
+            for (auto& q2 : adj[pr.first]) back = back || q2.first == i;
+            if (!back) return HPF_E_TOPOLOGY;
+        }
+    h->n_ties = n_entries / 2;
+    h->n_tb = 0;
+    h->m_border = 0;
+    if (h->n_ties == 0) return HPF_OK;
+    std::vector<int> tb_bus, tb_ptr(1, 0), tb_adj;
+    for (int i = 0; i < n; ++i) {
+        if (adj[i].empty()) continue;
+        tb_bus.push_back(i);
+        for (auto& pr : adj[i]) {
+            tb_adj.push_back(pr.first);
+            tb_adj.push_back(pr.second);
+            tb_adj.push_back(0);
+        }
+        tb_ptr.push_back((int)tb_adj.size() / 3);
+    }
+    h->n_tb = (int)tb_bus.size();
+    h->m_border = h->n_tb * 2 * d->Hn;
+    if (h->m_border > 1024 || wave_block_size(2 * d->Hn) == 0) return HPF_E_TOPOLOGY;   // stated bound of the bordered step (hpf.h)
+    int r;
+    if ((r = upload(h, &h->d_tb_bus, tb_bus))) return r;
+    if ((r = upload(h, &h->d_tb_ptr, tb_ptr))) return r;
+    if ((r = upload(h, &h->d_tb_adj, tb_adj))) return r;
+    const size_t m = (size_t)h->m_border;
+    if (hipMalloc((void**)&h->d_bM, sizeof(double) * m * m) != hipSuccess || hipMalloc((void**)&h->d_brhs, sizeof(double) * m) != hipSuccess ||
+        hipMalloc((void**)&h->d_bipiv, sizeof(int) * m) != hipSuccess || hipMalloc((void**)&h->d_binfo, sizeof(int)) != hipSuccess)
+        return HPF_E_NOMEM;
+    return HPF_OK;
+}
+
+// Newton step of a network with loop-closing lines (see the kernels above): for every running real scenario, 1 + m virtual
+// scenarios through tree_newton_step, then the border system.  Called with the launch context on h->stream over real slots.
+int tree_newton_step_bordered(hpf_handle* h, bool only_active) {
+    const int m = h->m_border, V = 1 + m, v0 = h->S_max;
+    const int b = 2 * h->Hn, BW = wave_block_size(b), n = h->n;
+    const int s0 = h->cur_s0, cnt = h->cur_S;
+    hipStream_t st = h->stream;
+    std::vector<int> todo;
+    for (int slot = s0; slot < s0 + cnt; ++slot) {
+        const int sc = only_active ? ((size_t)slot < h->host_act.size() ? h->host_act[slot] : -1) : slot;
+        if (sc >= 0) todo.push_back(sc);
+    }
+    const int save_groups = h->n_groups;
+    for (int r : todo) {
+        const int cmax = n * BW;
+        hipLaunchKernelGGL(k_border_prepare, dim3((unsigned)((cmax + 255) / 256), (unsigned)V), dim3(256), 0, st, n, h->Hn, BW, b, r, v0,
+                           h->d_tb_bus, h->d_U, h->d_E, h->d_I0, h->d_fb);
+        // the 1 + m virtual scenarios: slots [v0, v0 + V), scenario groups on their own streams as usual
+        {
+            const int G = V >= 24 ? (save_groups < 1 ? 1 : save_groups) : 1;
+            hipEventRecord(h->fork_ev, st);
+            int rc = HPF_OK;
+            for (int g = 0; g < G && rc == HPF_OK; ++g) {
+                const int a0 = (int)((long long)V * g / G), a1 = (int)((long long)V * (g + 1) / G);
+                hipStream_t gs = G > 1 ? h->gstream[g] : st;
+                if (G > 1) hipStreamWaitEvent(gs, h->fork_ev, 0);
+                h->cur_stream = gs;
+                h->cur_s0 = v0 + a0;
+                h->cur_S = a1 - a0;
+                rc = tree_newton_step(h, false);
+                if (G > 1) hipEventRecord(h->join_ev[g], gs);
+            }
+            if (G > 1)
+                for (int g = 0; g < G; ++g) hipStreamWaitEvent(st, h->join_ev[g], 0);
+            h->cur_stream = st;
+            h->cur_s0 = s0;
+            h->cur_S = cnt;
+            if (rc) return rc;
+        }
+        hipLaunchKernelGGL(k_border_build, dim3((unsigned)((m + 255) / 256), (unsigned)V), dim3(256), 0, st, h->M, BW, b, r, v0, m,
+                           h->d_tb_bus, h->d_tb_ptr, h->d_tb_adj, h->d_U, h->d_E, h->d_x, h->d_bM, h->d_brhs);
+        if (rocblas_set_stream(h->blas, st) != rocblas_status_success) return HPF_E_ROCSOLVER;
+        if (rocsolver_dgetrf(h->blas, m, m, h->d_bM, m, h->d_bipiv, h->d_binfo) != rocblas_status_success ||
+            rocsolver_dgetrs(h->blas, rocblas_operation_none, m, 1, h->d_bM, m, h->d_bipiv, h->d_brhs, m) != rocblas_status_success)
+            return HPF_E_ROCSOLVER;
+        hipLaunchKernelGGL(k_border_apply, dim3((unsigned)((cmax + 255) / 256)), dim3(256), 0, st, cmax, r, v0, m, h->d_brhs, h->d_x);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        h->last_detail = (int)e;
+        return HPF_E_HIP;
     }
     return HPF_OK;
 }

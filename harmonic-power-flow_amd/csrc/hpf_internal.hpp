@@ -110,6 +110,15 @@ struct hpf_handle {
     hpf::Model M{};                   // device pointers
     int n = 0, m = 0, c = 0, Hn = 0, nnz = 0, n_dev = 0, coupled = 0, solver = 0, device = 0;
     int S_max = 0, S = 0;
+    int S_alloc = 0;                  // scenario slots allocated = S_max (+ 1 + m_border virtual slots of the bordered Newton step)
+    // meshed networks on the block-tree path (hpf_block.hip, "bordered Newton step"): BFS spanning tree + loop-closing lines
+    int n_ties = 0, n_tb = 0, m_border = 0;      // tie lines, their distinct endpoint buses, border unknowns = n_tb * 2 Hn
+    int *d_tb_bus = nullptr;          // [n_tb] endpoint buses
+    int *d_tb_ptr = nullptr;          // [n_tb + 1] into d_tb_adj
+    int *d_tb_adj = nullptr;          // per (endpoint i, tie (i,j)): j, CSR entry (i,j), 0
+    double *d_bM = nullptr, *d_brhs = nullptr;   // border system (m x m column-major, m)
+    int *d_bipiv = nullptr, *d_binfo = nullptr;
+    std::vector<int> host_act;        // the slot list as the host last saw it (the bordered step walks the running scenarios)
     int N = 0, Nc = 0, Nf = 0;
     bool loads_set = false, state_set = false, mismatch_valid = false;
     int last_detail = 0;
@@ -209,11 +218,13 @@ struct ScopedTimer {
 };
 
 // block-tree solver (hpf_block.hip)
+int tree_find_ties(hpf_handle* h, const hpf_desc* d);    // spanning tree + loop-closing lines of the pattern (before any allocation)
 int tree_build(hpf_handle* h, const hpf_desc* d);
 hpf::Tree& active_tree(hpf_handle* h);
 void tree_free(hpf_handle* h);
 int tree_alloc_scenarios(hpf_handle* h);
 int tree_fund_step(hpf_handle* h, bool only_active);     // fundamental pf Newton step on the tree (2x2 blocks)
 int tree_newton_step(hpf_handle* h, bool only_active);   // assembles, eliminates, back-substitutes -> d_f holds the step
+int tree_newton_step_bordered(hpf_handle* h, bool only_active);   // the same for a network with loop-closing lines (h->n_ties > 0)
 
 }  // namespace hpf

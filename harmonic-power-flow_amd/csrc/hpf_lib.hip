@@ -441,7 +441,7 @@ inline void set_ctx(hpf_handle* h, hipStream_t st, int s0, int cnt) {
 inline void full_ctx(hpf_handle* h) { set_ctx(h, h->stream, 0, h->S); }
 
 inline int groups_for(const hpf_handle* h, int count) {
-    if (h->solver != HPF_SOLVER_BLOCK_TREE) return 1;
+    if (h->solver != HPF_SOLVER_BLOCK_TREE || h->n_ties > 0) return 1;
     int g = h->n_groups;
     while (g > 1 && count < 8 * g) --g;        // at least 8 scenarios per group
     return g < 1 ? 1 : g;
@@ -562,7 +562,10 @@ int launch_update(hpf_handle* h, const int* active) {
 template <bool FUND>
 int newton_step(hpf_handle* h, const int* active) {
     int r;
-    if (h->solver == HPF_SOLVER_BLOCK_TREE) return FUND ? tree_fund_step(h, active != nullptr) : tree_newton_step(h, active != nullptr);
+    if (h->solver == HPF_SOLVER_BLOCK_TREE && h->n_ties == 0)
+        return FUND ? tree_fund_step(h, active != nullptr) : tree_newton_step(h, active != nullptr);
+    if (h->solver == HPF_SOLVER_BLOCK_TREE && !FUND) return tree_newton_step_bordered(h, active != nullptr);
+    // (a meshed network on the block-tree path takes its fundamental power flow through the dense LU: Nf = 2n - 1 - c is small)
     const int Nsys = FUND ? h->Nf : h->N;
     if ((r = ensure_dense(h, Nsys))) return r;
     if ((r = launch_jacobian_dense<FUND>(h, active))) return r;
@@ -621,7 +624,7 @@ int nr_pass(hpf_handle* h, double thresh, int max_iter, const int* mask) {
     // frozen scenarios are skipped by every kernel, so the host only has to notice when NO scenario is active any more, and
     // noticing late changes nothing in the results.  BLOCK_TREE: the host looks every `chunk` iterations, and it looks at chunk
     // c - 1 while chunk c is already queued (pinned double buffer + events), so the device never drains between chunks.
-    const bool pipelined = !FUND && h->solver == HPF_SOLVER_BLOCK_TREE && !trace;
+    const bool pipelined = !FUND && h->solver == HPF_SOLVER_BLOCK_TREE && !trace && h->n_ties == 0;
     const int chunk = pipelined ? (S >= 8 ? 4 : 2) : 1;
     auto enqueue = [&](int todo, int slots) -> int {
         auto body = [&]() -> int {
@@ -689,6 +692,7 @@ int nr_pass(hpf_handle* h, double thresh, int max_iter, const int* mask) {
     int it = 0;
     while (nactive > 0 && it < max_iter) {
         was = act;                        // (no compaction on this path: slot i runs scenario i)
+        h->host_act = act;                // (the bordered step of a meshed network walks the running scenarios on the host)
         if ((r = enqueue(1, S))) return r;
         HIPCHK(hipMemcpyAsync(act.data(), h->d_active, sizeof(int) * S, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
@@ -813,7 +817,7 @@ const char* hpf_strerror(int code) {
         case HPF_OK: return "success";
         case HPF_E_ARG: return "invalid argument";
         case HPF_E_STATE: return "call order violated (loads/state/mismatch not set)";
-        case HPF_E_TOPOLOGY: return "BLOCK_TREE solver needs a radial network rooted at bus 0";
+        case HPF_E_TOPOLOGY: return "BLOCK_TREE solver: network not connected from bus 0, pattern not symmetric, or too many loop-closing lines (border > 1024 unknowns)";
         case HPF_E_NOMEM: return "out of device memory";
         case HPF_E_HIP: return "HIP runtime error";
         case HPF_E_ROCSOLVER: return "rocBLAS/rocSOLVER error";
@@ -881,7 +885,13 @@ int hpf_create(hpf_handle** out, const hpf_desc* d) {
     if (hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming) != hipSuccess) return fail(HPF_E_HIP);
     set_ctx(h, h->stream, 0, 0);
     if (rocblas_create_handle(&h->blas) != rocblas_status_success) return fail(HPF_E_ROCSOLVER);
-    const size_t HnN = (size_t)d->Hn * d->n, S = (size_t)d->max_scenarios;
+    h->S_alloc = h->S_max;
+    if (d->solver == HPF_SOLVER_BLOCK_TREE) {
+        // loop-closing lines of a meshed network: the bordered Newton step needs 1 + m virtual scenario slots behind the real ones
+        if ((r = tree_find_ties(h, d))) return fail(r);
+        if (h->n_ties > 0) h->S_alloc = h->S_max + 1 + h->m_border;
+    }
+    const size_t HnN = (size_t)d->Hn * d->n, S = (size_t)h->S_alloc;
     const size_t ynsz = (size_t)d->n_dev * d->Hn * (d->coupled ? d->Hn : 1);
     if ((r = dev_upload(h, &h->d_rowptr, d->rowptr, (size_t)d->n + 1))) return fail(r);
     if ((r = dev_upload(h, &h->d_col, d->col, (size_t)d->nnz))) return fail(r);

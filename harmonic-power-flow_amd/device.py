@@ -48,13 +48,21 @@ class DeviceModel:
         self.dev_of_bus = np.ascontiguousarray(dev_of_bus, dtype=np.int32)
         self.Y_N = np.ascontiguousarray(Y_N, dtype=np.complex128)
         self.I_N = np.ascontiguousarray(I_N, dtype=np.complex128)
-        if solver == "auto":
-            solver = "block_tree" if (is_radial(self.n, self.rowptr, self.col) and self.n >= 32) else "dense"
-        self.solver = solver
         N = 2 * self.n * self.Hn - 1 - self.c
+        if solver == "auto":
+            # radial feeders: block-tree elimination; small meshed networks: dense rocSOLVER LU; large meshed networks with a few
+            # loop-closing lines: the block-tree path's bordered step (tried first, dense if the library refuses the topology)
+            if is_radial(self.n, self.rowptr, self.col):
+                solver = "block_tree" if self.n >= 32 else "dense"
+            else:
+                solver = "block_tree_or_dense" if (self.n >= 32 and N > 8192) else "dense"
+        self._solver_request = solver
+        if solver == "block_tree_or_dense":
+            solver = "block_tree"
+        self.solver = solver
         if solver == "dense" and N * N >= 2 ** 31:
             raise ValueError("dense solver: N = %d unknowns exceeds rocSOLVER's 32-bit element addressing (N*N < 2^31); "
-                             "radial feeders of this size use solver='block_tree'" % N)
+                             "radial feeders and feeders with a few loop-closing lines of this size use solver='block_tree'" % N)
         d = _lib.hpf_desc()
         d.n, d.m, d.c, d.Hn, d.nnz = self.n, self.m, self.c, self.Hn, len(self.col)
         d.n_dev, d.coupled = int(n_dev), int(self.coupled)
@@ -66,7 +74,13 @@ class DeviceModel:
         d.Y_N = self.Y_N.view(np.float64).ctypes.data_as(_lib.c_dbl_p)
         d.I_N = self.I_N.view(np.float64).ctypes.data_as(_lib.c_dbl_p)
         self._h = C.c_void_p()
-        _lib.check(lib.hpf_create(C.byref(self._h), C.byref(d)), None, "hpf_create")
+        rc = lib.hpf_create(C.byref(self._h), C.byref(d))
+        if rc == -3 and self._solver_request == "block_tree_or_dense" and N * N < 2 ** 31:
+            # too many loop-closing lines for the bordered block-tree step: the dense GPU path (still no CPU path anywhere)
+            self.solver = "dense"
+            d.solver = _lib.SOLVER_DENSE
+            rc = lib.hpf_create(C.byref(self._h), C.byref(d))
+        _lib.check(rc, None, "hpf_create")
         self.S_max = int(max_scenarios)
         self.S = 0
         self.N = lib.hpf_num_unknowns(self._h)

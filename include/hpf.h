@@ -31,14 +31,19 @@ typedef struct hpf_handle hpf_handle;
 
 enum {
     HPF_SOLVER_DENSE = 0,      /* dense real FP64 Jacobian, rocSOLVER getrf/getrs (any topology); N*N < 2^31 (N <= 46 340), else HPF_E_ARG */
-    HPF_SOLVER_BLOCK_TREE = 1  /* bus-major 2Hn x 2Hn block elimination along the feeder tree (radial only)  */
+    HPF_SOLVER_BLOCK_TREE = 1  /* bus-major 2Hn x 2Hn block elimination along the feeder tree.  Radial networks directly; meshed
+                                  networks as BFS spanning tree + k loop-closing lines, solved as a bordered system on top of the
+                                  same tree factorisation (1 + m right-hand sides per scenario and Newton step, m = 2Hn x number
+                                  of distinct endpoint buses of the loop-closing lines, m x m border system on rocSOLVER);
+                                  m <= 1024 and 2Hn <= 100, else HPF_E_TOPOLOGY */
 };
 
 enum {
     HPF_OK = 0,
     HPF_E_ARG = -1,        /* null pointer / out-of-range argument */
     HPF_E_STATE = -2,      /* call order violated (e.g. solve before loads were set) */
-    HPF_E_TOPOLOGY = -3,   /* BLOCK_TREE requested for a network that is not a tree rooted at bus 0 */
+    HPF_E_TOPOLOGY = -3,   /* BLOCK_TREE: network not connected from bus 0 / pattern not symmetric / border of the loop-closing lines
+                              beyond the stated bound */
     HPF_E_NOMEM = -4,
     HPF_E_HIP = 1,         /* HIP runtime error (hpf_last_error_detail has the hipError_t) */
     HPF_E_ROCSOLVER = 2,   /* rocBLAS / rocSOLVER status != success */

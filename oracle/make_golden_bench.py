@@ -99,5 +99,47 @@ def cfg5():
                         loop_s=r["loop_s"])
 
 
+def add_ties(fl, n, k, seed=42):
+    """append k loop-closing lines (random bus pairs that are not yet connected, impedances from the feeder's palette) to a lines
+    CSV in the reference's dialect -> list of (from, to)"""
+    rows = open(fl).read().splitlines()
+    have = set()
+    for r in rows[1:]:
+        c = r.split(";")
+        have.add((min(int(c[1]), int(c[2])), max(int(c[1]), int(c[2]))))
+    rng = np.random.default_rng(seed)
+    pal = [(0.5, 0.5), (1, 4), (0.5, 1)]
+    out = []
+    lid = len(rows)
+    while len(out) < k:
+        a, b = int(rng.integers(2, n + 1)), int(rng.integers(2, n + 1))
+        if a == b or (min(a, b), max(a, b)) in have:
+            continue
+        have.add((min(a, b), max(a, b)))
+        r, x = pal[int(rng.integers(0, len(pal)))]
+        rows.append("%d;%d;%d;%.10g;%.10g;0;0" % (lid, a, b, r * 20.0 / n, x * 20.0 / n))
+        lid += 1
+        out.append((a, b))
+    open(fl, "w").write("\n".join(rows) + "\n")
+    return out
+
+
+def mesh():
+    """gen(1000, seed 0) + 5 loop-closing lines (add_ties seed 42), harmonics 1..51, coupled: N = 51 998 unknowns, beyond the dense
+    rocSOLVER limit -> the bordered block-tree step is the only GPU path; oracle = SuperLU on the meshed Jacobian."""
+    synth = _synth()
+    tmp = tempfile.mkdtemp()
+    fb, fl = synth.gen(1000, seed=0, outdir=tmp)
+    ties = add_ties(fl, 1000, 5)
+    H = o.harmonics_upto(51)
+    r, stop, fix, r2 = run(o.init_network(fb, fl), H)
+    print("meshed syn1000 + ties %s: %d it err %.3e; fixed point +%d it err %.3e" % (ties, r["n_iter_h"], r["err_h"], r2["n_iter_h"], r2["err_h"]), flush=True)
+    idx = np.arange(0, stop[0].size, 7)
+    Uf = fix[0] * np.exp(1j * fix[1])
+    np.savez_compressed(os.path.join(GOLD, "syn1000_H51_mesh5.npz"), ties=np.array(ties), n_iter=r["n_iter_h"], err_hist=r["err_hist"],
+                        idx=idx, V_stop_sample=np.stack([stop[0][idx], stop[1][idx]], 1), V_fix_sample=np.stack([fix[0][idx], fix[1][idx]], 1),
+                        seed_fund=np.stack(r["seed"], 1)[:1000], U_fix_abs_per_harmonic=np.abs(Uf).reshape(len(H), 1000).sum(1))
+
+
 if __name__ == "__main__":
-    {"scen": scen, "cfg5": cfg5}[sys.argv[1]]()
+    {"scen": scen, "cfg5": cfg5, "mesh": mesh}[sys.argv[1]]()

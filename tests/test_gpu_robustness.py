@@ -200,3 +200,108 @@ def test_fuzz_feeders_converged_voltages_block_tree_vs_dense(n, hmax, frac, n_pv
     Ub, Ud = bt["Vm"] * np.exp(1j * bt["Va"]), de["Vm"] * np.exp(1j * de["Va"])
     print("   fixed points differ by %.2e" % np.abs(Ub - Ud).max())
     assert np.abs(Ub - Ud).max() < TOL_V
+
+
+# ---- meshed networks on the block-tree path (bordered Newton step) ------------------------------------------------------------
+def _add_ties(fl, n, k, seed=42):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mgb", os.path.join(os.path.dirname(GOLD), "..", "oracle", "make_golden_bench.py"))
+    mgb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mgb)
+    return mgb.add_ties(fl, n, k, seed)
+
+
+@pytest.mark.parametrize("n,hmax,k", [(300, 51, 3), (120, 11, 1), (200, 27, 4)])
+def test_meshed_feeder_bordered_block_tree_vs_dense(n, hmax, k, tmp_path):
+    """A radial feeder plus k loop-closing lines: BFS spanning tree + bordered system on the block-tree path (1 + m virtual
+    scenarios per Newton step, m x m border system on rocSOLVER; fundamental pf through the dense LU) against the dense
+    rocSOLVER path on the full meshed Jacobian: pf seed, first Newton step, converged voltages (fixed point) within 1e-8."""
+    hp = _hp()
+    from harmonic_power_flow_amd import api, synth
+    fb, fl = synth.gen(n, seed=4, outdir=str(tmp_path))
+    ties = _add_ties(fl, n, k)
+    st = hp.Settings(H_MAX=hmax)
+    buses, lines, m, nn, c = hp.init_network(fb, fl, settings=st)
+    Y = hp.build_admittance_matrices(buses, lines, st.HARMONICS)
+    assert len(Y.col) == n + 2 * (n - 1) + 2 * k
+    NE = hp.import_Norton_Equivalents(buses, True, st, INPUTS)
+    out = {}
+    for solver in ("dense", "block_tree"):
+        dm = api._device_model(buses, Y, NE, True, st.HARMONICS, solver=solver)
+        try:
+            dm.set_loads(buses["P"].to_numpy(float), buses["Q"].to_numpy(float))
+            dm.set_state(None, None, n_scen=1)
+            nf, _, _ = dm.fund_pf(1e-6, 30)
+            v0 = dm.get_state()
+            if "dense" in out:
+                np.testing.assert_allclose(v0[0], out["dense"][0][0], rtol=0, atol=1e-12)
+                np.testing.assert_allclose(v0[1], out["dense"][0][1], rtol=0, atol=1e-12)
+                dm.set_state(*out["dense"][0])
+            dm.mismatch(want_f=False)
+            dm.iterate(1)
+            dm.sync()
+            v1 = dm.get_state()
+            dm.set_state(*(out["dense"][0] if "dense" in out else v0))
+            n_iter, err, _ = dm.solve(1e-4, 50)
+            stt = dm.stats()
+            dm.mismatch(want_f=False)
+            dm.iterate(2)
+            dm.sync()
+            out[solver] = (v0, v1, dm.get_state(), int(n_iter[0]), float(err[0]), stt)
+        finally:
+            dm.close()
+    (v0d, v1d, vfd, itd, ed, _), (v0b, v1b, vfb, itb, eb, stb) = out["dense"], out["block_tree"]
+    step = max(np.abs(v1d[0] - v0d[0]).max(), np.abs(v1d[1] - v0d[1]).max())
+    d1 = max(np.abs(v1d[0] - v1b[0]).max(), np.abs(v1d[1] - v1b[1]).max())
+    Ud = vfd[0][0] * np.exp(1j * vfd[1][0])
+    Ub = vfb[0][0] * np.exp(1j * vfb[1][0])
+    print("\nn=%d H_MAX=%d ties %s: first step %.1e (deviation %.1e); dense %d it (err %.1e), bordered block-tree %d it (err %.1e); fixed points differ by %.2e"
+          % (n, hmax, ties, step, d1, itd, ed, itb, eb, np.abs(Ud - Ub).max()))
+    assert d1 <= 1e-8 * max(1.0, step)
+    assert ed <= 1e-4 and eb <= 1e-4 and (stb["flags"][0] & 1)
+    assert np.abs(Ud - Ub).max() < TOL_V
+
+
+def test_meshed_headline_feeder_vs_oracle_fixture(tmp_path):
+    """gen(1000, seed 0) + 5 loop-closing lines, harmonics 1..51: N = 51 998 is beyond the dense limit (N*N < 2^31), so before
+    the bordered step such a feeder could not be solved on the GPU at all (missing #1).  solver="auto" must take
+    the block-tree path; result against the oracle (SuperLU on the meshed Jacobian; tests/golden/syn1000_H51_mesh5.npz)."""
+    path = os.path.join(GOLD, "syn1000_H51_mesh5.npz")
+    if not os.path.exists(path):
+        pytest.skip("fixture not generated (oracle/make_golden_bench.py mesh)")
+    hp = _hp()
+    from harmonic_power_flow_amd import api, synth
+    g = np.load(path)
+    fb, fl = synth.gen(1000, seed=0, outdir=str(tmp_path))
+    ties = _add_ties(fl, 1000, 5)
+    assert np.array_equal(np.array(ties), g["ties"])
+    st = hp.Settings(H_MAX=51)
+    buses, lines, m, n, c = hp.init_network(fb, fl, settings=st)
+    Y = hp.build_admittance_matrices(buses, lines, st.HARMONICS)
+    NE = hp.import_Norton_Equivalents(buses, True, st, INPUTS)
+    dm = api._device_model(buses, Y, NE, True, st.HARMONICS, solver="auto")
+    try:
+        assert dm.solver == "block_tree"
+        dm.set_loads(buses["P"].to_numpy(float), buses["Q"].to_numpy(float))
+        dm.set_state(None, None, n_scen=1)
+        dm.fund_pf(1e-6, 30)
+        seed = dm.get_state()
+        np.testing.assert_allclose(np.stack([seed[0][0][:1000], seed[1][0][:1000]], 1), g["seed_fund"], rtol=0, atol=1e-11)
+        n_iter, err, _ = dm.solve(1e-4, 50)
+        Vm, Va = dm.get_state()
+        dm.mismatch(want_f=False)
+        dm.iterate(2)
+        dm.sync()
+        Vm2, Va2 = dm.get_state()
+    finally:
+        dm.close()
+    idx = g["idx"]
+    U, U2 = Vm[0] * np.exp(1j * Va[0]), Vm2[0] * np.exp(1j * Va2[0])
+    Us = g["V_stop_sample"][:, 0] * np.exp(1j * g["V_stop_sample"][:, 1])
+    Uf = g["V_fix_sample"][:, 0] * np.exp(1j * g["V_fix_sample"][:, 1])
+    d_stop, d_fix = np.abs(U[idx] - Us).max(), np.abs(U2[idx] - Uf).max()
+    d_sum = np.abs(np.abs(U2).reshape(26, 1000).sum(1) - g["U_fix_abs_per_harmonic"]).max()
+    print("\nmeshed syn1000 + 5 ties: %d it (oracle %d) err %.2e; |dU| at the stop rule %.2e, at the fixed point %.2e; per-harmonic sum |U| deviation %.2e"
+          % (n_iter[0], int(g["n_iter"]), err[0], d_stop, d_fix, d_sum))
+    assert err[0] <= 1e-4 and n_iter[0] < 50
+    assert d_stop < 1e-6 and d_fix < TOL_V and d_sum < 1000 * TOL_V * 1e-2
