@@ -243,7 +243,7 @@ def main():
     step_bytes = S * (dm.solve_bytes() + bytes_mismatch + bytes_back + bytes_2x2 + bytes_update)
     traffic, traffic_note = pmc_traffic(args, S)
     step_traffic = pmc_step_traffic(args, S)
-    kname = "k_factor_q<%d,false>" % (52 if b > 28 else (28 if b > 12 else 12)) if bt and b <= 52 else ("k_tree_factor (generic)" if bt else "rocsolver_dgetrf/dgetrs")
+    kname = "k_factor_q<%d,false>" % (100 if b > 52 else (52 if b > 28 else (28 if b > 12 else 12))) if bt and b <= 100 else ("k_tree_factor (generic)" if bt else "rocsolver_dgetrf/dgetrs")
     out = {
         "metric": "NR iterations/sec + ms/iter, 1 000-bus x 25-harmonic feeder; |dV| vs reference",
         "value": value, "unit": "NR iterations/s", "n_gpus": world, "steps": K, "warmup": args.warmup,

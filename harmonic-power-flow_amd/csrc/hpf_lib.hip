@@ -62,6 +62,17 @@ __global__ void k_polar(int count, int stride, int Hn, const double* __restrict_
     E[o] = e;
 }
 
+// XCD-aware launch geometry of the per-element kernels (thread per (bus, harmonic) of one scenario): workgroups are dealt round-robin
+// over the 8 XCDs by their linear id (MI355X_MICROARCH.md, workgroup dispatch), and every XCD has its own 4 MiB L2.  A 1-D grid
+// whose id is (scenario block, x block, scenario mod 8) keeps ALL workgroups of a scenario on one XCD, so the scenario's voltages --
+// gathered again by the neighbours' rows and by the Norton rows of the same bus -- are fetched into one L2 instead of eight.
+__device__ __forceinline__ bool xcd_map(int nbx, int S, int& bx, int& slot) {
+    const int id = blockIdx.x, l8 = id & 7, rest = id >> 3;
+    bx = rest % nbx;
+    slot = (rest / nbx) * 8 + l8;
+    return slot < S;
+}
+
 // ||.||_inf with NaN propagation: |x| as its IEEE bit pattern is monotone for non-negative doubles, and every NaN
 // pattern compares above +inf, so an unsigned max reproduces np.linalg.norm(f, inf) including its NaN result
 // (HG:389) and is independent of the reduction order.
@@ -85,10 +96,12 @@ template <bool FUND>
 __global__ void k_mismatch(Model M, int count, int N, int Nc, const int* __restrict__ active, const cplx* __restrict__ U,
                            const double* __restrict__ P, const double* __restrict__ Q, double* __restrict__ f,
                            unsigned long long* __restrict__ errbits, cplx* __restrict__ I0, double* __restrict__ fb, int Bst,
-                           int s0) {
-    const int s = active ? active[blockIdx.y + s0] : (int)blockIdx.y + s0;   // slot -> scenario (active list; -1: frozen / empty slot)
+                           int s0, int S_cnt, int nbx) {
+    int bx, slot;
+    if (!xcd_map(nbx, S_cnt, bx, slot)) return;
+    const int s = active ? active[slot + s0] : slot + s0;   // slot -> scenario (active list; -1: frozen / empty slot)
     if (s < 0) return;
-    const int t = blockIdx.x * TPB + threadIdx.x;
+    const int t = bx * TPB + threadIdx.x;
     unsigned long long b = 0;
     if (t < count) {
         const int i = FUND ? t : t / M.Hn, q = FUND ? 0 : t - i * M.Hn;
@@ -497,9 +510,10 @@ int launch_mismatch(hpf_handle* h, const int* active, bool stacked = true) {
     const int Nc = FUND ? h->n - 1 : h->Nc;
     const bool img = !FUND && h->d_fb && bus_images(h);
     if (count > 1) {
-        hipLaunchKernelGGL((k_mismatch<FUND>), grid2(count, h->cur_S), dim3(TPB), 0, h->cur_stream, h->M, count, N, Nc,
+        const int nbx = (count + TPB - 1) / TPB;
+        hipLaunchKernelGGL((k_mismatch<FUND>), dim3((unsigned)(8 * ((h->cur_S + 7) / 8) * nbx)), dim3(TPB), 0, h->cur_stream, h->M, count, N, Nc,
                            active, h->d_U, h->d_P, h->d_Q, (stacked || !img) ? h->d_f : nullptr, h->d_errbits, h->d_I0,
-                           img ? h->d_fb : nullptr, tree_bst(h), h->cur_s0);
+                           img ? h->d_fb : nullptr, tree_bst(h), h->cur_s0, h->cur_S, nbx);
         HIPCHK(hipGetLastError());
     }
     return HPF_OK;
@@ -1060,9 +1074,8 @@ int hpf_solve(hpf_handle* h, double thresh, int max_iter, int* n_iter, double* e
     return nr_loop<false>(h, thresh, max_iter, n_iter, err, err_hist);
 }
 
-int hpf_iterate(hpf_handle* h, int iters) {
-    if (!h || iters < 0) return HPF_E_ARG;
-    if (!h->loads_set || !h->state_set || !h->mismatch_valid) return HPF_E_STATE;
+// `iters` unconditional iterations of every scenario, enqueued group by group on the group streams (fork / join with h->stream)
+static int iterate_enqueue(hpf_handle* h, int iters) {
     // iteration-major enqueue order (all groups' step i before any group's step i+1) keeps the group pipelines in phase
     const int G = groups_for(h);
     int r = HPF_OK;
@@ -1090,6 +1103,14 @@ int hpf_iterate(hpf_handle* h, int iters) {
     }
     full_ctx(h);
     return r;
+}
+
+int hpf_iterate(hpf_handle* h, int iters) {
+    if (!h || iters < 0) return HPF_E_ARG;
+    if (!h->loads_set || !h->state_set || !h->mismatch_valid) return HPF_E_STATE;
+    // (replaying a captured hipGraph of several iterations was measured again in round 2, with 3 / 4 / 6 / 8 scenario groups at
+    //  128 and 1 024 scenarios: 0..-6 % -- the step is not bound by the host's launch rate)
+    return iterate_enqueue(h, iters);
 }
 
 int hpf_get_stats(hpf_handle* h, hpf_stat* stats) {
