@@ -17,7 +17,7 @@ def test_header_symbols_exported_and_bound():
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     assert lib.hpf_version() >= 100
     assert lib.hpf_strerror(0) == b"success"
-    assert b"radial" in lib.hpf_strerror(-3)
+    assert b"loop-closing" in lib.hpf_strerror(-3)
 
 
 def test_struct_layouts_match_header():
