@@ -139,11 +139,15 @@ def _jac_to_csr(Jd):
 
 
 def hpf(buses, lines, coupled, thresh_h=1e-4, max_iter_h=50, plt_convergence=False, settings=None, ne_dir=None,
-        solver="auto", verbose=True, return_jacobian=True, details=None):
+        solver="auto", verbose=True, return_jacobian=True, details=None, extra_iters=0):
     """HG:511-560 -> (V, err_h, n_iter_h, J).
 
     `J` is the Jacobian of the last iteration as scipy CSR like the reference (only materialised for N <= 4096,
-    else None).  `details`, if a dict, receives err_hist, the pf seed, n_iter_f, solver name and device stats."""
+    else None).  `details`, if a dict, receives err_hist, the pf seed, n_iter_f, solver name and device stats.
+    `extra_iters` (not in the reference, default 0 = the reference's behaviour): Newton iterations taken AFTER the stop rule.
+    The reference stops at err_h <= 1e-4, up to 4e-7 p.u. away from the fixed point, and where exactly below the
+    threshold the last iterate lands depends on the rounding of the linear solver; one or two more iterations put the result on
+    the fixed point itself, which does not (n_iter_h and err_h still report the reference's stop)."""
     st = settings or globals()["settings"]
     harmonics = st.HARMONICS
     n = len(buses)
@@ -163,21 +167,26 @@ def hpf(buses, lines, coupled, thresh_h=1e-4, max_iter_h=50, plt_convergence=Fal
             else:
                 print("Warning! Maximum of " + str(int(nf[0])) + " iterations reached.")
         # (block-tree: hpf_solve itself watches the static pivot order and repeats a flagged scenario with partial pivoting)
+        want_J = return_jacobian and dm.N <= 4096
+        if want_J:
+            dm.set_option("keep_previous_state", 1)
         n_iter, err, hist = dm.solve(thresh_h, max_iter_h)                        # HG:530-542
         stats = dm.stats()
         if details is not None:
             details["repeated_with_pivoting"] = bool(stats["flags"][0] & 16)
         if verbose and (stats["flags"][0] & 16):
             print("Warning! Static-pivot block elimination was flagged; the solve was repeated with partial pivoting.")
+        if extra_iters > 0 and np.isfinite(err[0]):
+            dm.mismatch(want_f=False)
+            dm.iterate(int(extra_iters))
+            dm.sync()
         Vm_raw, Va_raw = dm.get_state()
         n_iter_h = int(n_iter[0])
         J = None
-        if return_jacobian and n_iter_h > 0 and dm.N <= 4096:
-            # the reference returns the Jacobian built in the last iteration, i.e. at the state before the last update
-            # deterministic replay up to that state, then one assembly (small systems only)
-            dm.set_state(seed[0], seed[1])
-            dm.solve(thresh_h, n_iter_h - 1)
-            J = _jac_to_csr(dm.jacobian(0))
+        if want_J and n_iter_h > 0:
+            # the reference returns the Jacobian built in its last iteration, i.e. at the state before the last update: the solve
+            # kept that state on the device (small systems only: J is handed back as a dense column-major copy)
+            J = _jac_to_csr(dm.jacobian_last(0))
         if details is not None:
             details.update(err_hist=hist[0, :n_iter_h + 1].copy(), seed=(seed[0][0].copy(), seed[1][0].copy()),
                            n_iter_f=int(nf[0]), err_f=hf[0, :int(nf[0])].copy(), solver=dm.solver,
@@ -276,13 +285,13 @@ def get_THD(V):
     return THD
 
 
-def solve(filename_buses, filename_lines, coupled=True, settings=None, ne_dir=None, solver="auto", verbose=False):
+def solve(filename_buses, filename_lines, coupled=True, settings=None, ne_dir=None, solver="auto", verbose=False, extra_iters=0):
     """Convenience wrapper (= init_network + hpf + get_THD) -> dict(V, err_h, n_iter_h, THD, details)."""
     st = settings or globals()["settings"]
     buses, lines, m, n, c = init_network(filename_buses, filename_lines, settings=st)
     details = {}
     V, err_h, n_iter_h, J = hpf(buses, lines, coupled, st.thresh_h, st.max_iter_h, settings=st, ne_dir=ne_dir,
-                                solver=solver, verbose=verbose, details=details)
+                                solver=solver, verbose=verbose, details=details, extra_iters=extra_iters)
     # converged = the stop rule err_h <= thresh_h was met (flags bit 0) -- not "the loop ended": a NaN mismatch ends it too
     return {"V": V, "err_h": err_h, "n_iter_h": n_iter_h, "THD": get_THD(V), "details": details,
             "converged": bool(details["stats"]["flags"][0] & 1)}

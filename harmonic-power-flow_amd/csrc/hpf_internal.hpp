@@ -144,6 +144,8 @@ struct hpf_handle {
                                       //     bit2: exactly zero pivot met by the pivoted wave Gauss-Jordan (k_factor_w)
     int* d_mask = nullptr;            // [S] scenarios of a repeat pass
     double *d_Vm0 = nullptr, *d_Va0 = nullptr;   // [S][Hn*n] state at the entry of hpf_solve (repeat with partial pivoting starts from it)
+    double *d_Vmp = nullptr, *d_Vap = nullptr;   // [S][Hn*n] option "keep_previous_state": the state each scenario's LAST Newton step started from
+    int keep_prev = 0;
     double* d_hist = nullptr;         // [S][hist_cap]
     int hist_cap = 0;
     hpf_stat* d_stats = nullptr;      // [S]

@@ -297,6 +297,19 @@ __global__ void k_mark_repeat(int S, const double* __restrict__ err, int* __rest
     }
 }
 
+// option "keep_previous_state": before a Newton step, the running scenarios' voltages -> the "previous state" copy (the reference
+// returns the Jacobian of the LAST iteration, HG:537/560, i.e. the one built at the state before the last update)
+__global__ void k_keep_prev(int count, const int* __restrict__ active, const double* __restrict__ Vm, const double* __restrict__ Va,
+                            double* __restrict__ Vmp, double* __restrict__ Vap, int s0) {
+    const int s = active ? active[blockIdx.y + s0] : (int)blockIdx.y + s0;
+    if (s < 0) return;
+    const int k = blockIdx.x * TPB + threadIdx.x;
+    if (k < count) {
+        Vmp[(size_t)s * count + k] = Vm[(size_t)s * count + k];
+        Vap[(size_t)s * count + k] = Va[(size_t)s * count + k];
+    }
+}
+
 // mask (per scenario, 0 / 1) -> slot list of a repeat pass: slot s runs scenario s or nothing
 __global__ void k_mask_to_list(int S, const int* __restrict__ mask, int* __restrict__ list) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -644,6 +657,9 @@ int nr_pass(hpf_handle* h, double thresh, int max_iter, const int* mask) {
         auto body = [&]() -> int {
             int rr;
             for (int j = 0; j < todo; ++j) {
+                if (!FUND && h->keep_prev && h->d_Vmp)
+                    hipLaunchKernelGGL(k_keep_prev, grid2(h->n * h->Hn, h->cur_S), dim3(TPB), 0, h->cur_stream, h->n * h->Hn,
+                                       h->d_active, h->d_Vm, h->d_Va, h->d_Vmp, h->d_Vap, h->cur_s0);
                 if ((rr = newton_step<FUND>(h, h->d_active))) return rr;
                 if ((rr = launch_update<FUND>(h, h->d_active))) return rr;
                 if ((rr = launch_mismatch<FUND>(h, h->d_active, false))) return rr;
@@ -796,7 +812,7 @@ int nr_loop(hpf_handle* h, double thresh, int max_iter, int* n_iter, double* err
 void free_all(hpf_handle* h) {
     void* ptrs[] = {h->d_rowptr, h->d_col, h->d_diag, h->d_erow, h->d_dev, h->d_Y, h->d_YN, h->d_YNt, h->d_IN, h->d_P, h->d_Q,
                     h->d_Vm, h->d_Va, h->d_U, h->d_E, h->d_I0, h->d_f, h->d_errbits, h->d_err, h->d_niter, h->d_active,
-                    h->d_nactive, h->d_pivflag, h->d_mask, h->d_Vm0, h->d_Va0, h->d_tstamp, h->d_hist, h->d_stats, h->d_J, h->d_ipiv, h->d_info, h->d_Z, h->d_w, h->d_x, h->d_linA, h->d_C, h->d_dbg, h->d_H, h->d_chG, h->d_chH, h->d_chD, h->d_chy, h->d_chZ, h->d_lfK, h->d_lfS, h->d_fb};
+                    h->d_nactive, h->d_pivflag, h->d_mask, h->d_Vm0, h->d_Va0, h->d_Vmp, h->d_Vap, h->d_tstamp, h->d_hist, h->d_stats, h->d_J, h->d_ipiv, h->d_info, h->d_Z, h->d_w, h->d_x, h->d_linA, h->d_C, h->d_dbg, h->d_H, h->d_chG, h->d_chH, h->d_chD, h->d_chy, h->d_chZ, h->d_lfK, h->d_lfS, h->d_fb};
     for (void* p : ptrs)
         if (p) hipFree(p);
     tree_free(h);
@@ -1062,6 +1078,32 @@ static int jacobian_impl(hpf_handle* h, bool fund, int scen, double* J) {
 }
 
 int hpf_jacobian(hpf_handle* h, int scen, double* J) { return jacobian_impl(h, false, scen, J); }
+
+int hpf_jacobian_last(hpf_handle* h, int scen, double* J) {
+    if (!h || !J || scen < 0 || scen >= h->S) return HPF_E_ARG;
+    if (!h->keep_prev || !h->d_Vmp || !h->state_set) return HPF_E_STATE;
+    // assemble at the kept state, then put the current one back (the swap goes through the repeat-pass buffers' siblings)
+    const size_t cnt = (size_t)h->S * h->n * h->Hn;
+    double *tm = nullptr, *ta = nullptr;
+    int r;
+    if ((r = dev_alloc(h, &tm, cnt))) return r;
+    if ((r = dev_alloc(h, &ta, cnt))) {
+        hipFree(tm);
+        return r;
+    }
+    hipMemcpyAsync(tm, h->d_Vm, sizeof(double) * cnt, hipMemcpyDeviceToDevice, h->stream);
+    hipMemcpyAsync(ta, h->d_Va, sizeof(double) * cnt, hipMemcpyDeviceToDevice, h->stream);
+    hipMemcpyAsync(h->d_Vm, h->d_Vmp, sizeof(double) * cnt, hipMemcpyDeviceToDevice, h->stream);
+    hipMemcpyAsync(h->d_Va, h->d_Vap, sizeof(double) * cnt, hipMemcpyDeviceToDevice, h->stream);
+    r = jacobian_impl(h, false, scen, J);
+    hipMemcpyAsync(h->d_Vm, tm, sizeof(double) * cnt, hipMemcpyDeviceToDevice, h->stream);
+    hipMemcpyAsync(h->d_Va, ta, sizeof(double) * cnt, hipMemcpyDeviceToDevice, h->stream);
+    if (!r) r = launch_polar<false>(h);
+    hipStreamSynchronize(h->stream);
+    hipFree(tm);
+    hipFree(ta);
+    return r;
+}
 int hpf_fund_jacobian(hpf_handle* h, int scen, double* J) { return jacobian_impl(h, true, scen, J); }
 
 int hpf_fund_pf(hpf_handle* h, double thresh, int max_iter, int* n_iter, double* err, double* err_hist) {
@@ -1148,6 +1190,15 @@ int hpf_set_option(hpf_handle* h, const char* name, int value) {
     if (!strcmp(name, "pivot_growth_limit_log10")) { // static pivot order: amplification limit of a 4x4 pivot block, 10^value
         if (value < 0 || value > 300) return HPF_E_ARG;
         h->piv_limit = pow(10.0, (double)value);
+        return HPF_OK;
+    }
+    if (!strcmp(name, "keep_previous_state")) {     // hpf_solve keeps, per scenario, the state its last Newton step started from
+        h->keep_prev = value ? 1 : 0;
+        if (h->keep_prev && !h->d_Vmp) {
+            int rr;
+            if ((rr = dev_alloc(h, &h->d_Vmp, (size_t)h->S_alloc * h->n * h->Hn))) return rr;
+            if ((rr = dev_alloc(h, &h->d_Vap, (size_t)h->S_alloc * h->n * h->Hn))) return rr;
+        }
         return HPF_OK;
     }
     if (!strcmp(name, "auto_repivot")) {            // 0: flagged scenarios are only reported (flags bit 3), not repeated

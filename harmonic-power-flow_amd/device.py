@@ -151,6 +151,12 @@ class DeviceModel:
         self._chk(fn(self._h, int(scen), J.ctypes.data_as(_lib.c_dbl_p)), "hpf_jacobian")
         return J
 
+    def jacobian_last(self, scen=0):
+        """Jacobian of the last iteration of the last solve (HG:537,560); needs set_option("keep_previous_state", 1) before it."""
+        J = np.empty((self.N, self.N), order="F")
+        self._chk(self.lib.hpf_jacobian_last(self._h, int(scen), J.ctypes.data_as(_lib.c_dbl_p)), "hpf_jacobian_last")
+        return J
+
     def fund_pf(self, thresh=1e-6, max_iter=30):
         n_iter = np.zeros(self.S, dtype=np.int32)
         err = np.empty(self.S)

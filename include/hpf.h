@@ -111,6 +111,10 @@ int  hpf_mismatch(hpf_handle* h, double* f, double* err);
 /* build_harmonic_jacobian (HG:401-473) of scenario `scen`, written as a dense column-major N x N matrix
  * (parity / debugging; the solver consumes the device copy directly). */
 int  hpf_jacobian(hpf_handle* h, int scen, double* J_colmajor);
+/* The Jacobian the reference's hpf() returns (HG:537,560): the one of the LAST iteration of the last hpf_solve, i.e. built at the
+ * state scenario `scen`'s last Newton step started from (needs option "keep_previous_state" = 1 before hpf_solve; the current state
+ * is left untouched). */
+int  hpf_jacobian_last(hpf_handle* h, int scen, double* J_colmajor);
 /* fund_mismatch + build_jacobian of the fundamental power flow (HG:195-223) for scenario `scen`: f [Nf], J [Nf*Nf]. */
 int  hpf_fund_mismatch(hpf_handle* h, double* f, double* err);
 int  hpf_fund_jacobian(hpf_handle* h, int scen, double* J_colmajor);
@@ -163,6 +167,7 @@ int  hpf_debug_stamps(hpf_handle* h, long long* out, int count);
  * "pivot_growth_limit_log10" (0..300, default 10): the static-pivot monitor flags a scenario when |a_ij W_ji| of a pivot block
  * (a lower bound of its condition number) exceeds 10^value; "auto_repivot" (default 1): hpf_solve repeats flagged scenarios
  * with partial pivoting (0: they are only reported in hpf_stat.flags).
+ * "keep_previous_state" (default 0): hpf_solve keeps per scenario the state its last Newton step started from (hpf_jacobian_last).
  * "scenario_groups" (1..8, default 3): independent scenario pipelines on separate HIP streams.
  * Environment read by hpf_create (diagnostics, A/B runs): HPF_LAZY=0 builds the elimination tree without lazy leaves (every
  * leaf writes its Schur complement; 1: only leaves directly under their dense parent), HPF_SLEAF=0 sends the nonlinear buses

@@ -106,3 +106,44 @@ def test_fuchs_4bus_known_answer():
     with open(os.path.join(GOLD, "hf_fuchs.json")) as fh:
         hf = np.array(json.load(fh)["V_final"])
     np.testing.assert_allclose(Vf, hf[:4], rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("name", ["net2_H11_c", "net3_H51_uc", "net1_H11_c"])
+def test_hpf_returns_the_jacobian_of_its_last_iteration(name):
+    """hpf() -> (V, err_h, n_iter_h, J) (HG:511-560): J is the Jacobian built in the LAST iteration, i.e. at the iterate before the
+    last update (HG:537) -- kept on the device by the solve (hpf_jacobian_last), compared with build_harmonic_jacobian at the
+    reference's own second-to-last iterate."""
+    hp = _hp()
+    st, buses, g, Y_all, idx, coupled = _setup(hp, name)
+    net_name = name.split("_")[0]
+    lines = hp.init_network(os.path.join(INPUTS, net_name + "_buses.csv"), os.path.join(INPUTS, net_name + "_lines.csv"), settings=st)[1]
+    V, err_h, n_iter_h, J = hp.hpf(buses, lines, coupled, settings=st, ne_dir=INPUTS, verbose=False)
+    assert n_iter_h == int(g["n_iter_h"]) and J is not None and J.shape == tuple(g["J0_shape"])
+    NE = hp.import_Norton_Equivalents(buses, coupled, st, INPUTS)
+    Vprev = pd.DataFrame(g["V_traj"][n_iter_h - 1], index=idx, columns=["V_m", "V_a"])
+    Jref = hp.build_harmonic_jacobian(Vprev, Y_all, NE, coupled, buses=buses)
+    assert abs(J - Jref).max() <= 1e-6 * abs(Jref).max()
+    J0 = hp.build_harmonic_jacobian(pd.DataFrame(g["V_traj"][0], index=idx, columns=["V_m", "V_a"]), Y_all, NE, coupled, buses=buses)
+    assert abs(J - J0).max() > 1e-3 * abs(Jref).max()            # (and it is not the iteration-0 Jacobian)
+
+
+def test_extra_iterations_reach_the_fixed_point(tmp_path):
+    """hpf(extra_iters=2): the iterate the reference's stop rule leaves is up to 1e-6 away from the fixed point and depends on the
+    linear solver's rounding; two more Newton iterations land on the fixed point, where the oracle (continued the same way) agrees
+    to 1e-8 whatever the solver path."""
+    import hpf_oracle as o
+    hp = _hp()
+    from harmonic_power_flow_amd import synth
+    fb, fl = synth.gen(200, seed=0, outdir=str(tmp_path))
+    st = hp.Settings(H_MAX=11)
+    buses, lines, m, n, c = hp.init_network(fb, fl, settings=st)
+    r = o.hpf(o.init_network(fb, fl), st.HARMONICS, True, INPUTS)
+    r2 = o.hpf_from_model(r["model"], r["Vm_raw"].copy(), r["Va_raw"].copy(), thresh_h=0.0, max_iter_h=2)
+    Vm_o, Va_o = o.postprocess(r2["Vm_raw"], r2["Va_raw"])
+    Uo = Vm_o * np.exp(1j * Va_o)
+    for solver in ("block_tree", "dense"):
+        V, err_h, n_iter_h, _ = hp.hpf(buses, lines, True, settings=st, ne_dir=INPUTS, verbose=False, solver=solver,
+                                       return_jacobian=False, extra_iters=2)
+        assert n_iter_h == r["n_iter_h"] and abs(err_h - r["err_h"]) <= 1e-3 * r["err_h"]      # the reference's stop is what is reported
+        Ud = V["V_m"].to_numpy() * np.exp(1j * V["V_a"].to_numpy())
+        assert np.abs(Ud - Uo).max() < 1e-10
