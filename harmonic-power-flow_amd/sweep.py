@@ -25,6 +25,36 @@ def gather_stats(rec, world):
     return torch.stack(parts, dim=1).reshape(-1, rec.shape[1])
 
 
+def solve_scenarios(dm, P, Q, thresh_f=1e-6, max_iter_f=30, thresh_h=1e-4, max_iter_h=50, want_voltages=False):
+    """Monte-Carlo / what-if sweep on ONE GPU: every row of P, Q [n_scen][n] (p.u. loads, HG:197,372) is one scenario of the
+    network `dm` (a DeviceModel) holds.  The scenarios run in waves of up to `dm.S_max` live scenarios (size the model for as many
+    as fit: 72 MB of solver state per scenario of the 1 000-bus x 25-harmonic feeder, i.e. 1 024 scenarios = 74 GB of the 288 GB;
+    larger waves amortise the latency-bound upper tree levels: 107 k NR it/s at 128 live scenarios, 150 k at 1 024).  Per wave:
+    reference start (HG:174-184), fundamental pf (HG:244), harmonic NR with the reference's stop rule (HG:536) -- per-scenario
+    freeze, running scenarios compacted between chunks of iterations.  -> structured array of per-scenario records
+    (n_iter, flags, err, thd_max: the 24-byte record of the multi-GPU gather) [+ raw Vm, Va [n_scen][Hn*n]]."""
+    P = np.ascontiguousarray(np.atleast_2d(P), dtype=np.float64)
+    Q = np.ascontiguousarray(np.atleast_2d(Q), dtype=np.float64)
+    n_scen = P.shape[0]
+    out = np.zeros(n_scen, dtype=STAT_DTYPE)
+    Vm = Va = None
+    if want_voltages:
+        Vm = np.empty((n_scen, dm.n * dm.Hn))
+        Va = np.empty_like(Vm)
+    for a in range(0, n_scen, dm.S_max):
+        b = min(a + dm.S_max, n_scen)
+        dm.set_loads(P[a:b], Q[a:b])
+        dm.set_state(None, None, n_scen=b - a)
+        dm.fund_pf(thresh_f, max_iter_f)
+        dm.solve(thresh_h, max_iter_h)
+        st = dm.stats()
+        for k in STAT_DTYPE.names:
+            out[k][a:b] = st[k]
+        if want_voltages:
+            Vm[a:b], Va[a:b] = dm.get_state()
+    return (out, Vm, Va) if want_voltages else out
+
+
 def summarize(raw):
     """raw: uint8 array [n, 24] -> convergence statistics of the sweep."""
     st = np.ascontiguousarray(raw).view(STAT_DTYPE).reshape(-1)

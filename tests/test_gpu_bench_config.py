@@ -149,3 +149,26 @@ def test_config5_full_size_vs_oracle_fixture(tmp_path):
     assert d_stop < 1e-6
     assert d_fix < TOL_V and d_vm < TOL_V
     assert d_sum < n * TOL_V * 1e-2
+
+
+def test_sweep_in_waves_equals_single_scenario_solves(tmp_path):
+    """sweep.solve_scenarios: 75 scenarios through a model sized for 32 live scenarios (waves of 32 + 32 + 11, two groups / one
+    group) -- every record and every voltage bit-identical to the scenario solved alone."""
+    hp = _hp()
+    from harmonic_power_flow_amd import api, sweep, synth
+    st, buses, Y, NE = _feeder(hp, 200, 27, tmp_path, seed=3)
+    n = len(buses)
+    P0, Q0 = buses["P"].to_numpy(float), buses["Q"].to_numpy(float)
+    scale = np.stack([synth.scenario_scale(n, s) for s in range(75)])
+    dm = api._device_model(buses, Y, NE, True, st.HARMONICS, solver="block_tree", max_scenarios=32)
+    try:
+        rec, Vm, Va = sweep.solve_scenarios(dm, P0 * scale, Q0 * scale, want_voltages=True)
+    finally:
+        dm.close()
+    assert rec.shape == (75,) and ((rec["flags"] & 1) == 1).all()
+    summ = sweep.summarize(rec.view(np.uint8).reshape(75, 24))
+    assert summ["scenarios"] == 75 and summ["converged"] == 75 and summ["iters_total"] == int(rec["n_iter"].sum())
+    for s in (0, 31, 32, 63, 64, 74):
+        it1, err1, Vm1, Va1, _, st1 = _run(hp, st, buses, Y, NE, [s])
+        assert rec["n_iter"][s] == it1[0] and rec["err"][s] == err1[0] and rec["thd_max"][s] == st1["thd_max"][0]
+        assert np.array_equal(Vm[s], Vm1[0]) and np.array_equal(Va[s], Va1[0])
