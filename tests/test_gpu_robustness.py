@@ -81,10 +81,10 @@ def test_static_pivot_monitor_and_repeat_with_partial_pivoting(tmp_path):
     np.testing.assert_array_equal(forced["hist"], ref["hist"])                # NaN tail included
     assert ((only_flag["stats"]["flags"] & 8) == 8).all() and ((only_flag["stats"]["flags"] & 16) == 0).all()
     assert np.array_equal(only_flag["Vm"], dflt["Vm"])                        # reported, not repeated: the static result
-    # both pivot orders end at the same voltages
+    # both pivot orders end at the same voltages (iterates at the stop rule: within what the stop rule guarantees)
     U0 = dflt["Vm"] * np.exp(1j * dflt["Va"])
     U1 = ref["Vm"] * np.exp(1j * ref["Va"])
-    assert np.array_equal(dflt["it"], ref["it"]) and np.abs(U0 - U1).max() < 1e-9
+    assert np.array_equal(dflt["it"], ref["it"]) and np.abs(U0 - U1).max() < 1e-6
 
 
 def test_converged_flag_and_api_details(tmp_path):
