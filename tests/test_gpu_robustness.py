@@ -305,3 +305,71 @@ def test_meshed_headline_feeder_vs_oracle_fixture(tmp_path):
           % (n_iter[0], int(g["n_iter"]), err[0], d_stop, d_fix, d_sum))
     assert err[0] <= 1e-4 and n_iter[0] < 50
     assert d_stop < 1e-6 and d_fix < TOL_V and d_sum < 1000 * TOL_V * 1e-2
+
+
+def test_meshed_feeder_several_scenarios_and_sweep_api(tmp_path):
+    """The bordered step with S > 1 real scenarios in one handle (the virtual slots sit behind them; scenarios that converge
+    drop out of the host's walk): every scenario lands on the dense path's fixed point and on its own single-scenario solve
+    (not bit for bit: the fundamental pf of a meshed handle goes through rocSOLVER, whose batched and single LU round differently)."""
+    hp = _hp()
+    from harmonic_power_flow_amd import api, synth
+    n, hmax, k, S = 150, 15, 2, 4
+    fb, fl = synth.gen(n, seed=9, outdir=str(tmp_path))
+    _add_ties(fl, n, k)
+    st = hp.Settings(H_MAX=hmax)
+    buses, lines, m, nn, c = hp.init_network(fb, fl, settings=st)
+    Y = hp.build_admittance_matrices(buses, lines, st.HARMONICS)
+    NE = hp.import_Norton_Equivalents(buses, True, st, INPUTS)
+    P0, Q0 = buses["P"].to_numpy(float), buses["Q"].to_numpy(float)
+    scale = np.stack([synth.scenario_scale(n, s) for s in range(S)])
+
+    def run(solver, ids):
+        dm = api._device_model(buses, Y, NE, True, st.HARMONICS, solver=solver, max_scenarios=len(ids))
+        try:
+            dm.set_loads(P0 * scale[ids], Q0 * scale[ids])
+            dm.set_state(None, None, n_scen=len(ids))
+            dm.fund_pf(1e-6, 30)
+            it, err, _ = dm.solve(1e-4, 50)
+            stop = dm.get_state()
+            dm.mismatch(want_f=False)
+            dm.iterate(2)
+            dm.sync()
+            return it, err, stop, dm.get_state()
+        finally:
+            dm.close()
+    itb, errb, stopb, fixb = run("block_tree", list(range(S)))
+    itd, errd, stopd, fixd = run("dense", list(range(S)))
+    assert (errb <= 1e-4).all() and (errd <= 1e-4).all()
+    Ub, Ud = fixb[0] * np.exp(1j * fixb[1]), fixd[0] * np.exp(1j * fixd[1])
+    print("\nmeshed, %d scenarios: bordered %s it, dense %s it, fixed points differ by %.2e" % (S, itb, itd, np.abs(Ub - Ud).max()))
+    assert np.abs(Ub - Ud).max() < TOL_V
+    for s in (0, S - 1):
+        it1, err1, stop1, fix1 = run("block_tree", [s])
+        U1 = fix1[0][0] * np.exp(1j * fix1[1][0])
+        assert it1[0] == itb[s] and np.abs(U1 - Ub[s]).max() < 1e-10
+
+
+def test_many_scenarios_compaction_over_several_tiles(tmp_path):
+    """1 500 scenarios of a small feeder in one handle: the slot-list compaction works in tiles of 1 024 slots, the scenario
+    groups split the compacted list -- every record equals the single-scenario solve of that scenario."""
+    hp = _hp()
+    from harmonic_power_flow_amd import api, sweep, synth
+    st, buses, Y, NE, _ = _feeder(hp, 40, 11, tmp_path, seed=11, frac_nl=0.35)
+    n, S = len(buses), 1500
+    P0, Q0 = buses["P"].to_numpy(float), buses["Q"].to_numpy(float)
+    scale = np.stack([synth.scenario_scale(n, s) for s in range(S)])
+    dm = api._device_model(buses, Y, NE, True, st.HARMONICS, solver="block_tree", max_scenarios=S)
+    try:
+        rec, Vm, Va = sweep.solve_scenarios(dm, P0 * scale, Q0 * scale, want_voltages=True)
+    finally:
+        dm.close()
+    assert ((rec["flags"] & 1) == 1).all()
+    assert rec["n_iter"].min() < rec["n_iter"].max()                 # (the compaction has something to do)
+    dm1 = api._device_model(buses, Y, NE, True, st.HARMONICS, solver="block_tree", max_scenarios=1)
+    try:
+        for s in (0, 1, 700, 1023, 1024, 1025, 1499):
+            r1, Vm1, Va1 = sweep.solve_scenarios(dm1, P0 * scale[s], Q0 * scale[s], want_voltages=True)
+            assert r1["n_iter"][0] == rec["n_iter"][s] and r1["err"][0] == rec["err"][s]
+            assert np.array_equal(Vm1[0], Vm[s]) and np.array_equal(Va1[0], Va[s])
+    finally:
+        dm1.close()
