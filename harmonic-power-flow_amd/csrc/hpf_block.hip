@@ -1196,7 +1196,8 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
     std::vector<long long> sl_off(n, -1);                      // offset of [Tc | Pb | Qb] in slimg
     std::vector<double> slimg, lbimg;
     const char* sl_env = getenv("HPF_SLEAF");
-    const bool sleaf_on = !(sl_env && atoi(sl_env) == 0);      // HPF_SLEAF=0: every bus with dense children takes the Gauss-Jordan path
+    const bool sleaf_on = !(sl_env && atoi(sl_env) == 0) && wave_block_size(b) <= 52;   // HPF_SLEAF=0: every bus with dense children takes the Gauss-Jordan path
+                                                                                       // (b > 52: plain constant-inverse leaves only, no lazy leaves / super-leaves yet)
     const int sleaf_mode = sl_env ? atoi(sl_env) : 2;          // 1: nonlinear buses only
     int n_sleaf = 0;
     const char* sb_env = getenv("HPF_SLBACK");
@@ -1218,7 +1219,7 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
     std::vector<std::vector<int>> lazy_of(n);
     std::vector<int> is_lazy(n, 0);
     const char* lz_env = getenv("HPF_LAZY");
-    const bool lazy_on = !(lz_env && atoi(lz_env) == 0);
+    const bool lazy_on = !(lz_env && atoi(lz_env) == 0) && wave_block_size(b) <= 52;
     const int lazy_mode = lz_env ? atoi(lz_env) : 2;          // 1: only leaves hanging directly under their dense parent
     constexpr int LZ_MAX = 4;
     const int BWc = wave_block_size(b);
@@ -1232,7 +1233,7 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
             return (long long)(e >> 1) * 2 * RG + (wv < NTq - 1 ? wv * 128 + (lg * 16 + jj) * 2 : (NTq - 1) * 128 + (lg * LW + jj) * 2) + (e & 1);
         return (long long)NP * 2 * RG + (wv < NTq - 1 ? wv * 64 + lg * 16 + jj : (NTq - 1) * 64 + lg * LW + jj);
     };
-    if (contract && d->coupled && BWc && BWc <= 52) {
+    if (contract && d->coupled && BWc) {
         typedef std::complex<double> cd;
         const int Hn = d->Hn, nnz = d->nnz;
         auto yv = [&](int q, int e) { return cd(d->Yval[((size_t)q * nnz + e) * 2], d->Yval[((size_t)q * nnz + e) * 2 + 1]); };
@@ -1399,7 +1400,7 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
                     const long long o = tile_off(row, col);
                     if (o >= 0) Mt[o] = (t == t2) ? z.real() : (t ? z.imag() : -z.imag());
                 }
-            {   // the same constants for k_leaf_batch: [0 Lr; 0 Ahh^-1] in MFMA A-operand layout, R(Lc), R(c0)
+            if (BWc <= 52) {   // the same constants for k_leaf_batch: [0 Lr; 0 Ahh^-1] in MFMA A-operand layout, R(Lc), R(c0)
                 const int NTR = (BWc + 15) / 16, KS = (BWc + 3) / 4, SZ = NTR * KS * 64 + 2 * BWc + 4;
                 lbimg.resize((size_t)T.n_cleaf * SZ, 0.0);
                 double* L = &lbimg[(size_t)cleaf_of[k] * SZ];
@@ -1991,7 +1992,7 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
 #undef HPF_FACTOR_CASE
                 case 100:       // 52 < b <= 100: general multi-wave kernel for every dense bus; pivoted mode = generic kernels below
                     if (h->gj_mode == 1) {
-                        r = launch_factor_q2<100, false>(h, td, T.d_fdesc + FDESC * (size_t)T.lvl_ptr[l], cnt, active);
+                        r = launch_factor_q<100>(h, td, T.d_fdesc + FDESC * (size_t)T.lvl_ptr[l], cnt, active, T.lvl_all_leaf[l] != 0);
                         break;
                     }
                     [[fallthrough]];

@@ -157,7 +157,7 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 52 ? 2 : (B > 28 ? (LEAF
     constexpr size_t CT = (size_t)NT * NT * 256;
     constexpr int tcB = B >> 4, jjB = B & 15;
     constexpr int RP = 16 * NT > 64 ? 16 * NT : 64;     // rows the per-row roles cover (one lane per row, 64 per wave: B > 64 takes two waves)
-    constexpr bool SPECIAL = B <= 52;                   // constant-inverse leaves, lazy leaves, super-leaves exist (tree_build: b <= 52 only)
+    constexpr bool SPECIAL = B <= 52;                   // lazy leaves and super-leaves exist (tree_build: b <= 52 only; constant-inverse leaves: every b)
     HPF_STAMP_DECL;      // cycle stamps of wave 0: -DHPF_FACTOR_STAMPS build only
 #ifdef HPF_FACTOR_STAMPS
     long long sa = 0, sc = 0, gown = 0, gwait = 0, gmf = 0;
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 52 ? 2 : (B > 28 ? (LEAF
     const bool via_chain = (nd3.z & 1) != 0; // linked to the dense parent through a contracted chain (k_chain_factor)
     const bool lazy_leaf = SPECIAL && (nd3.z & 2) != 0; // the parent rebuilds this leaf's Schur complement itself: only G w goes to HBM
     const int cleafv = nd3.w;                // constant-inverse leaf: 1 + slot in Minv (0: general path; < 0: lazy-leaf record)
-    const bool cleaf = SPECIAL && (LEAF || cleafv > 0);
+    const bool cleaf = LEAF || cleafv > 0;
     const bool sleaf = SPECIAL && !LEAF && (nd3.z & 4) != 0;   // super-leaf: every dense child is a lazy leaf -> bordered low-rank inverse, no Gauss-Jordan
     const bool slback = SPECIAL && !LEAF && (nd3.z & 8) != 0;  // ... whose back sweep rebuilds D^-1 t from T^-1 (k_sleaf_back_batch): no inverse goes to HBM
     const bool lazy = SPECIAL && !LEAF && cleafv < 0;   // this bus has lazy leaves below it
