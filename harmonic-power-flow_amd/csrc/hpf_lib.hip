@@ -694,12 +694,26 @@ int nr_pass(hpf_handle* h, double thresh, int max_iter, const int* mask) {
         int it = 0, c = 0, n_ub = S;
         if ((r = compact_and_post(0))) return r;
         for (;;) {
-            // queue chunk c + 1 (iterations it .. it + todo) before looking at the count chunk c left
-            const int todo = (max_iter - it) < chunk ? (max_iter - it) : chunk;
+            // With few scenarios left the device is not kept busy anyway: look at the count of the chunk just queued before queueing
+            // the next one (no trailing chunk of empty launches).  Otherwise queue chunk c + 1 (iterations it .. it + todo) BEFORE
+            // looking at the count chunk c left, so that the device never drains between chunks.
+            const bool lagged = n_ub > 8 || S <= 8;      // (a handle of a few scenarios keeps the queue fed: its chunks are short anyway)
+            const int ch = lagged ? chunk : 2;
+            if (!lagged) {
+                HIPCHK(hipEventSynchronize(h->poll_ev[c & 1]));
+                const int cnt0 = h->h_act[c & 1][0];
+                if (cnt0 == 0 || it >= max_iter) break;
+                n_ub = cnt0;
+            }
+            const int todo = (max_iter - it) < ch ? (max_iter - it) : ch;
             if (todo > 0) {
                 if ((r = enqueue(todo, n_ub))) return r;
                 if ((r = compact_and_post((c + 1) & 1))) return r;
                 it += todo;
+            }
+            if (!lagged) {
+                ++c;
+                continue;
             }
             HIPCHK(hipEventSynchronize(h->poll_ev[c & 1]));
             const int cnt = h->h_act[c & 1][0];
