@@ -89,27 +89,86 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
     return v;
 }
 
-// One thread per complex mismatch row of one scenario (blockIdx.y): thread t = i*Hn + q (bus-major, coalesced voltage
-// reads), stacked index k = q*n + i, k >= 1.  f: the reference's stacked real layout (HG:388; dense solver, C ABI) or nullptr;
-// fb: bus-major image [bus][2q + (Re|Im)] with stride Bst and zeros where there is no equation (tree kernels) or nullptr.
+// Norton injection of harmonic position q (HG:313-323: I_N[q] - sum_p Y_N[q,p] U_p) with both operands in LDS: the device type's
+// Y_N^T (ynl[p*Hn + q]) and the bus's Hn voltages (ul[p]).  Same operations in the same order as norton_injection (hpf_assembly.hpp):
+// the reference's zgemv_n rounding -- 4-column groups of FMA chains, groups added in order; the Hn % 4 tail rows fused per column.
+__device__ __forceinline__ cplx norton_injection_lds(const Model& M, int d, const cplx* __restrict__ ynl, const cplx* __restrict__ ul, int q) {
+    const int Hn = M.Hn;
+    const cplx in = M.IN[(size_t)d * Hn + q];
+    cplx acc = {0.0, 0.0};
+    if (q < (Hn & ~3)) {
+        for (int p0 = 0; p0 < Hn; p0 += 4) {
+            double rr = 0, ii = 0, ri = 0, ir = 0;
+            const int p1 = p0 + 4 < Hn ? p0 + 4 : Hn;
+            for (int p = p0; p < p1; ++p) {
+                const cplx u = ul[p], y = ynl[p * Hn + q];
+                rr = fma(y.re, u.re, rr);
+                ri = fma(y.re, u.im, ri);
+                ii = fma(y.im, u.im, ii);
+                ir = fma(y.im, u.re, ir);
+            }
+            acc.re += rr - ii;
+            acc.im += ri + ir;
+        }
+    } else {
+        for (int p = 0; p < Hn; ++p) {
+            const cplx u = ul[p], y = ynl[p * Hn + q];
+            acc.re += fma(y.re, u.re, -(y.im * u.im));
+            acc.im += fma(y.re, u.im, y.im * u.re);
+        }
+    }
+    return csub(in, acc);
+}
+
+// harmonic_mismatch (HG:360-390).  One workgroup = one scenario x a tile of consecutive buses (thread t = i*Hn + q: bus-major, so a
+// workgroup's 256 rows are ~10 whole buses and their voltages one contiguous run).  Staged in LDS per workgroup (coupled Norton data):
+// the device type's Y_N^T (Hn x Hn complex: 10.8 KB at K = 25, shared by every bus of that type -- L2-resident) and the tile's bus
+// voltages; the Norton coupling rows of a nonlinear bus (HG:313-323: the only O(Hn^2) part of the mismatch) then run out of LDS.
+// The network part walks the CSR row (ascending columns, csr_matvec order) with 16-byte gathers of the neighbours' voltages, which
+// the XCD-aware placement (xcd_map) keeps in ONE L2 per scenario.  ||f||_inf: wave shuffle + one u64 atomicMax per workgroup.
+// f: the reference's stacked real layout (HG:388; dense solver, C ABI) or nullptr; fb: bus-major image [bus][2q + (Re|Im)] with
+// stride Bst and zeros where there is no equation (tree kernels) or nullptr.
 template <bool FUND>
 __global__ void k_mismatch(Model M, int count, int N, int Nc, const int* __restrict__ active, const cplx* __restrict__ U,
                            const double* __restrict__ P, const double* __restrict__ Q, double* __restrict__ f,
                            unsigned long long* __restrict__ errbits, cplx* __restrict__ I0, double* __restrict__ fb, int Bst,
                            int s0, int S_cnt, int nbx) {
+    extern __shared__ cplx mm_lds[];                    // [Hn*Hn] Y_N^T of the tile's first device type | [tile buses][Hn] voltages
     int bx, slot;
     if (!xcd_map(nbx, S_cnt, bx, slot)) return;
     const int s = active ? active[slot + s0] : slot + s0;   // slot -> scenario (active list; -1: frozen / empty slot)
     if (s < 0) return;
     const int t = bx * TPB + threadIdx.x;
+    const cplx* Us = U + (size_t)s * M.n * M.Hn;
+    int d0 = -1, i_first = 0;
+    if (!FUND && M.coupled && M.YNt) {
+        const int Hn = M.Hn;
+        i_first = (bx * TPB) / Hn;
+        int i_last = (bx * TPB + TPB - 1) / Hn;
+        if (i_last > M.n - 1) i_last = M.n - 1;
+        if (i_last >= M.m) {                            // the tile holds nonlinear buses (they come last in the bus order, HG:83)
+            d0 = M.dev[i_first > M.m ? i_first : M.m];
+            const cplx* src = M.YNt + (size_t)d0 * Hn * Hn;
+            for (int e = threadIdx.x; e < Hn * Hn; e += TPB) mm_lds[e] = src[e];
+            cplx* ul = mm_lds + Hn * Hn;
+            const int nv = (i_last - i_first + 1) * Hn;
+            for (int e = threadIdx.x; e < nv; e += TPB) ul[e] = Us[(size_t)i_first * Hn + e];
+        }
+        __syncthreads();
+    }
     unsigned long long b = 0;
     if (t < count) {
         const int i = FUND ? t : t / M.Hn, q = FUND ? 0 : t - i * M.Hn;
         const int k = q * M.n + i;
         cplx v = {0.0, 0.0};
         if (k >= 1) {
-            v = mismatch_row<FUND>(M, U + (size_t)s * M.n * M.Hn, P + (size_t)s * M.n, Q + (size_t)s * M.n, k,
-                                   I0 ? I0 + (size_t)s * M.n : nullptr);
+            if (!FUND && d0 >= 0 && i >= M.m && M.dev[i] == d0) {
+                // current-balance row of a nonlinear bus (HG:351,354): network current + Norton injection out of LDS
+                const cplx I = row_current(M, Us, q, i);
+                v = cadd(I, norton_injection_lds(M, d0, mm_lds, mm_lds + M.Hn * M.Hn + (i - i_first) * M.Hn, q));
+            } else {
+                v = mismatch_row<FUND>(M, Us, P + (size_t)s * M.n, Q + (size_t)s * M.n, k, I0 ? I0 + (size_t)s * M.n : nullptr);
+            }
             if (f) store_mismatch(f + (size_t)s * N, Nc, M.c, k, v);
             b = abs_bits(v.re);
             if (k >= M.c) {
@@ -524,7 +583,10 @@ int launch_mismatch(hpf_handle* h, const int* active, bool stacked = true) {
     const bool img = !FUND && h->d_fb && bus_images(h);
     if (count > 1) {
         const int nbx = (count + TPB - 1) / TPB;
-        hipLaunchKernelGGL((k_mismatch<FUND>), dim3((unsigned)(8 * ((h->cur_S + 7) / 8) * nbx)), dim3(TPB), 0, h->cur_stream, h->M, count, N, Nc,
+        // LDS: Y_N^T of one device type + the voltages of the workgroup's tile of buses (harmonic mismatch with coupled Norton data)
+        const size_t lds = (!FUND && h->coupled && h->n > h->m)
+                               ? sizeof(cplx) * ((size_t)h->Hn * h->Hn + (size_t)(TPB / h->Hn + 2) * h->Hn) : 0;
+        hipLaunchKernelGGL((k_mismatch<FUND>), dim3((unsigned)(8 * ((h->cur_S + 7) / 8) * nbx)), dim3(TPB), lds, h->cur_stream, h->M, count, N, Nc,
                            active, h->d_U, h->d_P, h->d_Q, (stacked || !img) ? h->d_f : nullptr, h->d_errbits, h->d_I0,
                            img ? h->d_fb : nullptr, tree_bst(h), h->cur_s0, h->cur_S, nbx);
         HIPCHK(hipGetLastError());
