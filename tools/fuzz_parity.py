@@ -19,12 +19,21 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 worst = 0.0
 for case in range(cases):
     n = int(rng.integers(33, 420))
-    hmax = int(rng.choice([5, 11, 15, 19, 25, 27, 35, 51, 59]))
+    hmax = int(rng.choice([5, 11, 15, 19, 25, 27, 35, 51, 59, 75, 99]))
+    if hmax > 51:
+        n = min(n, 160)                     # (the dense comparator: N = 2 n Hn)
     frac = float(rng.choice([0.05, 0.15, 0.35, 0.6, 0.85]))
     n_pv = int(rng.choice([0, 0, 1, 2]))
+    n_ties = int(rng.choice([0, 0, 0, 1, 3]))
     seed = int(rng.integers(0, 10 ** 6))
     tmp = tempfile.mkdtemp()
     fb, fl = synth.gen(n, seed=seed, frac_nl=frac, outdir=tmp)
+    if n_ties:                              # loop-closing lines: the block-tree path's bordered step
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("mgb", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "make_golden_bench.py"))
+        mgb = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mgb)
+        mgb.add_ties(fl, n, n_ties, seed=seed)
     if n_pv:
         rows = open(fb).read().splitlines()
         for bid in range(2, 2 + n_pv):
@@ -59,8 +68,8 @@ for case in range(cases):
     dVa = np.abs(res["dense"][1] - res["block_tree"][1]).max()
     step = max(np.abs(res["dense"][0] - seed_state[0]).max(), np.abs(res["dense"][1] - seed_state[1]).max(), 1.0)
     worst = max(worst, dVm / step, dVa / step)
-    print("case %2d: n=%3d Hn=%2d (b=%3d) nl=%.2f pv=%d seed=%6d   first step max|dVm| %.1e max|dVa| %.1e   (step size %.1e)" %
-          (case, nn, Hn, 2 * Hn, frac, n_pv, seed, dVm, dVa, step), flush=True)
+    print("case %2d: n=%3d Hn=%2d (b=%3d) nl=%.2f pv=%d ties=%d seed=%6d   first step max|dVm| %.1e max|dVa| %.1e   (step size %.1e)" %
+          (case, nn, Hn, 2 * Hn, frac, n_pv, n_ties, seed, dVm, dVa, step), flush=True)
     assert np.isfinite(dVm) and np.isfinite(dVa)
 print("worst deviation relative to the step size %.2e" % worst)
 sys.exit(0 if worst < 1e-6 else 1)     # wrong algebra shows as O(1); ill-conditioned first steps (100 rad) reach 1e-7 on either path
