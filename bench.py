@@ -289,6 +289,15 @@ def main():
                               "traffic_gbs_over_step_wall": step_traffic / (ms_step * 1e-3) / 1e9 if step_traffic else None,
                               "note": "algorithmic bytes of a whole NR step (factor sweep + back sweep + 2x2 kernels + mismatch "
                                       "+ update) over the step wall time"},
+        "roofline_assembly": {"bound": "hbm", "kernel": "k_mismatch<false> (harmonic_mismatch HG:360-390: the mismatch half of the assembly; the "
+                                                         "Jacobian half is fused into the factor kernels and never reaches HBM)",
+                              "achieved": bytes_mismatch * S / max(tim["mismatch"][1] / max(K, 1), 1) / (tim["mismatch"][0] / max(tim["mismatch"][1], 1) * 1e-3) / 1e9
+                              if tim["mismatch"][1] else None,
+                              "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "bytes_per_launch": bytes_mismatch * S / max(tim["mismatch"][1] / max(K, 1), 1),
+                              "avg_ms_hip_event_span": tim["mismatch"][0] / max(tim["mismatch"][1], 1),
+                              "note": "algorithmic bytes (voltages in, mismatch image out) of one launch (one scenario group) / its HIP-event span; "
+                                      "rocprofv3 of the same command: profiles/*kernel_stats.csv, counters: profiles/pmc_traffic_latest.json"},
         "phase_ms_per_launch": {k: (v[0] / max(v[1], 1)) for k, v in tim.items() if v[1]},
         "phase_launches_per_step": {k: v[1] / max(K, 1) for k, v in tim.items() if v[1]},
         "phase_note": "HIP-event spans: gj = one per k_factor_q<B,false> launch; solve = one per launch of the other factor kernels "
