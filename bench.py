@@ -360,6 +360,7 @@ def sweep_one_gpu(hp, inp, args, dev_index):
     dm = hp.DeviceModel(n, inp["m"], inp["c"], inp["st"].HARMONICS, inp["Y"].rowptr, inp["Y"].col, inp["Y"].Yval,
                         inp["dev"], inp["Y_N"], inp["I_N"], inp["n_dev"], True, solver=args.solver,
                         device=dev_index, max_scenarios=S)
+    dm_Hn, N_unk, bytes_solve, bytes_back = dm.Hn, dm.N, dm.solve_bytes(), dm.back_bytes()
     try:
         dm.set_loads(P0 * scale, Q0 * scale)
         dm.set_state(None, None, n_scen=S)
@@ -388,7 +389,15 @@ def sweep_one_gpu(hp, inp, args, dev_index):
         out = summarize(rec)
     finally:
         dm.close()
+    Hn = dm_Hn
+    step_bytes = S * (bytes_solve + (16 * Hn * n + 8 * N_unk) + bytes_back + ((32 + 16) * 2 * Hn * n + 2 * 16 * Hn * n) +
+                      (16 * Hn * n + 2 * 8 * Hn * n + 2 * 8 * Hn * n + 2 * 16 * Hn * n))
     out.update({"scenarios": S, "lockstep_ms_per_step": 1e3 * t_lock / Kl, "lockstep_iters_per_s": S * Kl / t_lock,
+                "roofline_hbm_step": {"bound": "hbm", "achieved": step_bytes / (t_lock / Kl) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": step_bytes / (t_lock / Kl) / 1e9 / HBM_PEAK_GBS, "bytes_per_step": step_bytes,
+                                      "note": "algorithmic bytes of a whole lock-step NR iteration of all live scenarios over its wall time: with "
+                                              "1 024 live scenarios the latency-bound tree levels amortise and the step runs against the HBM "
+                                              "roof (counters of this configuration: profiles/r02/pmc_traffic_s1024.json, 26.2 GB per step)"},
                 "solve_wall_s": t_solve, "iters_per_s": float(n_iter.sum()) / t_solve, "pf_wall_s": t_pf,
                 "note": "one GPU, all scenarios live; solve = hpf_solve with the reference's stop rule (per-scenario freeze, "
                         "compaction of the running scenarios between chunks of 4 iterations, pipelined polling)"})

@@ -29,7 +29,9 @@ def short(name):
 def main():
     out_path = sys.argv[1]
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 7
-    calib = sys.argv[3] if len(sys.argv) > 3 else os.path.join(REPO, "profiles", "r02", "pmc_calib.json")
+    calib = sys.argv[3] if len(sys.argv) > 3 and sys.argv[3] != "-" else os.path.join(REPO, "profiles", "r02", "pmc_calib.json")
+    prefix = sys.argv[4] if len(sys.argv) > 4 else "pmc_"           # gpurun_out/<prefix>FETCH_SIZE, <prefix>WRITE_SIZE
+    command = sys.argv[5] if len(sys.argv) > 5 else None
     ff, wf = 2.0, 1.0
     if os.path.exists(calib):
         ck = json.load(open(calib))["kernels"]
@@ -37,7 +39,7 @@ def main():
         wf = 1.0 / ck["k_tile_store"]["WRITE_SIZE_over_known"]
     res = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
-        f = max(glob.glob(os.path.join(REPO, "gpurun_out", f"pmc_{c}", "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
+        f = max(glob.glob(os.path.join(REPO, "gpurun_out", f"{prefix}{c}", "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
         agg = collections.defaultdict(lambda: [0, 0.0])
         for r in csv.DictReader(open(f)):
             k = short(r["Kernel_Name"])
@@ -57,6 +59,8 @@ def main():
             continue                                            # set-up kernels (pf, initial state), not part of a timed step
         out["per_step_bytes"][k] = {"fetch": fe / steps, "write": wr / steps, "dispatches_per_step": nd / steps}
         out["per_launch_bytes"][k] = {"fetch": fe / nd, "write": wr / nd}
+    if command:
+        out["command"] = command
     g = [k for k in out["per_launch_bytes"] if k.startswith("k_factor_q<") and k.endswith("false>")]
     if g:
         out["per_launch_bytes"]["k_factor_q_general"] = out["per_launch_bytes"][g[0]]
