@@ -1205,6 +1205,7 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
     const bool slback_on = !(sb_env && atoi(sb_env) == 0) && !(lb_env && atoi(lb_env) == 0);   // super-leaves keep T^-1 only; k_sleaf_back_batch
                                                                                              // rebuilds D^-1 t (needs the batched back sweep)
     std::vector<int> sb_ord(n, -1), sb_m(n, 0);
+    std::vector<int> sl_nest(n, 0);                            // nesting order of a bordered bus: 0 = its dense children are leaves only
     // super-leaves whose parent rebuilds their Schur complement itself (like a lazy leaf's, with the m x m core T^-1): constants
     //   C0 = g Ahh^-1 h,  GP = g Pb (rows q >= 1),  QH = Qb h (columns q >= 1)
     struct LazySuper {
@@ -1215,6 +1216,8 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
     std::vector<std::vector<int>> slz_of(n);
     const char* sz_env = getenv("HPF_SLLAZY");
     const bool sllazy_on = !(sz_env && atoi(sz_env) == 0);     // HPF_SLLAZY=0: every super-leaf pushes its Schur complement itself
+    const char* sn_env = getenv("HPF_SLNEST");
+    const bool slnest_on = !(sn_env && atoi(sn_env) == 0);     // HPF_SLNEST=0: bordered buses below a bordered bus stay on the Gauss-Jordan path
     std::vector<double> sbimg;
     std::vector<std::vector<int>> lazy_of(n);
     std::vector<int> is_lazy(n, 0);
@@ -1445,18 +1448,50 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
         //      system with z_c = K_c Hr_c x and eliminate the harmonic part of x with the constant Ahh_k^-1:
         //          M_k^-1 = [0 0; 0 Ahh^-1] + Pb T^-1 Qb,    T = Tc + blockdiag(D_k, K_1^-1, ..., K_L^-1) - (G0/H0 borders),
         //      Tc, Pb (b x m), Qb (m x b), m = 2 + 2L constant per model; T is m x m per scenario (k_factor_q, "sleaf" branch).
+        //      Nested (round 2): a dense child may itself be a vector-only bordered bus c (M_c^-1 = Z0_c + Pb_c T_c^-1 Qb_c, border m_c): its
+        //      Schur complement onto k is  C0_c + (g Pb_c) T_c^-1 (Qb_c h)  -- the same form with the m_c x m_c per-scenario matrix T_c in the
+        //      place of K_c^-1 and its m_c/2 complex border columns (g Pb_c[:, i], Qb_c[i, :] h) in the place of the leaf's one -- so k
+        //      borders ITS system with all of them: m_k = 2 + 2 L + sum m_c, T_k carries the children's T_c (not their inverses) on its
+        //      diagonal.  Buses qualify bottom-up while m_k <= 10 (k_sleaf_batch: one thread per border row, 10 x 10 in LDS).
         for (int pos = 0; sleaf_on && pos < T.n_dense; ++pos) {
             const int k = T.lvl_nodes[pos];
             const int L = (int)lazy_of[k].size();
-            if (k < (d->c > 1 ? d->c : 1) || L == 0 || dchild_ptr[k + 1] - dchild_ptr[k] != L) continue;
+            const int LS = (int)slz_of[k].size();                      // vector-only bordered children (registered when THEY were built)
+            if (k < (d->c > 1 ? d->c : 1) || L + LS == 0 || dchild_ptr[k + 1] - dchild_ptr[k] != L + LS) continue;
             if (k < d->m && sleaf_mode < 2) continue;                  // linear (PQ) buses: power-row map W_k on the fundamental
+            // border columns: per lazy leaf one complex column (G, H), per bordered child its m1_c columns (g Pb_c[:, i], Qb_c[i, :] h)
+            std::vector<std::vector<cd>> colG, colH;
+            for (int li : lazy_of[k]) {
+                colG.push_back(lazies[li].G);
+                colH.push_back(lazies[li].H);
+            }
+            for (int zi : slz_of[k]) {
+                const int m1c = slzs[zi].m1;
+                for (int i = 0; i < m1c; ++i) {
+                    std::vector<cd> g(Hn, cd(0.0, 0.0)), hh(Hn, cd(0.0, 0.0));
+                    for (int q = 1; q < Hn; ++q) {
+                        g[q] = slzs[zi].GP[(size_t)q * m1c + i];
+                        hh[q] = slzs[zi].QH[(size_t)i * Hn + q];
+                    }
+                    colG.push_back(std::move(g));
+                    colH.push_back(std::move(hh));
+                }
+            }
+            for (int zi : slz_of[k]) sl_nest[k] = std::max(sl_nest[k], 1 + sl_nest[slzs[zi].k]);
+            const int NC = (int)colG.size();
+            const int m1 = 1 + NC, mr = 2 * m1;
+            const int pks = pard[k];
+            const bool can_slz = slback_on && sllazy_on && mr <= 10 && pks >= (d->c > 1 ? d->c : 1) && (int)slz_of[pks].size() < 2;
+            if (mr > 10 || (LS > 0 && !(can_slz && slnest_on))) continue;            // (a nested bus exists only in the scenario-batched, vector-only form)
             std::vector<cd> A, geff, heff, imgk;
             build_Yc(k, A, geff, heff);
             for (int li : lazy_of[k])
                 for (int q = 1; q < Hn; ++q)
                     for (int p2 = 1; p2 < Hn; ++p2) A[(size_t)q * Hn + p2] -= lazies[li].C0[(size_t)q * Hn + p2];
+            for (int zi : slz_of[k])
+                for (int q = 1; q < Hn; ++q)
+                    for (int p2 = 1; p2 < Hn; ++p2) A[(size_t)q * Hn + p2] -= slzs[zi].C0[(size_t)q * Hn + p2];
             if (!border_image(A, imgk)) continue;
-            const int m1 = 1 + L, mr = 2 * m1;
             auto Ainv = [&](int q, int p2) { return imgk[(size_t)q * Hn + p2]; };          // q, p2 >= 1
             std::vector<cd> Tc((size_t)m1 * m1, cd(0.0, 0.0)), Pb((size_t)Hn * m1, cd(0.0, 0.0)), Qb((size_t)m1 * Hn, cd(0.0, 0.0));
             Tc[0] = imgk[0];
@@ -1466,29 +1501,30 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
                 Pb[(size_t)q * m1] = imgk[(size_t)q * Hn];                                    // Lc
                 Qb[q] = imgk[q];                                                              // Lr
             }
-            for (int i = 0; i < L; ++i) {
-                const LazyLeaf& li = lazies[lazy_of[k][i]];
+            for (int i = 0; i < NC; ++i) {
+                const std::vector<cd>& Gi = colG[i];
+                const std::vector<cd>& Hi = colH[i];
                 cd t0c(0.0, 0.0), tc0(0.0, 0.0);
                 for (int q = 1; q < Hn; ++q) {
-                    t0c -= imgk[q] * li.G[q];                                                 // -Lr gh_c
-                    tc0 -= li.H[q] * imgk[(size_t)q * Hn];                                    // -hh_c Lc
+                    t0c -= imgk[q] * Gi[q];                                                   // -Lr gh_c
+                    tc0 -= Hi[q] * imgk[(size_t)q * Hn];                                      // -hh_c Lc
                     cd pbv(0.0, 0.0), qbv(0.0, 0.0);
                     for (int p2 = 1; p2 < Hn; ++p2) {
-                        pbv += Ainv(q, p2) * li.G[p2];                                        // Ahh^-1 gh_c
-                        qbv += li.H[p2] * Ainv(p2, q);                                        // hh_c Ahh^-1
+                        pbv += Ainv(q, p2) * Gi[p2];                                          // Ahh^-1 gh_c
+                        qbv += Hi[p2] * Ainv(p2, q);                                          // hh_c Ahh^-1
                     }
                     Pb[(size_t)q * m1 + 1 + i] = pbv;
                     Qb[(size_t)(1 + i) * Hn + q] = qbv;
                 }
                 Tc[1 + i] = t0c;
                 Tc[(size_t)(1 + i) * m1] = tc0;
-                for (int j = 0; j < L; ++j) {
-                    const LazyLeaf& lj = lazies[lazy_of[k][j]];
+            }
+            for (int i = 0; i < NC; ++i)
+                for (int j = 0; j < NC; ++j) {
                     cd v(0.0, 0.0);
-                    for (int q = 1; q < Hn; ++q) v -= Qb[(size_t)(1 + i) * Hn + q] * lj.G[q];   // -hh_i Ahh^-1 gh_j
+                    for (int q = 1; q < Hn; ++q) v -= Qb[(size_t)(1 + i) * Hn + q] * colG[j][q];   // -hh_i Ahh^-1 gh_j
                     Tc[(size_t)(1 + i) * m1 + 1 + j] = v;
                 }
-            }
             auto R = [](cd z, int t, int t2) { return (t == t2) ? z.real() : (t ? z.imag() : -z.imag()); };
             sl_slot[k] = ++T.n_cleaf;                                                         // Z0 image: [0 0; 0 Ahh^-1]
             minv.resize((size_t)T.n_cleaf * CTc, 0.0);
@@ -1505,8 +1541,7 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
                 for (int c2 = 0; c2 < mr; ++c2) slimg.push_back(R(Pb[(size_t)(row >> 1) * m1 + (c2 >> 1)], row & 1, c2 & 1));
             for (int r2 = 0; r2 < mr; ++r2)
                 for (int col = 0; col < b; ++col) slimg.push_back(R(Qb[(size_t)(r2 >> 1) * Hn + (col >> 1)], r2 & 1, col & 1));
-            const int pks = pard[k];
-            if (slback_on && sllazy_on && mr <= 10 && pks >= (d->c > 1 ? d->c : 1) && (int)slz_of[pks].size() < 2) {
+            if (can_slz) {
                 LazySuper z;
                 z.k = k;
                 z.m1 = m1;
@@ -1694,6 +1729,19 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
         bdesc[(size_t)pos * 4 + 1] = pard[kb];
         bdesc[(size_t)pos * 4 + 2] = cleaf_of[kb] + 1;
     }
+    {
+        int nc = 0, nb = 0, nn = 0;
+        for (int i = 0; i < n; ++i) {
+            if (!kept(i)) continue;
+            if (cleaf_of[i] >= 0) ++nc;
+            if (sl_off[i] >= 0 && lz_idx[i] >= 0) {
+                ++nb;
+                if (sl_nest[i] > 0) ++nn;
+            }
+        }
+        const int cs[8] = {T.n_dense, T.n_dense - nc - nb, nc, T.n_lazy_leaves, nb, nn, T.n_levels, T.n_depths};
+        for (int i = 0; i < 8; ++i) T.census[i] = cs[i];
+    }
     const double bd = b;
     // FP64 flop count of the dense part of the elimination (one scenario, one Newton step).  Gauss-Jordan bus: 2 b^3 (block
     // inversion) + 2 b^2 (w = D^-1 y) + b^2 per dense child (Schur complement subtracted) + 8 b^2 (push G D^-1 H) if not the
@@ -1724,8 +1772,9 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
         const int nch = dchild_ptr[i + 1] - dchild_ptr[i];
         const bool leaf = cleaf_of[i] >= 0;
         const int nlz = n_lazy[i];                                   // lazy leaves: 2x2 core + G w column in, rank-2 MFMA update
-        const bool sl = nlz > 0 && sl_off[i] >= 0;                    // super-leaf: m x m inversion, rank-4 MFMAs per 4 border unknowns, S^-1, w
-        const double msl = 2.0 + 2.0 * nlz;
+        const bool sl = sl_off[i] >= 0 && lz_idx[i] >= 0;             // bordered bus: m x m inversion, rank-4 MFMAs per 4 border unknowns, S^-1, w
+        double msl = 2.0 + 2.0 * nlz;
+        for (int zi : slz_of[i]) msl += 2.0 * slzs[zi].m1;                 // nested bordered children: their borders join this bus's
         double fl = 0.0, by = 0.0;
         if (sl)
             fl += 2.0 * msl * msl * msl + 2.0 * bd * bd * 4.0 * (double)((2 + 2 * nlz + 3) / 4) + 2.0 * bd * msl * 3.0 +
@@ -1790,12 +1839,19 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
     if ((r = upload(h, &T.d_child3, child3))) return r;
     if ((r = upload(h, &T.d_bdesc, bdesc))) return r;
     {
+        // back sweep of the bordered buses: a nested bus before the bordered children below it -> groups by nesting order, highest first
         std::vector<int> bsleaf;
-        for (int pos = 0; pos < T.n_dense; ++pos) {
-            const int kb = T.dep_nodes[pos];
-            if (sb_ord[kb] < 0 || sl_off[kb] < 0 || lz_idx[kb] < 0) continue;
-            const int rec[8] = {kb, pard[kb], sb_ord[kb], (int)(sl_base + sl_off[kb]), sb_m[kb], 0, 0, 0};
-            bsleaf.insert(bsleaf.end(), rec, rec + 8);
+        int max_nest = 0;
+        for (int i = 0; i < n; ++i) max_nest = std::max(max_nest, sl_nest[i]);
+        T.bsleaf_ptr.assign(1, 0);
+        for (int nest = max_nest; nest >= 0; --nest) {
+            for (int pos = 0; pos < T.n_dense; ++pos) {
+                const int kb = T.dep_nodes[pos];
+                if (sb_ord[kb] < 0 || sl_off[kb] < 0 || lz_idx[kb] < 0 || sl_nest[kb] != nest) continue;
+                const int rec[8] = {kb, pard[kb], sb_ord[kb], (int)(sl_base + sl_off[kb]), sb_m[kb], 0, 0, 0};
+                bsleaf.insert(bsleaf.end(), rec, rec + 8);
+            }
+            T.bsleaf_ptr.push_back((int)bsleaf.size() / 8);
         }
         T.n_bsleaf = (int)bsleaf.size() / 8;
         if ((r = upload(h, &T.d_bsleaf, bsleaf))) return r;
@@ -2062,11 +2118,15 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
         const int leafbatch_e = h->leafbatch;
         if (leafbatch_e && h->has_ctree && h->gj_mode == 1 && T.n_bsleaf > 0) {    // super-leaves first: leaves hang below them
             int r = HPF_OK;
-            switch (BW) {
-                case 12: r = launch_sleaf_back_batch<12>(h, T.d_bsleaf, T.n_bsleaf, active); break;
-                case 28: r = launch_sleaf_back_batch<28>(h, T.d_bsleaf, T.n_bsleaf, active); break;
-                case 52: r = launch_sleaf_back_batch<52>(h, T.d_bsleaf, T.n_bsleaf, active); break;
-                default: break;
+            for (size_t gi = 0; gi + 1 < T.bsleaf_ptr.size() && !r; ++gi) {      // nested bordered buses first (by nesting order)
+                const int b0 = T.bsleaf_ptr[gi], bc2 = T.bsleaf_ptr[gi + 1] - b0;
+                if (bc2 <= 0) continue;
+                switch (BW) {
+                    case 12: r = launch_sleaf_back_batch<12>(h, T.d_bsleaf + 8 * (size_t)b0, bc2, active); break;
+                    case 28: r = launch_sleaf_back_batch<28>(h, T.d_bsleaf + 8 * (size_t)b0, bc2, active); break;
+                    case 52: r = launch_sleaf_back_batch<52>(h, T.d_bsleaf + 8 * (size_t)b0, bc2, active); break;
+                    default: break;
+                }
             }
             if (r) return r;
         }

@@ -88,6 +88,8 @@ struct Tree {
                                       // in the level's records and go through k_sleaf_batch (16 scenarios per workgroup)
     std::vector<int> dep_nleaf;       // [n_depths] constant-inverse leaves of a back-sweep depth (they come first in the depth's records)
     std::vector<int> dep_nskip;       // [n_depths] leaves + batched super-leaves of a depth: k_back_q starts behind them
+    int census[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // hpf_tree_census
+    std::vector<int> bsleaf_ptr;      // back sweep of the bordered buses in groups by nesting order (nested ones first): offsets into d_bsleaf
     int n_bsleaf = 0;
     int* d_bsleaf = nullptr;          // [n_bsleaf][8] back-sweep records of the super-leaves (k_sleaf_back_batch)
     double* d_sbimg = nullptr;        // [n_bsleaf][NTR*KS*64] their [0 0; 0 Ahh^-1] images in MFMA A-operand layout

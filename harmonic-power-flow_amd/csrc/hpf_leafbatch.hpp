@@ -488,7 +488,9 @@ __global__ __launch_bounds__(256, 4) void k_sleaf_batch(
     const int k = nd0.x, par = nd0.y, diag_e = nd0.z;
     const int e_dn_k = nd1.x, e_up_k = nd1.y, lin_beg = nd1.z, lin_end = nd1.z + nd1.w;
     const bool via_chain = (nd3.z & 1) != 0;
-    const int L = lzA.y, m = 2 + 2 * L;
+    // nested bordered children (at most two): bus, border unknowns; their T (not inverted) sits on this bus's diagonal
+    const int L = lzA.y, cs0 = lzC.x, cs1 = lzC.y, mc0 = lzC.z & 0xff, mc1 = (lzC.z >> 8) & 0xff;
+    const int m = 2 + 2 * L + mc0 + mc1;
     const double* simg = T.lzimg + (size_t)lzB.w;                // Tc [m][m] | Pb [b][m] | Qb [m][b]
     const double* pbm = simg + m * m;
     const double* qbm = pbm + (size_t)b * m;
@@ -541,6 +543,8 @@ __global__ __launch_bounds__(256, 4) void k_sleaf_batch(
                 const double g0 = lzA.z >= 0 ? Cs[(size_t)lzA.z * CT + row] : 0.0, g1 = lzA.w >= 0 ? Cs[(size_t)lzA.w * CT + row] : 0.0;
                 const double g2 = lzB.x >= 0 ? Cs[(size_t)lzB.x * CT + row] : 0.0, g3 = lzB.y >= 0 ? Cs[(size_t)lzB.y * CT + row] : 0.0;
                 ay[pz] -= (g0 + g1) + (g2 + g3);
+                const double g4 = cs0 >= 0 ? Cs[(size_t)cs0 * CT + row] : 0.0, g5 = cs1 >= 0 ? Cs[(size_t)cs1 * CT + row] : 0.0;
+                ay[pz] -= g4 + g5;                                   // ... and of the bordered children
                 if (row < 2 && linear_k) {                           // power rows: the state-dependent diagonal of the fundamental
                     const Blk2 blk = blk_power_diag(M.Y[(size_t)diag_e * Hn], ukr[pz], ekr[pz], I0all[(size_t)s * n + k]);
                     a0[pz] += pick(blk, tr_, 0);
@@ -690,6 +694,24 @@ __global__ __launch_bounds__(256, 4) void k_sleaf_batch(
             aug[bc * 10 + 1] -= kk[9];
             aug[(bc + 1) * 10] -= kk[10];
             aug[(bc + 1) * 10 + 1] -= kk[11];
+        } else if (live && l16 - L - 1 < (cs0 >= 0) + (cs1 >= 0)) {
+            // bordered child: its T_c in the place of K_c^-1; of its border columns only the first (the child's own position 0)
+            // reaches position 0 here: -W_k^-1 (G0 S_c^-1) above, -W_c^-1 (H0 S_k^-1) on the left
+            const int zc = l16 - L - 1;
+            const int cb = zc == 0 ? cs0 : cs1, mc = zc == 0 ? mc0 : mc1, bc = 2 + 2 * L + (zc ? mc0 : 0);
+            const double* tcd = Zall + ((size_t)s * n + cb) * CT;     // T_c^-1 [10][10] | W_c^-1 [4] | T_c [10][10]
+            const double* kk = lfK + ((size_t)s * n + cb) * 12;
+            for (int i = 0; i < mc; ++i)
+                for (int j = 0; j < mc; ++j) aug[(bc + i) * 10 + bc + j] += tcd[104 + i * 10 + j];
+            aug[bc] -= fma(wi[1], kk[6], wi[0] * kk[4]);
+            aug[bc + 1] -= fma(wi[1], kk[7], wi[0] * kk[5]);
+            aug[10 + bc] -= fma(wi[3], kk[6], wi[2] * kk[4]);
+            aug[10 + bc + 1] -= fma(wi[3], kk[7], wi[2] * kk[5]);
+            const double* wc = tcd + 100;
+            aug[bc * 10] -= fma(wc[1], kk[10], wc[0] * kk[8]);
+            aug[bc * 10 + 1] -= fma(wc[1], kk[11], wc[0] * kk[9]);
+            aug[(bc + 1) * 10] -= fma(wc[3], kk[10], wc[2] * kk[8]);
+            aug[(bc + 1) * 10 + 1] -= fma(wc[3], kk[11], wc[2] * kk[9]);
         }
     }
     __syncthreads();
@@ -700,6 +722,12 @@ __global__ __launch_bounds__(256, 4) void k_sleaf_batch(
         double row[10];
 #pragma unroll
         for (int c2 = 0; c2 < 10; ++c2) row[c2] = (l16 < m && c2 < m) ? aug[l16 * 10 + c2] : 0.0;
+        if (live && l16 < m) {                                   // T itself for a bordered parent (behind T^-1 and W^-1)
+            double* tk = Zall + ((size_t)s * n + k) * CT + 104 + l16 * 10;
+#pragma unroll
+            for (int c2 = 0; c2 < 10; ++c2)
+                if (c2 < m) tk[c2] = row[c2];
+        }
         bool used = l16 >= m;
         int mycol = 0, pcol[10];
 #pragma unroll

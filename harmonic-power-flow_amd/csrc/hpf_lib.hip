@@ -1411,6 +1411,14 @@ int hpf_kernel_model(const hpf_handle* h, int which, double* bytes, double* flop
     return HPF_OK;
 }
 
+int hpf_tree_census(const hpf_handle* h, int* counts, int n_counts) {
+    if (!h || !counts || n_counts < 0) return HPF_E_ARG;
+    if (h->solver != HPF_SOLVER_BLOCK_TREE) return HPF_E_STATE;
+    const Tree& T = active_tree(const_cast<hpf_handle*>(h));
+    for (int i = 0; i < n_counts; ++i) counts[i] = i < 8 ? T.census[i] : (i == 8 ? h->n_ties : 0);
+    return HPF_OK;
+}
+
 double hpf_back_bytes(const hpf_handle* h) {
     if (!h || h->solver != HPF_SOLVER_BLOCK_TREE) return 0.0;
     return active_tree(const_cast<hpf_handle*>(h)).bytes_back;

@@ -225,6 +225,13 @@ class DeviceModel:
     def solve_flops(self):
         return float(self.lib.hpf_solve_flops(self._h))
 
+    def tree_census(self):
+        """Which kernel takes which bus of the block tree (hpf_tree_census)."""
+        out = (C.c_int32 * 9)()
+        self._chk(self.lib.hpf_tree_census(self._h, out, 9), "hpf_tree_census")
+        names = ("dense_buses", "gauss_jordan", "const_leaves", "lazy_leaves", "bordered", "nested_bordered", "levels", "depths", "ties")
+        return dict(zip(names, (int(v) for v in out)))
+
     def solve_bytes(self):
         """Algorithmic HBM bytes of the linear-solve span of one scenario and one Newton step (hpf_solve_bytes)."""
         return float(self.lib.hpf_solve_bytes(self._h))

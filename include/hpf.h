@@ -211,6 +211,11 @@ double hpf_back_bytes(const hpf_handle* h);
  * scenario-batched kernels k_leaf_batch / k_sleaf_batch and of the leaf-only instantiation are NOT in it); which == 2: the
  * whole factor sweep (= hpf_solve_bytes / hpf_solve_flops); which == 4: the back sweep.  Other classes: HPF_E_ARG. */
 int  hpf_kernel_model(const hpf_handle* h, int which, double* bytes, double* flops, int* launches);
+/* Census of the BLOCK_TREE elimination tree (diagnostic; which kernel takes which bus).  counts[0..8]: buses with a dense b x b
+ * block (the rest lives in the 2x2 algebra of the linear subtrees / contracted chains), Gauss-Jordan buses (k_factor_q<B,false>),
+ * constant-inverse leaves, of which lazy (vector-only, k_leaf_batch), bordered buses (super-leaves, m x m core), of which nested
+ * (bordered children below them), elimination levels, back-sweep depths, tie lines of a meshed network.  HPF_E_STATE for DENSE. */
+int  hpf_tree_census(const hpf_handle* h, int* counts, int n_counts);
 
 #ifdef __cplusplus
 }

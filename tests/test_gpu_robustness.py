@@ -57,9 +57,10 @@ def _solve(hp, st, buses, Y, NE, solver="block_tree", S=1, options=(), seed_stat
             dm.iterate(polish)
             dm.sync()
         Vm, Va = dm.get_state()
+        census = dm.tree_census() if solver == "block_tree" else None
     finally:
         dm.close()
-    return dict(it=it, err=err, Vm=Vm, Va=Va, seed=seed, stats=st_, hist=hist)
+    return dict(it=it, err=err, Vm=Vm, Va=Va, seed=seed, stats=st_, hist=hist, census=census)
 
 
 def test_static_pivot_monitor_and_repeat_with_partial_pivoting(tmp_path):
@@ -148,7 +149,8 @@ def test_per_iteration_state_dump_follows_the_reference_trajectory(name, solver,
 
 
 @pytest.mark.parametrize("env", [{"HPF_LAZY": "0"}, {"HPF_LAZY": "1"}, {"HPF_SLEAF": "0"}, {"HPF_SLEAF": "1"},
-                                 {"HPF_SLLAZY": "0"}, {"HPF_SLBACK": "0"}, {"HPF_LEAFBATCH": "0"}, {"HPF_GROUPS": "2"}])
+                                 {"HPF_SLLAZY": "0"}, {"HPF_SLBACK": "0"}, {"HPF_LEAFBATCH": "0"}, {"HPF_GROUPS": "2"},
+                                 {"HPF_SLNEST": "0"}])
 def test_tree_build_variants_take_the_same_newton_steps(env, tmp_path, monkeypatch):
     """Every diagnostic switch of hpf_create (hpf.h) selects a more general path for some class of buses (no lazy leaves, no
     super-leaves, super-leaves that push their Schur complement / store their inverse, leaves one workgroup per scenario): the
@@ -166,6 +168,29 @@ def test_tree_build_variants_take_the_same_newton_steps(env, tmp_path, monkeypat
     print("\n%s: iterations %s vs %s, max|dU| after one more iteration %.2e" % (env, var["it"][:4], base["it"][:4], np.abs(Ub - Uv).max()))
     assert (var["err"] <= 1e-4).all()
     assert np.abs(Ub - Uv).max() < TOL_V
+
+
+@pytest.mark.parametrize("n,hmax", [(1000, 51), (600, 11), (400, 27)])
+def test_nested_bordered_buses_match_the_gauss_jordan_path(n, hmax, tmp_path, monkeypatch):
+    """Bordered buses below bordered buses (the child's m_c x m_c core T_c sits on the parent's diagonal, total
+    border <= 10) replace Gauss-Jordan buses of the upper tree; with HPF_SLNEST=0 the same buses take the general kernel.  Same
+    converged voltages (fixed point: one Newton iteration past the stop rule on both sides; the iteration COUNTS of the load
+    scenarios of this feeder differ with any change of the rounding, SURVEY.md §0 trap #2) and the census says which path ran."""
+    hp = _hp()
+    st, buses, Y, NE, _ = _feeder(hp, n, hmax, tmp_path, seed=0)
+    S = 19                                                          # one full 16-scenario workgroup and a ragged one
+    nest = _solve(hp, st, buses, Y, NE, S=S, polish=1)
+    monkeypatch.setenv("HPF_SLNEST", "0")
+    flat = _solve(hp, st, buses, Y, NE, S=S, polish=1)
+    print("\nn=%d hmax=%d: nested %s\n               flat   %s" % (n, hmax, nest["census"], flat["census"]))
+    assert flat["census"]["nested_bordered"] == 0
+    assert nest["census"]["gauss_jordan"] + nest["census"]["nested_bordered"] == flat["census"]["gauss_jordan"]
+    if (n, hmax) == (1000, 51):                                     # the headline feeder: a quarter of its Gauss-Jordan buses
+        assert nest["census"]["nested_bordered"] >= 20
+        assert nest["census"]["gauss_jordan"] <= flat["census"]["gauss_jordan"] - 20
+    assert (nest["err"] <= 1e-4).all() and (flat["err"] <= 1e-4).all()
+    Un, Uf = nest["Vm"] * np.exp(1j * nest["Va"]), flat["Vm"] * np.exp(1j * flat["Va"])
+    assert np.abs(Un - Uf).max() < TOL_V
 
 
 # (n, H_MAX, share of nonlinear buses, PV buses, generator seed, iterations of the ORACLE [50 = the reference's own Newton iteration
