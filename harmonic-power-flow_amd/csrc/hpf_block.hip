@@ -823,6 +823,71 @@ int launch_back_w(hpf_handle* h, const TreeDev& T, const int* nodes, int count, 
 #include "hpf_quad.hpp"
 #include "hpf_leafbatch.hpp"
 
+// One launch per elimination level (b = 52 blocks, 256-thread workgroups): the scenario-batched workgroups of the level (lazy leaves
+// at level 0, vector-only bordered buses above: 16 scenarios each) and its Gauss-Jordan / leaf workgroups (one per bus and scenario)
+// are independent of each other, so they share ONE grid -- batched workgroups first (they live longest) -- instead of two
+// dependent launches in the stream: the level costs the longer of the two lives, not their sum.  The three bodies carve their LDS
+// from one buffer (the largest of the three).  kind: 0 no batched workgroups, 1 k_leaf_batch's, 2 k_sleaf_batch's.
+template <int B>
+constexpr int level_lds() {
+    constexpr int a = factor_q_lds<B>(), b2 = SLEAF_BATCH_LDS, c2 = LEAF_BATCH_LDS;
+    return a > b2 ? (a > c2 ? a : c2) : (b2 > c2 ? b2 : c2);
+}
+
+template <int B>
+__global__ __launch_bounds__(64 * ((B + 16) / 16), HPF_Q_OCC) void k_level(
+    Model M, TreeDev T, const int* __restrict__ nodes, int kind, int nbatch, int ngen, int b, int N, int Nc,
+    const int* __restrict__ active, int S_cnt, const cplx* __restrict__ Uall, const cplx* __restrict__ Eall,
+    const double* __restrict__ fall, double* __restrict__ Zall, double* __restrict__ wall, const double* __restrict__ linAall,
+    double* __restrict__ Call, double* __restrict__ Hall, const cplx* __restrict__ I0all, const double* __restrict__ chG,
+    const double* __restrict__ chH, const double* __restrict__ chD, const double* __restrict__ chy,
+    const double* __restrict__ Minv, const double* __restrict__ lbimg, const double* __restrict__ sbimg, double* __restrict__ lfK,
+    double* __restrict__ lfS, long long* __restrict__ dbg, int ablate, int s0, int* __restrict__ pivflag, double piv_limit,
+    unsigned long long* __restrict__ tstamp) {
+    static_assert(64 * ((B + 16) / 16) == 256, "the scenario-batched bodies are written for 256 threads");
+    __shared__ __attribute__((aligned(16))) double smem[level_lds<B>()];
+    const int ytiles = (S_cnt + LB_SB - 1) / LB_SB, nbb = kind ? nbatch * ytiles : 0;
+    if ((int)blockIdx.x < nbb) {
+        const int bx = (int)blockIdx.x % nbatch, by = (int)blockIdx.x / nbatch;
+        if (tstamp && threadIdx.x == 0) atomicMin(tstamp, (unsigned long long)wall_clock64());
+        if (kind == 1)
+            leaf_batch_body<B>(smem, bx, by, M, T, nodes, b, active, S_cnt, Uall, Eall, fall, wall, linAall, Call, Hall, chG, chH, chD, chy,
+                               lbimg, lfK, lfS, s0);
+        else
+            sleaf_batch_body<B>(smem, bx, by, M, T, nodes, b, active, S_cnt, Uall, Eall, fall, wall, linAall, Call, Hall, I0all, chG, chH,
+                                chD, chy, sbimg, Zall, lfK, lfS, s0, dbg, ablate);
+        if (tstamp) {
+            __syncthreads();
+            if (threadIdx.x == 0) atomicMax(tstamp + 1, (unsigned long long)wall_clock64());
+        }
+    } else {
+        const int i = (int)blockIdx.x - nbb;
+        factor_q_body<B, false>(smem, i % ngen, i / ngen, M, T, nodes + FDESC * (size_t)nbatch, b, N, Nc, active, Uall, Eall, fall, Zall, wall,
+                                linAall, Call, Hall, I0all, chG, chH, chD, chy, Minv, lfK, lfS, dbg, ablate, s0, pivflag, piv_limit, tstamp);
+    }
+}
+
+template <int B>
+int launch_level(hpf_handle* h, const TreeDev& T, const int* nodes, int kind, int nbatch, int ngen, const int* active) {
+    ScopedTimer t(h, T_GJ);
+    unsigned long long* ts = nullptr;                   // device-clock stamps of this launch (timing leg)
+    if (h->timing && h->d_tstamp && h->ts_next < hpf_handle::TS_CAP) ts = h->d_tstamp + 2 * (size_t)(h->ts_next++);
+    const Tree& tr = active_tree(h);
+    const unsigned ytiles = (unsigned)((h->cur_S + LB_SB - 1) / LB_SB);
+    const unsigned grid = (kind ? (unsigned)nbatch * ytiles : 0u) + (unsigned)ngen * (unsigned)h->cur_S;
+    if (grid == 0) return HPF_OK;
+    hipLaunchKernelGGL((k_level<B>), dim3(grid), dim3(64 * ((B + 16) / 16)), 0, h->cur_stream, h->M, T, nodes, kind, nbatch, ngen, 2 * h->Hn,
+                       h->N, h->Nc, active, h->cur_S, h->d_U, h->d_E, h->d_fb, h->d_Z, h->d_w, h->d_linA, h->d_C, h->d_H, h->d_I0, h->d_chG,
+                       h->d_chH, h->d_chD, h->d_chy, tr.d_Minv, tr.d_lbimg, tr.d_sbimg, h->d_lfK, h->d_lfS, h->d_dbg, h->debug_ablate,
+                       h->cur_s0, h->d_pivflag, h->piv_limit, ts);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        h->last_detail = (int)e;
+        return HPF_E_HIP;
+    }
+    return HPF_OK;
+}
+
 // padded block size of the multi-wave MFMA path: 12 / 28 / 52, and 100 for 52 < b <= 100 (K <= 49: BASELINE config 5; the general
 // Gauss-Jordan kernel only -- no constant-inverse leaves / lazy leaves / super-leaves there yet); 0: the 256-thread generic kernels
 int wave_block_size(int b) { return b <= 12 ? 12 : (b <= 28 ? 28 : (b <= 52 ? 52 : (b <= 100 ? 100 : 0))); }
@@ -1118,7 +1183,7 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
         }
     }
     // records of the level-parallel 2x2 kernels
-    std::vector<int> lrec, crec, cnode, arec;
+    std::vector<int> lrec, crec, cnode, arec, lbrec, lbptr;
     {
         std::vector<int> diag0(n, -1), hl(n, 0);
         for (int i = 0; i < n; ++i)
@@ -1146,6 +1211,53 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
                     lrec[lrec.size() - 2] = T.child_ptr[i + 1] - T.child_ptr[i];      // every child of such a bus is linear
                 }
             T.lh_ptr[hh + 1] = (int)lrec.size() / 8;
+        }
+        // bundles of whole all-linear subtrees for the one-launch kernels: subtrees in bus order, a bundle is closed before a height
+        // of it would need a second pass of the 256 threads (one thread per (bus, harmonic) of a height)
+        T.n_lin_bundles = 0;
+        const char* lt_env = getenv("HPF_LINTREE");
+        if (!(lt_env && atoi(lt_env) == 0) && T.n_lin_heights > 1) {
+            const int NH = T.n_lin_heights, cap = std::max(1, 256 / d->Hn);
+            std::vector<int> root_of(n, -1);
+            std::vector<std::vector<int>> sub;                       // buses of each subtree (top-down order)
+            std::vector<int> sub_id(n, -1);
+            for (int oi = 0; oi < n; ++oi) {
+                const int i = order[oi];
+                if (!T.lin[i]) continue;
+                const int pp = T.parent[i];
+                root_of[i] = (pp >= 0 && T.lin[pp]) ? root_of[pp] : i;
+                if (root_of[i] == i) {
+                    sub_id[i] = (int)sub.size();
+                    sub.emplace_back();
+                }
+                sub[sub_id[root_of[i]]].push_back(i);
+            }
+            std::vector<std::vector<int>> byh(NH);
+            auto flush = [&]() {
+                bool any = false;
+                for (int hh = 0; hh < NH; ++hh) any = any || !byh[hh].empty();
+                if (!any) return;
+                for (int hh = 0; hh < NH; ++hh) {
+                    lbptr.push_back((int)lbrec.size() / 8);
+                    for (int i : byh[hh]) {
+                        put(lbrec, i);
+                        lbrec[lbrec.size() - 2] = T.child_ptr[i + 1] - T.child_ptr[i];
+                    }
+                    byh[hh].clear();
+                }
+                lbptr.push_back((int)lbrec.size() / 8);
+                ++T.n_lin_bundles;
+            };
+            std::vector<int> cnt_h(NH);
+            for (const std::vector<int>& sb : sub) {
+                std::fill(cnt_h.begin(), cnt_h.end(), 0);
+                for (int i : sb) ++cnt_h[hl[i]];
+                bool over = false;
+                for (int hh = 0; hh < NH; ++hh) over = over || (int)byh[hh].size() + cnt_h[hh] > cap;
+                if (over) flush();
+                for (int i : sb) byh[hl[i]].push_back(i);
+            }
+            flush();
         }
         for (int r2 = 0; r2 < T.n_chains; ++r2) {
             const int ch = T.chain_ch[r2];
@@ -1873,6 +1985,8 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
     if ((r = upload(h, &T.d_lzimg, lzimg))) return r;
     if ((r = upload(h, &T.d_lbimg, lbimg))) return r;
     if ((r = upload(h, &T.d_lrec, lrec))) return r;
+    if ((r = upload(h, &T.d_lbrec, lbrec))) return r;
+    if ((r = upload(h, &T.d_lbptr, lbptr))) return r;
     if ((r = upload(h, &T.d_crec, crec))) return r;
     if ((r = upload(h, &T.d_cnode, cnode))) return r;
     if ((r = upload(h, &T.d_arec, arec))) return r;
@@ -1894,7 +2008,7 @@ static void tree_free_one(Tree& T) {
     void* ptrs[] = {T.d_parent, T.d_lvl_nodes, T.d_dep_nodes, T.d_child_ptr, T.d_child, T.d_e_up, T.d_e_dn,
                     T.d_child_mid, T.d_lin, T.d_lin_ptr, T.d_lin_post, T.d_all_ptr, T.d_all_post, T.d_fdesc, T.d_child3,
                     T.d_bdesc, T.d_dchild, T.d_chain_ptr, T.d_chain_nodes, T.d_chain_ch, T.d_Minv, T.d_lrec, T.d_crec, T.d_cnode, T.d_arec,
-                    T.d_lzrec, T.d_lzimg, T.d_lbimg, T.d_bleaf, T.d_bsleaf, T.d_sbimg};
+                    T.d_lzrec, T.d_lzimg, T.d_lbimg, T.d_bleaf, T.d_bsleaf, T.d_sbimg, T.d_lbrec, T.d_lbptr};
     for (void* p : ptrs)
         if (p) hipFree(p);
 }
@@ -1990,7 +2104,11 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
     {
         const bool lvl2x2 = h->has_ctree && h->gj_mode == 1;         // level-parallel 2x2 kernels (records of the contracted tree)
         if (lvl2x2) {
-            for (int hh = 0; hh < T.n_lin_heights; ++hh) {
+            if (T.n_lin_bundles > 0)                               // every height of the all-linear subtrees in one launch
+                hipLaunchKernelGGL(k_lin_tree_factor, dim3((unsigned)T.n_lin_bundles, (unsigned)h->cur_S), dim3(256), 0, h->cur_stream,
+                                   h->M, td, T.d_lbrec, T.d_lbptr, T.n_lin_heights, h->N, h->Nc, Bst, active, h->d_U, h->d_E,
+                                   h->d_fb, h->d_linA, h->d_w, h->d_I0, h->cur_s0);
+            for (int hh = 0; hh < T.n_lin_heights && T.n_lin_bundles == 0; ++hh) {
                 const int cnt = T.lh_ptr[hh + 1] - T.lh_ptr[hh];
                 if (cnt == 0) continue;
                 hipLaunchKernelGGL(k_lin_level_factor, dim3((unsigned)((cnt * h->Hn + 127) / 128), (unsigned)h->cur_S), dim3(128), 0,
@@ -2044,7 +2162,22 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
         break
                 HPF_FACTOR_CASE(12);
                 HPF_FACTOR_CASE(28);
-                HPF_FACTOR_CASE(52);
+                case 52:
+                    if (h->gj_mode == 1 && h->fuse_levels) {           // one launch per level: batched and per-scenario workgroups side by side
+                        r = launch_level<52>(h, td, T.d_fdesc + FDESC * (size_t)T.lvl_ptr[l], nbatch > 0 ? (slbatch ? 2 : 1) : 0, nbatch,
+                                             cnt - nbatch, active);
+                        break;
+                    }
+                    if (h->gj_mode == 1 && nbatch > 0) {
+                        r = slbatch ? launch_sleaf_batch<52>(h, td, T.d_fdesc + FDESC * (size_t)T.lvl_ptr[l], nbatch, active)
+                                    : launch_leaf_batch<52>(h, td, T.d_fdesc + FDESC * (size_t)T.lvl_ptr[l], nbatch, active);
+                        if (!r && cnt > nbatch)
+                            r = launch_factor_q<52>(h, td, T.d_fdesc + FDESC * (size_t)(T.lvl_ptr[l] + nbatch), cnt - nbatch, active, !slbatch);
+                        break;
+                    }
+                    r = h->gj_mode == 1 ? launch_factor_q<52>(h, td, T.d_fdesc + FDESC * (size_t)T.lvl_ptr[l], cnt, active, T.lvl_all_leaf[l] != 0)
+                                        : launch_factor_w<52>(h, td, nodes, cnt, active);
+                    break;
 #undef HPF_FACTOR_CASE
                 case 100:       // 52 < b <= 100: general multi-wave kernel for every dense bus; pivoted mode = generic kernels below
                     if (h->gj_mode == 1) {
@@ -2147,7 +2280,11 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
             hipLaunchKernelGGL(k_chain_back2, dim3((unsigned)((T.n_chains * h->Hn + 127) / 128), (unsigned)h->cur_S), dim3(128), 0,
                                h->cur_stream, h->M, td, T.d_crec, T.d_cnode, T.n_chains, h->N, h->Nc, Bst, active, h->d_U, h->d_E,
                                h->d_linA, h->d_w, h->d_x, (double*)nullptr, h->d_chZ, h->cur_s0);
-        for (int hh = T.n_lin_heights - 1; hh >= 0; --hh) {
+        if (T.n_lin_bundles > 0)
+            hipLaunchKernelGGL(k_lin_tree_back, dim3((unsigned)T.n_lin_bundles, (unsigned)h->cur_S), dim3(256), 0, h->cur_stream, h->M,
+                               td, T.d_lbrec, T.d_lbptr, T.n_lin_heights, h->N, h->Nc, Bst, active, h->d_U, h->d_E, h->d_linA, h->d_w,
+                               h->d_x, h->cur_s0);
+        for (int hh = T.n_lin_heights - 1; hh >= 0 && T.n_lin_bundles == 0; --hh) {
             const int cnt = T.lh_ptr[hh + 1] - T.lh_ptr[hh];
             if (cnt == 0) continue;
             hipLaunchKernelGGL(k_lin_level_back, dim3((unsigned)((cnt * h->Hn + 127) / 128), (unsigned)h->cur_S), dim3(128), 0,

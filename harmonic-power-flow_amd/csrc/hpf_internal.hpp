@@ -72,6 +72,11 @@ struct Tree {
     int n_lin_heights = 0;
     std::vector<int> lh_ptr;          // [n_lin_heights+1] into the records
     int* d_lrec = nullptr;
+    // ... and the same records once more, grouped into bundles of whole subtrees (k_lin_tree_factor / k_lin_tree_back: one launch
+    // for all heights): records sorted by (bundle, height), lb_ptr [n_lin_bundles][n_lin_heights + 1] offsets into them
+    int n_lin_bundles = 0;
+    int* d_lbrec = nullptr;
+    int* d_lbptr = nullptr;
     int* d_crec = nullptr;            // chain headers
     int* d_cnode = nullptr;           // chain node records
     int n_all_heights = 0;            // the whole tree by height (fundamental power flow)
@@ -126,6 +131,7 @@ struct hpf_handle {
     int last_detail = 0;
     int gj_mode = 1;                  // BLOCK_TREE block inversion: 0 pivoted wave Gauss-Jordan (VALU, uncontracted tree), 1 MFMA static 4x4 blocks, NT waves per bus (hpf_quad.hpp)
     double piv_limit = 1e10;          // static pivot order: amplification of a 4x4 pivot block's inverse beyond which a scenario is repeated with partial pivoting
+    int fuse_levels = 1;              // HPF_FUSELEVEL (read by hpf_create): 0 = separate launches for the batched and the per-scenario workgroups of a level
     int leafbatch = 1;                // HPF_LEAFBATCH (read by hpf_create): 0 = one workgroup per (leaf, scenario) instead of 16 scenarios per workgroup
     int debug_ablate = 0;             // HPF_DEBUG_ABLATE: timing-only ablation of factor-kernel phases (results invalid)
 

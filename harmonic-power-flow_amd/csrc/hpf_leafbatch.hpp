@@ -19,9 +19,11 @@ struct LeafBatchImg {
     static constexpr int SZ = NTR * KS * 64 + 2 * B + 4;
 };
 
+constexpr int LEAF_BATCH_LDS = 2 * 64 * LB_SB + LB_SB * 4 + LB_SB * 2;      // doubles
+
 template <int B>
-__global__ __launch_bounds__(256, 4) void k_leaf_batch(
-    Model M, TreeDev T, const int* __restrict__ nodes, int b, const int* __restrict__ active, int S_cnt,
+__device__ __forceinline__ void leaf_batch_body(
+    double* __restrict__ smem_, const int bx_, const int by_, const Model& M, const TreeDev& T, const int* __restrict__ nodes, int b, const int* __restrict__ active, int S_cnt,
     const cplx* __restrict__ Uall, const cplx* __restrict__ Eall, const double* __restrict__ fall, double* __restrict__ wall,
     const double* __restrict__ linAall, double* __restrict__ Call, double* __restrict__ Hall, const double* __restrict__ chG,
     const double* __restrict__ chH, const double* __restrict__ chD, const double* __restrict__ chy,
@@ -29,7 +31,7 @@ __global__ __launch_bounds__(256, 4) void k_leaf_batch(
     constexpr int NT = (B + 16) / 16;                       // tile columns of the block kernels (slot stride of C)
     constexpr size_t CT = (size_t)NT * NT * 256;
     constexpr int NTR = LeafBatchImg<B>::NTR, KS = LeafBatchImg<B>::KS, H2 = B / 2;
-    const int4* nd = reinterpret_cast<const int4*>(nodes) + (FDESC / 4) * (size_t)blockIdx.x;
+    const int4* nd = reinterpret_cast<const int4*>(nodes) + (FDESC / 4) * (size_t)bx_;
     const int4 nd0 = nd[0], nd1 = nd[1], nd3 = nd[3];
     const int k = nd0.x, par = nd0.y;
     const int e_dn_k = nd1.x, e_up_k = nd1.y, lin_beg = nd1.z, lin_end = nd1.z + nd1.w;
@@ -39,7 +41,7 @@ __global__ __launch_bounds__(256, 4) void k_leaf_batch(
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = M.n, c = M.c, Hn = M.Hn;
     const int sc = tid >> 4, l16 = tid & 15;                 // role mapping: 16 threads per scenario
-    const int sl = blockIdx.y * LB_SB + sc;                  // scenario inside the launch
+    const int sl = by_ * LB_SB + sc;                  // scenario inside the launch
     const int ss = sl < S_cnt ? (active ? active[sl + s0] : sl + s0) : -1;      // slot -> scenario (active list; -1: frozen / empty slot)
     const bool live = ss >= 0;
     const int s = live ? ss : 0;
@@ -50,12 +52,12 @@ __global__ __launch_bounds__(256, 4) void k_leaf_batch(
     const double* lcimg = img + NTR * KS * 64;               // R(Lc): [row][2] (rows 0, 1: identity)
     const double* c0img = lcimg + 2 * B;
 
-    __shared__ double Y[64 * LB_SB];                         // right-hand sides [row][scenario]
-    __shared__ double V[64 * LB_SB];                         // [0 Lr; 0 Ahh^-1] y
-    __shared__ double DL[LB_SB * 4];                         // Delta_polar per scenario
+    double* Y = smem_;                                       // right-hand sides [row][scenario]
+    double* V = Y + 64 * LB_SB;                              // [0 Lr; 0 Ahh^-1] y
+    double* DL = V + 64 * LB_SB;                             // Delta_polar per scenario
+    double* UK = DL + LB_SB * 4;                             // u = K (y0 + V0)
     constexpr int QI = (H2 + 15) / 16;                       // harmonics per thread of a scenario's 16
     double sir[QI][4], glr[QI][4];                           // S_q^-1 and A(parent, k) of the thread's harmonics (same mapping in R2, K, F)
-    __shared__ double UK[LB_SB * 2];                         // u = K (y0 + V0)
 
     // ---- R1. rows: right-hand side and the 2x2 term of the fundamental, the 2x2-algebra children folded in (k_factor_q, wave 0
     //      role + children, here one thread per (scenario, row) and every child of the bus in list order) -------------------------
@@ -233,6 +235,18 @@ __global__ __launch_bounds__(256, 4) void k_leaf_batch(
             Ck[2 * q + 1] = fma(g[3], w1, g[2] * w0);
         }
     }
+}
+
+template <int B>
+__global__ __launch_bounds__(256, 4) void k_leaf_batch(
+    Model M, TreeDev T, const int* __restrict__ nodes, int b, const int* __restrict__ active, int S_cnt,
+    const cplx* __restrict__ Uall, const cplx* __restrict__ Eall, const double* __restrict__ fall, double* __restrict__ wall,
+    const double* __restrict__ linAall, double* __restrict__ Call, double* __restrict__ Hall, const double* __restrict__ chG,
+    const double* __restrict__ chH, const double* __restrict__ chD, const double* __restrict__ chy,
+    const double* __restrict__ lbimg, double* __restrict__ lfK, double* __restrict__ lfS, int s0) {
+    __shared__ __attribute__((aligned(16))) double smem[LEAF_BATCH_LDS];
+    leaf_batch_body<B>(smem, blockIdx.x, blockIdx.y, M, T, nodes, b, active, S_cnt, Uall, Eall, fall, wall, linAall, Call, Hall, chG, chH, chD, chy,
+                       lbimg, lfK, lfS, s0);
 }
 
 template <int B>
@@ -473,17 +487,27 @@ int launch_sleaf_back_batch(hpf_handle* h, const int* nodes, int count, const in
 // Roles as in k_leaf_batch (plus the power-row diagonal of a linear bus and the G w of its lazy leaves), T assembled and inverted
 // per scenario by the scenario's 16 threads (thread r owns row r; the pivot row goes through LDS), the Ahh^-1 part on the matrix
 // cores.  nodes: Tree::d_fdesc records (int 39: slot of the bus's image in Tree::d_sbimg).
+constexpr int SLEAF_BATCH_LDS = 2 * 64 * LB_SB + LB_SB * 100 + LB_SB * 10 + 3 * LB_SB * 4 + 2 * 16 * LB_SB;      // doubles
+
 template <int B>
-__global__ __launch_bounds__(256, 4) void k_sleaf_batch(
-    Model M, TreeDev T, const int* __restrict__ nodes, int b, const int* __restrict__ active, int S_cnt,
+__device__ __forceinline__ void sleaf_batch_body(
+    double* __restrict__ smem_, const int bx_, const int by_, const Model& M, const TreeDev& T, const int* __restrict__ nodes, int b, const int* __restrict__ active, int S_cnt,
     const cplx* __restrict__ Uall, const cplx* __restrict__ Eall, const double* __restrict__ fall, double* __restrict__ wall,
     const double* __restrict__ linAall, double* __restrict__ Call, double* __restrict__ Hall, const cplx* __restrict__ I0all,
     const double* __restrict__ chG, const double* __restrict__ chH, const double* __restrict__ chD, const double* __restrict__ chy,
-    const double* __restrict__ sbimg, double* __restrict__ Zall, double* __restrict__ lfK, double* __restrict__ lfS, int s0) {
+    const double* __restrict__ sbimg, double* __restrict__ Zall, double* __restrict__ lfK, double* __restrict__ lfS, int s0,
+    long long* __restrict__ dbg, int ablate) {
+#ifdef HPF_FACTOR_STAMPS
+    long long tq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define HPF_SLSTAMP(i) if (ablate & 16) tq[i] = __builtin_amdgcn_s_memtime()
+#else
+#define HPF_SLSTAMP(i)
+#endif
+    HPF_SLSTAMP(0);
     constexpr int NT = (B + 16) / 16;
     constexpr size_t CT = (size_t)NT * NT * 256;
     constexpr int NTR = LeafBatchImg<B>::NTR, KS = LeafBatchImg<B>::KS, H2 = B / 2, QI = (H2 + 15) / 16;
-    const int4* nd = reinterpret_cast<const int4*>(nodes) + (FDESC / 4) * (size_t)blockIdx.x;
+    const int4* nd = reinterpret_cast<const int4*>(nodes) + (FDESC / 4) * (size_t)bx_;
     const int4 nd0 = nd[0], nd1 = nd[1], nd3 = nd[3], lzA = nd[7], lzB = nd[8], lzC = nd[9];
     const int k = nd0.x, par = nd0.y, diag_e = nd0.z;
     const int e_dn_k = nd1.x, e_up_k = nd1.y, lin_beg = nd1.z, lin_end = nd1.z + nd1.w;
@@ -499,7 +523,7 @@ __global__ __launch_bounds__(256, 4) void k_sleaf_batch(
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = M.n, c = M.c, Hn = M.Hn;
     const int sc = tid >> 4, l16 = tid & 15;
-    const int sl = blockIdx.y * LB_SB + sc;
+    const int sl = by_ * LB_SB + sc;
     const int ss = sl < S_cnt ? (active ? active[sl + s0] : sl + s0) : -1;      // slot -> scenario (active list; -1: frozen / empty slot)
     const bool live = ss >= 0;
     const int s = live ? ss : 0;
@@ -509,12 +533,15 @@ __global__ __launch_bounds__(256, 4) void k_sleaf_batch(
     const double* Cs = Call + (size_t)s * n * CT;
     const bool linear_k = k < M.m;
 
-    __shared__ double Y[64 * LB_SB];                             // v = Wd^-1 y, [row][scenario]
-    __shared__ double V[64 * LB_SB];
-    __shared__ double AUG[LB_SB * 100];                          // T, then T^-1, per scenario [10][10]
-    __shared__ double PR[LB_SB * 10];                            // pivot row of the step
-    __shared__ double DL[LB_SB * 4], S0[LB_SB * 4], WI[LB_SB * 4];
-    __shared__ double RR[16 * LB_SB], YY[16 * LB_SB];
+    double* Y = smem_;                                           // v = Wd^-1 y, [row][scenario]
+    double* V = Y + 64 * LB_SB;
+    double* AUG = V + 64 * LB_SB;                                // T, then T^-1, per scenario [10][10]
+    double* PR = AUG + LB_SB * 100;                              // pivot row of the step
+    double* DL = PR + LB_SB * 10;
+    double* S0 = DL + LB_SB * 4;
+    double* WI = S0 + LB_SB * 4;
+    double* RR = WI + LB_SB * 4;
+    double* YY = RR + 16 * LB_SB;
 
     // ---- R1. rows --------------------------------------------------------------------------------------------------------------
     {
@@ -591,6 +618,7 @@ __global__ __launch_bounds__(256, 4) void k_sleaf_batch(
             }
         }
     }
+    HPF_SLSTAMP(1);
     // ---- R2. harmonics ---------------------------------------------------------------------------------------------------------
     double sir[QI][4], glr[QI][4];
 #pragma unroll
@@ -659,7 +687,9 @@ __global__ __launch_bounds__(256, 4) void k_sleaf_batch(
     // T <- Tc (per scenario copy), rows by the scenario's threads
     if (l16 < m)
         for (int c2 = 0; c2 < m; ++c2) AUG[sc * 100 + l16 * 10 + c2] = simg[l16 * m + c2];
+    HPF_SLSTAMP(2);
     __syncthreads();
+    HPF_SLSTAMP(3);
     // ---- T. per-scenario parts of T (as in k_factor_q's super-leaf branch), v = Wd^-1 y -----------------------------------------
     {
         double* aug = AUG + sc * 100;
@@ -715,6 +745,7 @@ __global__ __launch_bounds__(256, 4) void k_sleaf_batch(
         }
     }
     __syncthreads();
+    HPF_SLSTAMP(4);
     // ---- I. in-place inversion with partial pivoting, one scenario per 16 threads (thread r = row r; pivot row through LDS) -----
     {
         double* aug = AUG + sc * 100;
@@ -776,6 +807,7 @@ __global__ __launch_bounds__(256, 4) void k_sleaf_batch(
         }
     }
     __syncthreads();
+    HPF_SLSTAMP(5);
     // ---- M. V = [0 0; 0 Ahh^-1] v on the matrix cores; r = Qb v -----------------------------------------------------------------
     if (wv < NTR) {
         d4_t acc = {0.0, 0.0, 0.0, 0.0};
@@ -807,6 +839,7 @@ __global__ __launch_bounds__(256, 4) void k_sleaf_batch(
         YY[l16 * LB_SB + sc] = y;
     }
     __syncthreads();
+    HPF_SLSTAMP(6);
     // ---- F. x_rect = V + Pb y, w = S^-1 x_rect, G w --------------------------------------------------------------------------
     if (live) {
         double* wk = wall + ((size_t)s * n + k) * B;
@@ -835,6 +868,34 @@ __global__ __launch_bounds__(256, 4) void k_sleaf_batch(
             Ck[2 * q + 1] = fma(g[3], w1, g[2] * w0);
         }
     }
+#ifdef HPF_FACTOR_STAMPS
+    if ((ablate & 16) && dbg && live && l16 == 0) {     // phases of this scenario's 16 threads (cycles): rows | harmonics | wait | T | inversion | MFMA + Qb v | T^-1 r | tail
+        HPF_SLSTAMP(7);
+        long long* o = dbg + ((size_t)s * n + k) * 8;
+        o[0] = tq[1] - tq[0];
+        o[1] = tq[2] - tq[1];
+        o[2] = tq[3] - tq[2];
+        o[3] = ((tq[4] - tq[3]) & 0xfffff) | (((tq[5] - tq[4]) & 0xfffff) << 20) | (((tq[6] - tq[5]) & 0xfffff) << 40);
+        o[4] = tq[7] - tq[6];
+        o[5] = tq[7] - tq[0];
+        o[6] = 1000 + m;
+        o[7] = (k >= M.m) | ((lin_end - lin_beg) << 1);
+    }
+#endif
+#undef HPF_SLSTAMP
+}
+
+template <int B>
+__global__ __launch_bounds__(256, 4) void k_sleaf_batch(
+    Model M, TreeDev T, const int* __restrict__ nodes, int b, const int* __restrict__ active, int S_cnt,
+    const cplx* __restrict__ Uall, const cplx* __restrict__ Eall, const double* __restrict__ fall, double* __restrict__ wall,
+    const double* __restrict__ linAall, double* __restrict__ Call, double* __restrict__ Hall, const cplx* __restrict__ I0all,
+    const double* __restrict__ chG, const double* __restrict__ chH, const double* __restrict__ chD, const double* __restrict__ chy,
+    const double* __restrict__ sbimg, double* __restrict__ Zall, double* __restrict__ lfK, double* __restrict__ lfS, int s0,
+    long long* __restrict__ dbg, int ablate) {
+    __shared__ __attribute__((aligned(16))) double smem[SLEAF_BATCH_LDS];
+    sleaf_batch_body<B>(smem, blockIdx.x, blockIdx.y, M, T, nodes, b, active, S_cnt, Uall, Eall, fall, wall, linAall, Call, Hall, I0all, chG, chH, chD,
+                        chy, sbimg, Zall, lfK, lfS, s0, dbg, ablate);
 }
 
 template <int B>
@@ -843,7 +904,7 @@ int launch_sleaf_batch(hpf_handle* h, const TreeDev& T, const int* nodes, int co
     const dim3 grid((unsigned)count, (unsigned)((h->cur_S + LB_SB - 1) / LB_SB));
     hipLaunchKernelGGL((k_sleaf_batch<B>), grid, dim3(256), 0, h->cur_stream, h->M, T, nodes, 2 * h->Hn, active, h->cur_S, h->d_U,
                        h->d_E, h->d_fb, h->d_w, h->d_linA, h->d_C, h->d_H, h->d_I0, h->d_chG, h->d_chH, h->d_chD, h->d_chy,
-                       active_tree(h).d_sbimg, h->d_Z, h->d_lfK, h->d_lfS, h->cur_s0);
+                       active_tree(h).d_sbimg, h->d_Z, h->d_lfK, h->d_lfS, h->cur_s0, h->d_dbg, h->debug_ablate);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         h->last_detail = (int)e;

@@ -980,6 +980,7 @@ int hpf_create(hpf_handle** out, const hpf_desc* d) {
     if (const char* ab = getenv("HPF_DEBUG_ABLATE")) h->debug_ablate = atoi(ab);
     if (const char* gm = getenv("HPF_GJ_MODE")) h->gj_mode = atoi(gm) ? 1 : 0;
     if (const char* lb = getenv("HPF_LEAFBATCH")) h->leafbatch = atoi(lb) ? 1 : 0;
+    if (const char* fl = getenv("HPF_FUSELEVEL")) h->fuse_levels = atoi(fl) ? 1 : 0;
     if (hipSetDevice(d->device) != hipSuccess) return fail(HPF_E_HIP);
     if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) return fail(HPF_E_HIP);
     h->stream = h->own_stream;
@@ -1391,7 +1392,9 @@ int hpf_kernel_model(const hpf_handle* h, int which, double* bytes, double* flop
     int ln = 0;
     if (h->solver == HPF_SOLVER_BLOCK_TREE) {
         const Tree& T = active_tree(const_cast<hpf_handle*>(h));
-        if (which == T_GJ) {
+        if (which == T_GJ && h->fuse_levels && 2 * h->Hn > 28 && 2 * h->Hn <= 52) {      // k_level<52>: every dense bus, one launch per level
+            by = T.bytes_factor; fl = T.flops_factor; ln = T.n_levels;
+        } else if (which == T_GJ) {
             by = T.bytes_gj; fl = T.flops_gj; ln = T.n_gj_launches;
         } else if (which == T_SOLVE) {
             by = T.bytes_factor; fl = T.flops_factor; ln = T.n_levels;

@@ -142,11 +142,16 @@ __device__ __forceinline__ void lz_aop(const double* p, double (&a)[NT]) {
 #define HPF_Q_OCC 4        // waves per SIMD the B = 52 factor kernel is compiled for (register budget 512 / HPF_Q_OCC)
 #endif
 
-// LEAF: every bus of the launch is a constant-inverse leaf (elimination level 0 of the contracted tree): the general path
-// (assembly, child sums, Gauss-Jordan) is compiled out and with it most of the register budget -> more workgroups per CU.
+// LDS of the factor kernel in doubles (carved from one buffer: the level kernel k_level shares it with the scenario-batched bodies)
+template <int B>
+constexpr int factor_q_lds() {
+    constexpr int NT = (B + 16) / 16, RP = 16 * NT > 64 ? 16 * NT : 64;
+    return (B / 2) * 8 + RP * 3 + NT * RP * 3 + 2 * NT * 64 + 32 + 32 + NT * 32 + NT * 32 + 2 * (B / 2) * (B / 2) + (B <= 52 ? 2 * B * 10 + 200 + 4 : 2);
+}
+
 template <int B, bool LEAF>
-__global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 52 ? 2 : (B > 28 ? (LEAF ? 6 : HPF_Q_OCC) : 5))) void k_factor_q(
-    Model M, TreeDev T, const int* __restrict__ nodes, int b, int N, int Nc, const int* __restrict__ active,
+__device__ __forceinline__ void factor_q_body(
+    double* __restrict__ smem_, const int bx_, const int by_, const Model& M, const TreeDev& T, const int* __restrict__ nodes, int b, int N, int Nc, const int* __restrict__ active,
     const cplx* __restrict__ Uall, const cplx* __restrict__ Eall, const double* __restrict__ fall, double* __restrict__ Zall,
     double* __restrict__ wall, const double* __restrict__ linAall, double* __restrict__ Call, double* __restrict__ Hall,
     const cplx* __restrict__ I0all, const double* __restrict__ chG, const double* __restrict__ chH,
@@ -163,12 +168,12 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 52 ? 2 : (B > 28 ? (LEAF
     long long sa = 0, sc = 0, gown = 0, gwait = 0, gmf = 0;
 #endif
     HPF_STAMP(st0);
-    const int s = active ? active[blockIdx.y + s0] : (int)blockIdx.y + s0;   // slot -> scenario (active list; -1: frozen / empty slot)
+    const int s = active ? active[by_ + s0] : (int)by_ + s0;   // slot -> scenario (active list; -1: frozen / empty slot)
     if (s < 0) return;
     // timing leg only (hpf_timing_enable): first start / last end of the launch's workgroups on the device's constant-rate clock
     if (tstamp && threadIdx.x == 0) atomicMin(tstamp, (unsigned long long)wall_clock64());
     // node record: everything the block needs to form its addresses, behind one scalar load (Tree::d_fdesc)
-    const int4* nd = reinterpret_cast<const int4*>(nodes) + (FDESC / 4) * (size_t)blockIdx.x;
+    const int4* nd = reinterpret_cast<const int4*>(nodes) + (FDESC / 4) * (size_t)bx_;
     const int4 nd0 = nd[0], nd1 = nd[1], nd2 = nd[2], nd3 = nd[3];
     const int k = nd0.x, par = nd0.y, diag_e = nd0.z, devk = nd0.w;
     const int e_dn_k = nd1.x, e_up_k = nd1.y, lin_beg = nd1.z, lin_end = nd1.z + nd1.w;
@@ -204,13 +209,17 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 52 ? 2 : (B > 28 ? (LEAF
     const cplx* E = Eall + so;
     const double* Cs = Call + (size_t)s * n * CT;
 
-    __shared__ double tab[(B / 2) * 8];
-    __shared__ double dgb[RP * 3];          // per row: harmonic-diagonal 2x2 part (d0, d1) and right-hand side y
-    __shared__ double cc[NT][RP * 3];       // the linear children's contributions to (d0, d1, y), one slot per wave
-    __shared__ double panel[2][NT * 64];
-    __shared__ double wl[2][16], pv[2][16];
-    __shared__ double gl[NT * 32], hl[NT * 32];
-    __shared__ cplx ynl[(B / 2) * (B / 2)];
+    // LDS (carved from the caller's buffer, factor_q_lds<B>() doubles; the Y_N image first: 16-byte aligned)
+    cplx* ynl = reinterpret_cast<cplx*>(smem_);
+    double* tab = smem_ + 2 * (B / 2) * (B / 2);
+    double* dgb = tab + (B / 2) * 8;          // per row: harmonic-diagonal 2x2 part (d0, d1) and right-hand side y
+    double (*cc)[RP * 3] = reinterpret_cast<double (*)[RP * 3]>(dgb + RP * 3);       // the linear children's contributions to (d0, d1, y), one slot per wave
+    double (*panel)[NT * 64] = reinterpret_cast<double (*)[NT * 64]>(dgb + RP * 3 + NT * RP * 3);
+    double (*wl)[16] = reinterpret_cast<double (*)[16]>(dgb + RP * 3 + NT * RP * 3 + 2 * NT * 64);
+    double (*pv)[16] = reinterpret_cast<double (*)[16]>(dgb + RP * 3 + NT * RP * 3 + 2 * NT * 64 + 32);
+    double* gl = dgb + RP * 3 + NT * RP * 3 + 2 * NT * 64 + 64;
+    double* hl = gl + NT * 32;
+    double* slb = hl + NT * 32;               // super-leaf constants (B <= 52)
 
     const bool nl = k >= M.m && M.coupled;
     const int col = 16 * wv + jj, p = col >> 1, t1 = col & 1;      // own column = (harmonic position p, component t1)
@@ -378,8 +387,8 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 52 ? 2 : (B > 28 ? (LEAF
             double e0 = 0.0, e1 = 0.0, ey = 0.0;
             // the first child of the slot comes with the node record (ints 16..27: child, e_dn, e_up), later ones through child3
             const int sl4 = slot < 4 ? slot : 0;
-            int4 cr = {nodes[FDESC * (size_t)blockIdx.x + 16 + 3 * sl4], nodes[FDESC * (size_t)blockIdx.x + 17 + 3 * sl4],
-                       nodes[FDESC * (size_t)blockIdx.x + 18 + 3 * sl4], 0};
+            int4 cr = {nodes[FDESC * (size_t)bx_ + 16 + 3 * sl4], nodes[FDESC * (size_t)bx_ + 17 + 3 * sl4],
+                       nodes[FDESC * (size_t)bx_ + 18 + 3 * sl4], 0};
             if (rowvalid) {
                 const double* ws = wall + (size_t)s * n * B;
                 const double* linA = linAall + so * 4;
@@ -532,7 +541,6 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 52 ? 2 : (B > 28 ? (LEAF
     }
     // super-leaf: stage the per-model constants and everything of T that does not depend on this bus's own roles (all of it but
     // the 2x2 term of the fundamental) while the roles' loads are in flight
-    __shared__ double slb[SPECIAL ? 2 * B * 10 + 200 + 4 : 1];
     if (sleaf) {
         const int L = lzA.y, m = 2 + 2 * L, m2 = 2 * m;
         const double* simg = T.lzimg + (size_t)lzB.w;                    // Tc [m][m] | Pb [b][m] | Qb [m][b]
@@ -1061,6 +1069,22 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 52 ? 2 : (B > 28 ? (LEAF
 #endif
 }
 
+// LEAF: every bus of the launch is a constant-inverse leaf (elimination level 0 of the contracted tree): the general path
+// (assembly, child sums, Gauss-Jordan) is compiled out and with it most of the register budget -> more workgroups per CU.
+template <int B, bool LEAF>
+__global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 52 ? 2 : (B > 28 ? (LEAF ? 6 : HPF_Q_OCC) : 5))) void k_factor_q(
+    Model M, TreeDev T, const int* __restrict__ nodes, int b, int N, int Nc, const int* __restrict__ active,
+    const cplx* __restrict__ Uall, const cplx* __restrict__ Eall, const double* __restrict__ fall, double* __restrict__ Zall,
+    double* __restrict__ wall, const double* __restrict__ linAall, double* __restrict__ Call, double* __restrict__ Hall,
+    const cplx* __restrict__ I0all, const double* __restrict__ chG, const double* __restrict__ chH,
+    const double* __restrict__ chD, const double* __restrict__ chy, const double* __restrict__ Minv,
+    double* __restrict__ lfK, double* __restrict__ lfS, long long* __restrict__ dbg, int ablate, int s0,
+    int* __restrict__ pivflag, double piv_limit, unsigned long long* __restrict__ tstamp) {
+    __shared__ __attribute__((aligned(16))) double smem[factor_q_lds<B>()];
+    factor_q_body<B, LEAF>(smem, blockIdx.x, blockIdx.y, M, T, nodes, b, N, Nc, active, Uall, Eall, fall, Zall, wall, linAall, Call, Hall, I0all, chG,
+                           chH, chD, chy, Minv, lfK, lfS, dbg, ablate, s0, pivflag, piv_limit, tstamp);
+}
+
 // root -> leaves: x_k = w_k - D_k^{-1} (A(k,parent) x_parent), inverse in tile layout; wave wv multiplies its tile column,
 // the partial row sums meet in LDS.  Constant-inverse leaves keep no inverse in HBM:  D^-1 t = S^-1 (M t - Mc K (Mr t))  with
 // the per-model M (tile layout, L2 / Infinity Cache), the Woodbury core K and S^-1 left by the factor kernel.
@@ -1251,19 +1275,13 @@ __device__ __forceinline__ void fold_children(const Model& M, const TreeDev& T, 
     }
 }
 
-__global__ __launch_bounds__(128) void k_lin_level_factor(Model M, TreeDev T, const int* __restrict__ rec, int count, int N, int Nc,
-                                                          int Bst, const int* __restrict__ active, const cplx* __restrict__ Uall,
-                                                          const cplx* __restrict__ Eall, const double* __restrict__ fall,
-                                                          double* __restrict__ linAall, double* __restrict__ wall,
-                                                          const cplx* __restrict__ I0all, int fund, int s0) {
-    // fund: fundamental power flow (HG:205-223) -- harmonic position 0 only, every bus a power row (m_eff = n), mismatch in
-    // the stacked order of `pf`; the records then cover the whole tree
-    const int s = active ? active[blockIdx.y + s0] : (int)blockIdx.y + s0;   // slot -> scenario (active list; -1: frozen / empty slot)
-    if (s < 0) return;
-    const int tix = blockIdx.x * 128 + threadIdx.x;
-    const int HnE = fund ? 1 : M.Hn;
-    if (tix >= count * HnE) return;
-    const int q = tix % HnE, pos = tix / HnE;
+// one (bus record, harmonic position, scenario) of the factor sweep of the 2x2 algebra: D_k^-1 and w_k = D_k^-1 y_k with the
+// children folded in.  fund: fundamental power flow (HG:205-223) -- harmonic position 0 only, every bus a power row
+// (m_eff = n), mismatch in the stacked order of `pf`; the records then cover the whole tree
+__device__ __forceinline__ void lin_factor_item(const Model& M, const TreeDev& T, const int* __restrict__ rec, int pos, int q, int s,
+                                                int N, int Nc, int Bst, const cplx* __restrict__ Uall, const cplx* __restrict__ Eall,
+                                                const double* __restrict__ fall, double* linAall, double* wall,
+                                                const cplx* __restrict__ I0all, int fund) {
     const int n = M.n, c = M.c, Hn = M.Hn;
     const int m_eff = fund ? n : M.m;
     const size_t so = (size_t)s * n * Hn;
@@ -1302,17 +1320,46 @@ __global__ __launch_bounds__(128) void k_lin_level_factor(Model M, TreeDev T, co
     wk[1] = fma(di[3], y1, di[2] * y0);
 }
 
-__global__ __launch_bounds__(128) void k_lin_level_back(Model M, TreeDev T, const int* __restrict__ rec, int count, int N, int Nc,
-                                                        int Bst, const int* __restrict__ active, const cplx* __restrict__ Uall,
-                                                        const cplx* __restrict__ Eall, const double* __restrict__ linAall,
-                                                        const double* __restrict__ wall, double* __restrict__ xall,
-                                                        double* __restrict__ step, int fund, int s0) {
+__global__ __launch_bounds__(128) void k_lin_level_factor(Model M, TreeDev T, const int* __restrict__ rec, int count, int N, int Nc,
+                                                          int Bst, const int* __restrict__ active, const cplx* __restrict__ Uall,
+                                                          const cplx* __restrict__ Eall, const double* __restrict__ fall,
+                                                          double* __restrict__ linAall, double* __restrict__ wall,
+                                                          const cplx* __restrict__ I0all, int fund, int s0) {
     const int s = active ? active[blockIdx.y + s0] : (int)blockIdx.y + s0;   // slot -> scenario (active list; -1: frozen / empty slot)
     if (s < 0) return;
     const int tix = blockIdx.x * 128 + threadIdx.x;
     const int HnE = fund ? 1 : M.Hn;
     if (tix >= count * HnE) return;
-    const int q = tix % HnE, pos = tix / HnE;
+    lin_factor_item(M, T, rec, tix / HnE, tix % HnE, s, N, Nc, Bst, Uall, Eall, fall, linAall, wall, I0all, fund);
+}
+
+// The same sweep in ONE launch (harmonic Newton step): the all-linear subtrees are independent of each other, so a workgroup takes
+// a bundle of WHOLE subtrees (records sorted by height inside the bundle, bptr: nh + 1 offsets per bundle) and walks the heights
+// with a workgroup barrier in between -- a parent's operands (D_child^-1, w_child) were written by threads of the same
+// workgroup.  Same arithmetic per (bus, harmonic) as the level kernel: bit-identical results, nh - 1 launches fewer.
+__global__ __launch_bounds__(256) void k_lin_tree_factor(Model M, TreeDev T, const int* __restrict__ rec, const int* __restrict__ bptr,
+                                                         int nh, int N, int Nc, int Bst, const int* __restrict__ active,
+                                                         const cplx* __restrict__ Uall, const cplx* __restrict__ Eall,
+                                                         const double* __restrict__ fall, double* linAall, double* wall,
+                                                         const cplx* __restrict__ I0all, int s0) {
+    const int s = active ? active[blockIdx.y + s0] : (int)blockIdx.y + s0;
+    if (s < 0) return;
+    const int* bp = bptr + (size_t)blockIdx.x * (nh + 1);
+    const int Hn = M.Hn, end = bp[nh];
+    for (int hh = 0; hh < nh; ++hh) {
+        const int beg = bp[hh], nxt = bp[hh + 1];
+        for (int it = threadIdx.x; it < (nxt - beg) * Hn; it += 256)
+            lin_factor_item(M, T, rec, beg + it / Hn, it % Hn, s, N, Nc, Bst, Uall, Eall, fall, linAall, wall, I0all, 0);
+        if (nxt == end) break;                                   // (uniform: nothing of this bundle above this height)
+        __syncthreads();
+    }
+}
+
+// one (bus record, harmonic position, scenario) of the back sweep of the 2x2 algebra: x_k = w_k - D_k^-1 A(k, parent) x_parent
+__device__ __forceinline__ void lin_back_item(const Model& M, const TreeDev& T, const int* __restrict__ rec, int pos, int q, int s, int N,
+                                              int Nc, int Bst, const cplx* __restrict__ Uall, const cplx* __restrict__ Eall,
+                                              const double* __restrict__ linAall, const double* __restrict__ wall, double* xall,
+                                              double* step, int fund) {
     const int n = M.n, c = M.c, Hn = M.Hn;
     const int m_eff = fund ? n : M.m;
     const size_t so = (size_t)s * n * Hn;
@@ -1348,6 +1395,41 @@ __global__ __launch_bounds__(128) void k_lin_level_back(Model M, TreeDev T, cons
         const int kst = q * n + k;
         if (kst >= 1) st[kst - 1] = x0;
         if (kst >= c) st[Nc + kst - c] = x1;
+    }
+}
+
+__global__ __launch_bounds__(128) void k_lin_level_back(Model M, TreeDev T, const int* __restrict__ rec, int count, int N, int Nc,
+                                                        int Bst, const int* __restrict__ active, const cplx* __restrict__ Uall,
+                                                        const cplx* __restrict__ Eall, const double* __restrict__ linAall,
+                                                        const double* __restrict__ wall, double* __restrict__ xall,
+                                                        double* __restrict__ step, int fund, int s0) {
+    const int s = active ? active[blockIdx.y + s0] : (int)blockIdx.y + s0;   // slot -> scenario (active list; -1: frozen / empty slot)
+    if (s < 0) return;
+    const int tix = blockIdx.x * 128 + threadIdx.x;
+    const int HnE = fund ? 1 : M.Hn;
+    if (tix >= count * HnE) return;
+    lin_back_item(M, T, rec, tix / HnE, tix % HnE, s, N, Nc, Bst, Uall, Eall, linAall, wall, xall, step, fund);
+}
+
+// ... and the back sweep in one launch: the same bundles, heights top-down (x of a subtree's root needs x of its dense / chain
+// parent, complete before this launch; below it every x_parent comes from the workgroup itself)
+__global__ __launch_bounds__(256) void k_lin_tree_back(Model M, TreeDev T, const int* __restrict__ rec, const int* __restrict__ bptr, int nh,
+                                                       int N, int Nc, int Bst, const int* __restrict__ active,
+                                                       const cplx* __restrict__ Uall, const cplx* __restrict__ Eall,
+                                                       const double* __restrict__ linAall, const double* __restrict__ wall,
+                                                       double* xall, int s0) {
+    const int s = active ? active[blockIdx.y + s0] : (int)blockIdx.y + s0;
+    if (s < 0) return;
+    const int* bp = bptr + (size_t)blockIdx.x * (nh + 1);
+    const int Hn = M.Hn, end = bp[nh];
+    bool first = true;
+    for (int hh = nh - 1; hh >= 0; --hh) {
+        const int beg = bp[hh], nxt = bp[hh + 1];
+        if (beg == end) continue;                                // (uniform: the bundle is lower than this height)
+        if (!first) __syncthreads();
+        first = false;
+        for (int it = threadIdx.x; it < (nxt - beg) * Hn; it += 256)
+            lin_back_item(M, T, rec, beg + it / Hn, it % Hn, s, N, Nc, Bst, Uall, Eall, linAall, wall, xall, nullptr, 0);
     }
 }
 

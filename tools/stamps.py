@@ -37,6 +37,19 @@ buf = np.zeros(S * n * 8, dtype=np.int64)
 dm._chk(dm.lib.hpf_debug_stamps(dm._h, buf.ctypes.data_as(C.POINTER(C.c_longlong)), buf.size), "hpf_debug_stamps")
 d = buf.reshape(S, n, 8)
 dense = d[:, :, 3].sum(axis=0) > 0
+# bordered buses of the scenario-batched kernel (k_sleaf_batch): o[6] = 1000 + m, phases in o[0..5]
+sl = d[0, :, 6] >= 1000
+if sl.any():
+    for mval in sorted(set(d[0, sl, 6] - 1000)):
+        sel = d[0, :, 6] == 1000 + mval
+        x = d[:, sel, :]
+        t = x[:, :, 3].reshape(-1)
+        ph = [np.median(x[:, :, 0]), np.median(x[:, :, 1]), np.median(x[:, :, 2]), np.median(t & 0xfffff), np.median((t >> 20) & 0xfffff),
+              np.median((t >> 40) & 0xfffff), np.median(x[:, :, 4]), np.median(x[:, :, 5])]
+        print("k_sleaf_batch m=%2d n=%3d (cycles of the 100 MHz*? s_memtime clock): rows %6.0f  harmonics %6.0f  barrier wait %6.0f  T %6.0f  inversion %6.0f  MFMA+Qb v %6.0f  tail %6.0f  total %7.0f"
+              % ((mval, sel.sum()) + tuple(ph)))
+    d[:, sl, :] = 0
+    dense = d[:, :, 3].sum(axis=0) > 0
 names = ["assembly", "rows->tiles", "child sums", "MFMA GJ", "store", "push"]
 print("dense buses: %d; cycles per block (median over scenarios and buses)" % dense.sum())
 for label, sel in (("nonlinear leaf (0 dense children)", dense & (d[0, :, 6] == 0) & ((d[0, :, 7] & 1) == 1)),
