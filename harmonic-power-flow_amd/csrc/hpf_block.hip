@@ -1675,16 +1675,29 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
                 const int NTR = (BWc + 15) / 16, KS = (BWc + 3) / 4;
                 sb_ord[k] = n_sleaf;
                 sb_m[k] = mr;
-                const size_t o0 = sbimg.size();
-                sbimg.resize(o0 + (size_t)NTR * KS * 64, 0.0);
+                // slot (SleafImg<B>): [NTR][KS][64] the image (+ the rows of Qb in the padding rows BW.. of the last row tile where
+                // they fit: r = Qb v then falls out of the same MFMAs) | [NTR][3][64] Pb as a second A operand (x += Pb y: 3 rank-4 steps)
+                const bool qb_rows = 16 * NTR - BWc >= 10;
+                const size_t o0 = sbimg.size(), o1 = o0 + (size_t)NTR * KS * 64;
+                sbimg.resize(o1 + (size_t)NTR * 3 * 64, 0.0);
                 for (int w2 = 0; w2 < NTR; ++w2)
-                    for (int ks = 0; ks < KS; ++ks)
-                        for (int lg = 0; lg < 4; ++lg)
-                            for (int jj = 0; jj < 16; ++jj) {
-                                const int row = 16 * w2 + jj, col = 4 * ks + lg;
-                                if (row >= 2 && col >= 2 && row < b && col < b)
-                                    sbimg[o0 + ((size_t)w2 * KS + ks) * 64 + lg * 16 + jj] = R(Ainv(row >> 1, col >> 1), row & 1, col & 1);
+                    for (int lg = 0; lg < 4; ++lg)
+                        for (int jj = 0; jj < 16; ++jj) {
+                            const int row = 16 * w2 + jj;
+                            for (int ks = 0; ks < KS; ++ks) {
+                                const int col = 4 * ks + lg;
+                                double v = 0.0;
+                                if (row >= 2 && col >= 2 && row < b && col < b) v = R(Ainv(row >> 1, col >> 1), row & 1, col & 1);
+                                if (qb_rows && row >= BWc && row - BWc < mr && col < b)
+                                    v = R(Qb[(size_t)((row - BWc) >> 1) * Hn + (col >> 1)], (row - BWc) & 1, col & 1);
+                                sbimg[o0 + ((size_t)w2 * KS + ks) * 64 + lg * 16 + jj] = v;
                             }
+                            for (int kp = 0; kp < 3; ++kp) {
+                                const int c2 = 4 * kp + lg;
+                                if (row < b && c2 < mr)
+                                    sbimg[o1 + ((size_t)w2 * 3 + kp) * 64 + lg * 16 + jj] = R(Pb[(size_t)(row >> 1) * m1 + (c2 >> 1)], row & 1, c2 & 1);
+                            }
+                        }
             }
             ++n_sleaf;
         }

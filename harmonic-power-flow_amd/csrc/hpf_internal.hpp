@@ -97,7 +97,7 @@ struct Tree {
     std::vector<int> bsleaf_ptr;      // back sweep of the bordered buses in groups by nesting order (nested ones first): offsets into d_bsleaf
     int n_bsleaf = 0;
     int* d_bsleaf = nullptr;          // [n_bsleaf][8] back-sweep records of the super-leaves (k_sleaf_back_batch)
-    double* d_sbimg = nullptr;        // [n_bsleaf][NTR*KS*64] their [0 0; 0 Ahh^-1] images in MFMA A-operand layout
+    double* d_sbimg = nullptr;        // [n_bsleaf][SleafImg<B>::SZ] their [0 0; 0 Ahh^-1] images (+ Qb rows) and Pb in MFMA A-operand layout
     int n_bleaf = 0;
     int* d_bleaf = nullptr;           // [n_bleaf][4] back-sweep records of ALL constant-inverse leaves: one k_leaf_back_batch launch after the last depth
     double* d_lbimg = nullptr;        // [leaf slot][LeafBatchImg::SZ]: the leaf images in MFMA A-operand layout (16 scenarios per workgroup)

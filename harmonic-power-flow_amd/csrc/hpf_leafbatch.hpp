@@ -19,6 +19,16 @@ struct LeafBatchImg {
     static constexpr int SZ = NTR * KS * 64 + 2 * B + 4;
 };
 
+// per-bus constants of a bordered bus (Tree::d_sbimg): A-operand image [NTR][KS][64] of [0 0; 0 Ahh^-1] -- with the rows of Qb in
+// the padding rows B.. of the last row tile when m <= 10 of them fit (QB_ROWS: r = Qb v falls out of the same MFMAs) -- and Pb
+// (b x m) as a second A operand [NTR][3][64] (x += Pb y: three rank-4 steps)
+template <int B>
+struct SleafImg {
+    static constexpr int NTR = (B + 15) / 16, KS = (B + 3) / 4, KP = 3;
+    static constexpr int MAIN = NTR * KS * 64, SZ = MAIN + NTR * KP * 64;
+    static constexpr bool QB_ROWS = 16 * NTR - B >= 10;
+};
+
 constexpr int LEAF_BATCH_LDS = 2 * 64 * LB_SB + LB_SB * 4 + LB_SB * 2;      // doubles
 
 template <int B>
@@ -272,7 +282,7 @@ __global__ __launch_bounds__(256) void k_leaf_back_batch(
     Model M, const int* __restrict__ nodes, int b, const int* __restrict__ active, int S_cnt, const double* __restrict__ wall,
     double* __restrict__ xall, const double* __restrict__ Hall, const double* __restrict__ lbimg, const double* __restrict__ lfK,
     const double* __restrict__ lfS, int s0) {
-    constexpr int NTR = LeafBatchImg<B>::NTR, KS = LeafBatchImg<B>::KS, H2 = B / 2;
+    constexpr int NTR = LeafBatchImg<B>::NTR, KS = LeafBatchImg<B>::KS, H2 = B / 2, QI = (H2 + 15) / 16;
     const int4 kp = reinterpret_cast<const int4*>(nodes)[blockIdx.x];
     const int k = kp.x, par = kp.y, slot = kp.z - 1;
     const int tid = threadIdx.x, lane = tid & 63, lg = lane >> 4, jj = lane & 15;
@@ -291,6 +301,37 @@ __global__ __launch_bounds__(256) void k_leaf_back_batch(
     __shared__ double V[64 * LB_SB];
     __shared__ double UK[LB_SB * 2];
 
+    // one round trip for everything addressed by the record: the lane's image column, K, and Lc / S^-1 / w of the thread's harmonics
+    double ia[KS], k4[4] = {0.0, 0.0, 0.0, 0.0}, lc4[QI][4], si4[QI][4], w4[QI][2];
+    if (wv < NTR) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) ia[ks] = img[((size_t)wv * KS + ks) * 64 + lane];
+    }
+    if (live && l16 == 0) {
+        const double* kk = lfK + ((size_t)s * n + k) * 12;
+        k4[0] = kk[0]; k4[1] = kk[1]; k4[2] = kk[2]; k4[3] = kk[3];
+    }
+#pragma unroll
+    for (int it = 0; it < QI; ++it) {
+        const int q = l16 + 16 * it;
+        w4[it][0] = w4[it][1] = 0.0;
+        si4[it][0] = si4[it][3] = 1.0;
+        si4[it][1] = si4[it][2] = 0.0;
+        lc4[it][0] = lc4[it][1] = lc4[it][2] = lc4[it][3] = 0.0;
+        if (live && q < H2) {
+            const double2 w2 = *reinterpret_cast<const double2*>(wall + ((size_t)s * n + k) * B + 2 * q);
+            w4[it][0] = w2.x;
+            w4[it][1] = w2.y;
+            const double2* lp = reinterpret_cast<const double2*>(lcimg + (2 * q) * 2);
+            const double2 l0 = lp[0], l1 = lp[1];
+            lc4[it][0] = l0.x; lc4[it][1] = l0.y; lc4[it][2] = l1.x; lc4[it][3] = l1.y;
+            if (q < Hn) {
+                const double2* sp = reinterpret_cast<const double2*>(lfS + (((size_t)s * n + k) * Hn + q) * 4);
+                const double2 a = sp[0], c2 = sp[1];
+                si4[it][0] = a.x; si4[it][1] = a.y; si4[it][2] = c2.x; si4[it][3] = c2.y;
+            }
+        }
+    }
     for (int q = l16; q < 32; q += 16) {
         double t0 = 0.0, t1 = 0.0;
         if (live && q < Hn) {
@@ -305,46 +346,34 @@ __global__ __launch_bounds__(256) void k_leaf_back_batch(
     __syncthreads();
     if (wv < NTR) {
         d4_t acc = {0.0, 0.0, 0.0, 0.0};
-        const double* ia = img + (size_t)wv * KS * 64 + lane;
-#pragma unroll 4
+#pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const double a = ia[(size_t)ks * 64];
             const double bop = TT[(4 * ks + lg) * LB_SB + jj];
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bop, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ia[ks], bop, acc, 0, 0, 0);
         }
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) V[(16 * wv + 4 * reg + lg) * LB_SB + jj] = acc[reg];
     }
     __syncthreads();
     if (l16 == 0) {
-        double k00 = 0.0, k01 = 0.0, k10 = 0.0, k11 = 0.0;
-        if (live) {
-            const double* kk = lfK + ((size_t)s * n + k) * 12;
-            k00 = kk[0]; k01 = kk[1]; k10 = kk[2]; k11 = kk[3];
-        }
         const double r0 = TT[sc] + V[sc], r1 = TT[LB_SB + sc] + V[LB_SB + sc];                      // [I Lr] t
-        UK[sc * 2] = fma(k01, r1, k00 * r0);
-        UK[sc * 2 + 1] = fma(k11, r1, k10 * r0);
+        UK[sc * 2] = fma(k4[1], r1, k4[0] * r0);
+        UK[sc * 2 + 1] = fma(k4[3], r1, k4[2] * r0);
     }
     __syncthreads();
     if (live) {
         const double u0 = UK[sc * 2], u1 = UK[sc * 2 + 1];
-        const double* wk = wall + ((size_t)s * n + k) * B;
-        for (int q = l16; q < H2; q += 16) {
+#pragma unroll
+        for (int it = 0; it < QI; ++it) {
+            const int q = l16 + 16 * it;
+            if (q >= H2) continue;
             double x0 = u0, x1 = u1;
             if (q > 0) {
-                const double* lc = lcimg + (2 * q) * 2;
-                x0 = V[(2 * q) * LB_SB + sc] + fma(lc[1], u1, lc[0] * u0);
-                x1 = V[(2 * q + 1) * LB_SB + sc] + fma(lc[3], u1, lc[2] * u0);
+                x0 = V[(2 * q) * LB_SB + sc] + fma(lc4[it][1], u1, lc4[it][0] * u0);
+                x1 = V[(2 * q + 1) * LB_SB + sc] + fma(lc4[it][3], u1, lc4[it][2] * u0);
             }
-            double d0 = x0, d1 = x1;
-            if (q < Hn) {
-                const double* si = lfS + (((size_t)s * n + k) * Hn + q) * 4;
-                d0 = fma(si[1], x1, si[0] * x0);
-                d1 = fma(si[3], x1, si[2] * x0);
-            }
-            const double2 w2 = *reinterpret_cast<const double2*>(wk + 2 * q);
-            *reinterpret_cast<double2*>(xs + (size_t)k * B + 2 * q) = double2{w2.x - d0, w2.y - d1};
+            const double d0 = fma(si4[it][1], x1, si4[it][0] * x0), d1 = fma(si4[it][3], x1, si4[it][2] * x0);
+            *reinterpret_cast<double2*>(xs + (size_t)k * B + 2 * q) = double2{w4[it][0] - d0, w4[it][1] - d1};
         }
     }
 }
@@ -374,11 +403,12 @@ __global__ __launch_bounds__(256) void k_sleaf_back_batch(
     const double* __restrict__ Zall, const double* __restrict__ lfS, int s0) {
     constexpr int NT = (B + 16) / 16;
     constexpr size_t CT = (size_t)NT * NT * 256;
-    constexpr int NTR = LeafBatchImg<B>::NTR, KS = LeafBatchImg<B>::KS, H2 = B / 2;
+    constexpr int NTR = SleafImg<B>::NTR, KS = SleafImg<B>::KS, KP = SleafImg<B>::KP, H2 = B / 2, QI = (H2 + 15) / 16;
+    constexpr bool QBR = SleafImg<B>::QB_ROWS;
     const int4* rec = reinterpret_cast<const int4*>(nodes) + 2 * (size_t)blockIdx.x;
     const int4 r0 = rec[0], r1 = rec[1];
     const int k = r0.x, par = r0.y, m = r1.x;
-    const double* img = sbimg + (size_t)r0.z * NTR * KS * 64;
+    const double* img = sbimg + (size_t)r0.z * SleafImg<B>::SZ;
     const double* pbm = lzimg + (size_t)r0.w + m * m;           // Pb [b][m]
     const double* qbm = pbm + (size_t)b * m;                    // Qb [m][b]
     const int tid = threadIdx.x, lane = tid & 63, lg = lane >> 4, jj = lane & 15;
@@ -397,6 +427,34 @@ __global__ __launch_bounds__(256) void k_sleaf_back_batch(
     __shared__ double RR[16 * LB_SB];                           // r = Qb v, then y = T^-1 r, [border unknown][scenario]
     __shared__ double YY[16 * LB_SB];
 
+    // every operand whose address comes from the record alone is requested here, in one round trip with A(k,parent) and x_parent:
+    // the image column of the lane's MFMAs, the thread's row of T^-1, S^-1 and w of its harmonics
+    double ia[KS], pa[KP], trow[10], w4[QI][2], si4[QI][4];
+    if (wv < NTR) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) ia[ks] = img[((size_t)wv * KS + ks) * 64 + lane];
+#pragma unroll
+        for (int kp = 0; kp < KP; ++kp) pa[kp] = img[SleafImg<B>::MAIN + ((size_t)wv * KP + kp) * 64 + lane];
+    }
+#pragma unroll
+    for (int j = 0; j < 10; ++j) trow[j] = (live && l16 < m && j < m) ? tk[l16 * 10 + j] : 0.0;
+#pragma unroll
+    for (int it = 0; it < QI; ++it) {
+        const int q = l16 + 16 * it;
+        w4[it][0] = w4[it][1] = 0.0;
+        si4[it][0] = si4[it][3] = 1.0;
+        si4[it][1] = si4[it][2] = 0.0;
+        if (live && q < H2) {
+            const double2 w2 = *reinterpret_cast<const double2*>(wall + ((size_t)s * n + k) * B + 2 * q);
+            w4[it][0] = w2.x;
+            w4[it][1] = w2.y;
+            if (q < Hn) {
+                const double2* sp = reinterpret_cast<const double2*>(lfS + (((size_t)s * n + k) * Hn + q) * 4);
+                const double2 a = sp[0], c2 = sp[1];
+                si4[it][0] = a.x; si4[it][1] = a.y; si4[it][2] = c2.x; si4[it][3] = c2.y;
+            }
+        }
+    }
     for (int q = l16; q < 32; q += 16) {
         double t0 = 0.0, t1 = 0.0;
         if (live && q < Hn) {
@@ -414,19 +472,22 @@ __global__ __launch_bounds__(256) void k_sleaf_back_batch(
         TT[(2 * q + 1) * LB_SB + sc] = t1;
     }
     __syncthreads();
+    d4_t acc = {0.0, 0.0, 0.0, 0.0};
     if (wv < NTR) {
-        d4_t acc = {0.0, 0.0, 0.0, 0.0};
-        const double* ia = img + (size_t)wv * KS * 64 + lane;
-#pragma unroll 4
-        for (int ks = 0; ks < KS; ++ks) {
-            const double a = ia[(size_t)ks * 64];
-            const double bop = TT[(4 * ks + lg) * LB_SB + jj];
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bop, acc, 0, 0, 0);
-        }
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) V[(16 * wv + 4 * reg + lg) * LB_SB + jj] = acc[reg];
+        for (int ks = 0; ks < KS; ++ks) {
+            const double bop = TT[(4 * ks + lg) * LB_SB + jj];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ia[ks], bop, acc, 0, 0, 0);
+        }
+        if (QBR && wv == NTR - 1) {                             // rows B.. of the last row tile: r = Qb v
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int j = 16 * (NTR - 1) + 4 * reg + lg - B;
+                if (j >= 0 && j < 16) RR[j * LB_SB + jj] = acc[reg];
+            }
+        }
     }
-    {
+    if (!QBR) {
         double r = 0.0;                                         // r_j = Qb[j][:] v   (thread (scenario, j))
         if (l16 < m) {
             const double* qr = qbm + (size_t)l16 * b;
@@ -437,34 +498,29 @@ __global__ __launch_bounds__(256) void k_sleaf_back_batch(
     __syncthreads();
     {
         double y = 0.0;                                         // y_i = T^-1[i][:] r
-        if (live && l16 < m) {
-            const double* tr = tk + l16 * 10;
-            for (int j = 0; j < m; ++j) y = fma(tr[j], RR[j * LB_SB + sc], y);
+#pragma unroll
+        for (int j = 0; j < 10; ++j) y = fma(trow[j], (j < m ? RR[j * LB_SB + sc] : 0.0), y);
+        YY[l16 * LB_SB + sc] = (live && l16 < m) ? y : 0.0;
+    }
+    __syncthreads();
+    if (wv < NTR) {                                             // V = [0 0; 0 Ahh^-1] v + Pb y
+#pragma unroll
+        for (int kp = 0; kp < KP; ++kp) {
+            const double bop = YY[(4 * kp + lg) * LB_SB + jj];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[kp], bop, acc, 0, 0, 0);
         }
-        YY[l16 * LB_SB + sc] = y;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) V[(16 * wv + 4 * reg + lg) * LB_SB + jj] = acc[reg];
     }
     __syncthreads();
     if (live) {
-        const double* wk = wall + ((size_t)s * n + k) * B;
-        for (int q = l16; q < H2; q += 16) {
-            double x0 = V[(2 * q) * LB_SB + sc], x1 = V[(2 * q + 1) * LB_SB + sc];
-            if (2 * q < b) {
-                const double* p0 = pbm + (size_t)(2 * q) * m;
-                const double* p1 = p0 + m;
-                for (int i = 0; i < m; ++i) {
-                    const double yi = YY[i * LB_SB + sc];
-                    x0 = fma(p0[i], yi, x0);
-                    x1 = fma(p1[i], yi, x1);
-                }
-            }
-            double d0 = x0, d1 = x1;
-            if (q < Hn) {
-                const double* si = lfS + (((size_t)s * n + k) * Hn + q) * 4;
-                d0 = fma(si[1], x1, si[0] * x0);
-                d1 = fma(si[3], x1, si[2] * x0);
-            }
-            const double2 w2 = *reinterpret_cast<const double2*>(wk + 2 * q);
-            *reinterpret_cast<double2*>(xs + (size_t)k * B + 2 * q) = double2{w2.x - d0, w2.y - d1};
+#pragma unroll
+        for (int it = 0; it < QI; ++it) {
+            const int q = l16 + 16 * it;
+            if (q >= H2) continue;
+            const double x0 = V[(2 * q) * LB_SB + sc], x1 = V[(2 * q + 1) * LB_SB + sc];
+            const double d0 = fma(si4[it][1], x1, si4[it][0] * x0), d1 = fma(si4[it][3], x1, si4[it][2] * x0);
+            *reinterpret_cast<double2*>(xs + (size_t)k * B + 2 * q) = double2{w4[it][0] - d0, w4[it][1] - d1};
         }
     }
 }
@@ -506,7 +562,8 @@ __device__ __forceinline__ void sleaf_batch_body(
     HPF_SLSTAMP(0);
     constexpr int NT = (B + 16) / 16;
     constexpr size_t CT = (size_t)NT * NT * 256;
-    constexpr int NTR = LeafBatchImg<B>::NTR, KS = LeafBatchImg<B>::KS, H2 = B / 2, QI = (H2 + 15) / 16;
+    constexpr int NTR = SleafImg<B>::NTR, KS = SleafImg<B>::KS, KP = SleafImg<B>::KP, H2 = B / 2, QI = (H2 + 15) / 16;
+    constexpr bool QBR = SleafImg<B>::QB_ROWS;
     const int4* nd = reinterpret_cast<const int4*>(nodes) + (FDESC / 4) * (size_t)bx_;
     const int4 nd0 = nd[0], nd1 = nd[1], nd3 = nd[3], lzA = nd[7], lzB = nd[8], lzC = nd[9];
     const int k = nd0.x, par = nd0.y, diag_e = nd0.z;
@@ -518,7 +575,7 @@ __device__ __forceinline__ void sleaf_batch_body(
     const double* simg = T.lzimg + (size_t)lzB.w;                // Tc [m][m] | Pb [b][m] | Qb [m][b]
     const double* pbm = simg + m * m;
     const double* qbm = pbm + (size_t)b * m;
-    const double* img = sbimg + (size_t)lzC.w * NTR * KS * 64;   // [0 0; 0 Ahh^-1], A-operand layout
+    const double* img = sbimg + (size_t)lzC.w * SleafImg<B>::SZ;   // [0 0; 0 Ahh^-1] (+ the rows of Qb), A-operand layout | Pb as an A operand
     const int tid = threadIdx.x, lane = tid & 63, lg = lane >> 4, jj = lane & 15;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = M.n, c = M.c, Hn = M.Hn;
@@ -808,9 +865,9 @@ __device__ __forceinline__ void sleaf_batch_body(
     }
     __syncthreads();
     HPF_SLSTAMP(5);
-    // ---- M. V = [0 0; 0 Ahh^-1] v on the matrix cores; r = Qb v -----------------------------------------------------------------
+    // ---- M. V = [0 0; 0 Ahh^-1] v on the matrix cores; r = Qb v (rows B.. of the same MFMAs where they fit) ------------------------
+    d4_t acc = {0.0, 0.0, 0.0, 0.0};
     if (wv < NTR) {
-        d4_t acc = {0.0, 0.0, 0.0, 0.0};
         const double* ia = img + (size_t)wv * KS * 64 + lane;
 #pragma unroll 4
         for (int ks = 0; ks < KS; ++ks) {
@@ -818,10 +875,15 @@ __device__ __forceinline__ void sleaf_batch_body(
             const double bop = Y[(4 * ks + lg) * LB_SB + jj];
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bop, acc, 0, 0, 0);
         }
+        if (QBR && wv == NTR - 1) {
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) V[(16 * wv + 4 * reg + lg) * LB_SB + jj] = acc[reg];
+            for (int reg = 0; reg < 4; ++reg) {
+                const int j = 16 * (NTR - 1) + 4 * reg + lg - B;
+                if (j >= 0 && j < 16) RR[j * LB_SB + jj] = acc[reg];
+            }
+        }
     }
-    {
+    if (!QBR) {
         double r = 0.0;
         if (l16 < m) {
             const double* qr = qbm + (size_t)l16 * b;
@@ -839,6 +901,18 @@ __device__ __forceinline__ void sleaf_batch_body(
         YY[l16 * LB_SB + sc] = y;
     }
     __syncthreads();
+    if (wv < NTR) {                                              // ... + Pb y: three more rank-4 steps on the same accumulators
+        const double* pa = img + SleafImg<B>::MAIN + (size_t)wv * KP * 64 + lane;
+#pragma unroll
+        for (int kp = 0; kp < KP; ++kp) {
+            const double a = pa[(size_t)kp * 64];
+            const double bop = YY[(4 * kp + lg) * LB_SB + jj];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bop, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) V[(16 * wv + 4 * reg + lg) * LB_SB + jj] = acc[reg];
+    }
+    __syncthreads();
     HPF_SLSTAMP(6);
     // ---- F. x_rect = V + Pb y, w = S^-1 x_rect, G w --------------------------------------------------------------------------
     if (live) {
@@ -848,16 +922,7 @@ __device__ __forceinline__ void sleaf_batch_body(
         for (int it = 0; it < QI; ++it) {
             const int q = l16 + 16 * it;
             if (q >= H2) continue;
-            double x0 = V[(2 * q) * LB_SB + sc], x1 = V[(2 * q + 1) * LB_SB + sc];
-            if (2 * q < b) {
-                const double* p0 = pbm + (size_t)(2 * q) * m;
-                const double* p1 = p0 + m;
-                for (int i = 0; i < m; ++i) {
-                    const double yi = YY[i * LB_SB + sc];
-                    x0 = fma(p0[i], yi, x0);
-                    x1 = fma(p1[i], yi, x1);
-                }
-            }
+            const double x0 = V[(2 * q) * LB_SB + sc], x1 = V[(2 * q + 1) * LB_SB + sc];
             const double* si = sir[it];
             const bool in = 2 * q < b;
             const double w0 = in ? fma(si[1], x1, si[0] * x0) : 0.0, w1 = in ? fma(si[3], x1, si[2] * x0) : 0.0;

@@ -150,7 +150,7 @@ def test_per_iteration_state_dump_follows_the_reference_trajectory(name, solver,
 
 @pytest.mark.parametrize("env", [{"HPF_LAZY": "0"}, {"HPF_LAZY": "1"}, {"HPF_SLEAF": "0"}, {"HPF_SLEAF": "1"},
                                  {"HPF_SLLAZY": "0"}, {"HPF_SLBACK": "0"}, {"HPF_LEAFBATCH": "0"}, {"HPF_GROUPS": "2"},
-                                 {"HPF_SLNEST": "0"}, {"HPF_LINTREE": "0"}])
+                                 {"HPF_SLNEST": "0"}, {"HPF_LINTREE": "0"}, {"HPF_FUSELEVEL": "0"}])
 def test_tree_build_variants_take_the_same_newton_steps(env, tmp_path, monkeypatch):
     """Every diagnostic switch of hpf_create (hpf.h) selects a more general path for some class of buses (no lazy leaves, no
     super-leaves, super-leaves that push their Schur complement / store their inverse, leaves one workgroup per scenario): the
