@@ -1183,7 +1183,7 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
         }
     }
     // records of the level-parallel 2x2 kernels
-    std::vector<int> lrec, crec, cnode, arec, lbrec, lbptr;
+    std::vector<int> lrec, crec, cnode, arec, lbrec, lbptr, lb2rec, lb2x, lb2ptr;
     {
         std::vector<int> diag0(n, -1), hl(n, 0);
         for (int i = 0; i < n; ++i)
@@ -1248,6 +1248,64 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
                 lbptr.push_back((int)lbrec.size() / 8);
                 ++T.n_lin_bundles;
             };
+            // bundles of the one-round-trip kernels: whole subtrees, at most 256 * NP items (bus, harmonic) per workgroup
+            {
+                size_t maxsub = 0;
+                for (const std::vector<int>& sb : sub) maxsub = std::max(maxsub, sb.size());
+                const size_t mi = maxsub * (size_t)d->Hn;
+                const char* lb_env2 = getenv("HPF_LINBUNDLE");
+                T.lin_np = (lb_env2 && atoi(lb_env2) == 0) ? 0 : (mi <= 256 ? 1 : (mi <= 512 ? 2 : (mi <= 1024 ? 4 : 0)));
+                T.n_lin_bundles2 = 0;
+                if (T.lin_np) {
+                    const size_t cap_items = 256 * (size_t)T.lin_np;
+                    std::vector<int> cur, loc(n, -1), csv(n, 0);
+                    auto flush2 = [&]() {
+                        if (cur.empty()) return;
+                        std::stable_sort(cur.begin(), cur.end(), [&](int a, int b2) { return hl[a] < hl[b2]; });
+                        const int base = (int)lb2rec.size() / 8;
+                        int csum = 0;
+                        for (size_t li = 0; li < cur.size(); ++li) {
+                            loc[cur[li]] = (int)li;
+                            csv[cur[li]] = csum;
+                            csum += T.child_ptr[cur[li] + 1] - T.child_ptr[cur[li]];
+                        }
+                        int hh = 0;
+                        lb2ptr.push_back(base);
+                        for (size_t li = 0; li < cur.size(); ++li) {
+                            const int i = cur[li];
+                            while (hh < hl[i]) {
+                                lb2ptr.push_back(base + (int)li);
+                                ++hh;
+                            }
+                            put(lb2rec, i);
+                            lb2rec[lb2rec.size() - 3] = csv[i];                                    // cbeg <- first child slot
+                            lb2rec[lb2rec.size() - 2] = T.child_ptr[i + 1] - T.child_ptr[i];       // every child is linear
+                            const int pp = T.parent[i];
+                            int slot = -1, lp = -1;
+                            if (pp >= 0 && T.lin[pp]) {
+                                int ord = 0;
+                                for (int cp = T.child_ptr[pp]; cp < T.child_ptr[pp + 1]; ++cp)
+                                    if (T.child[cp] == i) ord = cp - T.child_ptr[pp];
+                                slot = csv[pp] + ord;
+                                lp = loc[pp];
+                            }
+                            lb2x.push_back(slot);
+                            lb2x.push_back(lp);
+                        }
+                        while (hh < NH) {
+                            lb2ptr.push_back(base + (int)cur.size());
+                            ++hh;
+                        }
+                        cur.clear();
+                        ++T.n_lin_bundles2;
+                    };
+                    for (const std::vector<int>& sb : sub) {
+                        if ((cur.size() + sb.size()) * (size_t)d->Hn > cap_items) flush2();
+                        cur.insert(cur.end(), sb.begin(), sb.end());
+                    }
+                    flush2();
+                }
+            }
             std::vector<int> cnt_h(NH);
             for (const std::vector<int>& sb : sub) {
                 std::fill(cnt_h.begin(), cnt_h.end(), 0);
@@ -1998,6 +2056,9 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
     if ((r = upload(h, &T.d_lzimg, lzimg))) return r;
     if ((r = upload(h, &T.d_lbimg, lbimg))) return r;
     if ((r = upload(h, &T.d_lrec, lrec))) return r;
+    if ((r = upload(h, &T.d_lb2rec, lb2rec))) return r;
+    if ((r = upload(h, &T.d_lb2x, lb2x))) return r;
+    if ((r = upload(h, &T.d_lb2ptr, lb2ptr))) return r;
     if ((r = upload(h, &T.d_lbrec, lbrec))) return r;
     if ((r = upload(h, &T.d_lbptr, lbptr))) return r;
     if ((r = upload(h, &T.d_crec, crec))) return r;
@@ -2021,7 +2082,7 @@ static void tree_free_one(Tree& T) {
     void* ptrs[] = {T.d_parent, T.d_lvl_nodes, T.d_dep_nodes, T.d_child_ptr, T.d_child, T.d_e_up, T.d_e_dn,
                     T.d_child_mid, T.d_lin, T.d_lin_ptr, T.d_lin_post, T.d_all_ptr, T.d_all_post, T.d_fdesc, T.d_child3,
                     T.d_bdesc, T.d_dchild, T.d_chain_ptr, T.d_chain_nodes, T.d_chain_ch, T.d_Minv, T.d_lrec, T.d_crec, T.d_cnode, T.d_arec,
-                    T.d_lzrec, T.d_lzimg, T.d_lbimg, T.d_bleaf, T.d_bsleaf, T.d_sbimg, T.d_lbrec, T.d_lbptr};
+                    T.d_lzrec, T.d_lzimg, T.d_lbimg, T.d_bleaf, T.d_bsleaf, T.d_sbimg, T.d_lbrec, T.d_lbptr, T.d_lb2rec, T.d_lb2x, T.d_lb2ptr};
     for (void* p : ptrs)
         if (p) hipFree(p);
 }
@@ -2117,11 +2178,20 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
     {
         const bool lvl2x2 = h->has_ctree && h->gj_mode == 1;         // level-parallel 2x2 kernels (records of the contracted tree)
         if (lvl2x2) {
-            if (T.n_lin_bundles > 0)                               // every height of the all-linear subtrees in one launch
+            if (T.n_lin_bundles2 > 0) {                            // ... with one memory round trip (k_lin_bundle_factor)
+                const dim3 g2((unsigned)T.n_lin_bundles2, (unsigned)h->cur_S);
+#define HPF_LB_F(NP_)                                                                                                                  \
+    hipLaunchKernelGGL((k_lin_bundle_factor<NP_>), g2, dim3(256), 0, h->cur_stream, h->M, T.d_lb2rec, (const int2*)T.d_lb2x, T.d_lb2ptr, \
+                       T.n_lin_heights, Bst, active, h->d_U, h->d_E, h->d_fb, h->d_linA, h->d_w, h->d_I0, h->cur_s0)
+                if (T.lin_np == 1) HPF_LB_F(1);
+                else if (T.lin_np == 2) HPF_LB_F(2);
+                else HPF_LB_F(4);
+#undef HPF_LB_F
+            } else if (T.n_lin_bundles > 0)                        // every height of the all-linear subtrees in one launch
                 hipLaunchKernelGGL(k_lin_tree_factor, dim3((unsigned)T.n_lin_bundles, (unsigned)h->cur_S), dim3(256), 0, h->cur_stream,
                                    h->M, td, T.d_lbrec, T.d_lbptr, T.n_lin_heights, h->N, h->Nc, Bst, active, h->d_U, h->d_E,
                                    h->d_fb, h->d_linA, h->d_w, h->d_I0, h->cur_s0);
-            for (int hh = 0; hh < T.n_lin_heights && T.n_lin_bundles == 0; ++hh) {
+            for (int hh = 0; hh < T.n_lin_heights && T.n_lin_bundles == 0 && T.n_lin_bundles2 == 0; ++hh) {
                 const int cnt = T.lh_ptr[hh + 1] - T.lh_ptr[hh];
                 if (cnt == 0) continue;
                 hipLaunchKernelGGL(k_lin_level_factor, dim3((unsigned)((cnt * h->Hn + 127) / 128), (unsigned)h->cur_S), dim3(128), 0,
@@ -2293,11 +2363,20 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
             hipLaunchKernelGGL(k_chain_back2, dim3((unsigned)((T.n_chains * h->Hn + 127) / 128), (unsigned)h->cur_S), dim3(128), 0,
                                h->cur_stream, h->M, td, T.d_crec, T.d_cnode, T.n_chains, h->N, h->Nc, Bst, active, h->d_U, h->d_E,
                                h->d_linA, h->d_w, h->d_x, (double*)nullptr, h->d_chZ, h->cur_s0);
-        if (T.n_lin_bundles > 0)
+        if (T.n_lin_bundles2 > 0) {
+            const dim3 g2((unsigned)T.n_lin_bundles2, (unsigned)h->cur_S);
+#define HPF_LB_B(NP_)                                                                                                                \
+    hipLaunchKernelGGL((k_lin_bundle_back<NP_>), g2, dim3(256), 0, h->cur_stream, h->M, T.d_lb2rec, (const int2*)T.d_lb2x, T.d_lb2ptr, \
+                       T.n_lin_heights, Bst, active, h->d_U, h->d_E, h->d_linA, h->d_w, h->d_x, h->cur_s0)
+            if (T.lin_np == 1) HPF_LB_B(1);
+            else if (T.lin_np == 2) HPF_LB_B(2);
+            else HPF_LB_B(4);
+#undef HPF_LB_B
+        } else if (T.n_lin_bundles > 0)
             hipLaunchKernelGGL(k_lin_tree_back, dim3((unsigned)T.n_lin_bundles, (unsigned)h->cur_S), dim3(256), 0, h->cur_stream, h->M,
                                td, T.d_lbrec, T.d_lbptr, T.n_lin_heights, h->N, h->Nc, Bst, active, h->d_U, h->d_E, h->d_linA, h->d_w,
                                h->d_x, h->cur_s0);
-        for (int hh = T.n_lin_heights - 1; hh >= 0 && T.n_lin_bundles == 0; --hh) {
+        for (int hh = T.n_lin_heights - 1; hh >= 0 && T.n_lin_bundles == 0 && T.n_lin_bundles2 == 0; --hh) {
             const int cnt = T.lh_ptr[hh + 1] - T.lh_ptr[hh];
             if (cnt == 0) continue;
             hipLaunchKernelGGL(k_lin_level_back, dim3((unsigned)((cnt * h->Hn + 127) / 128), (unsigned)h->cur_S), dim3(128), 0,

@@ -74,6 +74,12 @@ struct Tree {
     int* d_lrec = nullptr;
     // ... and the same records once more, grouped into bundles of whole subtrees (k_lin_tree_factor / k_lin_tree_back: one launch
     // for all heights): records sorted by (bundle, height), lb_ptr [n_lin_bundles][n_lin_heights + 1] offsets into them
+    // ... and for the one-round-trip kernels (k_lin_bundle_factor / _back): bundles of at most 256 * lin_np items (bus, harmonic),
+    // records with cbeg = first child slot, d_lb2x[record] = (own slot | -1, local index of the parent | -1)
+    int n_lin_bundles2 = 0, lin_np = 0;
+    int* d_lb2rec = nullptr;
+    int* d_lb2x = nullptr;
+    int* d_lb2ptr = nullptr;
     int n_lin_bundles = 0;
     int* d_lbrec = nullptr;
     int* d_lbptr = nullptr;

@@ -1433,6 +1433,211 @@ __global__ __launch_bounds__(256) void k_lin_tree_back(Model M, TreeDev T, const
     }
 }
 
+// The 2x2 algebra of the all-linear subtrees with ONE memory round trip per sweep (harmonic Newton step; k_lin_tree_* above are the
+// fallback).  What an elimination step of bus k needs from memory does not depend on the steps before it: its own diagonal block and
+// right-hand side and the coupling blocks with its parent, G = A(par,k), H = A(k,par), come from the state (U, E), the network (Y)
+// and the mismatch image -- only D_child^-1 and w_child come from the children.  So a workgroup (a bundle of whole subtrees, NP
+// items (bus, harmonic) per thread) first requests the operands of ALL its items at once and forms (M0, y0, G, H) in registers; the
+// heights are then walked with a workgroup barrier in between and NOTHING but LDS traffic: a child leaves its Schur contribution
+// G D^-1 H, G w in the slot (parent's first child slot + its ordinal), the parent subtracts its children's slots in list order --
+// the arithmetic and its order are those of fold_children / lin_factor_item, bit for bit.  D^-1 and w go to HBM as before (dense
+// parents, chains and the back sweep read them).
+// Records: Rec8 with cbeg = first child slot of the bus; xrec[record] = (own slot or -1 for a subtree root, local index of the parent
+// inside the bundle or -1); bptr: nh + 1 record offsets per bundle (heights ascending).
+template <int NP>
+__global__ __launch_bounds__(256) void k_lin_bundle_factor(Model M, const int* __restrict__ rec, const int2* __restrict__ xrec,
+                                                           const int* __restrict__ bptr, int nh, int Bst, const int* __restrict__ active,
+                                                           const cplx* __restrict__ Uall, const cplx* __restrict__ Eall,
+                                                           const double* __restrict__ fall, double* __restrict__ linAall,
+                                                           double* __restrict__ wall, const cplx* __restrict__ I0all, int s0) {
+    const int s = active ? active[blockIdx.y + s0] : (int)blockIdx.y + s0;
+    if (s < 0) return;
+    __shared__ double ctr[256 * NP * 6];
+    const int* bp = bptr + (size_t)blockIdx.x * (nh + 1);
+    const int n = M.n, c = M.c, Hn = M.Hn, base = bp[0], nb = bp[nh] - base;
+    const int nitems = nb * Hn;
+    const size_t so = (size_t)s * n * Hn;
+    const cplx* U = Uall + so;
+    const cplx* E = Eall + so;
+    double* linA = linAall + so * 4;
+    double* ws = wall + (size_t)s * n * Bst;
+    int lbv[NP], qv[NP], kv[NP], slot[NP], cs[NP], nch[NP];
+    bool ok[NP];
+    int4 r0v[NP], r1v[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {                               // round trip 1: the records
+        const int i = threadIdx.x + 256 * p;
+        ok[p] = i < nitems;
+        const int ic = ok[p] ? i : 0;
+        lbv[p] = ic / Hn;
+        qv[p] = ic - lbv[p] * Hn;
+        r0v[p] = reinterpret_cast<const int4*>(rec)[2 * (size_t)(base + lbv[p])];
+        r1v[p] = reinterpret_cast<const int4*>(rec)[2 * (size_t)(base + lbv[p]) + 1];
+        slot[p] = xrec[base + lbv[p]].x;
+    }
+    cplx ydv[NP], ukv[NP], ekv[NP], I0v[NP], ynv[NP], ydnv[NP], yupv[NP], upv[NP], epv[NP];
+    double2 fyv[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {                               // round trip 2: every operand of every item
+        const int k = r0v[p].x, q = qv[p], par = r0v[p].z;
+        kv[p] = k;
+        cs[p] = r1v[p].y;
+        nch[p] = r1v[p].z;
+        ydv[p] = M.Y[(size_t)r0v[p].y * Hn + q];
+        ukv[p] = U[(size_t)k * Hn + q];
+        ekv[p] = E[(size_t)k * Hn + q];
+        I0v[p] = cplx{0.0, 0.0};
+        ynv[p] = cplx{0.0, 0.0};
+        if (q == 0 && k < M.m) I0v[p] = I0all[(size_t)s * n + k];
+        if (k >= M.m) ynv[p] = M.coupled ? M.YN[((size_t)r1v[p].w * Hn + q) * Hn + q] : M.YN[(size_t)r1v[p].w * Hn + q];
+        fyv[p] = *reinterpret_cast<const double2*>(fall + ((size_t)s * n + k) * Bst + 2 * q);
+        ydnv[p] = yupv[p] = upv[p] = epv[p] = cplx{0.0, 0.0};
+        if (slot[p] >= 0) {                                      // (a subtree root's coupling with its dense / chain parent is the parent's business)
+            ydnv[p] = M.Y[(size_t)r1v[p].x * Hn + q];
+            yupv[p] = M.Y[(size_t)r0v[p].w * Hn + q];
+            upv[p] = U[(size_t)par * Hn + q];
+            epv[p] = E[(size_t)par * Hn + q];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    double m2[NP][4], y2[NP][2], g4[NP][4], h4[NP][4];
+    int hgt[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int k = kv[p], q = qv[p], par = r0v[p].z;
+        diag2x2_val(n, c, M.m, q, k, ydv[p], ukv[p], ekv[p], I0v[p], ynv[p], m2[p]);
+        y2[p][0] = fyv[p].x;
+        y2[p][1] = fyv[p].y;
+        if (slot[p] >= 0) {
+            coupling_val(n, c, M.m, q, par, k, ydnv[p], upv[p], ukv[p], ekv[p], g4[p]);      // A(par, k)
+            coupling_val(n, c, M.m, q, k, par, yupv[p], ukv[p], upv[p], epv[p], h4[p]);      // A(k, par)
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g4[p][e] = h4[p][e] = 0.0;
+        }
+        int hh = 0;
+        for (int a = 1; a < nh; ++a) hh += (lbv[p] >= bp[a] - base) ? 1 : 0;
+        hgt[p] = ok[p] ? hh : -1;
+    }
+    for (int hh = 0; hh < nh; ++hh) {
+        if (hh > 0) __syncthreads();
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            if (hgt[p] != hh) continue;
+            const int q = qv[p];
+            double mm[4] = {m2[p][0], m2[p][1], m2[p][2], m2[p][3]}, y0 = y2[p][0], y1 = y2[p][1];
+            for (int j = 0; j < nch[p]; ++j) {
+                const double* c6 = ctr + ((size_t)(cs[p] + j) * Hn + q) * 6;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) mm[e] -= c6[e];
+                y0 -= c6[4];
+                y1 -= c6[5];
+            }
+            double di[4];
+            inv2(mm[0], mm[1], mm[2], mm[3], di[0], di[1], di[2], di[3]);
+            const double w0 = fma(di[1], y1, di[0] * y0), w1 = fma(di[3], y1, di[2] * y0);
+            double2* ik = reinterpret_cast<double2*>(linA + ((size_t)kv[p] * Hn + q) * 4);
+            ik[0] = double2{di[0], di[1]};
+            ik[1] = double2{di[2], di[3]};
+            *reinterpret_cast<double2*>(ws + (size_t)kv[p] * Bst + 2 * q) = double2{w0, w1};
+            if (slot[p] >= 0) {
+                double gi[4], gh[4];
+                mul22(g4[p], di, gi);
+                mul22(gi, h4[p], gh);
+                double* c6 = ctr + ((size_t)slot[p] * Hn + q) * 6;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) c6[e] = gh[e];
+                c6[4] = fma(g4[p][1], w1, g4[p][0] * w0);
+                c6[5] = fma(g4[p][3], w1, g4[p][2] * w0);
+            }
+        }
+        if (bp[hh + 1] == bp[nh]) break;                         // (uniform: nothing of this bundle above this height)
+    }
+}
+
+// ... and its back sweep: x_k = w_k - D_k^-1 (A(k,par) x_par).  D^-1, w, A(k,par) of every item in one round trip (a subtree root
+// also fetches x of its dense / chain parent), then the heights top-down with x_par through LDS.
+template <int NP>
+__global__ __launch_bounds__(256) void k_lin_bundle_back(Model M, const int* __restrict__ rec, const int2* __restrict__ xrec,
+                                                         const int* __restrict__ bptr, int nh, int Bst, const int* __restrict__ active,
+                                                         const cplx* __restrict__ Uall, const cplx* __restrict__ Eall,
+                                                         const double* __restrict__ linAall, const double* __restrict__ wall,
+                                                         double* __restrict__ xall, int s0) {
+    const int s = active ? active[blockIdx.y + s0] : (int)blockIdx.y + s0;
+    if (s < 0) return;
+    __shared__ double xl[256 * NP * 2];
+    const int* bp = bptr + (size_t)blockIdx.x * (nh + 1);
+    const int n = M.n, c = M.c, Hn = M.Hn, base = bp[0], nb = bp[nh] - base;
+    const int nitems = nb * Hn;
+    const size_t so = (size_t)s * n * Hn;
+    const cplx* U = Uall + so;
+    const cplx* E = Eall + so;
+    const double* linA = linAall + so * 4;
+    const double* ws = wall + (size_t)s * n * Bst;
+    double* xs = xall + (size_t)s * n * Bst;
+    int lbv[NP], qv[NP], lpar[NP];
+    bool ok[NP];
+    int4 r0v[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int i = threadIdx.x + 256 * p;
+        ok[p] = i < nitems;
+        const int ic = ok[p] ? i : 0;
+        lbv[p] = ic / Hn;
+        qv[p] = ic - lbv[p] * Hn;
+        r0v[p] = reinterpret_cast<const int4*>(rec)[2 * (size_t)(base + lbv[p])];
+        lpar[p] = xrec[base + lbv[p]].y;
+    }
+    cplx yupv[NP], ukv[NP], upv[NP], epv[NP];
+    double2 i01[NP], i23[NP], wkv[NP], xpv[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int k = r0v[p].x, par = r0v[p].z > 0 ? r0v[p].z : 0, q = qv[p];      // (par < 0: the network's root, when it is a 2x2 bus itself)
+        yupv[p] = M.Y[(size_t)r0v[p].w * Hn + q];
+        ukv[p] = U[(size_t)k * Hn + q];
+        upv[p] = U[(size_t)par * Hn + q];
+        epv[p] = E[(size_t)par * Hn + q];
+        const double2* pik = reinterpret_cast<const double2*>(linA + ((size_t)k * Hn + q) * 4);
+        i01[p] = pik[0];
+        i23[p] = pik[1];
+        wkv[p] = *reinterpret_cast<const double2*>(ws + (size_t)k * Bst + 2 * q);
+        xpv[p] = double2{0.0, 0.0};
+        if (lpar[p] < 0 && r0v[p].z >= 0) xpv[p] = *reinterpret_cast<const double2*>(xs + (size_t)par * Bst + 2 * q);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    double h4[NP][4];
+    int hgt[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        coupling_val(n, c, M.m, qv[p], r0v[p].x, r0v[p].z > 0 ? r0v[p].z : 0, yupv[p], ukv[p], upv[p], epv[p], h4[p]);      // A(k, parent)
+        if (r0v[p].z < 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h4[p][e] = 0.0;          // no parent: x = w
+        }
+        int hh = 0;
+        for (int a = 1; a < nh; ++a) hh += (lbv[p] >= bp[a] - base) ? 1 : 0;
+        hgt[p] = ok[p] ? hh : -1;
+    }
+    bool first = true;
+    for (int hh = nh - 1; hh >= 0; --hh) {
+        if (bp[hh] == bp[nh]) continue;                          // (uniform: the bundle is lower than this height)
+        if (!first) __syncthreads();
+        first = false;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            if (hgt[p] != hh) continue;
+            const int q = qv[p];
+            double2 xp = xpv[p];
+            if (lpar[p] >= 0) xp = *reinterpret_cast<const double2*>(xl + ((size_t)lpar[p] * Hn + q) * 2);
+            const double t0 = fma(h4[p][1], xp.y, h4[p][0] * xp.x), t1 = fma(h4[p][3], xp.y, h4[p][2] * xp.x);
+            const double x0 = wkv[p].x - fma(i01[p].y, t1, i01[p].x * t0);
+            const double x1 = wkv[p].y - fma(i23[p].y, t1, i23[p].x * t0);
+            *reinterpret_cast<double2*>(xl + ((size_t)lbv[p] * Hn + q) * 2) = double2{x0, x1};
+            *reinterpret_cast<double2*>(xs + (size_t)r0v[p].x * Bst + 2 * q) = double2{x0, x1};
+        }
+    }
+}
+
 // Contracted chains (see k_chain_factor for the algebra): same elimination, operands of a chain bus loaded in one batch.
 __global__ __launch_bounds__(128) void k_chain_factor2(Model M, TreeDev T, const int* __restrict__ crec, const int* __restrict__ cnode,
                                                        int nchains, int N, int Nc, int Bst, const int* __restrict__ active,
