@@ -16,8 +16,10 @@ of the real solves from the reference's start point (no scenario has converged y
 with `hpf_iterate`, i.e. without host synchronisation.  value = scenarios_total * K / t  [NR iterations / s].
 
 Untimed legs after the timed region (rank 0 prints ONE JSON line with all of them):
-  roofline        the dominant kernel k_factor_q<52,false> ALONE: HIP-event span of every one of its launches over K more steps
-                  against its own algorithmic bytes (hpf_kernel_model) — compare profiles/*kernel_stats.csv of the same command;
+  roofline        the dominant kernel ALONE -- k_level<52>, the factor sweep of the block tree, one launch per elimination level
+                  (Gauss-Jordan workgroups + the level's scenario-batched workgroups in one grid; k_factor_q<B,false> for other
+                  block sizes): device-clock span of every one of its launches over K more steps against its own algorithmic
+                  bytes (hpf_kernel_model) — compare profiles/*kernel_stats.csv of the same command;
   sweep           every rank finishes its solves with the reference's stop rule (`hpf_solve`: per-scenario freeze, compaction
                   of the running scenarios, pipelined polling); per-scenario records (24 B) all-gathered with RCCL;
   sweep_1gpu      (N = 1 only) the whole 1 024-scenario sweep of BASELINE config 4 on ONE GPU, all scenarios live (74 GB of
@@ -243,7 +245,17 @@ def main():
     step_bytes = S * (dm.solve_bytes() + bytes_mismatch + bytes_back + bytes_2x2 + bytes_update)
     traffic, traffic_note = pmc_traffic(args, S)
     step_traffic = pmc_step_traffic(args, S)
+    census = dm.tree_census() if bt else {}
+    fused = bool(census.get("fused_levels"))
     kname = "k_factor_q<%d,false>" % (100 if b > 52 else (52 if b > 28 else (28 if b > 12 else 12))) if bt and b <= 100 else ("k_tree_factor (generic)" if bt else "rocsolver_dgetrf/dgetrs")
+    kdesc = kname + (" alone (general multi-wave block-tree factor kernel: Gauss-Jordan buses and non-batched super-leaves; %d launches per "
+                     "Newton step and scenario group, one per tree level)" % ln_gj)
+    if fused:
+        kname = "k_level<52>"
+        kdesc = ("k_level<52>: the factor sweep of the block tree, one launch per elimination level (%d per Newton step and scenario group) -- "
+                 "Gauss-Jordan workgroups (one per bus and scenario: %d buses) and the scenario-batched workgroups of the constant-inverse "
+                 "leaves (%d) and bordered buses (%d) of the level in one grid" % (ln_gj, census["gauss_jordan"], census["const_leaves"],
+                                                                                  census["bordered"]))
     out = {
         "metric": "NR iterations/sec + ms/iter, 1 000-bus x 25-harmonic feeder; |dV| vs reference",
         "value": value, "unit": "NR iterations/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
@@ -258,8 +270,7 @@ def main():
                    "pf_iterations": int(nf.max())},
         "ms_per_iter_per_scenario": ms_step / S,
         "roofline": {"bound": "hbm",
-                     "kernel": kname + " alone (general multi-wave block-tree factor kernel: Gauss-Jordan buses and non-batched "
-                               "super-leaves; %d launches per Newton step and scenario group, one per tree level)" % ln_gj,
+                     "kernel": kdesc, "tree_census": census,
                      "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS if achieved_gbs else None,
                      "traffic": traffic, "traffic_note": traffic_note,
@@ -278,7 +289,7 @@ def main():
                              "overlap on separate streams, so a launch shares the chip with the other groups' kernels.  arithmetic intensity %.2f flop/B "
                              "< ridge %.1f: HBM-bound by the roofline, in practice bound by workgroup latency (DESIGN.md §5)"
                              % (gj_n, G, fl_gj / max(by_gj, 1.0), FP64_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS)},
-        "roofline_factor_sweep": {"bound": "hbm", "kernels": "all factor kernels of a step (k_leaf_batch, k_sleaf_batch, k_factor_q)",
+        "roofline_factor_sweep": {"bound": "hbm", "kernels": "all factor kernels of a step (k_level, or k_leaf_batch + k_sleaf_batch + k_factor_q)",
                                   "achieved": sweep_bytes / (ms_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": sweep_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_step": sweep_bytes,
                                   "note": "algorithmic bytes of the factor sweep of all scenarios / step wall time"},
@@ -300,8 +311,8 @@ def main():
                                       "rocprofv3 of the same command: profiles/*kernel_stats.csv, counters: profiles/pmc_traffic_latest.json"},
         "phase_ms_per_launch": {k: (v[0] / max(v[1], 1)) for k, v in tim.items() if v[1]},
         "phase_launches_per_step": {k: v[1] / max(K, 1) for k, v in tim.items() if v[1]},
-        "phase_note": "HIP-event spans: gj = one per k_factor_q<B,false> launch; solve = one per launch of the other factor kernels "
-                      "(k_leaf_batch, k_sleaf_batch, leaf-only k_factor_q); mismatch / update: per launch; back: per scenario "
+        "phase_note": "HIP-event spans: gj = one per k_level / k_factor_q<B,false> launch; solve = one per launch of the other factor kernels "
+                      "(k_leaf_batch, k_sleaf_batch, leaf-only k_factor_q: none with k_level); mismatch / update: per launch; back: per scenario "
                       "group and step (%d groups overlap on separate streams)" % G,
         "vs_reference_measured": value / 0.0257,
     }

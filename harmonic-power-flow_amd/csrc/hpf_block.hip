@@ -1183,7 +1183,7 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
         }
     }
     // records of the level-parallel 2x2 kernels
-    std::vector<int> lrec, crec, cnode, arec, lbrec, lbptr, lb2rec, lb2x, lb2ptr;
+    std::vector<int> lrec, crec, cnode, arec, lbrec, lbptr, lb2rec, lb2x, lb2ptr, lb2cptr, lb2clist;
     {
         std::vector<int> diag0(n, -1), hl(n, 0);
         for (int i = 0; i < n; ++i)
@@ -1248,19 +1248,42 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
                 lbptr.push_back((int)lbrec.size() / 8);
                 ++T.n_lin_bundles;
             };
-            // bundles of the one-round-trip kernels: whole subtrees, at most 256 * NP items (bus, harmonic) per workgroup
+            // bundles of the one-round-trip kernels: units of whole subtrees -- a contracted chain with the subtrees hanging off its
+            // buses is ONE unit (the chain walk follows its subtrees in the same workgroup) --, at most 256 * NP items (bus, harmonic)
+            // and 256 / Hn chains per workgroup
             {
-                size_t maxsub = 0;
-                for (const std::vector<int>& sb : sub) maxsub = std::max(maxsub, sb.size());
-                const size_t mi = maxsub * (size_t)d->Hn;
                 const char* lb_env2 = getenv("HPF_LINBUNDLE");
+                const char* cb_env = getenv("HPF_CHAINBUNDLE");
+                const bool chb = !(cb_env && atoi(cb_env) == 0) && T.n_chains > 0;
+                std::vector<int> node_chain(n, -1);
+                for (int r2 = 0; r2 < T.n_chains; ++r2)
+                    for (int idx = T.chain_ptr[r2]; idx < T.chain_ptr[r2 + 1]; ++idx) node_chain[T.chain_nodes[idx]] = r2;
+                // units: [0, n_chains) the chains (when bundled), then the free subtrees
+                std::vector<std::vector<int>> unit_bus(chb ? T.n_chains : 0);
+                std::vector<int> unit_chain;
+                for (int r2 = 0; chb && r2 < T.n_chains; ++r2) unit_chain.push_back(r2);
+                for (const std::vector<int>& sb : sub) {
+                    const int pp = T.parent[sb[0]];
+                    const int r2 = (chb && pp >= 0) ? node_chain[pp] : -1;
+                    if (r2 >= 0) {
+                        unit_bus[r2].insert(unit_bus[r2].end(), sb.begin(), sb.end());
+                    } else {
+                        unit_bus.push_back(sb);
+                        unit_chain.push_back(-1);
+                    }
+                }
+                size_t maxunit = 0;
+                for (const std::vector<int>& ub : unit_bus) maxunit = std::max(maxunit, ub.size());
+                const size_t mi = maxunit * (size_t)d->Hn;
                 T.lin_np = (lb_env2 && atoi(lb_env2) == 0) ? 0 : (mi <= 256 ? 1 : (mi <= 512 ? 2 : (mi <= 1024 ? 4 : 0)));
                 T.n_lin_bundles2 = 0;
+                T.chains_bundled = 0;
                 if (T.lin_np) {
-                    const size_t cap_items = 256 * (size_t)T.lin_np;
-                    std::vector<int> cur, loc(n, -1), csv(n, 0);
+                    const size_t cap_items = 256 * (size_t)T.lin_np, cap_chains = (size_t)std::max(1, 256 / d->Hn);
+                    std::vector<int> cur, curch, loc(n, -1), csv(n, 0);
+                    lb2cptr.assign(1, 0);
                     auto flush2 = [&]() {
-                        if (cur.empty()) return;
+                        if (cur.empty() && curch.empty()) return;
                         std::stable_sort(cur.begin(), cur.end(), [&](int a, int b2) { return hl[a] < hl[b2]; });
                         const int base = (int)lb2rec.size() / 8;
                         int csum = 0;
@@ -1296,14 +1319,23 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
                             lb2ptr.push_back(base + (int)cur.size());
                             ++hh;
                         }
+                        lb2clist.insert(lb2clist.end(), curch.begin(), curch.end());
+                        lb2cptr.push_back((int)lb2clist.size());
                         cur.clear();
+                        curch.clear();
                         ++T.n_lin_bundles2;
                     };
-                    for (const std::vector<int>& sb : sub) {
-                        if ((cur.size() + sb.size()) * (size_t)d->Hn > cap_items) flush2();
-                        cur.insert(cur.end(), sb.begin(), sb.end());
+                    for (size_t u = 0; u < unit_bus.size(); ++u) {
+                        const bool isch = unit_chain[u] >= 0;
+                        if ((cur.size() + unit_bus[u].size()) * (size_t)d->Hn > cap_items || (isch && curch.size() + 1 > cap_chains)) flush2();
+                        cur.insert(cur.end(), unit_bus[u].begin(), unit_bus[u].end());
+                        if (isch) curch.push_back(unit_chain[u]);
                     }
                     flush2();
+                    T.chains_bundled = chb ? 1 : 0;
+                    for (int e = 0; e < 8; ++e) lb2rec.push_back(0);           // (a bundle of chains only reads one record slot: keep it inside the array)
+                    lb2x.push_back(-1);
+                    lb2x.push_back(-1);
                 }
             }
             std::vector<int> cnt_h(NH);
@@ -2059,6 +2091,8 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
     if ((r = upload(h, &T.d_lb2rec, lb2rec))) return r;
     if ((r = upload(h, &T.d_lb2x, lb2x))) return r;
     if ((r = upload(h, &T.d_lb2ptr, lb2ptr))) return r;
+    if ((r = upload(h, &T.d_lb2cptr, lb2cptr))) return r;
+    if ((r = upload(h, &T.d_lb2clist, lb2clist))) return r;
     if ((r = upload(h, &T.d_lbrec, lbrec))) return r;
     if ((r = upload(h, &T.d_lbptr, lbptr))) return r;
     if ((r = upload(h, &T.d_crec, crec))) return r;
@@ -2082,7 +2116,7 @@ static void tree_free_one(Tree& T) {
     void* ptrs[] = {T.d_parent, T.d_lvl_nodes, T.d_dep_nodes, T.d_child_ptr, T.d_child, T.d_e_up, T.d_e_dn,
                     T.d_child_mid, T.d_lin, T.d_lin_ptr, T.d_lin_post, T.d_all_ptr, T.d_all_post, T.d_fdesc, T.d_child3,
                     T.d_bdesc, T.d_dchild, T.d_chain_ptr, T.d_chain_nodes, T.d_chain_ch, T.d_Minv, T.d_lrec, T.d_crec, T.d_cnode, T.d_arec,
-                    T.d_lzrec, T.d_lzimg, T.d_lbimg, T.d_bleaf, T.d_bsleaf, T.d_sbimg, T.d_lbrec, T.d_lbptr, T.d_lb2rec, T.d_lb2x, T.d_lb2ptr};
+                    T.d_lzrec, T.d_lzimg, T.d_lbimg, T.d_bleaf, T.d_bsleaf, T.d_sbimg, T.d_lbrec, T.d_lbptr, T.d_lb2rec, T.d_lb2x, T.d_lb2ptr, T.d_lb2cptr, T.d_lb2clist};
     for (void* p : ptrs)
         if (p) hipFree(p);
 }
@@ -2182,7 +2216,9 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
                 const dim3 g2((unsigned)T.n_lin_bundles2, (unsigned)h->cur_S);
 #define HPF_LB_F(NP_)                                                                                                                  \
     hipLaunchKernelGGL((k_lin_bundle_factor<NP_>), g2, dim3(256), 0, h->cur_stream, h->M, T.d_lb2rec, (const int2*)T.d_lb2x, T.d_lb2ptr, \
-                       T.n_lin_heights, Bst, active, h->d_U, h->d_E, h->d_fb, h->d_linA, h->d_w, h->d_I0, h->cur_s0)
+                       T.n_lin_heights, Bst, active, h->d_U, h->d_E, h->d_fb, h->d_linA, h->d_w, h->d_I0, h->cur_s0, td,                   \
+                       T.chains_bundled ? T.d_lb2cptr : (const int*)nullptr, T.d_lb2clist, T.d_crec, T.d_cnode, h->d_chG, h->d_chH, h->d_chD, \
+                       h->d_chy, h->d_chZ)
                 if (T.lin_np == 1) HPF_LB_F(1);
                 else if (T.lin_np == 2) HPF_LB_F(2);
                 else HPF_LB_F(4);
@@ -2198,7 +2234,7 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
                                    h->cur_stream, h->M, td, T.d_lrec + 8 * (size_t)T.lh_ptr[hh], cnt, h->N, h->Nc, Bst, active,
                                    h->d_U, h->d_E, h->d_fb, h->d_linA, h->d_w, h->d_I0, 0, h->cur_s0);
             }
-            if (T.n_chains > 0)
+            if (T.n_chains > 0 && !(T.chains_bundled && T.n_lin_bundles2 > 0))
                 hipLaunchKernelGGL(k_chain_factor2, dim3((unsigned)((T.n_chains * h->Hn + 127) / 128), (unsigned)h->cur_S), dim3(128),
                                    0, h->cur_stream, h->M, td, T.d_crec, T.d_cnode, T.n_chains, h->N, h->Nc, Bst, active, h->d_U,
                                    h->d_E, h->d_fb, h->d_linA, h->d_w, h->d_I0, h->d_chG, h->d_chH, h->d_chD, h->d_chy, h->d_chZ,
@@ -2359,7 +2395,7 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
     }
     const bool lvl2x2b = h->has_ctree && h->gj_mode == 1;
     if (lvl2x2b) {
-        if (T.n_chains > 0)
+        if (T.n_chains > 0 && !(T.chains_bundled && T.n_lin_bundles2 > 0))
             hipLaunchKernelGGL(k_chain_back2, dim3((unsigned)((T.n_chains * h->Hn + 127) / 128), (unsigned)h->cur_S), dim3(128), 0,
                                h->cur_stream, h->M, td, T.d_crec, T.d_cnode, T.n_chains, h->N, h->Nc, Bst, active, h->d_U, h->d_E,
                                h->d_linA, h->d_w, h->d_x, (double*)nullptr, h->d_chZ, h->cur_s0);
@@ -2367,7 +2403,8 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
             const dim3 g2((unsigned)T.n_lin_bundles2, (unsigned)h->cur_S);
 #define HPF_LB_B(NP_)                                                                                                                \
     hipLaunchKernelGGL((k_lin_bundle_back<NP_>), g2, dim3(256), 0, h->cur_stream, h->M, T.d_lb2rec, (const int2*)T.d_lb2x, T.d_lb2ptr, \
-                       T.n_lin_heights, Bst, active, h->d_U, h->d_E, h->d_linA, h->d_w, h->d_x, h->cur_s0)
+                       T.n_lin_heights, Bst, active, h->d_U, h->d_E, h->d_linA, h->d_w, h->d_x, h->cur_s0,                                 \
+                       T.chains_bundled ? T.d_lb2cptr : (const int*)nullptr, T.d_lb2clist, T.d_crec, T.d_cnode, h->d_chZ)
             if (T.lin_np == 1) HPF_LB_B(1);
             else if (T.lin_np == 2) HPF_LB_B(2);
             else HPF_LB_B(4);

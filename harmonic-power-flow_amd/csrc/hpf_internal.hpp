@@ -80,6 +80,9 @@ struct Tree {
     int* d_lb2rec = nullptr;
     int* d_lb2x = nullptr;
     int* d_lb2ptr = nullptr;
+    int chains_bundled = 0;           // the contracted chains ride in the bundle launches (d_lb2cptr [bundle + 1] into d_lb2clist: chain ids)
+    int* d_lb2cptr = nullptr;
+    int* d_lb2clist = nullptr;
     int n_lin_bundles = 0;
     int* d_lbrec = nullptr;
     int* d_lbptr = nullptr;

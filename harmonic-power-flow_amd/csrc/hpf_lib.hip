@@ -1418,7 +1418,8 @@ int hpf_tree_census(const hpf_handle* h, int* counts, int n_counts) {
     if (!h || !counts || n_counts < 0) return HPF_E_ARG;
     if (h->solver != HPF_SOLVER_BLOCK_TREE) return HPF_E_STATE;
     const Tree& T = active_tree(const_cast<hpf_handle*>(h));
-    for (int i = 0; i < n_counts; ++i) counts[i] = i < 8 ? T.census[i] : (i == 8 ? h->n_ties : 0);
+    const int fused = (h->fuse_levels && h->gj_mode == 1 && 2 * h->Hn > 28 && 2 * h->Hn <= 52) ? 1 : 0;
+    for (int i = 0; i < n_counts; ++i) counts[i] = i < 8 ? T.census[i] : (i == 8 ? h->n_ties : (i == 9 ? fused : 0));
     return HPF_OK;
 }
 

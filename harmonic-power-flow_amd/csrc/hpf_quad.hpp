@@ -1433,6 +1433,163 @@ __global__ __launch_bounds__(256) void k_lin_tree_back(Model M, TreeDev T, const
     }
 }
 
+// Contracted chains (see k_chain_factor for the algebra): same elimination, operands of a chain bus loaded in one batch.
+__device__ __forceinline__ void chain_factor_item(const Model& M, const TreeDev& T, const int* __restrict__ crec, const int* __restrict__ cnode,
+                                                  int r, int q, int s, int Bst, const cplx* __restrict__ Uall, const cplx* __restrict__ Eall,
+                                                  const double* __restrict__ fall, double* linAall, double* wall,
+                                                  const cplx* __restrict__ I0all, double* __restrict__ chG, double* __restrict__ chH,
+                                                  double* __restrict__ chD, double* __restrict__ chy, double* __restrict__ chZ) {
+    const int n = M.n, c = M.c, Hn = M.Hn;
+    const size_t so = (size_t)s * n * Hn;
+    const cplx* U = Uall + so;
+    const cplx* E = Eall + so;
+    double* linA = linAall + so * 4;
+    double* ws = wall + (size_t)s * n * Bst;
+    const int4 h0 = reinterpret_cast<const int4*>(crec)[2 * r], h1 = reinterpret_cast<const int4*>(crec)[2 * r + 1];
+    const int ch = h0.x, beg = h0.w, len = h1.x;
+    const cplx uch = U[(size_t)ch * Hn + q], ech = E[(size_t)ch * Hn + q];
+    const cplx y_kc = M.Y[(size_t)h0.y * Hn + q], y_ck = M.Y[(size_t)h0.z * Hn + q];
+    double a_kc[4], a_ck[4];
+    double dD[4] = {0.0, 0.0, 0.0, 0.0}, dy[2] = {0.0, 0.0}, cD[4] = {0.0, 0.0, 0.0, 0.0}, cy[2] = {0.0, 0.0};
+    for (int idx = 0; idx < len; ++idx) {
+        const int4 r0 = reinterpret_cast<const int4*>(cnode)[2 * (beg + idx)], r1 = reinterpret_cast<const int4*>(cnode)[2 * (beg + idx) + 1];
+        const int k = r0.x, up = r0.z;
+        const cplx yd = M.Y[(size_t)r0.y * Hn + q];
+        const cplx uk = U[(size_t)k * Hn + q], ek = E[(size_t)k * Hn + q];
+        const cplx uu = U[(size_t)up * Hn + q], eu = E[(size_t)up * Hn + q];
+        const cplx y_ku = M.Y[(size_t)r0.w * Hn + q], y_uk = M.Y[(size_t)r1.x * Hn + q];
+        cplx I0v = {0.0, 0.0};
+        if (q == 0 && k < M.m) I0v = I0all[(size_t)s * n + k];
+        const double2 fy = *reinterpret_cast<const double2*>(fall + ((size_t)s * n + k) * Bst + 2 * q);
+        double y0 = fy.x + cy[0];
+        double y1 = fy.y + cy[1];
+        __builtin_amdgcn_sched_barrier(0);
+        if (idx == 0) {
+            coupling_val(n, c, M.m, q, k, ch, y_kc, uk, uch, ech, a_kc);     // A(k1, ch)
+            coupling_val(n, c, M.m, q, ch, k, y_ck, uch, uk, ek, a_ck);      // A(ch, k1)
+        }
+        double m2[4];
+        diag2x2_val(n, c, M.m, q, k, yd, uk, ek, I0v, cplx{0.0, 0.0}, m2);      // chain buses are linear buses
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m2[e] += cD[e];
+        fold_children(M, T, U, E, linA, ws, Bst, q, k, uk, ek, r1.y, r1.z, m2, y0, y1, M.m);
+        double di[4];
+        inv2(m2[0], m2[1], m2[2], m2[3], di[0], di[1], di[2], di[3]);
+        double* ik = linA + ((size_t)k * Hn + q) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ik[e] = di[e];
+        const double w0 = fma(di[1], y1, di[0] * y0), w1 = fma(di[3], y1, di[2] * y0);
+        double* wk = ws + (size_t)k * Bst + 2 * q;
+        wk[0] = w0;
+        wk[1] = w1;
+        double a_ku[4], a_uk[4], zc[4], zu[4], t4[4];
+        coupling_val(n, c, M.m, q, k, up, y_ku, uk, uu, eu, a_ku);           // A(k, up)
+        coupling_val(n, c, M.m, q, up, k, y_uk, uu, uk, ek, a_uk);           // A(up, k)
+        mul22(di, a_kc, zc);
+        mul22(di, a_ku, zu);
+        double* zk = chZ + (so + (size_t)k * Hn + q) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) zk[e] = zc[e];
+        mul22(a_ck, zc, t4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dD[e] -= t4[e];
+        dy[0] -= fma(a_ck[1], w1, a_ck[0] * w0);
+        dy[1] -= fma(a_ck[3], w1, a_ck[2] * w0);
+        double n_ck[4], n_kc[4];
+        mul22(a_ck, zu, n_ck);
+        mul22(a_uk, zc, n_kc);
+        mul22(a_uk, zu, t4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            cD[e] = -t4[e];
+            a_ck[e] = -n_ck[e];
+            a_kc[e] = -n_kc[e];
+        }
+        cy[0] = -fma(a_uk[1], w1, a_uk[0] * w0);
+        cy[1] = -fma(a_uk[3], w1, a_uk[2] * w0);
+    }
+    const size_t o = (so + (size_t)ch * Hn + q);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        chG[o * 4 + e] = a_kc[e];
+        chH[o * 4 + e] = a_ck[e];
+        chD[o * 4 + e] = dD[e];
+    }
+    chy[o * 2 + 0] = dy[0];
+    chy[o * 2 + 1] = dy[1];
+}
+
+__global__ __launch_bounds__(128) void k_chain_factor2(Model M, TreeDev T, const int* __restrict__ crec, const int* __restrict__ cnode,
+                                                       int nchains, int N, int Nc, int Bst, const int* __restrict__ active,
+                                                       const cplx* __restrict__ Uall, const cplx* __restrict__ Eall,
+                                                       const double* __restrict__ fall, double* __restrict__ linAall,
+                                                       double* __restrict__ wall, const cplx* __restrict__ I0all,
+                                                       double* __restrict__ chG, double* __restrict__ chH, double* __restrict__ chD,
+                                                       double* __restrict__ chy, double* __restrict__ chZ, int s0) {
+    const int s = active ? active[blockIdx.y + s0] : (int)blockIdx.y + s0;   // slot -> scenario (active list; -1: frozen / empty slot)
+    if (s < 0) return;
+    const int tix = blockIdx.x * 128 + threadIdx.x;
+    if (tix >= nchains * M.Hn) return;
+    chain_factor_item(M, T, crec, cnode, tix / M.Hn, tix % M.Hn, s, Bst, Uall, Eall, fall, linAall, wall, I0all, chG, chH, chD, chy, chZ);
+}
+
+__device__ __forceinline__ void chain_back_item(const Model& M, const int* __restrict__ crec, const int* __restrict__ cnode, int r, int q, int s,
+                                                int N, int Nc, int Bst, const cplx* __restrict__ Uall, const cplx* __restrict__ Eall,
+                                                const double* __restrict__ linAall, const double* __restrict__ wall, double* xall,
+                                                double* step, const double* __restrict__ chZ) {
+    const int n = M.n, c = M.c, Hn = M.Hn;
+    const size_t so = (size_t)s * n * Hn;
+    const cplx* U = Uall + so;
+    const cplx* E = Eall + so;
+    const double* linA = linAall + so * 4;
+    const double* ws = wall + (size_t)s * n * Bst;
+    double* xs = xall + (size_t)s * n * Bst;
+    double* st = step + (size_t)s * N;
+    const int4 h0 = reinterpret_cast<const int4*>(crec)[2 * r], h1 = reinterpret_cast<const int4*>(crec)[2 * r + 1];
+    const int ch = h0.x, beg = h0.w, len = h1.x;
+    const double2 xc = *reinterpret_cast<const double2*>(xs + (size_t)ch * Bst + 2 * q);
+    for (int idx = len - 1; idx >= 0; --idx) {
+        const int4 r0 = reinterpret_cast<const int4*>(cnode)[2 * (beg + idx)];
+        const int k = r0.x, up = r0.z;
+        const cplx y_ku = M.Y[(size_t)r0.w * Hn + q];
+        const cplx uk = U[(size_t)k * Hn + q];
+        const cplx uu = U[(size_t)up * Hn + q], eu = E[(size_t)up * Hn + q];
+        const double2 xp = *reinterpret_cast<const double2*>(xs + (size_t)up * Bst + 2 * q);
+        const double2* pik = reinterpret_cast<const double2*>(linA + ((size_t)k * Hn + q) * 4);
+        const double2 i01 = pik[0], i23 = pik[1];
+        const double2* pzk = reinterpret_cast<const double2*>(chZ + (so + (size_t)k * Hn + q) * 4);
+        const double2 z01 = pzk[0], z23 = pzk[1];
+        const double2 wk = *reinterpret_cast<const double2*>(ws + (size_t)k * Bst + 2 * q);
+        __builtin_amdgcn_sched_barrier(0);
+        double h4[4];
+        coupling_val(n, c, M.m, q, k, up, y_ku, uk, uu, eu, h4);             // A(k, up)
+        const double t0 = fma(h4[1], xp.y, h4[0] * xp.x), t1 = fma(h4[3], xp.y, h4[2] * xp.x);
+        const double x0 = wk.x - fma(i01.y, t1, i01.x * t0) - fma(z01.y, xc.y, z01.x * xc.x);
+        const double x1 = wk.y - fma(i23.y, t1, i23.x * t0) - fma(z23.y, xc.y, z23.x * xc.x);
+        double* xk = xs + (size_t)k * Bst + 2 * q;
+        xk[0] = x0;
+        xk[1] = x1;
+        if (step) {
+            const int kst = q * n + k;
+            if (kst >= 1) st[kst - 1] = x0;
+            if (kst >= c) st[Nc + kst - c] = x1;
+        }
+    }
+}
+
+__global__ __launch_bounds__(128) void k_chain_back2(Model M, TreeDev T, const int* __restrict__ crec, const int* __restrict__ cnode,
+                                                     int nchains, int N, int Nc, int Bst, const int* __restrict__ active,
+                                                     const cplx* __restrict__ Uall, const cplx* __restrict__ Eall,
+                                                     const double* __restrict__ linAall, const double* __restrict__ wall,
+                                                     double* __restrict__ xall, double* __restrict__ step,
+                                                     const double* __restrict__ chZ, int s0) {
+    const int s = active ? active[blockIdx.y + s0] : (int)blockIdx.y + s0;   // slot -> scenario (active list; -1: frozen / empty slot)
+    if (s < 0) return;
+    const int tix = blockIdx.x * 128 + threadIdx.x;
+    if (tix >= nchains * M.Hn) return;
+    chain_back_item(M, crec, cnode, tix / M.Hn, tix % M.Hn, s, N, Nc, Bst, Uall, Eall, linAall, wall, xall, step, chZ);
+}
+
 // The 2x2 algebra of the all-linear subtrees with ONE memory round trip per sweep (harmonic Newton step; k_lin_tree_* above are the
 // fallback).  What an elimination step of bus k needs from memory does not depend on the steps before it: its own diagonal block and
 // right-hand side and the coupling blocks with its parent, G = A(par,k), H = A(k,par), come from the state (U, E), the network (Y)
@@ -1442,14 +1599,21 @@ __global__ __launch_bounds__(256) void k_lin_tree_back(Model M, TreeDev T, const
 // G D^-1 H, G w in the slot (parent's first child slot + its ordinal), the parent subtracts its children's slots in list order --
 // the arithmetic and its order are those of fold_children / lin_factor_item, bit for bit.  D^-1 and w go to HBM as before (dense
 // parents, chains and the back sweep read them).
+// The contracted chains ride in the same launches: a chain and the linear subtrees hanging off its buses sit in one bundle, the
+// chain walk (chain_factor_item: it folds those subtrees from D^-1, w in HBM, written by this workgroup) follows the last height;
+// the back sweep walks the chains first.  cbptr / cblist: chains per bundle (null: chains have their own launches).
 // Records: Rec8 with cbeg = first child slot of the bus; xrec[record] = (own slot or -1 for a subtree root, local index of the parent
 // inside the bundle or -1); bptr: nh + 1 record offsets per bundle (heights ascending).
 template <int NP>
 __global__ __launch_bounds__(256) void k_lin_bundle_factor(Model M, const int* __restrict__ rec, const int2* __restrict__ xrec,
                                                            const int* __restrict__ bptr, int nh, int Bst, const int* __restrict__ active,
                                                            const cplx* __restrict__ Uall, const cplx* __restrict__ Eall,
-                                                           const double* __restrict__ fall, double* __restrict__ linAall,
-                                                           double* __restrict__ wall, const cplx* __restrict__ I0all, int s0) {
+                                                           const double* __restrict__ fall, double* linAall, double* wall,
+                                                           const cplx* __restrict__ I0all, int s0, TreeDev T,
+                                                           const int* __restrict__ cbptr, const int* __restrict__ cblist,
+                                                           const int* __restrict__ crec, const int* __restrict__ cnode,
+                                                           double* __restrict__ chG, double* __restrict__ chH, double* __restrict__ chD,
+                                                           double* __restrict__ chy, double* __restrict__ chZ) {
     const int s = active ? active[blockIdx.y + s0] : (int)blockIdx.y + s0;
     if (s < 0) return;
     __shared__ double ctr[256 * NP * 6];
@@ -1553,6 +1717,15 @@ __global__ __launch_bounds__(256) void k_lin_bundle_factor(Model M, const int* _
         }
         if (bp[hh + 1] == bp[nh]) break;                         // (uniform: nothing of this bundle above this height)
     }
+    if (cbptr) {                                                 // the bundle's contracted chains (their linear subtrees are done)
+        const int c0 = cbptr[blockIdx.x], nc2 = cbptr[blockIdx.x + 1] - c0;
+        if (nc2 > 0) {
+            __syncthreads();
+            for (int t = threadIdx.x; t < nc2 * Hn; t += 256)
+                chain_factor_item(M, T, crec, cnode, cblist[c0 + t / Hn], t % Hn, s, Bst, Uall, Eall, fall, linAall, wall, I0all, chG, chH, chD,
+                                  chy, chZ);
+        }
+    }
 }
 
 // ... and its back sweep: x_k = w_k - D_k^-1 (A(k,par) x_par).  D^-1, w, A(k,par) of every item in one round trip (a subtree root
@@ -1562,7 +1735,9 @@ __global__ __launch_bounds__(256) void k_lin_bundle_back(Model M, const int* __r
                                                          const int* __restrict__ bptr, int nh, int Bst, const int* __restrict__ active,
                                                          const cplx* __restrict__ Uall, const cplx* __restrict__ Eall,
                                                          const double* __restrict__ linAall, const double* __restrict__ wall,
-                                                         double* __restrict__ xall, int s0) {
+                                                         double* xall, int s0, const int* __restrict__ cbptr,
+                                                         const int* __restrict__ cblist, const int* __restrict__ crec,
+                                                         const int* __restrict__ cnode, const double* __restrict__ chZ) {
     const int s = active ? active[blockIdx.y + s0] : (int)blockIdx.y + s0;
     if (s < 0) return;
     __shared__ double xl[256 * NP * 2];
@@ -1602,8 +1777,18 @@ __global__ __launch_bounds__(256) void k_lin_bundle_back(Model M, const int* __r
         i23[p] = pik[1];
         wkv[p] = *reinterpret_cast<const double2*>(ws + (size_t)k * Bst + 2 * q);
         xpv[p] = double2{0.0, 0.0};
-        if (lpar[p] < 0 && r0v[p].z >= 0) xpv[p] = *reinterpret_cast<const double2*>(xs + (size_t)par * Bst + 2 * q);
     }
+    if (cbptr) {                                                 // the bundle's chains first: subtree roots below take x of their chain bus
+        const int c0 = cbptr[blockIdx.x], nc2 = cbptr[blockIdx.x + 1] - c0;
+        if (nc2 > 0) {
+            for (int t = threadIdx.x; t < nc2 * Hn; t += 256)
+                chain_back_item(M, crec, cnode, cblist[c0 + t / Hn], t % Hn, s, 0, 0, Bst, Uall, Eall, linAall, wall, xall, nullptr, chZ);
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+        if (lpar[p] < 0 && r0v[p].z >= 0) xpv[p] = *reinterpret_cast<const double2*>(xs + (size_t)r0v[p].z * Bst + 2 * qv[p]);
     __builtin_amdgcn_sched_barrier(0);
     double h4[NP][4];
     int hgt[NP];
@@ -1638,146 +1823,3 @@ __global__ __launch_bounds__(256) void k_lin_bundle_back(Model M, const int* __r
     }
 }
 
-// Contracted chains (see k_chain_factor for the algebra): same elimination, operands of a chain bus loaded in one batch.
-__global__ __launch_bounds__(128) void k_chain_factor2(Model M, TreeDev T, const int* __restrict__ crec, const int* __restrict__ cnode,
-                                                       int nchains, int N, int Nc, int Bst, const int* __restrict__ active,
-                                                       const cplx* __restrict__ Uall, const cplx* __restrict__ Eall,
-                                                       const double* __restrict__ fall, double* __restrict__ linAall,
-                                                       double* __restrict__ wall, const cplx* __restrict__ I0all,
-                                                       double* __restrict__ chG, double* __restrict__ chH, double* __restrict__ chD,
-                                                       double* __restrict__ chy, double* __restrict__ chZ, int s0) {
-    const int s = active ? active[blockIdx.y + s0] : (int)blockIdx.y + s0;   // slot -> scenario (active list; -1: frozen / empty slot)
-    if (s < 0) return;
-    const int tix = blockIdx.x * 128 + threadIdx.x;
-    if (tix >= nchains * M.Hn) return;
-    const int q = tix % M.Hn, r = tix / M.Hn;
-    const int n = M.n, c = M.c, Hn = M.Hn;
-    const size_t so = (size_t)s * n * Hn;
-    const cplx* U = Uall + so;
-    const cplx* E = Eall + so;
-    double* linA = linAall + so * 4;
-    double* ws = wall + (size_t)s * n * Bst;
-    const int4 h0 = reinterpret_cast<const int4*>(crec)[2 * r], h1 = reinterpret_cast<const int4*>(crec)[2 * r + 1];
-    const int ch = h0.x, beg = h0.w, len = h1.x;
-    const cplx uch = U[(size_t)ch * Hn + q], ech = E[(size_t)ch * Hn + q];
-    const cplx y_kc = M.Y[(size_t)h0.y * Hn + q], y_ck = M.Y[(size_t)h0.z * Hn + q];
-    double a_kc[4], a_ck[4];
-    double dD[4] = {0.0, 0.0, 0.0, 0.0}, dy[2] = {0.0, 0.0}, cD[4] = {0.0, 0.0, 0.0, 0.0}, cy[2] = {0.0, 0.0};
-    for (int idx = 0; idx < len; ++idx) {
-        const int4 r0 = reinterpret_cast<const int4*>(cnode)[2 * (beg + idx)], r1 = reinterpret_cast<const int4*>(cnode)[2 * (beg + idx) + 1];
-        const int k = r0.x, up = r0.z;
-        const cplx yd = M.Y[(size_t)r0.y * Hn + q];
-        const cplx uk = U[(size_t)k * Hn + q], ek = E[(size_t)k * Hn + q];
-        const cplx uu = U[(size_t)up * Hn + q], eu = E[(size_t)up * Hn + q];
-        const cplx y_ku = M.Y[(size_t)r0.w * Hn + q], y_uk = M.Y[(size_t)r1.x * Hn + q];
-        cplx I0v = {0.0, 0.0};
-        if (q == 0 && k < M.m) I0v = I0all[(size_t)s * n + k];
-        const double2 fy = *reinterpret_cast<const double2*>(fall + ((size_t)s * n + k) * Bst + 2 * q);
-        double y0 = fy.x + cy[0];
-        double y1 = fy.y + cy[1];
-        __builtin_amdgcn_sched_barrier(0);
-        if (idx == 0) {
-            coupling_val(n, c, M.m, q, k, ch, y_kc, uk, uch, ech, a_kc);     // A(k1, ch)
-            coupling_val(n, c, M.m, q, ch, k, y_ck, uch, uk, ek, a_ck);      // A(ch, k1)
-        }
-        double m2[4];
-        diag2x2_val(n, c, M.m, q, k, yd, uk, ek, I0v, cplx{0.0, 0.0}, m2);      // chain buses are linear buses
-#pragma unroll
-        for (int e = 0; e < 4; ++e) m2[e] += cD[e];
-        fold_children(M, T, U, E, linA, ws, Bst, q, k, uk, ek, r1.y, r1.z, m2, y0, y1, M.m);
-        double di[4];
-        inv2(m2[0], m2[1], m2[2], m2[3], di[0], di[1], di[2], di[3]);
-        double* ik = linA + ((size_t)k * Hn + q) * 4;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) ik[e] = di[e];
-        const double w0 = fma(di[1], y1, di[0] * y0), w1 = fma(di[3], y1, di[2] * y0);
-        double* wk = ws + (size_t)k * Bst + 2 * q;
-        wk[0] = w0;
-        wk[1] = w1;
-        double a_ku[4], a_uk[4], zc[4], zu[4], t4[4];
-        coupling_val(n, c, M.m, q, k, up, y_ku, uk, uu, eu, a_ku);           // A(k, up)
-        coupling_val(n, c, M.m, q, up, k, y_uk, uu, uk, ek, a_uk);           // A(up, k)
-        mul22(di, a_kc, zc);
-        mul22(di, a_ku, zu);
-        double* zk = chZ + (so + (size_t)k * Hn + q) * 4;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) zk[e] = zc[e];
-        mul22(a_ck, zc, t4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) dD[e] -= t4[e];
-        dy[0] -= fma(a_ck[1], w1, a_ck[0] * w0);
-        dy[1] -= fma(a_ck[3], w1, a_ck[2] * w0);
-        double n_ck[4], n_kc[4];
-        mul22(a_ck, zu, n_ck);
-        mul22(a_uk, zc, n_kc);
-        mul22(a_uk, zu, t4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            cD[e] = -t4[e];
-            a_ck[e] = -n_ck[e];
-            a_kc[e] = -n_kc[e];
-        }
-        cy[0] = -fma(a_uk[1], w1, a_uk[0] * w0);
-        cy[1] = -fma(a_uk[3], w1, a_uk[2] * w0);
-    }
-    const size_t o = (so + (size_t)ch * Hn + q);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        chG[o * 4 + e] = a_kc[e];
-        chH[o * 4 + e] = a_ck[e];
-        chD[o * 4 + e] = dD[e];
-    }
-    chy[o * 2 + 0] = dy[0];
-    chy[o * 2 + 1] = dy[1];
-}
-
-__global__ __launch_bounds__(128) void k_chain_back2(Model M, TreeDev T, const int* __restrict__ crec, const int* __restrict__ cnode,
-                                                     int nchains, int N, int Nc, int Bst, const int* __restrict__ active,
-                                                     const cplx* __restrict__ Uall, const cplx* __restrict__ Eall,
-                                                     const double* __restrict__ linAall, const double* __restrict__ wall,
-                                                     double* __restrict__ xall, double* __restrict__ step,
-                                                     const double* __restrict__ chZ, int s0) {
-    const int s = active ? active[blockIdx.y + s0] : (int)blockIdx.y + s0;   // slot -> scenario (active list; -1: frozen / empty slot)
-    if (s < 0) return;
-    const int tix = blockIdx.x * 128 + threadIdx.x;
-    if (tix >= nchains * M.Hn) return;
-    const int q = tix % M.Hn, r = tix / M.Hn;
-    const int n = M.n, c = M.c, Hn = M.Hn;
-    const size_t so = (size_t)s * n * Hn;
-    const cplx* U = Uall + so;
-    const cplx* E = Eall + so;
-    const double* linA = linAall + so * 4;
-    const double* ws = wall + (size_t)s * n * Bst;
-    double* xs = xall + (size_t)s * n * Bst;
-    double* st = step + (size_t)s * N;
-    const int4 h0 = reinterpret_cast<const int4*>(crec)[2 * r], h1 = reinterpret_cast<const int4*>(crec)[2 * r + 1];
-    const int ch = h0.x, beg = h0.w, len = h1.x;
-    const double2 xc = *reinterpret_cast<const double2*>(xs + (size_t)ch * Bst + 2 * q);
-    for (int idx = len - 1; idx >= 0; --idx) {
-        const int4 r0 = reinterpret_cast<const int4*>(cnode)[2 * (beg + idx)];
-        const int k = r0.x, up = r0.z;
-        const cplx y_ku = M.Y[(size_t)r0.w * Hn + q];
-        const cplx uk = U[(size_t)k * Hn + q];
-        const cplx uu = U[(size_t)up * Hn + q], eu = E[(size_t)up * Hn + q];
-        const double2 xp = *reinterpret_cast<const double2*>(xs + (size_t)up * Bst + 2 * q);
-        const double2* pik = reinterpret_cast<const double2*>(linA + ((size_t)k * Hn + q) * 4);
-        const double2 i01 = pik[0], i23 = pik[1];
-        const double2* pzk = reinterpret_cast<const double2*>(chZ + (so + (size_t)k * Hn + q) * 4);
-        const double2 z01 = pzk[0], z23 = pzk[1];
-        const double2 wk = *reinterpret_cast<const double2*>(ws + (size_t)k * Bst + 2 * q);
-        __builtin_amdgcn_sched_barrier(0);
-        double h4[4];
-        coupling_val(n, c, M.m, q, k, up, y_ku, uk, uu, eu, h4);             // A(k, up)
-        const double t0 = fma(h4[1], xp.y, h4[0] * xp.x), t1 = fma(h4[3], xp.y, h4[2] * xp.x);
-        const double x0 = wk.x - fma(i01.y, t1, i01.x * t0) - fma(z01.y, xc.y, z01.x * xc.x);
-        const double x1 = wk.y - fma(i23.y, t1, i23.x * t0) - fma(z23.y, xc.y, z23.x * xc.x);
-        double* xk = xs + (size_t)k * Bst + 2 * q;
-        xk[0] = x0;
-        xk[1] = x1;
-        if (step) {
-            const int kst = q * n + k;
-            if (kst >= 1) st[kst - 1] = x0;
-            if (kst >= c) st[Nc + kst - c] = x1;
-        }
-    }
-}

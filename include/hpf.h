@@ -214,7 +214,9 @@ int  hpf_kernel_model(const hpf_handle* h, int which, double* bytes, double* flo
 /* Census of the BLOCK_TREE elimination tree (diagnostic; which kernel takes which bus).  counts[0..8]: buses with a dense b x b
  * block (the rest lives in the 2x2 algebra of the linear subtrees / contracted chains), Gauss-Jordan buses (k_factor_q<B,false>),
  * constant-inverse leaves, of which lazy (vector-only, k_leaf_batch), bordered buses (super-leaves, m x m core), of which nested
- * (bordered children below them), elimination levels, back-sweep depths, tie lines of a meshed network.  HPF_E_STATE for DENSE. */
+ * (bordered children below them), elimination levels, back-sweep depths, tie lines of a meshed network, [9] 1 if every elimination
+ * level is ONE launch (k_level: scenario-batched and per-scenario workgroups in one grid; timing class 5 then covers it).
+ * HPF_E_STATE for DENSE. */
 int  hpf_tree_census(const hpf_handle* h, int* counts, int n_counts);
 
 #ifdef __cplusplus

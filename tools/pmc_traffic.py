@@ -61,7 +61,8 @@ def main():
         out["per_launch_bytes"][k] = {"fetch": fe / nd, "write": wr / nd}
     if command:
         out["command"] = command
-    g = [k for k in out["per_launch_bytes"] if k.startswith("k_factor_q<") and k.endswith("false>")]
+    g = [k for k in out["per_launch_bytes"] if k.startswith("k_level<")] or \
+        [k for k in out["per_launch_bytes"] if k.startswith("k_factor_q<") and k.endswith("false>")]    # (k_level: one launch per level)
     if g:
         out["per_launch_bytes"]["k_factor_q_general"] = out["per_launch_bytes"][g[0]]
     tot = sum(v["fetch"] + v["write"] for v in out["per_step_bytes"].values())
