@@ -173,7 +173,12 @@ int  hpf_debug_stamps(hpf_handle* h, long long* out, int count);
  * leaf writes its Schur complement; 1: only leaves directly under their dense parent), HPF_SLEAF=0 sends the nonlinear buses
  * whose dense children are all lazy leaves (super-leaves: bordered low-rank inverse) through Gauss-Jordan like every other bus,
  * HPF_LEAFBATCH=0 runs the lazy leaves one workgroup per (leaf, scenario) instead of 16 scenarios per workgroup on the matrix
- * cores, HPF_SLBACK=0 lets the super-leaves store their inverse for the per-scenario back sweep instead of keeping T^-1 only, HPF_TREE_INFO=1 prints the tree statistics to stderr, HPF_GROUPS=n presets "scenario_groups". */
+ * cores, HPF_SLBACK=0 lets the super-leaves store their inverse for the per-scenario back sweep instead of keeping T^-1 only,
+ * HPF_SLNEST=0 keeps bordered buses below bordered buses on the Gauss-Jordan path, HPF_FUSELEVEL=0 launches the scenario-batched
+ * and the per-scenario workgroups of an elimination level separately (k_leaf_batch / k_sleaf_batch + k_factor_q instead of k_level),
+ * HPF_LINBUNDLE=0 / HPF_LINTREE=0 run the 2x2 algebra of the linear subtrees height by height in one launch / in one launch per
+ * height, HPF_CHAINBUNDLE=0 gives the contracted chains their own launches, HPF_TREE_INFO=1 prints the tree statistics to stderr,
+ * HPF_GROUPS=n presets "scenario_groups".  Every switch selects a path with the same Newton steps (tests/test_gpu_robustness.py). */
 int  hpf_set_option(hpf_handle* h, const char* name, int value);
 
 /* Stream plumbing: run on a caller stream (e.g. torch's current stream) instead of the handle's own; NULL restores. */
@@ -185,7 +190,8 @@ int  hpf_sync(hpf_handle* h);
  * 2 linear solve (DENSE: getrf+getrs, one span per step; BLOCK_TREE: one span per launch of a factor kernel OTHER than the
  *   general one: k_leaf_batch, k_sleaf_batch, the leaf-only k_factor_q<B,true>, the pivoted / generic kernels),
  * 3 state update, 4 back-substitution sweep (BLOCK_TREE only; one span per Newton step and scenario group),
- * 5 BLOCK_TREE: one span per launch of the general factor kernel k_factor_q<B,false> (the dominant kernel of a step),
+ * 5 BLOCK_TREE: one span per launch of the dominant factor kernel: k_level<52> (one launch per elimination level, every dense bus)
+ *   where hpf_tree_census reports fused levels, else the general kernel k_factor_q<B,false>,
  * 6 the same launches on the DEVICE clock: last workgroup end - first workgroup start (wall_clock64 stamps written by the kernel
  *   while timing is enabled) -- what rocprofv3 --kernel-trace reports as the kernel's duration; a HIP-event span additionally
  *   holds the event packets and the queue gaps around a ~25 us kernel.
