@@ -862,7 +862,7 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), HPF_Q_OCC) void k_level(
         }
     } else {
         const int i = (int)blockIdx.x - nbb;
-        factor_q_body<B, false>(smem, i % ngen, i / ngen, M, T, nodes + FDESC * (size_t)nbatch, b, N, Nc, active, Uall, Eall, fall, Zall, wall,
+        factor_q_body<B, false>(FqLds<B>::carve(smem), i % ngen, i / ngen, M, T, nodes + FDESC * (size_t)nbatch, b, N, Nc, active, Uall, Eall, fall, Zall, wall,
                                 linAall, Call, Hall, I0all, chG, chH, chD, chy, Minv, lfK, lfS, dbg, ablate, s0, pivflag, piv_limit, tstamp);
     }
 }

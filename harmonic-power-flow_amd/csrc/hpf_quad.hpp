@@ -142,7 +142,38 @@ __device__ __forceinline__ void lz_aop(const double* p, double (&a)[NT]) {
 #define HPF_Q_OCC 4        // waves per SIMD the B = 52 factor kernel is compiled for (register budget 512 / HPF_Q_OCC)
 #endif
 
-// LDS of the factor kernel in doubles (carved from one buffer: the level kernel k_level shares it with the scenario-batched bodies)
+// LDS arrays of the factor body.  k_factor_q hands in its own static arrays (the ones an instantiation never touches -- most of
+// them for LEAF -- then cost nothing); k_level carves them from the buffer it shares with the scenario-batched bodies.
+template <int B>
+struct FqLds {
+    static constexpr int NT = (B + 16) / 16, RP = 16 * NT > 64 ? 16 * NT : 64;
+    cplx* ynl;                      // [(B/2)^2]   Y_N of the bus's device type
+    double* tab;                    // [(B/2) * 8]
+    double* dgb;                    // [RP * 3]    per row: harmonic-diagonal 2x2 part (d0, d1) and right-hand side y
+    double (*cc)[RP * 3];           // [NT]        the linear children's contributions to (d0, d1, y), one slot per wave
+    double (*panel)[NT * 64];       // [2]
+    double (*wl)[16];               // [2]
+    double (*pv)[16];               // [2]
+    double* gl;                     // [NT * 32]
+    double* hl;                     // [NT * 32]
+    double* slb;                    // [2 * B * 10 + 204]  super-leaf constants (B <= 52)
+    __device__ __forceinline__ static FqLds carve(double* smem_) {
+        FqLds L;
+        L.ynl = reinterpret_cast<cplx*>(smem_);                  // (first: 16-byte aligned)
+        L.tab = smem_ + 2 * (B / 2) * (B / 2);
+        L.dgb = L.tab + (B / 2) * 8;
+        L.cc = reinterpret_cast<double (*)[RP * 3]>(L.dgb + RP * 3);
+        L.panel = reinterpret_cast<double (*)[NT * 64]>(L.dgb + RP * 3 + NT * RP * 3);
+        L.wl = reinterpret_cast<double (*)[16]>(L.dgb + RP * 3 + NT * RP * 3 + 2 * NT * 64);
+        L.pv = reinterpret_cast<double (*)[16]>(L.dgb + RP * 3 + NT * RP * 3 + 2 * NT * 64 + 32);
+        L.gl = L.dgb + RP * 3 + NT * RP * 3 + 2 * NT * 64 + 64;
+        L.hl = L.gl + NT * 32;
+        L.slb = L.hl + NT * 32;
+        return L;
+    }
+};
+
+// LDS of the factor kernel in doubles when carved from one buffer (FqLds::carve)
 template <int B>
 constexpr int factor_q_lds() {
     constexpr int NT = (B + 16) / 16, RP = 16 * NT > 64 ? 16 * NT : 64;
@@ -151,7 +182,7 @@ constexpr int factor_q_lds() {
 
 template <int B, bool LEAF>
 __device__ __forceinline__ void factor_q_body(
-    double* __restrict__ smem_, const int bx_, const int by_, const Model& M, const TreeDev& T, const int* __restrict__ nodes, int b, int N, int Nc, const int* __restrict__ active,
+    const FqLds<B>& lds_, const int bx_, const int by_, const Model& M, const TreeDev& T, const int* __restrict__ nodes, int b, int N, int Nc, const int* __restrict__ active,
     const cplx* __restrict__ Uall, const cplx* __restrict__ Eall, const double* __restrict__ fall, double* __restrict__ Zall,
     double* __restrict__ wall, const double* __restrict__ linAall, double* __restrict__ Call, double* __restrict__ Hall,
     const cplx* __restrict__ I0all, const double* __restrict__ chG, const double* __restrict__ chH,
@@ -209,17 +240,16 @@ __device__ __forceinline__ void factor_q_body(
     const cplx* E = Eall + so;
     const double* Cs = Call + (size_t)s * n * CT;
 
-    // LDS (carved from the caller's buffer, factor_q_lds<B>() doubles; the Y_N image first: 16-byte aligned)
-    cplx* ynl = reinterpret_cast<cplx*>(smem_);
-    double* tab = smem_ + 2 * (B / 2) * (B / 2);
-    double* dgb = tab + (B / 2) * 8;          // per row: harmonic-diagonal 2x2 part (d0, d1) and right-hand side y
-    double (*cc)[RP * 3] = reinterpret_cast<double (*)[RP * 3]>(dgb + RP * 3);       // the linear children's contributions to (d0, d1, y), one slot per wave
-    double (*panel)[NT * 64] = reinterpret_cast<double (*)[NT * 64]>(dgb + RP * 3 + NT * RP * 3);
-    double (*wl)[16] = reinterpret_cast<double (*)[16]>(dgb + RP * 3 + NT * RP * 3 + 2 * NT * 64);
-    double (*pv)[16] = reinterpret_cast<double (*)[16]>(dgb + RP * 3 + NT * RP * 3 + 2 * NT * 64 + 32);
-    double* gl = dgb + RP * 3 + NT * RP * 3 + 2 * NT * 64 + 64;
-    double* hl = gl + NT * 32;
-    double* slb = hl + NT * 32;               // super-leaf constants (B <= 52)
+    cplx* const ynl = lds_.ynl;
+    double* const tab = lds_.tab;
+    double* const dgb = lds_.dgb;
+    double (*const cc)[RP * 3] = lds_.cc;
+    double (*const panel)[NT * 64] = lds_.panel;
+    double (*const wl)[16] = lds_.wl;
+    double (*const pv)[16] = lds_.pv;
+    double* const gl = lds_.gl;
+    double* const hl = lds_.hl;
+    double* const slb = lds_.slb;
 
     const bool nl = k >= M.m && M.coupled;
     const int col = 16 * wv + jj, p = col >> 1, t1 = col & 1;      // own column = (harmonic position p, component t1)
@@ -1080,8 +1110,13 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 52 ? 2 : (B > 28 ? (LEAF
     const double* __restrict__ chD, const double* __restrict__ chy, const double* __restrict__ Minv,
     double* __restrict__ lfK, double* __restrict__ lfS, long long* __restrict__ dbg, int ablate, int s0,
     int* __restrict__ pivflag, double piv_limit, unsigned long long* __restrict__ tstamp) {
-    __shared__ __attribute__((aligned(16))) double smem[factor_q_lds<B>()];
-    factor_q_body<B, LEAF>(smem, blockIdx.x, blockIdx.y, M, T, nodes, b, N, Nc, active, Uall, Eall, fall, Zall, wall, linAall, Call, Hall, I0all, chG,
+    constexpr int NT = (B + 16) / 16, RP = 16 * NT > 64 ? 16 * NT : 64;
+    __shared__ cplx ynl[(B / 2) * (B / 2)];
+    __shared__ double tab[(B / 2) * 8], dgb[RP * 3], cc[NT][RP * 3], panel[2][NT * 64], wl[2][16], pv[2][16], gl[NT * 32], hl[NT * 32];
+    __shared__ double slb[B <= 52 ? 2 * B * 10 + 200 + 4 : 1];
+    FqLds<B> lds;
+    lds.ynl = ynl; lds.tab = tab; lds.dgb = dgb; lds.cc = cc; lds.panel = panel; lds.wl = wl; lds.pv = pv; lds.gl = gl; lds.hl = hl; lds.slb = slb;
+    factor_q_body<B, LEAF>(lds, blockIdx.x, blockIdx.y, M, T, nodes, b, N, Nc, active, Uall, Eall, fall, Zall, wall, linAall, Call, Hall, I0all, chG,
                            chH, chD, chy, Minv, lfK, lfS, dbg, ablate, s0, pivflag, piv_limit, tstamp);
 }
 
