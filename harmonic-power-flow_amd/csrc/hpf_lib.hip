@@ -66,12 +66,21 @@ __global__ void k_polar(int count, int stride, int Hn, const double* __restrict_
 // over the 8 XCDs by their linear id (MI355X_MICROARCH.md, workgroup dispatch), and every XCD has its own 4 MiB L2.  A 1-D grid
 // whose id is (scenario block, x block, scenario mod 8) keeps ALL workgroups of a scenario on one XCD, so the scenario's voltages --
 // gathered again by the neighbours' rows and by the Norton rows of the same bus -- are fetched into one L2 instead of eight.
+// With fewer than 8 scenarios that placement would leave XCDs empty (ONE scenario: the whole kernel on 32 of the 256 CUs -- 196 us
+// instead of 30 for the mismatch of the 10 000-bus x 49-harmonic feeder): the workgroups are then dealt over the whole chip.
 __device__ __forceinline__ bool xcd_map(int nbx, int S, int& bx, int& slot) {
-    const int id = blockIdx.x, l8 = id & 7, rest = id >> 3;
+    const int id = blockIdx.x;
+    if (S < 8) {
+        bx = id % nbx;
+        slot = id / nbx;
+        return slot < S;
+    }
+    const int l8 = id & 7, rest = id >> 3;
     bx = rest % nbx;
     slot = (rest / nbx) * 8 + l8;
     return slot < S;
 }
+__host__ inline unsigned xcd_grid(int nbx, int S) { return (unsigned)((S < 8 ? S : 8 * ((S + 7) / 8)) * nbx); }
 
 // ||.||_inf with NaN propagation: |x| as its IEEE bit pattern is monotone for non-negative doubles, and every NaN
 // pattern compares above +inf, so an unsigned max reproduces np.linalg.norm(f, inf) including its NaN result
@@ -586,7 +595,7 @@ int launch_mismatch(hpf_handle* h, const int* active, bool stacked = true) {
         // LDS: Y_N^T of one device type + the voltages of the workgroup's tile of buses (harmonic mismatch with coupled Norton data)
         const size_t lds = (!FUND && h->coupled && h->n > h->m)
                                ? sizeof(cplx) * ((size_t)h->Hn * h->Hn + (size_t)(TPB / h->Hn + 2) * h->Hn) : 0;
-        hipLaunchKernelGGL((k_mismatch<FUND>), dim3((unsigned)(8 * ((h->cur_S + 7) / 8) * nbx)), dim3(TPB), lds, h->cur_stream, h->M, count, N, Nc,
+        hipLaunchKernelGGL((k_mismatch<FUND>), dim3(xcd_grid(nbx, h->cur_S)), dim3(TPB), lds, h->cur_stream, h->M, count, N, Nc,
                            active, h->d_U, h->d_P, h->d_Q, (stacked || !img) ? h->d_f : nullptr, h->d_errbits, h->d_I0,
                            img ? h->d_fb : nullptr, tree_bst(h), h->cur_s0, h->cur_S, nbx);
         HIPCHK(hipGetLastError());
