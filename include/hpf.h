@@ -174,7 +174,9 @@ int  hpf_debug_stamps(hpf_handle* h, long long* out, int count);
  * whose dense children are all lazy leaves (super-leaves: bordered low-rank inverse) through Gauss-Jordan like every other bus,
  * HPF_LEAFBATCH=0 runs the lazy leaves one workgroup per (leaf, scenario) instead of 16 scenarios per workgroup on the matrix
  * cores, HPF_SLBACK=0 lets the super-leaves store their inverse for the per-scenario back sweep instead of keeping T^-1 only,
- * HPF_SLNEST=0 keeps bordered buses below bordered buses on the Gauss-Jordan path, HPF_FUSELEVEL=0 launches the scenario-batched
+ * HPF_SLLAZY=0 lets every super-leaf push its Schur complement itself (no vector-only bordered buses, hence no nested ones: the
+ * faster build up to about 24 live scenarios), HPF_SLNEST=0 keeps bordered buses below bordered buses on the
+ * Gauss-Jordan path, HPF_FUSELEVEL=0 launches the scenario-batched
  * and the per-scenario workgroups of an elimination level separately (k_leaf_batch / k_sleaf_batch + k_factor_q instead of k_level),
  * HPF_LINBUNDLE=0 / HPF_LINTREE=0 run the 2x2 algebra of the linear subtrees height by height in one launch / in one launch per
  * height, HPF_CHAINBUNDLE=0 gives the contracted chains their own launches, HPF_TREE_INFO=1 prints the tree statistics to stderr,

@@ -66,3 +66,13 @@ def test_dense_solver_size_limit_is_refused_on_the_host():
     d.Yval, d.dev_of_bus, d.Y_N, d.I_N = dp(Yval), dev.ctypes.data_as(_lib.c_int_p), dp(YN), dp(IN)
     h = C.c_void_p()
     assert _lib.load().hpf_create(C.byref(h), C.byref(d)) == -1
+
+
+def test_every_environment_switch_of_the_library_is_documented_in_the_header():
+    """hpf_create reads diagnostic / A-B switches from the environment (HPF_*): each of them must be described in include/hpf.h."""
+    import glob
+    import re
+    src = "".join(open(f).read() for f in glob.glob(os.path.join(REPO, "harmonic-power-flow_amd", "csrc", "*")))
+    envs = set(re.findall(r'getenv\("(HPF_[A-Z_0-9]+)"\)', src))
+    hdr = open(os.path.join(REPO, "include", "hpf.h")).read()
+    assert envs and not [e for e in sorted(envs) if e not in hdr]
