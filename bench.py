@@ -251,8 +251,8 @@ def main():
     kdesc = kname + (" alone (general multi-wave block-tree factor kernel: Gauss-Jordan buses and non-batched super-leaves; %d launches per "
                      "Newton step and scenario group, one per tree level)" % ln_gj)
     if fused:
-        kname = "k_level<52>"
-        kdesc = ("k_level<52>: the factor sweep of the block tree, one launch per elimination level (%d per Newton step and scenario group) -- "
+        kname = "k_level<%d>" % (52 if b > 28 else (28 if b > 12 else 12))
+        kdesc = (kname + ": the factor sweep of the block tree, one launch per elimination level (%d per Newton step and scenario group) -- "
                  "Gauss-Jordan workgroups (one per bus and scenario: %d buses) and the scenario-batched workgroups of the constant-inverse "
                  "leaves (%d) and bordered buses (%d) of the level in one grid" % (ln_gj, census["gauss_jordan"], census["const_leaves"],
                                                                                   census["bordered"]))

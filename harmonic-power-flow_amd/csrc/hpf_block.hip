@@ -835,7 +835,7 @@ constexpr int level_lds() {
 }
 
 template <int B>
-__global__ __launch_bounds__(64 * ((B + 16) / 16), HPF_Q_OCC) void k_level(
+__global__ __launch_bounds__(256, HPF_Q_OCC) void k_level(
     Model M, TreeDev T, const int* __restrict__ nodes, int kind, int nbatch, int ngen, int b, int N, int Nc,
     const int* __restrict__ active, int S_cnt, const cplx* __restrict__ Uall, const cplx* __restrict__ Eall,
     const double* __restrict__ fall, double* __restrict__ Zall, double* __restrict__ wall, const double* __restrict__ linAall,
@@ -844,7 +844,10 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), HPF_Q_OCC) void k_level(
     const double* __restrict__ Minv, const double* __restrict__ lbimg, const double* __restrict__ sbimg, double* __restrict__ lfK,
     double* __restrict__ lfS, long long* __restrict__ dbg, int ablate, int s0, int* __restrict__ pivflag, double piv_limit,
     unsigned long long* __restrict__ tstamp) {
-    static_assert(64 * ((B + 16) / 16) == 256, "the scenario-batched bodies are written for 256 threads");
+    // 256 threads: what the scenario-batched bodies are written for.  The factor body of a smaller block (b <= 28: 2 wavefronts, b <= 12:
+    // one) runs on the first 64 * NT threads; the other wavefronts of such a workgroup end at once (a workgroup barrier waits for the
+    // surviving wavefronts only).
+    static_assert(64 * ((B + 16) / 16) <= 256, "k_level: blocks of up to 52 rows");
     __shared__ __attribute__((aligned(16))) double smem[level_lds<B>()];
     const int ytiles = (S_cnt + LB_SB - 1) / LB_SB, nbb = kind ? nbatch * ytiles : 0;
     if ((int)blockIdx.x < nbb) {
@@ -861,6 +864,7 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), HPF_Q_OCC) void k_level(
             if (threadIdx.x == 0) atomicMax(tstamp + 1, (unsigned long long)wall_clock64());
         }
     } else {
+        if (64 * ((B + 16) / 16) < 256 && (int)threadIdx.x >= 64 * ((B + 16) / 16)) return;
         const int i = (int)blockIdx.x - nbb;
         factor_q_body<B, false>(FqLds<B>::carve(smem), i % ngen, i / ngen, M, T, nodes + FDESC * (size_t)nbatch, b, N, Nc, active, Uall, Eall, fall, Zall, wall,
                                 linAall, Call, Hall, I0all, chG, chH, chD, chy, Minv, lfK, lfS, dbg, ablate, s0, pivflag, piv_limit, tstamp);
@@ -876,7 +880,7 @@ int launch_level(hpf_handle* h, const TreeDev& T, const int* nodes, int kind, in
     const unsigned ytiles = (unsigned)((h->cur_S + LB_SB - 1) / LB_SB);
     const unsigned grid = (kind ? (unsigned)nbatch * ytiles : 0u) + (unsigned)ngen * (unsigned)h->cur_S;
     if (grid == 0) return HPF_OK;
-    hipLaunchKernelGGL((k_level<B>), dim3(grid), dim3(64 * ((B + 16) / 16)), 0, h->cur_stream, h->M, T, nodes, kind, nbatch, ngen, 2 * h->Hn,
+    hipLaunchKernelGGL((k_level<B>), dim3(grid), dim3(256), 0, h->cur_stream, h->M, T, nodes, kind, nbatch, ngen, 2 * h->Hn,
                        h->N, h->Nc, active, h->cur_S, h->d_U, h->d_E, h->d_fb, h->d_Z, h->d_w, h->d_linA, h->d_C, h->d_H, h->d_I0, h->d_chG,
                        h->d_chH, h->d_chD, h->d_chy, tr.d_Minv, tr.d_lbimg, tr.d_sbimg, h->d_lfK, h->d_lfS, h->d_dbg, h->debug_ablate,
                        h->cur_s0, h->d_pivflag, h->piv_limit, ts);
@@ -2268,6 +2272,11 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
             switch (BW) {                       // (timing spans: one per kernel launch, inside the launch helpers)
 #define HPF_FACTOR_CASE(BB_)                                                                                  \
     case BB_:                                                                                                 \
+        if (h->gj_mode == 1 && h->fuse_levels) {     /* one launch per level: batched and per-scenario workgroups side by side */ \
+            r = launch_level<BB_>(h, td, T.d_fdesc + FDESC * (size_t)T.lvl_ptr[l], nbatch > 0 ? (slbatch ? 2 : 1) : 0, nbatch,       \
+                                  cnt - nbatch, active);                                                      \
+            break;                                                                                            \
+        }                                                                                                     \
         if (h->gj_mode == 1 && nbatch > 0) {                                                                  \
             r = slbatch ? launch_sleaf_batch<BB_>(h, td, T.d_fdesc + FDESC * (size_t)T.lvl_ptr[l], nbatch, active) \
                         : launch_leaf_batch<BB_>(h, td, T.d_fdesc + FDESC * (size_t)T.lvl_ptr[l], nbatch, active); \
@@ -2281,22 +2290,7 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
         break
                 HPF_FACTOR_CASE(12);
                 HPF_FACTOR_CASE(28);
-                case 52:
-                    if (h->gj_mode == 1 && h->fuse_levels) {           // one launch per level: batched and per-scenario workgroups side by side
-                        r = launch_level<52>(h, td, T.d_fdesc + FDESC * (size_t)T.lvl_ptr[l], nbatch > 0 ? (slbatch ? 2 : 1) : 0, nbatch,
-                                             cnt - nbatch, active);
-                        break;
-                    }
-                    if (h->gj_mode == 1 && nbatch > 0) {
-                        r = slbatch ? launch_sleaf_batch<52>(h, td, T.d_fdesc + FDESC * (size_t)T.lvl_ptr[l], nbatch, active)
-                                    : launch_leaf_batch<52>(h, td, T.d_fdesc + FDESC * (size_t)T.lvl_ptr[l], nbatch, active);
-                        if (!r && cnt > nbatch)
-                            r = launch_factor_q<52>(h, td, T.d_fdesc + FDESC * (size_t)(T.lvl_ptr[l] + nbatch), cnt - nbatch, active, !slbatch);
-                        break;
-                    }
-                    r = h->gj_mode == 1 ? launch_factor_q<52>(h, td, T.d_fdesc + FDESC * (size_t)T.lvl_ptr[l], cnt, active, T.lvl_all_leaf[l] != 0)
-                                        : launch_factor_w<52>(h, td, nodes, cnt, active);
-                    break;
+                HPF_FACTOR_CASE(52);
 #undef HPF_FACTOR_CASE
                 case 100:       // 52 < b <= 100: general multi-wave kernel for every dense bus; pivoted mode = generic kernels below
                     if (h->gj_mode == 1) {

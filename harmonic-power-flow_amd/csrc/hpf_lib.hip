@@ -1401,7 +1401,7 @@ int hpf_kernel_model(const hpf_handle* h, int which, double* bytes, double* flop
     int ln = 0;
     if (h->solver == HPF_SOLVER_BLOCK_TREE) {
         const Tree& T = active_tree(const_cast<hpf_handle*>(h));
-        if (which == T_GJ && h->fuse_levels && 2 * h->Hn > 28 && 2 * h->Hn <= 52) {      // k_level<52>: every dense bus, one launch per level
+        if (which == T_GJ && h->fuse_levels && 2 * h->Hn <= 52) {      // k_level: every dense bus, one launch per level
             by = T.bytes_factor; fl = T.flops_factor; ln = T.n_levels;
         } else if (which == T_GJ) {
             by = T.bytes_gj; fl = T.flops_gj; ln = T.n_gj_launches;
@@ -1427,7 +1427,7 @@ int hpf_tree_census(const hpf_handle* h, int* counts, int n_counts) {
     if (!h || !counts || n_counts < 0) return HPF_E_ARG;
     if (h->solver != HPF_SOLVER_BLOCK_TREE) return HPF_E_STATE;
     const Tree& T = active_tree(const_cast<hpf_handle*>(h));
-    const int fused = (h->fuse_levels && h->gj_mode == 1 && 2 * h->Hn > 28 && 2 * h->Hn <= 52) ? 1 : 0;
+    const int fused = (h->fuse_levels && h->gj_mode == 1 && 2 * h->Hn <= 52) ? 1 : 0;
     for (int i = 0; i < n_counts; ++i) counts[i] = i < 8 ? T.census[i] : (i == 8 ? h->n_ties : (i == 9 ? fused : 0));
     return HPF_OK;
 }

@@ -192,7 +192,7 @@ int  hpf_sync(hpf_handle* h);
  * 2 linear solve (DENSE: getrf+getrs, one span per step; BLOCK_TREE: one span per launch of a factor kernel OTHER than the
  *   general one: k_leaf_batch, k_sleaf_batch, the leaf-only k_factor_q<B,true>, the pivoted / generic kernels),
  * 3 state update, 4 back-substitution sweep (BLOCK_TREE only; one span per Newton step and scenario group),
- * 5 BLOCK_TREE: one span per launch of the dominant factor kernel: k_level<52> (one launch per elimination level, every dense bus)
+ * 5 BLOCK_TREE: one span per launch of the dominant factor kernel: k_level<B> (b <= 52: one launch per elimination level, every dense bus)
  *   where hpf_tree_census reports fused levels, else the general kernel k_factor_q<B,false>,
  * 6 the same launches on the DEVICE clock: last workgroup end - first workgroup start (wall_clock64 stamps written by the kernel
  *   while timing is enabled) -- what rocprofv3 --kernel-trace reports as the kernel's duration; a HIP-event span additionally

@@ -227,6 +227,23 @@ def test_fuzz_feeders_converged_voltages_block_tree_vs_dense(n, hmax, frac, n_pv
     assert np.abs(Ub - Ud).max() < TOL_V
 
 
+@pytest.mark.parametrize("n,hmax", [(400, 27), (600, 11), (300, 51)])
+def test_level_kernel_for_every_block_size_matches_separate_launches(n, hmax, tmp_path, monkeypatch):
+    """k_level (one launch per elimination level) runs b <= 12, <= 28 and <= 52 blocks alike: the factor body of a smaller block uses
+    the first 64 NT threads of the 256-thread workgroup.  Same Newton steps as the separate launches (HPF_FUSELEVEL=0)."""
+    hp = _hp()
+    st, buses, Y, NE, _ = _feeder(hp, n, hmax, tmp_path, seed=1)
+    S = 21
+    fused = _solve(hp, st, buses, Y, NE, S=S, polish=1)
+    monkeypatch.setenv("HPF_FUSELEVEL", "0")
+    plain = _solve(hp, st, buses, Y, NE, S=S, polish=1)
+    assert fused["census"]["fused_levels"] == 1 and plain["census"]["fused_levels"] == 0
+    assert (fused["err"] <= 1e-4).all() and (plain["err"] <= 1e-4).all()
+    Uf, Up = fused["Vm"] * np.exp(1j * fused["Va"]), plain["Vm"] * np.exp(1j * plain["Va"])
+    print("\nn=%d hmax=%d: iterations %s vs %s, max|dU| %.2e" % (n, hmax, fused["it"][:4], plain["it"][:4], np.abs(Uf - Up).max()))
+    assert np.abs(Uf - Up).max() < TOL_V
+
+
 @pytest.mark.parametrize("n,hmax,frac,seed,S", [(150, 51, 0.6, 11, 20), (220, 27, 0.35, 5, 33), (120, 51, 0.85, 3, 17)])
 def test_many_scenarios_block_tree_vs_dense_fixed_points(n, hmax, frac, seed, S, tmp_path):
     """The scenario-batched kernels (16 scenarios per workgroup: lazy leaves, bordered and nested bordered buses; full and ragged tiles,
