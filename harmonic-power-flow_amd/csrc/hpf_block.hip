@@ -39,7 +39,7 @@ using namespace hpf;
 
 namespace {
 
-constexpr int FDESC = 40;   // ints per node record of the multi-wave factor kernel (Tree::d_fdesc)
+constexpr int FDESC = 48;   // ints per node record of the multi-wave factor kernel (Tree::d_fdesc)
 
 struct TreeDev {
     const int* parent;
@@ -57,6 +57,10 @@ struct TreeDev {
     const int* chain_ch;    // the dense bus below the chain
     const int* lzrec;       // lazy-leaf records of the parents (Tree::d_lzrec)
     const double* lzimg;    // and their per-model images (Tree::d_lzimg)
+    double* cF;             // compress steps: per-scenario slots (hpf_handle::d_F), A(v,c) blocks (d_H2), the pending children
+    double* cH2;
+    const int* comp_child;
+    int n_comp;
 };
 
 // validity of local index l = 2q+t of bus i as an unknown / equation (same rule for both, see hpf_assembly.hpp)
@@ -1017,6 +1021,7 @@ __global__ __launch_bounds__(256) void k_border_apply(int count, int r, int v0, 
 
 namespace hpf {
 
+static void tree_free_one_fwd(Tree& T);
 static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contract) {
     const int n = d->n;
     const int b = 2 * d->Hn;
@@ -1796,6 +1801,153 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
             ++n_sleaf;
         }
     }
+    // ---- compress steps on the Gauss-Jordan skeleton -------------------------------------------------------------
+    // Leaf-first elimination has as many dependent levels as the dense tree is high, and every level costs one workgroup life whatever
+    // its width.  Parallel tree contraction shortens the chain: a Gauss-Jordan bus v whose tallest dense child c is alone on v's
+    // critical path is eliminated BEFORE c, as soon as its other children are done.  Its elimination pushes onto both neighbours
+    // (parent p and c) and leaves the dense fill A'(p,c) = -A(p,v) D_v^-1 A(v,c), A'(c,p) = -A(c,v) D_v^-1 A(v,p): c then hangs under p
+    // with a dense coupling pair (one rank-b product pair on the matrix cores when it is eliminated).  One round: a pending child is
+    // not compressed itself (its pushes would be products of dense blocks).  Back sweep: x_p -> x_c -> x_v.
+    std::vector<int> comp_role(n, 0), comp_idx(n, -1), comp_child(n, -1);
+    T.n_comp = 0;
+    T.comp_v.clear();
+    T.comp_c.clear();
+    {
+        const char* cp_env = getenv("HPF_COMPRESS");
+        const bool compress_on = contract && d->coupled && BWc != 0 && BWc <= 100 && !(cp_env && atoi(cp_env) == 0) && T.n_dense > 2;
+        auto is_gj = [&](int k2) { return kept(k2) && cleaf_of[k2] < 0 && sl_off[k2] < 0; };
+        std::vector<int> cc(n, -1), isc(n, 0), keptl;
+        for (int i = 0; i < n; ++i)
+            if (kept(i)) keptl.push_back(i);
+        std::vector<int> gjb(n, 0);
+        for (int k2 : keptl) gjb[k2] = is_gj(k2) ? 1 : 0;
+        if (compress_on) {
+            // choice of the steps: bottom-up over the dense tree, up[k] = the level at which everything k's parent waits for on k's
+            // side is done -- k eliminated leaves first: max(children) + 1; k compressed with pending child c: the level of c, which
+            // waits for its own children and for k, while k only waits for its OTHER children -- take the smaller; top-down a pending
+            // child is forced to the leaf-first form (one round)
+            std::vector<int> byh(keptl), up(n, 0), nrm(n, 0), bestc(n, -1), forced(n, 0);
+            std::stable_sort(byh.begin(), byh.end(), [&](int a, int b2) { return height[a] < height[b2]; });
+            for (int k2 : byh) {
+                int m1 = -1, m2 = -1, a1 = -1;
+                for (int i = dchild_ptr[k2]; i < dchild_ptr[k2 + 1]; ++i) {
+                    const int u = up[dchild[i]];
+                    if (u > m1) {
+                        m2 = m1;
+                        m1 = u;
+                        a1 = dchild[i];
+                    } else if (u > m2) {
+                        m2 = u;
+                    }
+                }
+                nrm[k2] = std::max(gjb[k2], m1 + 1);
+                int best = nrm[k2], bc = -1;
+                if (gjb[k2] && pard[k2] >= 0 && gjb[pard[k2]])
+                    for (int i = dchild_ptr[k2]; i < dchild_ptr[k2 + 1]; ++i) {
+                        const int c1 = dchild[i];
+                        if (!gjb[c1]) continue;
+                        const int levk = std::max(1, (c1 == a1 ? m2 : m1) + 1), levc = std::max(nrm[c1], levk + 1);
+                        if (levc < best) {
+                            best = levc;
+                            bc = c1;
+                        }
+                    }
+                up[k2] = best;
+                bestc[k2] = bc;
+            }
+            for (auto it = byh.rbegin(); it != byh.rend(); ++it) {
+                const int v = *it;
+                if (forced[v] || bestc[v] < 0) continue;
+                cc[v] = bestc[v];
+                isc[bestc[v]] = 1;
+                forced[bestc[v]] = 1;
+            }
+        }
+        // elimination level of every dense bus under a compress set = longest path of the dependencies (fixpoint on a DAG):
+        // k waits for its dense children except its pending child; the pending child waits for v; p waits for v's pending child
+        const std::vector<int> pard0(pard);
+        auto levels = [&](const std::vector<int>& cset, std::vector<int>& lev) -> int {
+            lev.assign(n, 0);
+            int top = 0;
+            for (bool changed = true; changed;) {
+                changed = false;
+                for (int k2 : keptl) {
+                    int l = gjb[k2];                              // (level 0 stays the leaves' own: k_leaf_batch)
+                    for (int i = dchild_ptr[k2]; i < dchild_ptr[k2 + 1]; ++i) {
+                        const int ch = dchild[i];
+                        if (cset[k2] != ch) l = std::max(l, lev[ch] + 1);
+                        if (cset[ch] >= 0) l = std::max(l, lev[cset[ch]] + 1);
+                    }
+                    if (pard0[k2] >= 0 && cset[pard0[k2]] == k2) l = std::max(l, lev[pard0[k2]] + 1);
+                    if (l != lev[k2]) {
+                        lev[k2] = l;
+                        changed = true;
+                    }
+                    top = std::max(top, l);
+                }
+            }
+            return top;
+        };
+        std::vector<int> lev;
+        if (compress_on) {
+            int top = levels(cc, lev);
+            std::vector<int> cand;
+            for (int v : keptl)
+                if (cc[v] >= 0) cand.push_back(v);
+            std::stable_sort(cand.begin(), cand.end(), [&](int a, int b2) { return height[a] < height[b2]; });
+            for (int v : cand) {                                  // keep only the steps that shorten the chain
+                const int c1 = cc[v];
+                cc[v] = -1;
+                std::vector<int> l2;
+                if (levels(cc, l2) <= top) continue;
+                cc[v] = c1;
+            }
+            levels(cc, lev);
+            for (int v : keptl) {
+                if (cc[v] < 0) continue;
+                const int ci = T.n_comp++;
+                comp_role[v] = 1;
+                comp_role[cc[v]] = 2;
+                comp_idx[v] = comp_idx[cc[v]] = ci;
+                comp_child[v] = cc[v];
+                T.comp_v.push_back(v);
+                T.comp_c.push_back(cc[v]);
+            }
+        }
+        if (T.n_comp > 0) {
+            for (int i = 0; i < T.n_comp; ++i) pard[T.comp_c[i]] = pard0[T.comp_v[i]];
+            for (int k2 : keptl) height[k2] = lev[k2];
+            // back sweep: x_k needs x of its (new) dense parent; a compressed bus needs its pending child's as well, which comes later
+            for (int k2 : keptl) depth[k2] = 0;
+            for (bool changed = true; changed;) {
+                changed = false;
+                for (int k2 : keptl) {
+                    const int bd2 = comp_role[k2] == 1 ? comp_child[k2] : pard[k2];
+                    const int dd = bd2 < 0 ? 0 : depth[bd2] + 1;
+                    if (dd != depth[k2]) {
+                        depth[k2] = dd;
+                        changed = true;
+                    }
+                }
+            }
+            int mh = 0, md = 0;
+            for (int k2 : keptl) {
+                mh = std::max(mh, height[k2]);
+                md = std::max(md, depth[k2]);
+            }
+            T.n_levels = mh + 1;
+            T.n_depths = md + 1;
+            bucket(height, T.n_levels, T.lvl_ptr, T.lvl_nodes);
+            bucket(depth, T.n_depths, T.dep_ptr, T.dep_nodes);
+            std::fill(dchild_ptr.begin(), dchild_ptr.end(), 0);
+            for (int k2 : keptl)
+                if (pard[k2] >= 0) dchild_ptr[pard[k2] + 1]++;
+            for (int i = 0; i < n; ++i) dchild_ptr[i + 1] += dchild_ptr[i];
+            std::vector<int> pos(dchild_ptr.begin(), dchild_ptr.end() - 1);
+            for (int k2 : keptl)
+                if (pard[k2] >= 0) dchild[pos[pard[k2]]++] = k2;
+        }
+    }
     // per-parent lazy records and images; the parent's dense-child list keeps its non-lazy children first
     std::vector<int> lzrec, lz_idx(n, -1), n_lazy(n, 0), n_slz(n, 0);
     std::vector<double> lzimg;
@@ -1943,10 +2095,23 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
             r[35] = (int)(sl_base + sl_off[k]);
             r[39] = sb_ord[k] >= 0 ? sb_ord[k] : 0;                // its image in Tree::d_sbimg (k_sleaf_batch)
         }
+        for (int i = 40; i < FDESC; ++i) r[i] = 0;
+        if (comp_role[k]) {                                        // compress step: role, slot, (v:) pending child c, entries (v,c), (c,v), c behind a chain
+            r[40] = comp_role[k];
+            r[41] = comp_idx[k];
+            if (comp_role[k] == 1) {
+                const int cb = comp_child[k];
+                r[42] = cb;
+                r[43] = e_dn[cb];
+                r[44] = e_up[cb];
+                r[45] = pass[T.parent[cb]] ? 1 : 0;
+            }
+        }
         const int kb = T.dep_nodes[pos];
         bdesc[(size_t)pos * 4 + 0] = kb;
         bdesc[(size_t)pos * 4 + 1] = pard[kb];
         bdesc[(size_t)pos * 4 + 2] = cleaf_of[kb] + 1;
+        bdesc[(size_t)pos * 4 + 3] = comp_role[kb] ? ((comp_role[kb] << 28) | comp_idx[kb]) : 0;
     }
     {
         int nc = 0, nb = 0, nn = 0;
@@ -2026,7 +2191,17 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
             T.bytes_gj += by;
         }
     }
-    T.flops_per_solve = T.flops_factor + 2.0 * bd * bd * n_dense_nonroot;
+    // compress steps: three more tile images out of v and into c (c's extra Schur complement, Gd, Hd), three more element-wise pushes,
+    // the dense push of c (two rank-b products), Hd once more and a dense matrix-vector product in the back sweep
+    if (T.n_comp > 0) {
+        const double nc2 = (double)T.n_comp;
+        T.flops_factor += nc2 * (3.0 * 8.0 * bd * bd + 4.0 * bd * bd * bd + bd * bd);
+        T.bytes_factor += nc2 * 6.0 * TB;
+        T.flops_gj += nc2 * (3.0 * 8.0 * bd * bd + 4.0 * bd * bd * bd + bd * bd);
+        T.bytes_gj += nc2 * 6.0 * TB;
+        T.bytes_back += nc2 * (TB + 8.0 * bd + 32.0 * d->Hn);
+    }
+    T.flops_per_solve = T.flops_factor + 2.0 * bd * bd * (n_dense_nonroot + T.n_comp);
     if (getenv("HPF_TREE_INFO")) {
         int sl_nl = 0, sl_lin = 0, sl_lvl[4] = {0, 0, 0, 0};
         for (int i = 1; i < n; ++i)
@@ -2040,6 +2215,19 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
     if (getenv("HPF_TREE_INFO"))
         fprintf(stderr, "hpf tree (%s): %d buses, %d dense in %d levels, %d chains, %d constant-inverse leaves, %d lazy under %d parents\n",
                 contract ? "contracted" : "plain", n, T.n_dense, T.n_levels, T.n_chains, T.n_cleaf, T.n_lazy_leaves, T.n_lazy_parents);
+    if (const char* dump_path = getenv("HPF_TREE_DUMP")) {     // host-side plan of the dense tree (tools/tree_plan.py): one line per dense bus
+        if (FILE* fp = fopen(dump_path, contract ? "w" : "a")) {
+            fprintf(fp, "# %s tree: k pard height depth kind(0 gauss-jordan, 1 constant-inverse leaf, 2 bordered) vector_only hbm_children via_chain compress_role\n",
+                    contract ? "contracted" : "plain");
+            for (int pos = 0; pos < T.n_dense; ++pos) {
+                const int k = T.lvl_nodes[pos];
+                const int kind = cleaf_of[k] >= 0 ? 1 : ((sl_off[k] >= 0 && lz_idx[k] >= 0) ? 2 : 0);
+                fprintf(fp, "%d %d %d %d %d %d %d %d %d\n", k, pard[k], height[k], depth[k], kind, is_lazy[k],
+                        dchild_ptr[k + 1] - dchild_ptr[k] - n_lazy[k] - n_slz[k], (k > 0 && pass[T.parent[k]]) ? 1 : 0, comp_role[k]);
+            }
+            fclose(fp);
+        }
+    }
     int r;
     if ((r = upload(h, &T.d_parent, T.parent))) return r;
     if ((r = upload(h, &T.d_lvl_nodes, T.lvl_nodes))) return r;
@@ -2084,6 +2272,7 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
         if ((r = upload(h, &T.d_bleaf, bleaf))) return r;
     }
     if ((r = upload(h, &T.d_dchild, dchild))) return r;
+    if ((r = upload(h, &T.d_comp_child, T.comp_c))) return r;
     if ((r = upload(h, &T.d_chain_ptr, T.chain_ptr))) return r;
     if ((r = upload(h, &T.d_chain_nodes, T.chain_nodes))) return r;
     if ((r = upload(h, &T.d_chain_ch, T.chain_ch))) return r;
@@ -2105,6 +2294,16 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
     return HPF_OK;
 }
 
+// host-only: runs the tree planning of a radial model and writes the HPF_TREE_DUMP file; the uploads fail without a device, which is fine
+int tree_plan_dump(const hpf_desc* d) {
+    hpf_handle tmp;
+    tmp.n = d->n; tmp.m = d->m; tmp.c = d->c; tmp.Hn = d->Hn; tmp.nnz = d->nnz; tmp.coupled = d->coupled;
+    Tree T;
+    const int r = tree_build_into(&tmp, d, T, true);
+    tree_free_one_fwd(T);
+    return r;
+}
+
 int tree_build(hpf_handle* h, const hpf_desc* d) {
     int r = tree_build_into(h, d, h->tree, false);
     if (r) return r;
@@ -2116,11 +2315,14 @@ int tree_build(hpf_handle* h, const hpf_desc* d) {
 // the tree the Newton step of the current mode runs on
 Tree& active_tree(hpf_handle* h) { return (h->has_ctree && h->gj_mode == 1) ? h->ctree : h->tree; }
 
+static void tree_free_one(Tree& T);
+static void tree_free_one_fwd(Tree& T) { tree_free_one(T); }
 static void tree_free_one(Tree& T) {
     void* ptrs[] = {T.d_parent, T.d_lvl_nodes, T.d_dep_nodes, T.d_child_ptr, T.d_child, T.d_e_up, T.d_e_dn,
                     T.d_child_mid, T.d_lin, T.d_lin_ptr, T.d_lin_post, T.d_all_ptr, T.d_all_post, T.d_fdesc, T.d_child3,
                     T.d_bdesc, T.d_dchild, T.d_chain_ptr, T.d_chain_nodes, T.d_chain_ch, T.d_Minv, T.d_lrec, T.d_crec, T.d_cnode, T.d_arec,
-                    T.d_lzrec, T.d_lzimg, T.d_lbimg, T.d_bleaf, T.d_bsleaf, T.d_sbimg, T.d_lbrec, T.d_lbptr, T.d_lb2rec, T.d_lb2x, T.d_lb2ptr, T.d_lb2cptr, T.d_lb2clist};
+                    T.d_lzrec, T.d_lzimg, T.d_lbimg, T.d_bleaf, T.d_bsleaf, T.d_sbimg, T.d_lbrec, T.d_lbptr, T.d_lb2rec, T.d_lb2x, T.d_lb2ptr, T.d_lb2cptr, T.d_lb2clist,
+                    T.d_comp_child};
     for (void* p : ptrs)
         if (p) hipFree(p);
 }
@@ -2152,7 +2354,10 @@ int tree_alloc_scenarios(hpf_handle* h) {
                           (e = hipMalloc((void**)&h->d_lfK, sizeof(double) * S * n * 12)) != hipSuccess ||
                           (e = hipMalloc((void**)&h->d_lfS, sizeof(double) * S * n * (size_t)h->Hn * 4)) != hipSuccess)) ||
         ((h->debug_ablate & 16) && (e = hipMalloc((void**)&h->d_dbg, sizeof(long long) * S * n * 8)) != hipSuccess) ||
-        (bw && (e = hipMalloc((void**)&h->d_C, sizeof(double) * S * n * (size_t)(((bw + 16) / 16) * ((bw + 16) / 16) * 256))) != hipSuccess)) {
+        (bw && (e = hipMalloc((void**)&h->d_C, sizeof(double) * S * n * (size_t)(((bw + 16) / 16) * ((bw + 16) / 16) * 256))) != hipSuccess) ||
+        (h->has_ctree && h->ctree.n_comp > 0 &&
+         ((e = hipMalloc((void**)&h->d_F, sizeof(double) * S * (size_t)h->ctree.n_comp * 3 * ct)) != hipSuccess ||
+          (e = hipMalloc((void**)&h->d_H2, sizeof(double) * S * (size_t)h->ctree.n_comp * (size_t)h->Hn * 4)) != hipSuccess))) {
         h->last_detail = (int)e;
         return e == hipErrorOutOfMemory ? HPF_E_NOMEM : HPF_E_HIP;
     }
@@ -2207,7 +2412,8 @@ int tree_fund_step(hpf_handle* h, bool only_active) {
 int tree_newton_step(hpf_handle* h, bool only_active) {
     Tree& T = active_tree(h);
     const int* active = only_active ? h->d_active : nullptr;
-    const TreeDev td{T.d_parent, T.d_child_ptr, T.d_child, T.d_e_up, T.d_e_dn, T.d_child_mid, T.d_lin_ptr, T.d_lin_post, T.d_child3, T.d_dchild, T.d_chain_ptr, T.d_chain_nodes, T.d_chain_ch, T.d_lzrec, T.d_lzimg};
+    const TreeDev td{T.d_parent, T.d_child_ptr, T.d_child, T.d_e_up, T.d_e_dn, T.d_child_mid, T.d_lin_ptr, T.d_lin_post, T.d_child3, T.d_dchild, T.d_chain_ptr, T.d_chain_nodes, T.d_chain_ch, T.d_lzrec, T.d_lzimg,
+                     h->d_F, h->d_H2, T.d_comp_child, T.n_comp};
     const int b = 2 * h->Hn;
     const int R = (b + 15) / 16;
     const int BW = wave_block_size(b);

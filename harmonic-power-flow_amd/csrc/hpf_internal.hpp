@@ -112,6 +112,12 @@ struct Tree {
     double* d_lbimg = nullptr;        // [leaf slot][LeafBatchImg::SZ]: the leaf images in MFMA A-operand layout (16 scenarios per workgroup)
     int* d_lzrec = nullptr;           // [n_lazy_parents][8]: image offset (doubles), L, leaf ids[4] (-1: none), 0, 0
     double* d_lzimg = nullptr;        // per parent: sum of constant parts (tile layout) | A operands [pair][tr][64] | row factors [pair][tc][2][64]
+    // compress steps on the Gauss-Jordan skeleton (contracted tree, HPF_COMPRESS != 0): bus v = comp_v[i] is eliminated BEFORE its
+    // pending child c = comp_c[i] (its tallest dense child, alone on v's critical path); c then hangs under v's parent p with a dense
+    // coupling pair, the elimination levels / back-sweep depths are the longest paths of the new dependencies
+    int n_comp = 0;
+    std::vector<int> comp_v, comp_c;
+    int* d_comp_child = nullptr;      // [n_comp] c of compress step i (k_back_q: x_v needs x_c)
     double flops_per_solve = 0.0;     // factor sweep + back sweep
     double flops_factor = 0.0;        // factor sweep only (k_tree_factor, all levels)
     double bytes_back = 0.0;          // algorithmic HBM bytes of the dense back sweep, one scenario and step
@@ -196,6 +202,8 @@ struct hpf_handle {
     double* d_lfS = nullptr;          // [S][n][Hn][4] constant-inverse leaves: S_q^-1 (polar <- rectangular), row-major
     double* d_chZ = nullptr;          // [S][n][Hn][4] D_k^-1 A'(k, ch) of the chain buses k (back substitution)
     double* d_linA = nullptr;         // [S][n][Hn][4] inverse 2x2 blocks of the all-linear-subtree buses
+    double* d_F = nullptr;            // [S][n_comp][3][tile image] compress steps: A(c,v) D_v^-1 A(v,c) | Gd = A'(p,c) (MFMA A-operand order) | Hd = A'(c,p)
+    double* d_H2 = nullptr;           // [S][n_comp][Hn][4] A(v,c) of the compressed buses (back sweep)
 
     hipStream_t own_stream = nullptr, stream = nullptr;
     // launch context: stream and scenario slice the launch helpers currently target (scenario groups run as independent
@@ -239,6 +247,7 @@ struct ScopedTimer {
 // block-tree solver (hpf_block.hip)
 int tree_find_ties(hpf_handle* h, const hpf_desc* d);    // spanning tree + loop-closing lines of the pattern (before any allocation)
 int tree_build(hpf_handle* h, const hpf_desc* d);
+int tree_plan_dump(const hpf_desc* d);                    // host-only planning run (HPF_TREE_DUMP), no device needed
 hpf::Tree& active_tree(hpf_handle* h);
 void tree_free(hpf_handle* h);
 int tree_alloc_scenarios(hpf_handle* h);

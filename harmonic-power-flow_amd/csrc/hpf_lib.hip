@@ -897,7 +897,7 @@ int nr_loop(hpf_handle* h, double thresh, int max_iter, int* n_iter, double* err
 void free_all(hpf_handle* h) {
     void* ptrs[] = {h->d_rowptr, h->d_col, h->d_diag, h->d_erow, h->d_dev, h->d_Y, h->d_YN, h->d_YNt, h->d_IN, h->d_P, h->d_Q,
                     h->d_Vm, h->d_Va, h->d_U, h->d_E, h->d_I0, h->d_f, h->d_errbits, h->d_err, h->d_niter, h->d_active,
-                    h->d_nactive, h->d_pivflag, h->d_mask, h->d_Vm0, h->d_Va0, h->d_Vmp, h->d_Vap, h->d_tstamp, h->d_hist, h->d_stats, h->d_J, h->d_ipiv, h->d_info, h->d_Z, h->d_w, h->d_x, h->d_linA, h->d_C, h->d_dbg, h->d_H, h->d_chG, h->d_chH, h->d_chD, h->d_chy, h->d_chZ, h->d_lfK, h->d_lfS, h->d_fb};
+                    h->d_nactive, h->d_pivflag, h->d_mask, h->d_Vm0, h->d_Va0, h->d_Vmp, h->d_Vap, h->d_tstamp, h->d_hist, h->d_stats, h->d_J, h->d_ipiv, h->d_info, h->d_Z, h->d_w, h->d_x, h->d_linA, h->d_C, h->d_dbg, h->d_H, h->d_chG, h->d_chH, h->d_chD, h->d_chy, h->d_chZ, h->d_lfK, h->d_lfS, h->d_fb, h->d_F, h->d_H2};
     for (void* p : ptrs)
         if (p) hipFree(p);
     tree_free(h);
@@ -1428,7 +1428,19 @@ int hpf_tree_census(const hpf_handle* h, int* counts, int n_counts) {
     if (h->solver != HPF_SOLVER_BLOCK_TREE) return HPF_E_STATE;
     const Tree& T = active_tree(const_cast<hpf_handle*>(h));
     const int fused = (h->fuse_levels && h->gj_mode == 1 && 2 * h->Hn <= 52) ? 1 : 0;
-    for (int i = 0; i < n_counts; ++i) counts[i] = i < 8 ? T.census[i] : (i == 8 ? h->n_ties : (i == 9 ? fused : 0));
+    for (int i = 0; i < n_counts; ++i) counts[i] = i < 8 ? T.census[i] : (i == 8 ? h->n_ties : (i == 9 ? fused : (i == 10 ? T.n_comp : 0)));
+    return HPF_OK;
+}
+
+int hpf_tree_plan(const hpf_desc* d, const char* path) {
+    if (!d || !path || d->n < 1 || !d->rowptr || !d->col || !d->Yval || !d->dev_of_bus) return HPF_E_ARG;
+    if (d->nnz != d->n + 2 * (d->n - 1)) return HPF_E_TOPOLOGY;           // radial models only
+    setenv("HPF_TREE_DUMP", path, 1);
+    tree_plan_dump(d);                                                      // (its uploads fail without a device: ignored)
+    unsetenv("HPF_TREE_DUMP");
+    FILE* fp = fopen(path, "r");
+    if (!fp) return HPF_E_ARG;
+    fclose(fp);
     return HPF_OK;
 }
 

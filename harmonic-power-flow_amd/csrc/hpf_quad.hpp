@@ -157,6 +157,9 @@ struct FqLds {
     double* gl;                     // [NT * 32]
     double* hl;                     // [NT * 32]
     double* slb;                    // [2 * B * 10 + 204]  super-leaf constants (B <= 52)
+    double* gl2;                    // [NT * 32]   compress step: A(c, k) and A(k, c) of the pending child c (B <= 52: inside slb -- a
+    double* hl2;                    // [NT * 32]   compressed bus is never a bordered one)
+    double* pbuf;                   // [min(B, 64) * (B + 1)]  dense push of a bus with a dense coupling block: the whole buffer, reused
     __device__ __forceinline__ static FqLds carve(double* smem_) {
         FqLds L;
         L.ynl = reinterpret_cast<cplx*>(smem_);                  // (first: 16-byte aligned)
@@ -169,6 +172,9 @@ struct FqLds {
         L.gl = L.dgb + RP * 3 + NT * RP * 3 + 2 * NT * 64 + 64;
         L.hl = L.gl + NT * 32;
         L.slb = L.hl + NT * 32;
+        L.gl2 = B <= 52 ? L.slb : L.slb + 2;
+        L.hl2 = L.gl2 + NT * 32;
+        L.pbuf = smem_;
         return L;
     }
 };
@@ -177,8 +183,11 @@ struct FqLds {
 template <int B>
 constexpr int factor_q_lds() {
     constexpr int NT = (B + 16) / 16, RP = 16 * NT > 64 ? 16 * NT : 64;
-    return (B / 2) * 8 + RP * 3 + NT * RP * 3 + 2 * NT * 64 + 32 + 32 + NT * 32 + NT * 32 + 2 * (B / 2) * (B / 2) + (B <= 52 ? 2 * B * 10 + 200 + 4 : 2);
+    return (B / 2) * 8 + RP * 3 + NT * RP * 3 + 2 * NT * 64 + 32 + 32 + NT * 32 + NT * 32 + 2 * (B / 2) * (B / 2) +
+           (B <= 52 ? 2 * B * 10 + 200 + 4 : 2 + 2 * NT * 32);
 }
+static_assert(factor_q_lds<52>() >= 52 * 53 && factor_q_lds<28>() >= 28 * 29 && factor_q_lds<12>() >= 12 * 13 && factor_q_lds<100>() >= 64 * 101,
+              "dense-push buffer of a compress step fits the factor body's LDS");
 
 template <int B, bool LEAF>
 __device__ __forceinline__ void factor_q_body(
@@ -217,6 +226,17 @@ __device__ __forceinline__ void factor_q_body(
     const bool slback = SPECIAL && !LEAF && (nd3.z & 8) != 0;  // ... whose back sweep rebuilds D^-1 t from T^-1 (k_sleaf_back_batch): no inverse goes to HBM
     const bool lazy = SPECIAL && !LEAF && cleafv < 0;   // this bus has lazy leaves below it
     const bool cleafr = cleaf || sleaf;      // roles of a constant-part bus: S^-1 staged, network diagonal lives in the images
+    // compress steps on the Gauss-Jordan skeleton (tree_build_into, "compress"): role 1 = this bus v is eliminated BEFORE its pending
+    // child c (four pushes: onto the parent p, onto c, and the two dense fill blocks between p and c); role 2 = this bus is such a
+    // child: one more Schur complement (from v), and its coupling with its new parent p is the dense pair (Gd, Hd) left by v
+    int4 cpA = {0, 0, 0, 0}, cpB = {0, 0, 0, 0};
+    if (!LEAF) {
+        cpA = nd[10];
+        cpB = nd[11];
+    }
+    const int crole = LEAF ? 0 : cpA.x;
+    const bool cmp_v = crole == 1, cmp_c = crole == 2;
+    const int cmp_ci = cpA.y;
     // lazy-leaf record (Tree::d_lzrec, 8 ints: image offset, L, leaf ids[4])
     int4 lzA = {0, 0, -1, -1}, lzB = {-1, -1, 0, 0}, lzC = {-1, -1, 0, 0};
     if (lazy) {                               // (inline copy of the record: ints 28..39 of the node record, same scalar round trip)
@@ -307,7 +327,7 @@ __device__ __forceinline__ void factor_q_body(
         }
     }
     // wave 1: coupling blocks with the parent, G = A(parent, k) and H = A(k, parent), for the push (E) and the back sweep
-    if (par >= 0 && wv == (NT > 1 ? 1 : 0) && lane < NT * 8) {
+    if (par >= 0 && !cmp_c && wv == (NT > 1 ? 1 : 0) && lane < NT * 8) {
         double g4[4] = {0.0, 0.0, 0.0, 0.0}, h4[4] = {0.0, 0.0, 0.0, 0.0};
         cplx lzu = {0.0, -1.0}, lze = {0.0, 1.0}, lzup = {0.0, -1.0}, lzep = {0.0, 1.0};
         if (lazy_leaf && lane == 0) {        // fundamental voltages of the leaf and of its dense parent (polar maps S_c, S_p at q = 0)
@@ -354,6 +374,41 @@ __device__ __forceinline__ void factor_q_body(
         }
         if (lane < Hn) {
             double* Hk = Hall + ((size_t)s * n + k) * Hn * 4 + lane * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Hk[e] = h4[e];
+        }
+    }
+    // compress step: G2 = A(c, k), H2 = A(k, c) of the pending child c (the line itself or what the contracted chain between the two
+    // left of it, exactly as the child's own role would form them); H2 is kept for the back sweep (x_k needs x_c as well)
+    if (cmp_v && wv == (NT > 2 ? 2 : 0) && lane < NT * 8) {
+        double g4[4] = {0.0, 0.0, 0.0, 0.0}, h4[4] = {0.0, 0.0, 0.0, 0.0};
+        const int cb = cpA.z;
+        if (lane < Hn) {
+            const int q = lane;
+            if (cpB.y) {                                     // chG[c] = A'(k, c), chH[c] = A'(c, k)
+                const double2* pg = reinterpret_cast<const double2*>(chG + (so + (size_t)cb * Hn + q) * 4);
+                const double2* ph = reinterpret_cast<const double2*>(chH + (so + (size_t)cb * Hn + q) * 4);
+                const double2 ga = pg[0], gb = pg[1], ha = ph[0], hb = ph[1];
+                h4[0] = ga.x; h4[1] = ga.y; h4[2] = gb.x; h4[3] = gb.y;
+                g4[0] = ha.x; g4[1] = ha.y; g4[2] = hb.x; g4[3] = hb.y;
+            } else {
+                const cplx ydn = M.Y[(size_t)cpA.w * Hn + q], yup = M.Y[(size_t)cpB.x * Hn + q];   // entries (k, c), (c, k)
+                const cplx uk = U[(size_t)k * Hn + q], ek = E[(size_t)k * Hn + q];
+                const cplx uc = U[(size_t)cb * Hn + q], ec = E[(size_t)cb * Hn + q];
+                __builtin_amdgcn_sched_barrier(0);
+                const Blk2 hh = (q == 0 && k < M.m) ? blk_power_off(ydn, uk, uc, ec) : blk_current(ydn, uc, ec);     // row k, col c
+                const Blk2 g = (q == 0 && cb < M.m) ? blk_power_off(yup, uc, uk, ek) : blk_current(yup, uk, ek);     // row c, col k
+                mask_block(n, c, q, cb, k, g, g4);
+                mask_block(n, c, q, k, cb, hh, h4);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            lds_.gl2[lane * 4 + e] = g4[e];
+            lds_.hl2[lane * 4 + e] = h4[e];
+        }
+        if (lane < Hn) {
+            double* Hk = T.cH2 + ((size_t)s * T.n_comp + cmp_ci) * Hn * 4 + lane * 4;
 #pragma unroll
             for (int e = 0; e < 4; ++e) Hk[e] = h4[e];
         }
@@ -944,6 +999,14 @@ __device__ __forceinline__ void factor_q_body(
             if (16 * (e >> 2) + 4 * (e & 3) < B) sumc[e] += tmp[e];
         __builtin_amdgcn_sched_barrier(0);
     }
+    if (cmp_c) {                                            // compress step: A(k, v) D_v^-1 A(v, k) and A(k, v) w_v from the bus v above
+        double tmp[NT * 4];
+        TileIO<B>::load(T.cF + ((size_t)s * T.n_comp + cmp_ci) * 3 * CT, wv, lg, jj, tmp);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < NT * 4; ++e)
+            if (16 * (e >> 2) + 4 * (e & 3) < B) sumc[e] += tmp[e];
+    }
 #pragma unroll
     for (int e = 0; e < NT * 4; ++e)
         if (16 * (e >> 2) + 4 * (e & 3) < B) ct[e >> 2][e & 3] -= sumc[e];
@@ -1041,33 +1104,39 @@ __device__ __forceinline__ void factor_q_body(
     HPF_STAMP(st5);
     // ---- E. push: Schur complement of this bus for its parent, C = G A^-1 H and G w in column B (schur_tiles on the own
     //      tile column; gl / hl were staged in A1) ---------------------------------------------------------------------------
-    if (par >= 0 && (!lazy_leaf || wv == tcB)) {            // (lazy leaf: only the right-hand-side column G w is needed)
+    // element-wise form of  sign * Gs A^-1 Hs  for harmonic-diagonal Gs, Hs (LDS, 2x2 per harmonic); column B: Gs w if rhs, else 0
+    auto schur_tiles = [&](const double* gsrc, const double* hsrc, const double sign, const bool rhs, double (&cv)[NT * 4]) {
         const int ti = lg & 1, tcn = jj & 1;
-        double ha = hl[p * 4 + 2 * tcn + tcn];              // H[tcn][tcn]
-        double hb = hl[p * 4 + 2 * (tcn ^ 1) + tcn];        // H[tcn^1][tcn]
+        double ha = hsrc[p * 4 + 2 * tcn + tcn];            // H[tcn][tcn]
+        double hb = hsrc[p * 4 + 2 * (tcn ^ 1) + tcn];      // H[tcn^1][tcn]
         if (col == B) {                                     // right-hand-side column: G w
-            ha = 1.0;
+            ha = rhs ? 1.0 : 0.0;
             hb = 0.0;
         }
         if (col > B) {
             ha = 0.0;
             hb = 0.0;
         }
-        double* Ck = Call + ((size_t)s * n + k) * CT;
-        double cv[NT * 4];
+        ha *= sign;
+        hb *= sign;
 #pragma unroll
         for (int tr = 0; tr < NT; ++tr)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int q = 8 * tr + 2 * reg + (lg >> 1);
-                const double ga = gl[q * 4 + 2 * ti + ti];          // G[ti][ti]
-                const double gb = gl[q * 4 + 2 * ti + (ti ^ 1)];    // G[ti][ti^1]
+                const double ga = gsrc[q * 4 + 2 * ti + ti];          // G[ti][ti]
+                const double gb = gsrc[q * 4 + 2 * ti + (ti ^ 1)];    // G[ti][ti^1]
                 const double own = ct[tr][reg];
                 const double rowp = xor16_f64(own);
                 const double colp = xor1_f64(own);
                 const double both = xor1_f64(rowp);
                 cv[tr * 4 + reg] = fma(gb, fma(both, hb, rowp * ha), ga * fma(colp, hb, own * ha));
             }
+    };
+    if (par >= 0 && !cmp_c && (!lazy_leaf || wv == tcB)) {            // (lazy leaf: only the right-hand-side column G w is needed)
+        double* Ck = Call + ((size_t)s * n + k) * CT;
+        double cv[NT * 4];
+        schur_tiles(gl, hl, 1.0, true, cv);
         if (!lazy_leaf) {
             TileIO<B>::store(Ck, wv, lg, jj, cv);
         } else if (col == B) {                                   // lazy leaf: only G w, by rows, at the head of the slot
@@ -1075,6 +1144,98 @@ __device__ __forceinline__ void factor_q_body(
             for (int e = 0; e < NT * 4; ++e)
                 if (16 * (e >> 2) + 4 * (e & 3) < B) Ck[16 * (e >> 2) + 4 * (e & 3) + lg] = cv[e];
         }
+    }
+    if (!LEAF && cmp_v) {
+        // compress step, the three more pushes of a bus eliminated before its pending child c:  A(c,k) A^-1 A(k,c) (+ A(c,k) w) for c's
+        // diagonal block and right-hand side, and the dense fill  Gd = -A(p,k) A^-1 A(k,c) = A'(p,c),  Hd = -A(c,k) A^-1 A(k,p) = A'(c,p)
+        // -- Gd in MFMA A-operand order [block step][row tile][lane] (c multiplies it from the left), Hd as a tile image.  One row
+        // group at a time (partner values formed once, three results, stored at once: nothing is held across row groups).
+        double* Fk = T.cF + ((size_t)s * T.n_comp + cmp_ci) * 3 * CT;
+        const int ti = lg & 1, tcn = jj & 1;
+        const bool mcol = col < B;
+        const double ha = mcol ? hl[p * 4 + 2 * tcn + tcn] : 0.0, hb = mcol ? hl[p * 4 + 2 * (tcn ^ 1) + tcn] : 0.0;
+        double ha2 = mcol ? lds_.hl2[p * 4 + 2 * tcn + tcn] : 0.0, hb2 = mcol ? lds_.hl2[p * 4 + 2 * (tcn ^ 1) + tcn] : 0.0;
+        if (col == B) ha2 = 1.0;                            // right-hand-side column of c's Schur complement: A(c,k) w
+        const bool st_ok = TileIO<B>::ok(wv, jj);
+        double* Ga = Fk + CT + ((size_t)(col >> 2) * NT) * 64 + (col & 3) * 16 + lg;
+#pragma unroll
+        for (int e = 0; e < TileIO<B>::NE; ++e) {
+            const int tr = e >> 2, reg = e & 3;
+            const int q = 8 * tr + 2 * reg + (lg >> 1);
+            const double ga = gl[q * 4 + 2 * ti + ti], gb = gl[q * 4 + 2 * ti + (ti ^ 1)];
+            const double ga2 = lds_.gl2[q * 4 + 2 * ti + ti], gb2 = lds_.gl2[q * 4 + 2 * ti + (ti ^ 1)];
+            const double own = ct[tr][reg];
+            const double rowp = xor16_f64(own);
+            const double colp = xor1_f64(own);
+            const double both = xor1_f64(rowp);
+            const double uh = fma(colp, hb, own * ha), vh = fma(both, hb, rowp * ha);          // (A^-1 H)[own row | partner row]
+            const double uh2 = fma(colp, hb2, own * ha2), vh2 = fma(both, hb2, rowp * ha2);    // (A^-1 H2)
+            const double fcc = fma(gb2, vh2, ga2 * uh2);
+            const double hd = -fma(gb2, vh, ga2 * uh);
+            const double gd = -fma(gb, vh2, ga * uh2);
+            if (st_ok) {
+                const size_t o = TileIO<B>::off(tr, reg, wv, lg, jj);
+                Fk[o] = fcc;
+                Fk[2 * CT + o] = hd;
+            }
+            if (mcol) Ga[tr * 64 + 4 * reg] = gd;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (mcol) {                                          // (rows B.. of the A operands: zero)
+#pragma unroll
+            for (int e = TileIO<B>::NE; e < NT * 4; ++e) Ga[(e >> 2) * 64 + 4 * (e & 3)] = 0.0;
+        }
+    }
+    if (!LEAF && cmp_c && par >= 0) {
+        // dense push of a bus whose coupling with its parent is the dense pair (Gd, Hd):  C = Gd A^-1 Hd,  column B = Gd w.
+        //   P = Gd [A^-1 | w]:  the own tile column of A^-1 is the B operand as it stands (row group 4 st of the accumulators), the A
+        //   operands come from v's image;  C = P Hd:  P goes through LDS (A operand: rows of P), Hd's tile image is the B operand.
+        const double* Fk = T.cF + ((size_t)s * T.n_comp + cmp_ci) * 3 * CT;
+        const double* Ga = Fk + CT + lane;
+        d4_t pt[NT];
+#pragma unroll
+        for (int tr = 0; tr < NT; ++tr) pt[tr] = d4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int st = 0; st < B / 4; ++st) {
+            double aop[NT];
+#pragma unroll
+            for (int tr = 0; tr < NT; ++tr) aop[tr] = Ga[((size_t)st * NT + tr) * 64];
+#pragma unroll
+            for (int tr = 0; tr < NT; ++tr) pt[tr] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[tr], ct[st >> 2][st & 3], pt[tr], 0, 0, 0);
+        }
+        double hd[NT * 4];
+        TileIO<B>::load(Fk + 2 * CT, wv, lg, jj, hd);
+        if (col >= B) {
+#pragma unroll
+            for (int e = 0; e < NT * 4; ++e) hd[e] = 0.0;
+        }
+        constexpr int PS = B + 1;                            // row stride of P in LDS
+        constexpr int TRP = NT < 4 ? NT : 4;                 // row tiles of P per pass (B = 100: two passes)
+        double* const pl = lds_.pbuf;
+        double cv[NT * 4];
+#pragma unroll
+        for (int tr0 = 0; tr0 < NT; tr0 += TRP) {
+            __syncthreads();                                 // (the Gauss-Jordan panels / the previous pass are done with)
+#pragma unroll
+            for (int tr = tr0; tr < tr0 + TRP && tr < NT; ++tr)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+                    if (16 * tr + 4 * reg < B && col < B) pl[(16 * (tr - tr0) + 4 * reg + lg) * PS + col] = pt[tr][reg];
+            __syncthreads();
+#pragma unroll
+            for (int tr = tr0; tr < tr0 + TRP && tr < NT; ++tr) {
+                d4_t acc = {0.0, 0.0, 0.0, 0.0};
+                const int prow = 16 * (tr - tr0) + jj;
+#pragma unroll
+                for (int st = 0; st < B / 4; ++st) {
+                    const double a = (16 * tr + jj < B) ? pl[prow * PS + 4 * st + lg] : 0.0;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, hd[st], acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) cv[tr * 4 + reg] = col == B ? pt[tr][reg] : acc[reg];
+            }
+        }
+        TileIO<B>::store(Call + ((size_t)s * n + k) * CT, wv, lg, jj, cv);
     }
     if (tstamp) {
         __syncthreads();
@@ -1111,11 +1272,17 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 52 ? 2 : (B > 28 ? (LEAF
     double* __restrict__ lfK, double* __restrict__ lfS, long long* __restrict__ dbg, int ablate, int s0,
     int* __restrict__ pivflag, double piv_limit, unsigned long long* __restrict__ tstamp) {
     constexpr int NT = (B + 16) / 16, RP = 16 * NT > 64 ? 16 * NT : 64;
-    __shared__ cplx ynl[(B / 2) * (B / 2)];
-    __shared__ double tab[(B / 2) * 8], dgb[RP * 3], cc[NT][RP * 3], panel[2][NT * 64], wl[2][16], pv[2][16], gl[NT * 32], hl[NT * 32];
-    __shared__ double slb[B <= 52 ? 2 * B * 10 + 200 + 4 : 1];
     FqLds<B> lds;
-    lds.ynl = ynl; lds.tab = tab; lds.dgb = dgb; lds.cc = cc; lds.panel = panel; lds.wl = wl; lds.pv = pv; lds.gl = gl; lds.hl = hl; lds.slb = slb;
+    if constexpr (LEAF) {                    // (the arrays a leaf-only launch never touches cost nothing as separate objects)
+        __shared__ cplx ynl[(B / 2) * (B / 2)];
+        __shared__ double tab[(B / 2) * 8], dgb[RP * 3], cc[NT][RP * 3], panel[2][NT * 64], wl[2][16], pv[2][16], gl[NT * 32], hl[NT * 32];
+        __shared__ double slb[B <= 52 ? 2 * B * 10 + 200 + 4 : 1];
+        lds.ynl = ynl; lds.tab = tab; lds.dgb = dgb; lds.cc = cc; lds.panel = panel; lds.wl = wl; lds.pv = pv; lds.gl = gl; lds.hl = hl; lds.slb = slb;
+        lds.gl2 = lds.hl2 = lds.pbuf = nullptr;
+    } else {
+        __shared__ __attribute__((aligned(16))) double smem[factor_q_lds<B>()];
+        lds = FqLds<B>::carve(smem);
+    }
     factor_q_body<B, LEAF>(lds, blockIdx.x, blockIdx.y, M, T, nodes, b, N, Nc, active, Uall, Eall, fall, Zall, wall, linAall, Call, Hall, I0all, chG,
                            chH, chD, chy, Minv, lfK, lfS, dbg, ablate, s0, pivflag, piv_limit, tstamp);
 }
@@ -1135,6 +1302,9 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16)) void k_back_q(
     if (s < 0) return;
     const int4 kp = reinterpret_cast<const int4*>(nodes)[blockIdx.x];          // Tree::d_bdesc: (bus, parent, leaf slot + 1, 0)
     const int k = kp.x, par = kp.y, cleaf = kp.z;
+    // compress steps (tree_build_into): role 1 = bus eliminated before its pending child c: x_k = w_k - D_k^-1 (A(k,p) x_p + A(k,c) x_c), it
+    // comes AFTER c; role 2 = such a child: its coupling block with the parent p is the dense Hd = A'(k,p) the compress step left
+    const int crole = kp.w >> 28, cinfo = kp.w & 0x0fffffff;
     const int tid = threadIdx.x, lane = tid & 63, lg = lane >> 4, jj = lane & 15;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = M.n, c = M.c, Hn = M.Hn;
@@ -1153,10 +1323,35 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16)) void k_back_q(
         }
         const int col = 16 * wv + jj, p = col >> 1, t1 = col & 1;
         double tv = 0.0;
-        if (col < b) {
+        if (crole == 2) {                                         // t = Hd x_p: a dense product, row sums like the inverse's below
+            double hr[NT * 4];
+            TileIO<B>::load(T.cF + (((size_t)s * T.n_comp + cinfo) * 3 + 2) * CT, wv, lg, jj, hr);
+            const double xpc = col < b ? xs[(size_t)par * B + col] : 0.0;
+#pragma unroll
+            for (int e = 0; e < NT * 4; ++e)
+                if (16 * (e >> 2) + 4 * (e & 3) < B) {
+                    const double r = row_sum16(hr[e] * xpc);
+                    if (jj == 0) part[wv][16 * (e >> 2) + lg + 4 * (e & 3)] = r;
+                }
+            __syncthreads();
+            if (tid < B) {
+                double acc = part[0][tid];
+#pragma unroll
+                for (int w2 = 1; w2 < NT; ++w2) acc += part[w2][tid];
+                zl[tid] = acc;
+            }
+            __syncthreads();
+            tv = col < b ? zl[col] : 0.0;
+            __syncthreads();                                      // (part / zl are reused below)
+        } else if (col < b) {
             const double* hk = Hall + ((size_t)s * n + k) * Hn * 4 + p * 4 + t1 * 2;
             const double* xp = xs + (size_t)par * B;
             tv = fma(hk[1], xp[2 * p + 1], hk[0] * xp[2 * p]);
+            if (crole == 1) {
+                const double* h2 = T.cH2 + ((size_t)s * T.n_comp + cinfo) * Hn * 4 + p * 4 + t1 * 2;
+                const double* xc = xs + (size_t)T.comp_child[cinfo] * B;
+                tv += fma(h2[1], xc[2 * p + 1], h2[0] * xc[2 * p]);
+            }
         }
         if (cleaf && tid < 2) zl[tid] = tv;                        // t[0], t[1]
         const double tvs = (cleaf && col < 2) ? 0.0 : tv;          // leaf image: columns 0, 1 hold the border, not the inverse

@@ -179,7 +179,8 @@ int  hpf_debug_stamps(hpf_handle* h, long long* out, int count);
  * Gauss-Jordan path, HPF_FUSELEVEL=0 launches the scenario-batched
  * and the per-scenario workgroups of an elimination level separately (k_leaf_batch / k_sleaf_batch + k_factor_q instead of k_level),
  * HPF_LINBUNDLE=0 / HPF_LINTREE=0 run the 2x2 algebra of the linear subtrees height by height in one launch / in one launch per
- * height, HPF_CHAINBUNDLE=0 gives the contracted chains their own launches, HPF_TREE_INFO=1 prints the tree statistics to stderr,
+ * height, HPF_CHAINBUNDLE=0 gives the contracted chains their own launches, HPF_COMPRESS=0 eliminates the Gauss-Jordan buses strictly
+ * leaves first (no compress steps: one elimination level per unit of tree height), HPF_TREE_INFO=1 prints the tree statistics to stderr,
  * HPF_GROUPS=n presets "scenario_groups".  Every switch selects a path with the same Newton steps (tests/test_gpu_robustness.py). */
 int  hpf_set_option(hpf_handle* h, const char* name, int value);
 
@@ -223,9 +224,14 @@ int  hpf_kernel_model(const hpf_handle* h, int which, double* bytes, double* flo
  * block (the rest lives in the 2x2 algebra of the linear subtrees / contracted chains), Gauss-Jordan buses (k_factor_q<B,false>),
  * constant-inverse leaves, of which lazy (vector-only, k_leaf_batch), bordered buses (super-leaves, m x m core), of which nested
  * (bordered children below them), elimination levels, back-sweep depths, tie lines of a meshed network, [9] 1 if every elimination
- * level is ONE launch (k_level: scenario-batched and per-scenario workgroups in one grid; timing class 5 then covers it).
+ * level is ONE launch (k_level: scenario-batched and per-scenario workgroups in one grid; timing class 5 then covers it),
+ * [10] compress steps (Gauss-Jordan buses eliminated before their tallest dense child: levels counts the shortened chain).
  * HPF_E_STATE for DENSE. */
 int  hpf_tree_census(const hpf_handle* h, int* counts, int n_counts);
+/* Host-only planning run of the BLOCK_TREE elimination tree of a radial model (no device, no handle): builds the contracted tree
+ * exactly as hpf_create would and writes one line per dense bus (bus, dense parent, elimination level, back-sweep depth, kind, ...)
+ * to `path` (the file env HPF_TREE_DUMP would name; tools/tree_plan.py reads it).  Returns HPF_OK when the plan was written. */
+int  hpf_tree_plan(const hpf_desc* d, const char* path);
 
 #ifdef __cplusplus
 }

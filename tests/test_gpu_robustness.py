@@ -63,6 +63,25 @@ def _solve(hp, st, buses, Y, NE, solver="block_tree", S=1, options=(), seed_stat
     return dict(it=it, err=err, Vm=Vm, Va=Va, seed=seed, stats=st_, hist=hist, census=census)
 
 
+def _first_step(hp, st, buses, Y, NE, S):
+    """state after ONE Newton iteration from the fundamental power-flow seed (block-tree path)"""
+    from harmonic_power_flow_amd import api, synth
+    n = len(buses)
+    dm = api._device_model(buses, Y, NE, True, st.HARMONICS, solver="block_tree", max_scenarios=S)
+    try:
+        P0, Q0 = buses["P"].to_numpy(float), buses["Q"].to_numpy(float)
+        scale = np.stack([np.ones(n)] + [synth.scenario_scale(n, s) for s in range(1, S)])
+        dm.set_loads(P0 * scale, Q0 * scale)
+        dm.set_state(None, None, n_scen=S)
+        dm.fund_pf(1e-6, 30)
+        dm.mismatch(want_f=False)
+        dm.iterate(1)
+        dm.sync()
+        return dm.get_state()
+    finally:
+        dm.close()
+
+
 def test_static_pivot_monitor_and_repeat_with_partial_pivoting(tmp_path):
     """With the growth limit at 10^0 every pivot block counts as weak: every scenario is flagged (flags bit 3) and repeated with
     partial pivoting (bit 4) inside hpf_solve; the result must be bit-identical to an explicit block_pivoting = 1 solve.  With
@@ -150,7 +169,8 @@ def test_per_iteration_state_dump_follows_the_reference_trajectory(name, solver,
 
 @pytest.mark.parametrize("env", [{"HPF_LAZY": "0"}, {"HPF_LAZY": "1"}, {"HPF_SLEAF": "0"}, {"HPF_SLEAF": "1"},
                                  {"HPF_SLLAZY": "0"}, {"HPF_SLBACK": "0"}, {"HPF_LEAFBATCH": "0"}, {"HPF_GROUPS": "2"},
-                                 {"HPF_SLNEST": "0"}, {"HPF_LINTREE": "0"}, {"HPF_FUSELEVEL": "0"}, {"HPF_LINBUNDLE": "0"}, {"HPF_CHAINBUNDLE": "0"}])
+                                 {"HPF_SLNEST": "0"}, {"HPF_LINTREE": "0"}, {"HPF_FUSELEVEL": "0"}, {"HPF_LINBUNDLE": "0"}, {"HPF_CHAINBUNDLE": "0"},
+                                 {"HPF_COMPRESS": "0"}])
 def test_tree_build_variants_take_the_same_newton_steps(env, tmp_path, monkeypatch):
     """Every diagnostic switch of hpf_create (hpf.h) selects a more general path for some class of buses (no lazy leaves, no
     super-leaves, super-leaves that push their Schur complement / store their inverse, leaves one workgroup per scenario): the
@@ -191,6 +211,33 @@ def test_nested_bordered_buses_match_the_gauss_jordan_path(n, hmax, tmp_path, mo
     assert (nest["err"] <= 1e-4).all() and (flat["err"] <= 1e-4).all()
     Un, Uf = nest["Vm"] * np.exp(1j * nest["Va"]), flat["Vm"] * np.exp(1j * flat["Va"])
     assert np.abs(Un - Uf).max() < TOL_V
+
+
+@pytest.mark.parametrize("n,hmax", [(1000, 51), (600, 11), (400, 27)])
+def test_compress_steps_shorten_the_level_chain_and_keep_the_newton_step(n, hmax, tmp_path, monkeypatch):
+    """Compress steps: Gauss-Jordan buses of the skeleton are eliminated BEFORE their tallest dense child (four pushes,
+    dense fill blocks, a dense push and a dense back-substitution term for that child).  Fewer elimination levels than the strictly
+    leaf-first order (HPF_COMPRESS=0), the same Newton step at rounding level, the same fixed point."""
+    hp = _hp()
+    st, buses, Y, NE, _ = _feeder(hp, n, hmax, tmp_path, seed=0)
+    S = 5
+    comp = _solve(hp, st, buses, Y, NE, S=S, polish=1)
+    one_c = _first_step(hp, st, buses, Y, NE, S)
+    monkeypatch.setenv("HPF_COMPRESS", "0")
+    flat = _solve(hp, st, buses, Y, NE, S=S, polish=1)
+    one_f = _first_step(hp, st, buses, Y, NE, S)
+    print("\nn=%d hmax=%d: compress %s\n               leaf-first %s" % (n, hmax, comp["census"], flat["census"]))
+    assert flat["census"]["compress_steps"] == 0
+    assert comp["census"]["compress_steps"] > 0
+    assert comp["census"]["levels"] < flat["census"]["levels"]
+    assert comp["census"]["gauss_jordan"] == flat["census"]["gauss_jordan"]
+    d1 = np.abs(one_c[0] - one_f[0]).max(), np.abs(one_c[1] - one_f[1]).max()
+    print("first Newton step: max|dVm| %.2e  max|dVa| %.2e" % d1)
+    assert d1[0] < 1e-9 and d1[1] < 1e-8                      # (the first steps of these feeders are tens of radians long)
+    assert (comp["err"] <= 1e-4).all() and (flat["err"] <= 1e-4).all()
+    Uc, Uf = comp["Vm"] * np.exp(1j * comp["Va"]), flat["Vm"] * np.exp(1j * flat["Va"])
+    print("fixed points: max|dU| %.2e" % np.abs(Uc - Uf).max())
+    assert np.abs(Uc - Uf).max() < TOL_V
 
 
 # (n, H_MAX, share of nonlinear buses, PV buses, generator seed, iterations of the ORACLE [50 = the reference's own Newton iteration

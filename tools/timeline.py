@@ -6,7 +6,7 @@ d = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof"
 import os
 f = max(glob.glob(d + "/*/*_kernel_trace.csv"), key=os.path.getmtime)
 rows = list(csv.DictReader(open(f)))
-keys = ("k_sleaf_batch", "k_sleaf_back_batch", "k_leaf_back_batch", "k_leaf_batch", "k_leafsum", "k_factor_q", "k_factor_w", "k_back_q", "k_back_w", "k_lin_level_factor", "k_lin_level_back", "k_lin_factor", "k_lin_back", "k_chain_factor", "k_chain_back", "k_mismatch", "k_update", "k_tree", "k_finalize")
+keys = ("k_level", "k_lin_bundle_factor", "k_lin_bundle_back", "k_sleaf_batch", "k_sleaf_back_batch", "k_leaf_back_batch", "k_leaf_batch", "k_leafsum", "k_factor_q", "k_factor_w", "k_back_q", "k_back_w", "k_lin_level_factor", "k_lin_level_back", "k_lin_factor", "k_lin_back", "k_chain_factor", "k_chain_back", "k_mismatch", "k_update", "k_tree", "k_finalize")
 mine = sorted([r for r in rows if any(k in r["Kernel_Name"] for k in keys)], key=lambda r: int(r["Start_Timestamp"]))
 mm = [i for i, r in enumerate(mine) if "k_mismatch" in r["Kernel_Name"]]       # a step ends with its mismatch kernel
 step = mine[mm[-2] + 1:mm[-1] + 1]
