@@ -48,8 +48,8 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--scenarios", type=int, default=128, help="Monte-Carlo scenarios per GPU")
     ap.add_argument("--buses", type=int, default=1000)
     ap.add_argument("--hmax", type=int, default=51)
@@ -112,7 +112,7 @@ def cpu_baseline_start(args):
     it1 = one[0]["n_iter"] / one[0]["loop_s"]
     loop_max = max(o["loop_s"] for o in many)
     itn = sum(o["n_iter"] for o in many) / loop_max
-    return {"value": itn, "unit": "NR iterations/s", "cores": nw, "kind": "port",
+    return {"value": itn, "unit": "NR iterations/s", "cores": nw, "cores_note": "%d of %d host cores" % (nw, cores), "kind": "port",
             "sample": "%d NR iterations of each of %d Monte-Carlo scenarios of the same %d-bus x %d-harmonic feeder, one oracle process "
                       "per core (NumPy/SciPy SuperLU restatement, bit-identical to the reference on its golden cases; BLAS pinned to 1 "
                       "thread per process); the reference itself measured 0.0257 it/s (38.9 s/it) on this feeder in the build container"
@@ -127,7 +127,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    cpu = cpu_baseline_start(args) if (rank == 0 and world == 1) else None      # child processes: before any GPU initialisation
+    cpu = cpu_baseline_start(args) if rank == 0 else None      # rank 0 of every world size; child processes, before any GPU initialisation
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -180,9 +180,10 @@ def main():
         elapsed = float(t.item())
     # per-kernel HIP-event timing (on the streams the kernels run on) over K more steps of the same configuration, continued
     # from the state the timed region left; kept out of the headline region because every span costs two event records
+    Kt = min(args.steps, 20)                     # steps of each timing leg (bounded: every span is a pair of event records)
     dm.timing(True)
     dm.timing_reset()
-    dm.iterate(args.steps)
+    dm.iterate(Kt)
     dm.sync()
     tim = dm.timing_get()
     dm.timing(False)
@@ -190,7 +191,7 @@ def main():
     # (a HIP event record is a barrier packet with cache maintenance: it perturbs the ~25 us kernels it brackets)
     dm.timing(2)
     dm.timing_reset()
-    dm.iterate(args.steps)
+    dm.iterate(Kt)
     dm.sync()
     tim["gj_dev"] = dm.timing_get()["gj_dev"]
     dm.timing(False)
@@ -224,12 +225,12 @@ def main():
     ms_step = 1e3 * elapsed / K
     b = 2 * Hn
     bt = args.solver == "block_tree"
-    G = 3 if S >= 24 else (2 if S >= 16 else 1)
+    G = dm.scenario_groups(S) if bt else 1
     # ---- roofline of the dominant kernel, alone: k_factor_q<B,false> (block_tree) / the rocSOLVER LU (dense) ----------------------
     gj_ms, gj_n = tim["gj_dev"] if (bt and tim.get("gj_dev", (0, 0))[1]) else (tim["gj"] if bt else tim["solve"])
     ev_ms, ev_n = tim["gj"] if bt else tim["solve"]
     by_gj, fl_gj, ln_gj = dm.kernel_model("gj") if bt else dm.kernel_model("solve")
-    launches_per_step = gj_n / max(K, 1)                                     # all scenario groups
+    launches_per_step = gj_n / max(Kt, 1)                                    # all scenario groups
     bytes_per_launch = by_gj * S / max(launches_per_step, 1)                 # average over its launches (tree levels x groups)
     flops_per_launch = fl_gj * S / max(launches_per_step, 1)
     avg_ms = gj_ms / max(gj_n, 1)
@@ -243,10 +244,13 @@ def main():
     bytes_2x2 = (32 + 16) * 2 * Hn * n + 2 * 16 * Hn * n
     bytes_update = 16 * Hn * n + 2 * 8 * Hn * n + 2 * 8 * Hn * n + 2 * 16 * Hn * n
     step_bytes = S * (dm.solve_bytes() + bytes_mismatch + bytes_back + bytes_2x2 + bytes_update)
-    traffic, traffic_note = pmc_traffic(args, S)
+    traffic, traffic_note, traffic_source = pmc_traffic(args, S)
     step_traffic = pmc_step_traffic(args, S)
     census = dm.tree_census() if bt else {}
     fused = bool(census.get("fused_levels"))
+    # k_mismatch (harmonic_mismatch HG:360-390, the assembly kernel that reaches HBM): algorithmic bytes of a launch / its HIP-event span
+    asm_gbs = (bytes_mismatch * S / max(tim["mismatch"][1] / max(Kt, 1), 1) / (tim["mismatch"][0] / max(tim["mismatch"][1], 1) * 1e-3) / 1e9
+               if tim["mismatch"][1] else None)
     kname = "k_factor_q<%d,false>" % (100 if b > 52 else (52 if b > 28 else (28 if b > 12 else 12))) if bt and b <= 100 else ("k_tree_factor (generic)" if bt else "rocsolver_dgetrf/dgetrs")
     kdesc = kname + (" alone (general multi-wave block-tree factor kernel: Gauss-Jordan buses and non-batched super-leaves; %d launches per "
                      "Newton step and scenario group, one per tree level)" % ln_gj)
@@ -273,7 +277,11 @@ def main():
                      "kernel": kdesc, "tree_census": census,
                      "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS if achieved_gbs else None,
-                     "traffic": traffic, "traffic_note": traffic_note,
+                     "traffic": traffic, "traffic_note": traffic_note, "traffic_source": traffic_source,
+                     "mfma_frac": achieved_tf / FP64_PEAK_TFLOPS if achieved_tf else None,
+                     "mfma_tflops": achieved_tf,
+                     "assembly_gbs": asm_gbs, "assembly_frac": asm_gbs / HBM_PEAK_GBS if asm_gbs else None,
+                     "step_hbm_frac": step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "bytes_per_launch": bytes_per_launch, "flop_per_launch": flops_per_launch,
                      "avg_ms": avg_ms, "avg_ms_hip_event_spans": ev_ms / max(ev_n, 1), "launches_timed": gj_n,
                      "launches_per_step": launches_per_step,
@@ -302,15 +310,15 @@ def main():
                                       "+ update) over the step wall time"},
         "roofline_assembly": {"bound": "hbm", "kernel": "k_mismatch<false> (harmonic_mismatch HG:360-390: the mismatch half of the assembly; the "
                                                          "Jacobian half is fused into the factor kernels and never reaches HBM)",
-                              "achieved": bytes_mismatch * S / max(tim["mismatch"][1] / max(K, 1), 1) / (tim["mismatch"][0] / max(tim["mismatch"][1], 1) * 1e-3) / 1e9
+                              "achieved": bytes_mismatch * S / max(tim["mismatch"][1] / max(Kt, 1), 1) / (tim["mismatch"][0] / max(tim["mismatch"][1], 1) * 1e-3) / 1e9
                               if tim["mismatch"][1] else None,
                               "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "bytes_per_launch": bytes_mismatch * S / max(tim["mismatch"][1] / max(K, 1), 1),
+                              "bytes_per_launch": bytes_mismatch * S / max(tim["mismatch"][1] / max(Kt, 1), 1),
                               "avg_ms_hip_event_span": tim["mismatch"][0] / max(tim["mismatch"][1], 1),
                               "note": "algorithmic bytes (voltages in, mismatch image out) of one launch (one scenario group) / its HIP-event span; "
                                       "rocprofv3 of the same command: profiles/*kernel_stats.csv, counters: profiles/pmc_traffic_latest.json"},
         "phase_ms_per_launch": {k: (v[0] / max(v[1], 1)) for k, v in tim.items() if v[1]},
-        "phase_launches_per_step": {k: v[1] / max(K, 1) for k, v in tim.items() if v[1]},
+        "phase_launches_per_step": {k: v[1] / max(Kt, 1) for k, v in tim.items() if v[1]},
         "phase_note": "HIP-event spans: gj = one per k_level / k_factor_q<B,false> launch; solve = one per launch of the other factor kernels "
                       "(k_leaf_batch, k_sleaf_batch, leaf-only k_factor_q: none with k_level); mismatch / update: per launch; back: per scenario "
                       "group and step (%d groups overlap on separate streams)" % G,
@@ -319,40 +327,60 @@ def main():
     if sweep is not None:
         out["sweep"] = sweep
         out["sweep_iters_per_s"] = sweep["iters_per_s_rank0"] * world
-    if world == 1 and args.sweep_1gpu > 0 and bt:
+    if args.sweep_1gpu > 0 and bt:               # rank 0 of every world size: the whole sweep on ONE GPU, the strong-scaling comparator
         dm.close()
         dm = None
         out["sweep_1gpu"] = sweep_one_gpu(hp, inp, args, dev_index)
+        # N GPUs with `scenarios` each against ONE GPU that holds all of them ("scaling": "weak" above is per-GPU work held fixed)
+        out["sweep_1gpu_lockstep_iters_per_s"] = out["sweep_1gpu"]["lockstep_iters_per_s"]
+        out["scaling_strong_vs_1gpu"] = value / out["sweep_1gpu"]["lockstep_iters_per_s"]
+        out["scaling_strong_8gpu_projection"] = 8.0 * (value / world) / out["sweep_1gpu"]["lockstep_iters_per_s"]
     if (args.single or world == 1) and not args.no_single:
         out["single_scenario"] = single_scenario(hp, inp, args)
+        out["single_ms_per_iter"] = out["single_scenario"]["ms_per_iter"]
     out["cpu_baseline"] = cpu
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
 
 
-def pmc_traffic(args, S):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/pmc_traffic.py); only valid for the
-    default workload they were collected on."""
+def lib_sha16():
+    import hashlib
+    lib = os.path.join(REPO, "harmonic-power-flow_amd", "libhpf.so")
+    return hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16] if os.path.exists(lib) else None
+
+
+def pmc_file(args, S):
+    """The committed PMC passes (tools/pmc_traffic.py) -- only if they were collected on this workload AND with the very libhpf.so
+    that is running now (the JSON records the library's hash)."""
     path = os.path.join(REPO, "profiles", "pmc_traffic_latest.json")
     if not os.path.exists(path) or (args.buses, args.hmax, S, args.solver) != (1000, 51, 128, "block_tree"):
         return None, "no PMC pass for this workload"
     j = json.load(open(path))
     if j.get("format") != 2:
         return None, "no PMC pass in the current format"
+    if j.get("lib_sha16") != lib_sha16():
+        return None, "profiles/pmc_traffic_latest.json was collected with another build of libhpf.so (%s, running %s): not reported" % (
+            j.get("lib_sha16"), lib_sha16())
+    return j, ""
+
+
+def pmc_traffic(args, S):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes; None unless they belong to the running library."""
+    j, why = pmc_file(args, S)
+    if j is None:
+        return None, why, None
     d = j.get("per_launch_bytes", {}).get("k_factor_q_general")
     if not d:
-        return None, "no PMC pass for this kernel"
-    return d["fetch"] + d["write"], j.get("note", "")
+        return None, "no PMC pass for this kernel", None
+    return d["fetch"] + d["write"], j.get("note", ""), {"file": "profiles/pmc_traffic_latest.json", "lib_sha16": j.get("lib_sha16"),
+                                                         "command": j.get("command")}
 
 
 def pmc_step_traffic(args, S):
-    """Counter bytes of a whole NR step (all kernels) from the committed PMC passes."""
-    path = os.path.join(REPO, "profiles", "pmc_traffic_latest.json")
-    if not os.path.exists(path) or (args.buses, args.hmax, S, args.solver) != (1000, 51, 128, "block_tree"):
-        return None
-    j = json.load(open(path))
-    t = j.get("per_step_bytes") if j.get("format") == 2 else None
+    """Counter bytes of a whole NR step (all kernels) from the committed PMC passes (same rule)."""
+    j, _ = pmc_file(args, S)
+    t = j.get("per_step_bytes") if j else None
     if not t:
         return None
     return sum(v["fetch"] + v["write"] for v in t.values())

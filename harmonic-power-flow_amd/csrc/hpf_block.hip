@@ -1814,7 +1814,11 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
     T.comp_c.clear();
     {
         const char* cp_env = getenv("HPF_COMPRESS");
-        const bool compress_on = contract && d->coupled && BWc != 0 && BWc <= 100 && !(cp_env && atoi(cp_env) == 0) && T.n_dense > 2;
+        // default: handles of up to 256 scenarios -- a compress step trades a shorter chain of levels for more matrix-core work (the dense
+        // push of the pending child), which pays while the levels do not fill the chip (measured crossover between 256 and 384 live
+        // scenarios on the headline feeder, tools/groups_sweep.py); HPF_COMPRESS=1 / 0 force it on / off
+        const bool compress_on = contract && d->coupled && BWc != 0 && BWc <= 100 && T.n_dense > 2 &&
+                                 (cp_env ? atoi(cp_env) != 0 : h->S_max <= 256);
         auto is_gj = [&](int k2) { return kept(k2) && cleaf_of[k2] < 0 && sl_off[k2] < 0; };
         std::vector<int> cc(n, -1), isc(n, 0), keptl;
         for (int i = 0; i < n; ++i)

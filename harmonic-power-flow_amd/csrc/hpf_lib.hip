@@ -537,7 +537,7 @@ inline void full_ctx(hpf_handle* h) { set_ctx(h, h->stream, 0, h->S); }
 inline int groups_for(const hpf_handle* h, int count) {
     if (h->solver != HPF_SOLVER_BLOCK_TREE || h->n_ties > 0) return 1;
     int g = h->n_groups;
-    while (g > 1 && count < 8 * g) --g;        // at least 8 scenarios per group
+    while (g > 1 && count < 32 * g) --g;       // at least 32 scenarios per group (below that the launches of a group no longer fill their levels: tools/groups_sweep.py)
     return g < 1 ? 1 : g;
 }
 inline int groups_for(const hpf_handle* h) { return groups_for(h, h->S); }
@@ -1430,6 +1430,11 @@ int hpf_tree_census(const hpf_handle* h, int* counts, int n_counts) {
     const int fused = (h->fuse_levels && h->gj_mode == 1 && 2 * h->Hn <= 52) ? 1 : 0;
     for (int i = 0; i < n_counts; ++i) counts[i] = i < 8 ? T.census[i] : (i == 8 ? h->n_ties : (i == 9 ? fused : (i == 10 ? T.n_comp : 0)));
     return HPF_OK;
+}
+
+int hpf_scenario_groups(const hpf_handle* h, int live) {
+    if (!h || live < 0) return HPF_E_ARG;
+    return groups_for(h, live);
 }
 
 int hpf_tree_plan(const hpf_desc* d, const char* path) {

@@ -222,6 +222,10 @@ class DeviceModel:
             out[name] = (ms.value, cnt.value)
         return out
 
+    def scenario_groups(self, live):
+        """Scenario groups (streams) a step of `live` running scenarios is split into (hpf_scenario_groups)."""
+        return int(self.lib.hpf_scenario_groups(self._h, int(live)))
+
     def solve_flops(self):
         return float(self.lib.hpf_solve_flops(self._h))
 

@@ -168,7 +168,7 @@ int  hpf_debug_stamps(hpf_handle* h, long long* out, int count);
  * (a lower bound of its condition number) exceeds 10^value; "auto_repivot" (default 1): hpf_solve repeats flagged scenarios
  * with partial pivoting (0: they are only reported in hpf_stat.flags).
  * "keep_previous_state" (default 0): hpf_solve keeps per scenario the state its last Newton step started from (hpf_jacobian_last).
- * "scenario_groups" (1..8, default 3): independent scenario pipelines on separate HIP streams.
+ * "scenario_groups" (1..8, default 3 -- with the host framework's own streams a fourth busy queue is a cliff --; at least 32 running scenarios per group): independent scenario pipelines on separate HIP streams.
  * Environment read by hpf_create (diagnostics, A/B runs): HPF_LAZY=0 builds the elimination tree without lazy leaves (every
  * leaf writes its Schur complement; 1: only leaves directly under their dense parent), HPF_SLEAF=0 sends the nonlinear buses
  * whose dense children are all lazy leaves (super-leaves: bordered low-rank inverse) through Gauss-Jordan like every other bus,
@@ -180,7 +180,8 @@ int  hpf_debug_stamps(hpf_handle* h, long long* out, int count);
  * and the per-scenario workgroups of an elimination level separately (k_leaf_batch / k_sleaf_batch + k_factor_q instead of k_level),
  * HPF_LINBUNDLE=0 / HPF_LINTREE=0 run the 2x2 algebra of the linear subtrees height by height in one launch / in one launch per
  * height, HPF_CHAINBUNDLE=0 gives the contracted chains their own launches, HPF_COMPRESS=0 eliminates the Gauss-Jordan buses strictly
- * leaves first (no compress steps: one elimination level per unit of tree height), HPF_TREE_INFO=1 prints the tree statistics to stderr,
+ * leaves first (no compress steps: one elimination level per unit of tree height; the default for handles of more than 256 scenarios,
+ * whose levels fill the chip -- HPF_COMPRESS=1 forces the compress steps there too), HPF_TREE_INFO=1 prints the tree statistics to stderr,
  * HPF_GROUPS=n presets "scenario_groups".  Every switch selects a path with the same Newton steps (tests/test_gpu_robustness.py). */
 int  hpf_set_option(hpf_handle* h, const char* name, int value);
 
@@ -228,6 +229,9 @@ int  hpf_kernel_model(const hpf_handle* h, int which, double* bytes, double* flo
  * [10] compress steps (Gauss-Jordan buses eliminated before their tallest dense child: levels counts the shortened chain).
  * HPF_E_STATE for DENSE. */
 int  hpf_tree_census(const hpf_handle* h, int* counts, int n_counts);
+/* Number of scenario groups (independent pipelines on separate HIP streams) a Newton step of `live` running scenarios is split into:
+ * option "scenario_groups" bounded by a minimum group size; 1 for DENSE and for meshed networks. */
+int  hpf_scenario_groups(const hpf_handle* h, int live);
 /* Host-only planning run of the BLOCK_TREE elimination tree of a radial model (no device, no handle): builds the contracted tree
  * exactly as hpf_create would and writes one line per dense bus (bus, dense parent, elimination level, back-sweep depth, kind, ...)
  * to `path` (the file env HPF_TREE_DUMP would name; tools/tree_plan.py reads it).  Returns HPF_OK when the plan was written. */

@@ -18,7 +18,7 @@ inp = bench.build_inputs(args, hp)
 n = inp["n"]
 P0, Q0 = inp["buses"]["P"].to_numpy(float), inp["buses"]["Q"].to_numpy(float)
 for S in Ss:
-    for groups in (3, 4, 5, 6, 8):
+    for groups in [int(g) for g in os.environ.get("GROUPS_LIST", "3,4,5,6,8").split(",")]:
         dm = hp.DeviceModel(n, inp["m"], inp["c"], inp["st"].HARMONICS, inp["Y"].rowptr, inp["Y"].col, inp["Y"].Yval, inp["dev"],
                             inp["Y_N"], inp["I_N"], inp["n_dev"], True, solver="block_tree", max_scenarios=S)
         dm.set_option("scenario_groups", groups)

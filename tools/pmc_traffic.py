@@ -61,6 +61,9 @@ def main():
         out["per_launch_bytes"][k] = {"fetch": fe / nd, "write": wr / nd}
     if command:
         out["command"] = command
+    import hashlib
+    lib = os.path.join(REPO, "harmonic-power-flow_amd", "libhpf.so")
+    out["lib_sha16"] = hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16] if os.path.exists(lib) else None
     g = [k for k in out["per_launch_bytes"] if k.startswith("k_level<")] or \
         [k for k in out["per_launch_bytes"] if k.startswith("k_factor_q<") and k.endswith("false>")]    # (k_level: one launch per level)
     if g:
