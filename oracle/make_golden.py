@@ -244,6 +244,18 @@ def main(argv):
         for k in ("err", "err_h"):
             if k in ns:
                 hf[k] = float(ns[k])
+        # the harmonic NR of HF:185-356: every iterate (V_h_log, HF:186), the injections (I_inj_log, HF:251), the printed error
+        # list (HF:354) and the LAST iteration's linear system as the script leaves it in its namespace (J_5 HF:339, dM HF:257,
+        # U HF:190, U_new HF:346) -- the known-answer data of the oracle's restatement (oracle/hf_oracle.py) and of hpf_dense_solve
+        hf["V_h_log"] = [ns["V_h_log"][i].to_numpy().astype(float).tolist() for i in range(hf["n_iter_h"])]
+        hf["I_inj_log"] = [ns["I_inj_log"][i].to_numpy().astype(float).tolist() for i in range(hf["n_iter_h"])]
+        hf["err_f_list"] = [float(l.split(":")[1]) for l in buf.getvalue().splitlines() if l.startswith("error_f:")]
+        hf["err_h_list"] = [float(l.split(":")[1]) for l in buf.getvalue().splitlines() if l.startswith("error_h:")]
+        for k in ("J_5", "dM", "U", "U_new", "J"):
+            hf[k + "_last"] = np.asarray(ns[k], dtype=float)
+        for k in ("Y_f", "Y_5"):
+            hf[k + "_re"] = np.asarray(ns[k]).real
+            hf[k + "_im"] = np.asarray(ns[k]).imag
         with open(os.path.join(GOLD, "hf_fuchs.json"), "w") as f:
             json.dump({k: (v.tolist() if isinstance(v, np.ndarray) else v) for k, v in hf.items()}, f, indent=1)
         # the reference's own committed golden: iteration-0 rows of V_log.json (fundamental 4-bus NR result)

@@ -147,3 +147,17 @@ def test_extra_iterations_reach_the_fixed_point(tmp_path):
         assert n_iter_h == r["n_iter_h"] and abs(err_h - r["err_h"]) <= 1e-3 * r["err_h"]      # the reference's stop is what is reported
         Ud = V["V_m"].to_numpy() * np.exp(1j * V["V_a"].to_numpy())
         assert np.abs(Ud - Uo).max() < 1e-10
+
+
+def test_fuchs_script_last_newton_step_through_hpf_dense_solve():
+    """hcne_based_on_fuchs.py:345-346 (`U_new = U - inv(J_5).dot(dM)`): the script's OWN last linear system (14 x 14 J_5, dM, U captured
+    from the unmodified script by oracle/make_golden.py; cond(J_5) = 4.4e4, |U| up to 2.5e2 rad) through update_harmonic_state_vec's
+    device path (hpf_dense_solve: rocSOLVER LU) lands on the script's U_new."""
+    import json
+    hp = _hp()
+    with open(os.path.join(GOLD, "hf_fuchs.json")) as fh:
+        g = json.load(fh)
+    J, dM, U, U_new = (np.array(g[k + "_last"]) for k in ("J_5", "dM", "U", "U_new"))
+    assert J.shape == (14, 14)
+    x = hp.update_harmonic_state_vec(J, U, dM)
+    assert np.abs(np.asarray(x).ravel() - U_new).max() < 1e-10 * max(1.0, np.abs(U_new).max())

@@ -134,6 +134,31 @@ def test_oracle_pf_lands_on_the_reference_committed_fuchs_golden():
         assert abs(Vm[k] - r["V_m"]) < 1e-9 and abs(Va[k] - r["V_a"]) < 1e-9
 
 
+def test_hf_oracle_reproduces_the_fuchs_script_harmonic_newton_raphson():
+    """hcne_based_on_fuchs.py:185-356 (the harmonic NR of the fixed 4-bus example with the analytic load g(), HF:170-173), restated in
+    oracle/hf_oracle.py, against the run of the unmodified script captured by oracle/make_golden.py -- BIT FOR BIT: both admittance
+    matrices, the 3 printed fundamental errors, all 11 harmonic iterates (V_h_log), injections and printed errors, the last iteration's
+    linear system (J_5, dM, U, U_new) and the final voltages, V(5, bus 4) = 0.0253363651 at -1.6765972645."""
+    import hf_oracle as hf
+    with open(os.path.join(GOLD, "hf_fuchs.json")) as f:
+        g = json.load(f)
+    for h, k in ((1, "Y_f"), (5, "Y_5")):
+        assert np.array_equal(hf.admittances(h), np.array(g[k + "_re"]) + 1j * np.array(g[k + "_im"]))
+    r = hf.run()
+    assert (r["n_iter"], r["n_iter_h"]) == (4, 11) == (g["n_iter"], g["n_iter_h"])
+    assert r["err_f_list"] == g["err_f_list"] and r["err_h_list"] == g["err_h_list"] and g["err_h_list"][0] == 200.0
+    assert r["err_h"] == g["err_h"]
+    L, M = np.array(g["V_h_log"]), np.array(r["V_h_log"])
+    assert L.shape == M.shape == (11, 8, 2) and np.array_equal(L, M)
+    assert np.array_equal(np.array(g["I_inj_log"]), np.array(r["I_inj_log"]))
+    Vf = np.array(g["V_final"])
+    assert np.array_equal(Vf[:, 0], r["Vm"].ravel()) and np.array_equal(Vf[:, 1], r["Va"].ravel())
+    assert abs(r["Vm"][1, 3] - 0.0253363651) < 1e-10 and abs(r["Va"][1, 3] + 1.6765972645) < 1e-9
+    for k in ("J_5", "dM", "U", "U_new"):
+        assert np.array_equal(np.array(g[k + "_last"]), r["last"][k]), k
+    assert np.array_equal(np.array(g["J_last"]), r["J_fund"])                        # the stale fundamental block (HF:261)
+
+
 def test_oracle_syn1000_headline_shape(tmp_path):
     """The north-star shape (1 000 buses x 25 harmonics, coupled): 27 iterations, err 7.047e-10."""
     import importlib.util
