@@ -956,12 +956,13 @@ int launch_factor(hpf_handle* h, const TreeDev& T, const int* nodes, int count, 
 // voltages, different mismatch images) through the unchanged block-tree kernels -- every kernel stays as tested; the m x m
 // border system goes to rocSOLVER.  Cost: (1 + m) x one scenario's step per real scenario (m <= 1024).
 // =============================================================================================================
-// virtual slot v0 + v <- state of real scenario r; mismatch image: v = 0 the scenario's own, v >= 1 the unit vector of border row v - 1
-__global__ __launch_bounds__(256) void k_border_prepare(int n, int Hn, int Bst, int b, int r, int v0, const int* __restrict__ tb_bus,
-                                                        cplx* __restrict__ U, cplx* __restrict__ E, cplx* __restrict__ I0,
-                                                        double* __restrict__ fb) {
-    const int v = blockIdx.y;
-    const size_t dst = (size_t)(v0 + v);
+// virtual slot v0 + j <- state of real scenario r, j = blockIdx.y; mismatch image of right-hand side v = vfirst + j: v = 0 the scenario's
+// own, v >= 1 the unit vector of border row v - 1; with g (second pass): the scenario's own minus E_T g
+__global__ __launch_bounds__(256) void k_border_prepare(int n, int Hn, int Bst, int b, int r, int v0, int vfirst, const int* __restrict__ tb_bus,
+                                                        int n_tb, const double* __restrict__ g, cplx* __restrict__ U, cplx* __restrict__ E,
+                                                        cplx* __restrict__ I0, double* __restrict__ fb) {
+    const int j = blockIdx.y, v = vfirst + j;
+    const size_t dst = (size_t)(v0 + j);
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t < n * Hn) {
         U[dst * n * Hn + t] = U[(size_t)r * n * Hn + t];
@@ -972,6 +973,12 @@ __global__ __launch_bounds__(256) void k_border_prepare(int n, int Hn, int Bst, 
         double val = 0.0;
         if (v == 0) {
             val = fb[(size_t)r * n * Bst + t];
+            if (g) {                                           // second pass: f - E_T g
+                const int bus = t / Bst, l = t - bus * Bst;
+                if (l < b)
+                    for (int a = 0; a < n_tb; ++a)
+                        if (tb_bus[a] == bus) val -= g[a * b + l];
+            }
         } else {
             const int a = (v - 1) / b, l = (v - 1) - a * b;
             if (t == tb_bus[a] * Bst + l) val = 1.0;
@@ -980,19 +987,19 @@ __global__ __launch_bounds__(256) void k_border_prepare(int n, int Hn, int Bst, 
     }
 }
 
-// border system: M[row, col] = delta + (Q^T z_col)[row], rhs[row] = (Q^T y)[row]; row = (endpoint a, local row l), z_col = x of virtual
-// slot v0 + 1 + col, y = x of virtual slot v0
-__global__ __launch_bounds__(256) void k_border_build(Model M, int Bst, int b, int r, int v0, int m, const int* __restrict__ tb_bus,
+// border system: M[row, col] = delta + (Q^T z_col)[row], rhs[row] = (Q^T y)[row]; row = (endpoint a, local row l), right-hand side
+// v = vfirst + blockIdx.y sits in virtual slot v0 + blockIdx.y: v = 0 -> y (the border system's right-hand side), v >= 1 -> column v - 1
+__global__ __launch_bounds__(256) void k_border_build(Model M, int Bst, int b, int r, int v0, int vfirst, int m, const int* __restrict__ tb_bus,
                                                       const int* __restrict__ tb_ptr, const int* __restrict__ tb_adj,
                                                       const cplx* __restrict__ Uall, const cplx* __restrict__ Eall,
                                                       const double* __restrict__ xall, double* __restrict__ bM, double* __restrict__ brhs) {
     const int row = blockIdx.x * 256 + threadIdx.x;
-    const int col = blockIdx.y;                        // 0: right-hand side, 1 + c: column c of the border matrix
+    const int col = vfirst + blockIdx.y;               // 0: right-hand side, 1 + c: column c of the border matrix
     if (row >= m) return;
     const int a = row / b, l = row - a * b, q = l >> 1, t = l & 1;
     const int i = tb_bus[a];
     const size_t so = (size_t)r * M.n * M.Hn;
-    const double* x = xall + (size_t)(v0 + col) * M.n * Bst;
+    const double* x = xall + (size_t)(v0 + blockIdx.y) * M.n * Bst;
     double acc = 0.0;
     for (int e = tb_ptr[a]; e < tb_ptr[a + 1]; ++e) {
         const int j = tb_adj[3 * e], ent = tb_adj[3 * e + 1];
@@ -1007,14 +1014,14 @@ __global__ __launch_bounds__(256) void k_border_build(Model M, int Bst, int b, i
         bM[(size_t)(col - 1) * m + row] = acc + (row == col - 1 ? 1.0 : 0.0);
 }
 
-// x(real scenario r) = y - Z g
-__global__ __launch_bounds__(256) void k_border_apply(int count, int r, int v0, int m, const double* __restrict__ g,
-                                                      double* __restrict__ xall) {
+// x(real scenario r) <- x(virtual slot v0) (second pass: J_t^-1 (f - E_T g)); the virtual sweeps' static-pivot flags fold into r's
+__global__ __launch_bounds__(256) void k_border_finish(int count, int r, int v0, int nv, double* __restrict__ xall, int* __restrict__ pivflag) {
     const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= count) return;
-    double acc = xall[(size_t)v0 * count + t];
-    for (int c2 = 0; c2 < m; ++c2) acc = fma(-g[c2], xall[(size_t)(v0 + 1 + c2) * count + t], acc);
-    xall[(size_t)r * count + t] = acc;
+    if (t < count) xall[(size_t)r * count + t] = xall[(size_t)v0 * count + t];
+    if (t < nv && pivflag[v0 + t]) {
+        atomicOr(pivflag + r, pivflag[v0 + t]);
+        pivflag[v0 + t] = 0;
+    }
 }
 
 }  // namespace
@@ -2482,7 +2489,8 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
             switch (BW) {                       // (timing spans: one per kernel launch, inside the launch helpers)
 #define HPF_FACTOR_CASE(BB_)                                                                                  \
     case BB_:                                                                                                 \
-        if (h->gj_mode == 1 && h->fuse_levels) {     /* one launch per level: batched and per-scenario workgroups side by side */ \
+        if (h->gj_mode == 1 && h->fuse_levels && (nbatch > 0 || BB_ == 52)) {     /* one launch per level: batched and per-scenario workgroups   \
+                                                      side by side (small blocks without batched workgroups: k_factor_q's own grid and LDS) */ \
             r = launch_level<BB_>(h, td, T.d_fdesc + FDESC * (size_t)T.lvl_ptr[l], nbatch > 0 ? (slbatch ? 2 : 1) : 0, nbatch,       \
                                   cnt - nbatch, active);                                                      \
             break;                                                                                            \
@@ -2696,7 +2704,8 @@ int tree_find_ties(hpf_handle* h, const hpf_desc* d) {
     }
     h->n_tb = (int)tb_bus.size();
     h->m_border = h->n_tb * 2 * d->Hn;
-    if (h->m_border > 1024 || wave_block_size(2 * d->Hn) == 0) return HPF_E_TOPOLOGY;   // stated bound of the bordered step (hpf.h)
+    if (h->m_border > 16384 || wave_block_size(2 * d->Hn) == 0) return HPF_E_TOPOLOGY;  // stated bound of the bordered step (hpf.h): the
+                                                                                        // m x m border system is dense (2 GiB at 16 384)
     int r;
     if ((r = upload(h, &h->d_tb_bus, tb_bus))) return r;
     if ((r = upload(h, &h->d_tb_ptr, tb_ptr))) return r;
@@ -2708,10 +2717,16 @@ int tree_find_ties(hpf_handle* h, const hpf_desc* d) {
     return HPF_OK;
 }
 
-// Newton step of a network with loop-closing lines (see the kernels above): for every running real scenario, 1 + m virtual
-// scenarios through tree_newton_step, then the border system.  Called with the launch context on h->stream over real slots.
+// Newton step of a network with loop-closing lines (see the kernels above), per running real scenario r:
+//   pass 1: the right-hand sides f and the m unit vectors of the border rows through tree_newton_step, border_slots(h) virtual slots at a
+//           time (same voltages as r) -> the m x m border system, one chunk of columns per sweep; rocSOLVER LU -> g;
+//   pass 2: x = J_t^-1 (f - E_T g), one more sweep in the first virtual slot.
+// Nothing of Z = J_t^-1 E_T is kept, so m is bounded by the dense border system only.  Called with the launch context on h->stream
+// over real slots.
+int border_slots(const hpf_handle* h) { return h->m_border + 1 < 256 ? h->m_border + 1 : 256; }
+
 int tree_newton_step_bordered(hpf_handle* h, bool only_active) {
-    const int m = h->m_border, V = 1 + m, v0 = h->S_max;
+    const int m = h->m_border, VC = border_slots(h), v0 = h->S_max;
     const int b = 2 * h->Hn, BW = wave_block_size(b), n = h->n;
     const int s0 = h->cur_s0, cnt = h->cur_S;
     hipStream_t st = h->stream;
@@ -2721,39 +2736,58 @@ int tree_newton_step_bordered(hpf_handle* h, bool only_active) {
         if (sc >= 0) todo.push_back(sc);
     }
     const int save_groups = h->n_groups;
-    for (int r : todo) {
-        const int cmax = n * BW;
-        hipLaunchKernelGGL(k_border_prepare, dim3((unsigned)((cmax + 255) / 256), (unsigned)V), dim3(256), 0, st, n, h->Hn, BW, b, r, v0,
-                           h->d_tb_bus, h->d_U, h->d_E, h->d_I0, h->d_fb);
-        // the 1 + m virtual scenarios: slots [v0, v0 + V), scenario groups on their own streams as usual
-        {
-            const int G = V >= 24 ? (save_groups < 1 ? 1 : save_groups) : 1;
-            hipEventRecord(h->fork_ev, st);
-            int rc = HPF_OK;
-            for (int g = 0; g < G && rc == HPF_OK; ++g) {
-                const int a0 = (int)((long long)V * g / G), a1 = (int)((long long)V * (g + 1) / G);
-                hipStream_t gs = G > 1 ? h->gstream[g] : st;
-                if (G > 1) hipStreamWaitEvent(gs, h->fork_ev, 0);
-                h->cur_stream = gs;
-                h->cur_s0 = v0 + a0;
-                h->cur_S = a1 - a0;
-                rc = tree_newton_step(h, false);
-                if (G > 1) hipEventRecord(h->join_ev[g], gs);
-            }
-            if (G > 1)
-                for (int g = 0; g < G; ++g) hipStreamWaitEvent(st, h->join_ev[g], 0);
-            h->cur_stream = st;
-            h->cur_s0 = s0;
-            h->cur_S = cnt;
-            if (rc) return rc;
+    const int cmax = n * BW;
+    // the virtual scenarios of one chunk: slots [v0, v0 + V), scenario groups on their own streams as usual
+    auto sweep = [&](int V) -> int {
+        const int G = V >= 96 ? (save_groups < 1 ? 1 : (save_groups > 3 ? 3 : save_groups)) : 1;
+        if (G > 1) hipEventRecord(h->fork_ev, st);
+        int rc = HPF_OK;
+        for (int g = 0; g < G && rc == HPF_OK; ++g) {
+            const int a0 = (int)((long long)V * g / G), a1 = (int)((long long)V * (g + 1) / G);
+            hipStream_t gs = G > 1 ? h->gstream[g] : st;
+            if (G > 1) hipStreamWaitEvent(gs, h->fork_ev, 0);
+            h->cur_stream = gs;
+            h->cur_s0 = v0 + a0;
+            h->cur_S = a1 - a0;
+            rc = tree_newton_step(h, false);
+            if (G > 1) hipEventRecord(h->join_ev[g], gs);
         }
-        hipLaunchKernelGGL(k_border_build, dim3((unsigned)((m + 255) / 256), (unsigned)V), dim3(256), 0, st, h->M, BW, b, r, v0, m,
-                           h->d_tb_bus, h->d_tb_ptr, h->d_tb_adj, h->d_U, h->d_E, h->d_x, h->d_bM, h->d_brhs);
+        if (G > 1)
+            for (int g = 0; g < G; ++g) hipStreamWaitEvent(st, h->join_ev[g], 0);
+        h->cur_stream = st;
+        h->cur_s0 = s0;
+        h->cur_S = cnt;
+        return rc;
+    };
+    for (int r : todo) {
+        for (int c0 = 0; c0 < 1 + m; c0 += VC) {
+            const int V = 1 + m - c0 < VC ? 1 + m - c0 : VC;
+            hipLaunchKernelGGL(k_border_prepare, dim3((unsigned)((cmax + 255) / 256), (unsigned)V), dim3(256), 0, st, n, h->Hn, BW, b, r, v0, c0,
+                               h->d_tb_bus, h->n_tb, (const double*)nullptr, h->d_U, h->d_E, h->d_I0, h->d_fb);
+            int rc = sweep(V);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_border_build, dim3((unsigned)((m + 255) / 256), (unsigned)V), dim3(256), 0, st, h->M, BW, b, r, v0, c0, m,
+                               h->d_tb_bus, h->d_tb_ptr, h->d_tb_adj, h->d_U, h->d_E, h->d_x, h->d_bM, h->d_brhs);
+        }
         if (rocblas_set_stream(h->blas, st) != rocblas_status_success) return HPF_E_ROCSOLVER;
         if (rocsolver_dgetrf(h->blas, m, m, h->d_bM, m, h->d_bipiv, h->d_binfo) != rocblas_status_success ||
             rocsolver_dgetrs(h->blas, rocblas_operation_none, m, 1, h->d_bM, m, h->d_bipiv, h->d_brhs, m) != rocblas_status_success)
             return HPF_E_ROCSOLVER;
-        hipLaunchKernelGGL(k_border_apply, dim3((unsigned)((cmax + 255) / 256)), dim3(256), 0, st, cmax, r, v0, m, h->d_brhs, h->d_x);
+        int info = 0;
+        if (hipMemcpyAsync(&info, h->d_binfo, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+            h->last_detail = (int)hipGetLastError();
+            return HPF_E_HIP;
+        }
+        if (info != 0) {                                  // exactly singular border system (rocSOLVER info > 0)
+            h->last_detail = r;
+            return HPF_E_SINGULAR;
+        }
+        hipLaunchKernelGGL(k_border_prepare, dim3((unsigned)((cmax + 255) / 256), 1u), dim3(256), 0, st, n, h->Hn, BW, b, r, v0, 0,
+                           h->d_tb_bus, h->n_tb, (const double*)h->d_brhs, h->d_U, h->d_E, h->d_I0, h->d_fb);
+        int rc = sweep(1);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_border_finish, dim3((unsigned)((std::max(cmax, VC) + 255) / 256)), dim3(256), 0, st, cmax, r, v0, VC, h->d_x,
+                           h->d_pivflag);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

@@ -169,6 +169,7 @@ struct hpf_handle {
     double *d_Vm0 = nullptr, *d_Va0 = nullptr;   // [S][Hn*n] state at the entry of hpf_solve (repeat with partial pivoting starts from it)
     double *d_Vmp = nullptr, *d_Vap = nullptr;   // [S][Hn*n] option "keep_previous_state": the state each scenario's LAST Newton step started from
     int keep_prev = 0;
+    bool prev_valid = false;          // d_Vmp / d_Vap belong to the last hpf_solve (set_state / set_loads invalidate them)
     double* d_hist = nullptr;         // [S][hist_cap]
     int hist_cap = 0;
     hpf_stat* d_stats = nullptr;      // [S]
@@ -178,6 +179,7 @@ struct hpf_handle {
     int J_scen_alloc = 0;
     int* d_ipiv = nullptr;
     int* d_info = nullptr;
+    bool info64 = false;              // the last dense factorisation went through rocSOLVER's 64-bit entry points (int64 pivots / info)
     // block-tree solver
     hpf::Tree tree;                   // elimination tree as the network gives it (single-wave / generic kernels, pf)
     hpf::Tree ctree;                  // the same with pass-through buses contracted (multi-wave kernels, gj_mode 1)
@@ -254,5 +256,6 @@ int tree_alloc_scenarios(hpf_handle* h);
 int tree_fund_step(hpf_handle* h, bool only_active);     // fundamental pf Newton step on the tree (2x2 blocks)
 int tree_newton_step(hpf_handle* h, bool only_active);   // assembles, eliminates, back-substitutes -> d_f holds the step
 int tree_newton_step_bordered(hpf_handle* h, bool only_active);   // the same for a network with loop-closing lines (h->n_ties > 0)
+int border_slots(const hpf_handle* h);                            // virtual scenario slots of the bordered step (behind the S_max real ones)
 
 }  // namespace hpf

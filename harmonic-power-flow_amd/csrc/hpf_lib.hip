@@ -470,8 +470,7 @@ int dev_upload(hpf_handle* h, T** p, const T* src, size_t count) {
 inline dim3 grid2(int count, int S) { return dim3((unsigned)((count + TPB - 1) / TPB), (unsigned)S, 1); }
 
 int ensure_dense(hpf_handle* h, int Nsys) {
-    size_t want = (size_t)Nsys * Nsys;
-    if (want >= ((size_t)1 << 31)) return HPF_E_ARG;           // 32-bit element offsets inside rocSOLVER
+    size_t want = (size_t)Nsys * Nsys;                         // (N * N >= 2^31: rocSOLVER's 64-bit entry points, dense_solve)
     if (h->solver == HPF_SOLVER_DENSE && (size_t)h->N * h->N > want) want = (size_t)h->N * h->N;
     if (h->d_J && h->J_elems_per_scen >= want) return HPF_OK;
     if (h->d_J) {
@@ -485,9 +484,9 @@ int ensure_dense(hpf_handle* h, int Nsys) {
     int r = dev_alloc(h, &h->d_J, want * (size_t)h->S_max);
     if (r) return r;
     const int Nmax = h->N > h->Nf ? h->N : h->Nf;
-    if ((r = dev_alloc(h, &h->d_ipiv, (size_t)Nmax * h->S_max))) return r;
-    if ((r = dev_alloc(h, &h->d_info, (size_t)h->S_max))) return r;
-    HIPCHK(hipMemset(h->d_info, 0, sizeof(int) * h->S_max));
+    if ((r = dev_alloc(h, &h->d_ipiv, 2 * (size_t)Nmax * h->S_max))) return r;       // (room for the int64 pivots of the 64-bit path)
+    if ((r = dev_alloc(h, &h->d_info, 2 * (size_t)h->S_max))) return r;
+    HIPCHK(hipMemset(h->d_info, 0, sizeof(int) * 2 * h->S_max));
     h->J_elems_per_scen = want;
     return HPF_OK;
 }
@@ -555,8 +554,11 @@ int for_groups(hpf_handle* h, int count, F body) {
     }
     HIPCHK(hipEventRecord(h->fork_ev, h->stream));
     int rc = HPF_OK;
+    // group boundaries on multiples of 16 slots: the scenario-batched workgroups of the tree kernels take 16 scenarios each, an even
+    // split of e.g. 128 into 43 + 43 + 42 would run 3 x 3 tiles with ragged ends instead of 3 + 2 + 3 full ones
+    auto bound = [&](int g) { return g >= G ? count : (int)(16 * (((long long)count * g / G + 8) / 16)); };
     for (int g = 0; g < G && rc == HPF_OK; ++g) {
-        const int s0 = (int)((long long)count * g / G), s1 = (int)((long long)count * (g + 1) / G);
+        const int s0 = bound(g), s1 = bound(g + 1);
         HIPCHK(hipStreamWaitEvent(h->gstream[g], h->fork_ev, 0));
         set_ctx(h, h->gstream[g], s0, s1 - s0);
         rc = body();
@@ -595,6 +597,14 @@ int launch_mismatch(hpf_handle* h, const int* active, bool stacked = true) {
         // LDS: Y_N^T of one device type + the voltages of the workgroup's tile of buses (harmonic mismatch with coupled Norton data)
         const size_t lds = (!FUND && h->coupled && h->n > h->m)
                                ? sizeof(cplx) * ((size_t)h->Hn * h->Hn + (size_t)(TPB / h->Hn + 2) * h->Hn) : 0;
+        if (lds > 64 * 1024) {                      // Hn >= 62 (H_MAX >= 123): beyond the default dynamic-LDS limit of a kernel
+            static bool attr_set = false;
+            if (!attr_set) {
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mismatch<FUND>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr_set = true;
+            }
+            if (lds > 160 * 1024) return HPF_E_ARG;
+        }
         hipLaunchKernelGGL((k_mismatch<FUND>), dim3(xcd_grid(nbx, h->cur_S)), dim3(TPB), lds, h->cur_stream, h->M, count, N, Nc,
                            active, h->d_U, h->d_P, h->d_Q, (stacked || !img) ? h->d_f : nullptr, h->d_errbits, h->d_I0,
                            img ? h->d_fb : nullptr, tree_bst(h), h->cur_s0, h->cur_S, nbx);
@@ -627,6 +637,21 @@ int dense_solve(hpf_handle* h, int Nsys) {
     ScopedTimer t(h, T_SOLVE);
     if (Nsys <= 0) return HPF_OK;
     BLASCHK(rocblas_set_stream(h->blas, h->stream));
+    if ((long long)Nsys * Nsys >= (1ll << 31)) {
+        // beyond 32-bit element offsets (N > 46 340, e.g. the 1 000-bus x 26-harmonic feeder as a dense system: 21.6 GB per scenario):
+        // rocSOLVER's 64-bit entry points, one scenario after the other; int64 pivots / info (check_info reads them as such)
+        const int Nmax = h->N > h->Nf ? h->N : h->Nf;
+        int64_t* ip = reinterpret_cast<int64_t*>(h->d_ipiv);
+        int64_t* inf = reinterpret_cast<int64_t*>(h->d_info);
+        for (int sc = 0; sc < h->S; ++sc) {
+            double* Js = h->d_J + (size_t)sc * h->J_elems_per_scen;
+            BLASCHK(rocsolver_dgetrf_64(h->blas, Nsys, Nsys, Js, Nsys, ip + (size_t)sc * Nmax, inf + sc));
+            BLASCHK(rocsolver_dgetrs_64(h->blas, rocblas_operation_none, Nsys, 1, Js, Nsys, ip + (size_t)sc * Nmax, h->d_f + (size_t)sc * Nsys, Nsys));
+        }
+        h->info64 = true;
+        return HPF_OK;
+    }
+    h->info64 = false;
     if (h->S == 1) {
         BLASCHK(rocsolver_dgetrf(h->blas, Nsys, Nsys, h->d_J, Nsys, h->d_ipiv, h->d_info));
         BLASCHK(rocsolver_dgetrs(h->blas, rocblas_operation_none, Nsys, 1, h->d_J, Nsys, h->d_ipiv, h->d_f, Nsys));
@@ -672,14 +697,16 @@ int newton_step(hpf_handle* h, const int* active) {
 
 int check_info(hpf_handle* h, const std::vector<int>& was_active) {
     if (!h->d_info) return HPF_OK;
-    std::vector<int> info(h->S);
-    HIPCHK(hipMemcpyAsync(info.data(), h->d_info, sizeof(int) * h->S, hipMemcpyDeviceToHost, h->stream));
+    std::vector<int> info(2 * (size_t)h->S);
+    HIPCHK(hipMemcpyAsync(info.data(), h->d_info, sizeof(int) * 2 * h->S, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    for (int s = 0; s < h->S; ++s)
-        if (was_active[s] >= 0 && info[s] != 0) {
-            h->last_detail = info[s];
+    for (int s = 0; s < h->S; ++s) {
+        const long long v = h->info64 ? reinterpret_cast<const int64_t*>(info.data())[s] : (long long)info[s];
+        if (was_active[s] >= 0 && v != 0) {
+            h->last_detail = (int)v;
             return HPF_E_SINGULAR;
         }
+    }
     return HPF_OK;
 }
 
@@ -841,7 +868,8 @@ int nr_loop(hpf_handle* h, double thresh, int max_iter, int* n_iter, double* err
     // (inv4_cofactor_lane): a scenario in which one amplifies by more than piv_limit, or whose mismatch becomes non-finite, is
     // repeated from the state this call was entered with, with partial pivoting over the whole block (pivoted wave Gauss-Jordan
     // on the uncontracted tree).  hpf_stat.flags bit 3 / bit 4 report it.
-    const bool can_repeat = !FUND && h->solver == HPF_SOLVER_BLOCK_TREE && h->has_ctree && h->gj_mode == 1 && h->auto_repivot;
+    const bool can_repeat = !FUND && h->solver == HPF_SOLVER_BLOCK_TREE && h->has_ctree && h->gj_mode == 1 && h->auto_repivot &&
+                            h->n_ties == 0;      // (the bordered step of a meshed network runs in the bus-image layout of the static-pivot kernels only)
     const size_t count = (size_t)h->n * h->Hn;
     if (!FUND) HIPCHK(hipMemsetAsync(h->d_pivflag, 0, sizeof(int) * S, h->stream));
     if (can_repeat) {
@@ -872,6 +900,7 @@ int nr_loop(hpf_handle* h, double thresh, int max_iter, int* n_iter, double* err
         }
     }
     h->mismatch_valid = false;   // frozen scenarios leave stale rows in d_f: hpf_mismatch before hpf_iterate
+    if (!FUND) h->prev_valid = h->keep_prev && h->d_Vmp;
     if (n_iter) HIPCHK(hipMemcpy(n_iter, h->d_niter, sizeof(int) * S, hipMemcpyDeviceToHost));
     if (err) HIPCHK(hipMemcpy(err, h->d_err, sizeof(double) * S, hipMemcpyDeviceToHost));
     if (err_hist) {
@@ -980,12 +1009,8 @@ int hpf_create(hpf_handle** out, const hpf_desc* d) {
     h->Nc = d->n * d->Hn - 1;
     h->N = 2 * h->Nc - (d->c - 1);
     h->Nf = 2 * d->n - 1 - d->c;
-    // rocSOLVER's LU addresses the matrix with 32-bit element offsets: a dense system beyond N*N = 2^31 faults the GPU.
-    // (1 000 buses x 26 harmonics is already N = 51 998: such feeders need the block-tree solver.)
-    if (d->solver == HPF_SOLVER_DENSE && (long long)h->N * h->N >= (1ll << 31)) {
-        delete h;
-        return HPF_E_ARG;
-    }
+    // (dense systems beyond N * N = 2^31 -- 1 000 buses x 26 harmonics is already N = 51 998 -- go through rocSOLVER's 64-bit entry
+    //  points, dense_solve; memory, 8 N^2 bytes per scenario, is what bounds them: HPF_E_NOMEM from the allocation)
     if (const char* ab = getenv("HPF_DEBUG_ABLATE")) h->debug_ablate = atoi(ab);
     if (const char* gm = getenv("HPF_GJ_MODE")) h->gj_mode = atoi(gm) ? 1 : 0;
     if (const char* lb = getenv("HPF_LEAFBATCH")) h->leafbatch = atoi(lb) ? 1 : 0;
@@ -1005,7 +1030,8 @@ int hpf_create(hpf_handle** out, const hpf_desc* d) {
     if (d->solver == HPF_SOLVER_BLOCK_TREE) {
         // loop-closing lines of a meshed network: the bordered Newton step needs 1 + m virtual scenario slots behind the real ones
         if ((r = tree_find_ties(h, d))) return fail(r);
-        if (h->n_ties > 0) h->S_alloc = h->S_max + 1 + h->m_border;
+        if (h->n_ties > 0) h->gj_mode = 1;           // (HPF_GJ_MODE=0 does not apply: the bordered step needs the static-pivot kernels' layout)
+        if (h->n_ties > 0) h->S_alloc = h->S_max + border_slots(h);
     }
     const size_t HnN = (size_t)d->Hn * d->n, S = (size_t)h->S_alloc;
     const size_t ynsz = (size_t)d->n_dev * d->Hn * (d->coupled ? d->Hn : 1);
@@ -1083,6 +1109,7 @@ int hpf_set_loads(hpf_handle* h, int n_scen, const double* P, const double* Q) {
     HIPCHK(hipStreamSynchronize(h->stream));
     h->loads_set = true;
     h->mismatch_valid = false;
+    h->prev_valid = false;
     return HPF_OK;
 }
 
@@ -1111,6 +1138,7 @@ int hpf_set_state(hpf_handle* h, int n_scen, const double* Vm, const double* Va)
     HIPCHK(hipStreamSynchronize(h->stream));
     h->state_set = true;
     h->mismatch_valid = false;
+    h->prev_valid = false;
     return HPF_OK;
 }
 
@@ -1168,6 +1196,11 @@ int hpf_jacobian(hpf_handle* h, int scen, double* J) { return jacobian_impl(h, f
 int hpf_jacobian_last(hpf_handle* h, int scen, double* J) {
     if (!h || !J || scen < 0 || scen >= h->S) return HPF_E_ARG;
     if (!h->keep_prev || !h->d_Vmp || !h->state_set) return HPF_E_STATE;
+    {   // the kept state exists for scenarios that took at least one Newton step in the last hpf_solve
+        int ni = 0;
+        HIPCHK(hipMemcpy(&ni, h->d_niter + scen, sizeof(int), hipMemcpyDeviceToHost));
+        if (ni <= 0 || !h->prev_valid) return HPF_E_STATE;
+    }
     // assemble at the kept state, then put the current one back (the swap goes through the repeat-pass buffers' siblings)
     const size_t cnt = (size_t)h->S * h->n * h->Hn;
     double *tm = nullptr, *ta = nullptr;
@@ -1270,6 +1303,7 @@ int hpf_set_option(hpf_handle* h, const char* name, int value) {
         return HPF_OK;
     }
     if (!strcmp(name, "block_pivoting")) {          // 1: partial pivoting (wave Gauss-Jordan), 0: static 4x4 blocks on MFMA
+        if (value && h->n_ties > 0) return HPF_E_STATE;    // meshed network: the bordered Newton step exists for the static-pivot kernels only
         h->gj_mode = value ? 0 : 1;
         return HPF_OK;
     }

@@ -60,9 +60,9 @@ class DeviceModel:
         if solver == "block_tree_or_dense":
             solver = "block_tree"
         self.solver = solver
-        if solver == "dense" and N * N >= 2 ** 31:
-            raise ValueError("dense solver: N = %d unknowns exceeds rocSOLVER's 32-bit element addressing (N*N < 2^31); "
-                             "radial feeders and feeders with a few loop-closing lines of this size use solver='block_tree'" % N)
+        if solver == "dense" and 8 * N * N * int(max_scenarios) > 240e9:
+            raise ValueError("dense solver: N = %d unknowns x %d scenarios need %.0f GB for the Jacobians alone; radial feeders and feeders "
+                             "with loop-closing lines of this size use solver='block_tree'" % (N, max_scenarios, 8e-9 * N * N * max_scenarios))
         d = _lib.hpf_desc()
         d.n, d.m, d.c, d.Hn, d.nnz = self.n, self.m, self.c, self.Hn, len(self.col)
         d.n_dev, d.coupled = int(n_dev), int(self.coupled)
@@ -75,7 +75,7 @@ class DeviceModel:
         d.I_N = self.I_N.view(np.float64).ctypes.data_as(_lib.c_dbl_p)
         self._h = C.c_void_p()
         rc = lib.hpf_create(C.byref(self._h), C.byref(d))
-        if rc == -3 and self._solver_request == "block_tree_or_dense" and N * N < 2 ** 31:
+        if rc == -3 and self._solver_request == "block_tree_or_dense" and 8 * N * N * int(max_scenarios) <= 240e9:
             # too many loop-closing lines for the bordered block-tree step: the dense GPU path (still no CPU path anywhere)
             self.solver = "dense"
             d.solver = _lib.SOLVER_DENSE

@@ -30,12 +30,14 @@ extern "C" {
 typedef struct hpf_handle hpf_handle;
 
 enum {
-    HPF_SOLVER_DENSE = 0,      /* dense real FP64 Jacobian, rocSOLVER getrf/getrs (any topology); N*N < 2^31 (N <= 46 340), else HPF_E_ARG */
+    HPF_SOLVER_DENSE = 0,      /* dense real FP64 Jacobian, rocSOLVER getrf/getrs (any topology).  N*N < 2^31 (N <= 46 340): the batched
+                                  32-bit entry points; larger systems (8 N^2 bytes per scenario: 21.6 GB at N = 51 998) go through
+                                  rocSOLVER's 64-bit entry points one scenario after the other; HPF_E_NOMEM when they do not fit */
     HPF_SOLVER_BLOCK_TREE = 1  /* bus-major 2Hn x 2Hn block elimination along the feeder tree.  Radial networks directly; meshed
                                   networks as BFS spanning tree + k loop-closing lines, solved as a bordered system on top of the
-                                  same tree factorisation (1 + m right-hand sides per scenario and Newton step, m = 2Hn x number
-                                  of distinct endpoint buses of the loop-closing lines, m x m border system on rocSOLVER);
-                                  m <= 1024 and 2Hn <= 100, else HPF_E_TOPOLOGY */
+                                  same tree factorisation (m + 2 right-hand sides per scenario and Newton step, m = 2Hn x number
+                                  of distinct endpoint buses of the loop-closing lines, in chunks of up to 256 virtual scenarios;
+                                  m x m border system on rocSOLVER); m <= 16 384 and 2Hn <= 100, else HPF_E_TOPOLOGY */
 };
 
 enum {

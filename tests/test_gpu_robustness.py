@@ -322,11 +322,12 @@ def _add_ties(fl, n, k, seed=42):
     return mgb.add_ties(fl, n, k, seed)
 
 
-@pytest.mark.parametrize("n,hmax,k", [(300, 51, 3), (120, 11, 1), (200, 27, 4)])
+@pytest.mark.parametrize("n,hmax,k", [(300, 51, 3), (120, 11, 1), (200, 27, 4), (260, 51, 12)])
 def test_meshed_feeder_bordered_block_tree_vs_dense(n, hmax, k, tmp_path):
-    """A radial feeder plus k loop-closing lines: BFS spanning tree + bordered system on the block-tree path (1 + m virtual
-    scenarios per Newton step, m x m border system on rocSOLVER; fundamental pf through the dense LU) against the dense
-    rocSOLVER path on the full meshed Jacobian: pf seed, first Newton step, converged voltages (fixed point) within 1e-8."""
+    """A radial feeder plus k loop-closing lines: BFS spanning tree + bordered system on the block-tree path (m + 2 right-hand sides
+    per Newton step in chunks of up to 256 virtual scenarios, m x m border system on rocSOLVER; fundamental pf through the dense LU)
+    against the dense rocSOLVER path on the full meshed Jacobian: pf seed, first Newton step, converged voltages (fixed point)
+    within 1e-8.  The last case (12 tie lines at K = 25: m = 1 196 border unknowns, five chunks) is beyond round 2's bound of 1 024."""
     hp = _hp()
     from harmonic_power_flow_amd import api, synth
     fb, fl = synth.gen(n, seed=4, outdir=str(tmp_path))
@@ -371,6 +372,60 @@ def test_meshed_feeder_bordered_block_tree_vs_dense(n, hmax, k, tmp_path):
     assert d1 <= 1e-8 * max(1.0, step)
     assert ed <= 1e-4 and eb <= 1e-4 and (stb["flags"][0] & 1)
     assert np.abs(Ud - Ub).max() < TOL_V
+
+
+def test_meshed_handle_refuses_the_pivoted_mode(tmp_path):
+    """The bordered Newton step of a meshed network exists in the bus-image layout of the static-pivot kernels only: asking such a handle
+    for partial pivoting (option block_pivoting = 1) is refused with HPF_E_STATE instead of taking silently wrong steps, and env
+    HPF_GJ_MODE=0 does not apply to it."""
+    hp = _hp()
+    from harmonic_power_flow_amd import _lib, api, synth
+    fb, fl = synth.gen(120, seed=4, outdir=str(tmp_path))
+    _add_ties(fl, 120, 2)
+    st = hp.Settings(H_MAX=11)
+    buses, lines, m, nn, c = hp.init_network(fb, fl, settings=st)
+    Y = hp.build_admittance_matrices(buses, lines, st.HARMONICS)
+    NE = hp.import_Norton_Equivalents(buses, True, st, INPUTS)
+    dm = api._device_model(buses, Y, NE, True, st.HARMONICS, solver="block_tree")
+    try:
+        assert dm.tree_census()["ties"] == 2
+        with pytest.raises(_lib.HpfError) as ei:
+            dm.set_option("block_pivoting", 1)
+        assert ei.value.code == -2
+        dm.set_option("block_pivoting", 0)
+    finally:
+        dm.close()
+
+
+def test_dense_solver_beyond_32_bit_offsets_matches_the_block_tree_step(tmp_path):
+    """N = 51 998 (the headline feeder as ONE dense system, 21.6 GB): beyond rocSOLVER's 32-bit element offsets, refused until round 2;
+    now through the 64-bit entry points.  The first Newton step from the same pf seed against the block-tree path (the second one
+    already amplifies the rounding difference of two solvers a thousandfold on this feeder: SURVEY.md trap #2)."""
+    hp = _hp()
+    from harmonic_power_flow_amd import api
+    st, buses, Y, NE, _ = _feeder(hp, 1000, 51, tmp_path, seed=0)
+    out = {}
+    for solver in ("block_tree", "dense"):
+        dm = api._device_model(buses, Y, NE, True, st.HARMONICS, solver=solver)
+        try:
+            assert dm.N == 51998
+            dm.set_loads(buses["P"].to_numpy(float), buses["Q"].to_numpy(float))
+            dm.set_state(None, None, n_scen=1)
+            dm.fund_pf(1e-6, 30)
+            if out:
+                dm.set_state(*out["block_tree"][0])
+            v0 = dm.get_state()
+            dm.mismatch(want_f=False)
+            dm.iterate(1)
+            dm.sync()
+            out[solver] = (v0, dm.get_state())
+        finally:
+            dm.close()
+    (v0, vb), (_, vd) = out["block_tree"], out["dense"]
+    step = max(np.abs(vb[0] - v0[0]).max(), np.abs(vb[1] - v0[1]).max())
+    d = max(np.abs(vb[0] - vd[0]).max(), np.abs(vb[1] - vd[1]).max())
+    print("\ndense (64-bit rocSOLVER) vs block tree after one Newton iteration: %.2e (step of %.1e)" % (d, step))
+    assert d <= 1e-8 * max(1.0, step)
 
 
 def test_meshed_headline_feeder_vs_oracle_fixture(tmp_path):
