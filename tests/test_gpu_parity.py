@@ -226,7 +226,20 @@ def test_reference_nets_through_the_bordered_block_tree_path(name):
     assert err_h <= 1e-4 and n_iter_h < 50
     if name not in SOLVER_SENSITIVE and name != "net2_H51_c":      # (net2 K=25 coupled: the strict case, its count holds on the dense path)
         assert n_iter_h == int(g["n_iter_h"])
-    assert np.abs(Ud - Ug).max() < (TOL_V if n_iter_h == int(g["n_iter_h"]) else 1e-6)
+    if n_iter_h == int(g["n_iter_h"]):
+        assert np.abs(Ud - Ug).max() < TOL_V
+    else:
+        # another iteration count = another iterate below the stop threshold: what the stop rule guarantees at the stopped iterates,
+        # and the north-star tolerance at the FIXED POINT -- the reference's algorithm (the oracle, bit-identical to it on this case)
+        # continued until the mismatch stops falling, against this path continued by three more iterations
+        assert np.abs(Ud - Ug).max() < 1e-6
+        r = o.hpf(o.init_network(*_paths(net_name)), st.HARMONICS, coupled, INPUTS, thresh_h=1e-13, max_iter_h=int(g["n_iter_h"]) + 6)
+        Uo = r["Vm"] * np.exp(1j * r["Va"])
+        V2, _, _, _ = hp.hpf(buses, lines, coupled, settings=st, ne_dir=INPUTS, verbose=False, solver="block_tree", return_jacobian=False,
+                             extra_iters=3)
+        U2 = V2["V_m"].to_numpy() * np.exp(1j * V2["V_a"].to_numpy())
+        print(f"   fixed points (oracle continued to err {r['err_h']:.1e}): max|dU| {np.abs(U2 - Uo).max():.2e}")
+        assert np.abs(U2 - Uo).max() < TOL_V
 
 
 def test_max_iter_and_nonconvergence_reporting():
