@@ -68,11 +68,16 @@ def build_inputs(args, hp):
     tmp = tempfile.mkdtemp(prefix="hpf_bench_")
     fb, fl = synth.gen(args.buses, seed=0, outdir=tmp)
     st = hp.Settings(H_MAX=args.hmax)
+    t0 = time.perf_counter()
     buses, lines, m, n, c = hp.init_network(fb, fl, settings=st)
+    t1 = time.perf_counter()
     Y = hp.build_admittance_matrices(buses, lines, st.HARMONICS)
+    t2 = time.perf_counter()
     NE = hp.import_Norton_Equivalents(buses, True, st, INPUTS)
     dev, Y_N, I_N, n_dev = ingest.norton_arrays(buses, NE, True, len(st.HARMONICS))
-    return dict(st=st, buses=buses, n=n, m=m, c=c, Y=Y, dev=dev, Y_N=Y_N, I_N=I_N, n_dev=n_dev, files=(fb, fl))
+    t3 = time.perf_counter()
+    setup = {"ingest_csv_ms": 1e3 * (t1 - t0), "admittance_ms": 1e3 * (t2 - t1), "norton_ms": 1e3 * (t3 - t2)}
+    return dict(st=st, buses=buses, n=n, m=m, c=c, Y=Y, dev=dev, Y_N=Y_N, I_N=I_N, n_dev=n_dev, files=(fb, fl), setup=setup)
 
 
 def cpu_model():
@@ -155,6 +160,9 @@ def main():
     dm = hp.DeviceModel(n, inp["m"], inp["c"], inp["st"].HARMONICS, inp["Y"].rowptr, inp["Y"].col, inp["Y"].Yval,
                         inp["dev"], inp["Y_N"], inp["I_N"], inp["n_dev"], True, solver=args.solver,
                         device=dev_index, max_scenarios=S)
+    setup = dict(inp["setup"])
+    setup.update(dm.setup_times())                       # hpf_create: tree planning on the host, uploads, per-scenario allocation
+    setup["model_setup_ms"] = setup["ingest_csv_ms"] + setup["admittance_ms"] + setup["norton_ms"] + setup["create_ms"]
     dm.set_loads(P0 * scale, Q0 * scale)
     dm.set_state(None, None, n_scen=S)
     nf, _, _ = dm.fund_pf(inp["st"].thresh_f, inp["st"].max_iter_f)
@@ -273,6 +281,7 @@ def main():
                    "solver": dm.solver, "step": "one NR iteration of every scenario (HG:537-540)",
                    "pf_iterations": int(nf.max())},
         "ms_per_iter_per_scenario": ms_step / S,
+        "setup_ms": setup["model_setup_ms"], "setup": setup,
         "roofline": {"bound": "hbm",
                      "kernel": kdesc, "tree_census": census,
                      "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",

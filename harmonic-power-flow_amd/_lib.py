@@ -64,6 +64,7 @@ SYMBOLS = {
     "hpf_back_bytes": (C.c_double, [_H]),
     "hpf_kernel_model": (C.c_int, [_H, C.c_int, c_dbl_p, c_dbl_p, c_int_p]),
     "hpf_tree_census": (C.c_int, [_H, c_int_p, C.c_int]),
+    "hpf_setup_times": (C.c_int, [_H, c_dbl_p, C.c_int]),
     "hpf_scenario_groups": (C.c_int, [_H, C.c_int]),
     "hpf_tree_plan": (C.c_int, [C.POINTER(hpf_desc), C.c_char_p]),
 }

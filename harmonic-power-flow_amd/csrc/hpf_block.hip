@@ -17,10 +17,12 @@
 // broadcast through LDS (2 barriers per step); Z_k (b x b) and w_k (b) are the only HBM writes.
 // Bound: FP64 FMA rate (2 b^3 flop per bus) against 24 b^2 bytes of Z traffic per bus -> ~4.3 flop/B at b = 52.
 #include <algorithm>
+#include <chrono>
 #include <complex>
 #include <cstdio>
 #include <cstdlib>
 #include <rocsolver/rocsolver.h>
+#include <thread>
 
 #include "hpf_internal.hpp"
 #include "hpf_gj.hpp"
@@ -1026,10 +1028,43 @@ __global__ __launch_bounds__(256) void k_border_finish(int count, int r, int v0,
 
 }  // namespace
 
+// row update of the host-side complex Gauss-Jordan (tree_build_into): r -= f * c on split re / im rows; an AVX2 build of the same loop is
+// picked at run time where the CPU has it (the set-up of a 10 000-bus model is two thousand 49 x 49 complex inversions)
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+__attribute__((target("avx2"))) static void cplx_row_axpy_avx2(double* __restrict__ rr, double* __restrict__ ri, const double* __restrict__ cr,
+                                                                const double* __restrict__ ci, double fr, double fi, int nn) {
+    for (int c2 = 0; c2 < nn; ++c2) {
+        rr[c2] -= fr * cr[c2] - fi * ci[c2];
+        ri[c2] -= fr * ci[c2] + fi * cr[c2];
+    }
+}
+#endif
+// host threads of the model set-up (HPF_HOST_THREADS, default: the hardware's, at most 16)
+static unsigned host_threads() {
+    if (const char* e = getenv("HPF_HOST_THREADS")) return atoi(e) < 1 ? 1u : (unsigned)atoi(e);
+    const unsigned hw = std::thread::hardware_concurrency();
+    return hw < 1 ? 1u : (hw > 16 ? 16u : hw);
+}
+static void cplx_row_axpy(double* __restrict__ rr, double* __restrict__ ri, const double* __restrict__ cr, const double* __restrict__ ci,
+                          double fr, double fi, int nn) {
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+    static const bool has_avx2 = __builtin_cpu_supports("avx2");
+    if (has_avx2) {
+        cplx_row_axpy_avx2(rr, ri, cr, ci, fr, fi, nn);
+        return;
+    }
+#endif
+    for (int c2 = 0; c2 < nn; ++c2) {
+        rr[c2] -= fr * cr[c2] - fi * ci[c2];
+        ri[c2] -= fr * ci[c2] + fi * cr[c2];
+    }
+}
+
 namespace hpf {
 
 static void tree_free_one_fwd(Tree& T);
 static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contract) {
+    const auto t_begin = std::chrono::steady_clock::now();
     const int n = d->n;
     const int b = 2 * d->Hn;
     if (b > 16 * 7) return HPF_E_ARG;                          // register tile limit (K <= 55)
@@ -1454,6 +1489,10 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
             return (long long)(e >> 1) * 2 * RG + (wv < NTq - 1 ? wv * 128 + (lg * 16 + jj) * 2 : (NTq - 1) * 128 + (lg * LW + jj) * 2) + (e & 1);
         return (long long)NP * 2 * RG + (wv < NTq - 1 ? wv * 64 + lg * 16 + jj : (NTq - 1) * 64 + lg * LW + jj);
     };
+    std::vector<int> toff_tab((size_t)b * b, -1);                // tile_off of every (row, col) of a block, once
+    if (BWc)
+        for (int row = 0; row < b; ++row)
+            for (int col = 0; col < b; ++col) toff_tab[(size_t)row * b + col] = (int)tile_off(row, col);
     if (contract && d->coupled && BWc) {
         typedef std::complex<double> cd;
         const int Hn = d->Hn, nnz = d->nnz;
@@ -1555,38 +1594,70 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
             //     [Ah0      Ahh]      =    [0  Ahh^-1] + [ Lc_h ] (c0 + D)^-1  [ I  Lr_h ],   Lc_h = -Ahh^-1 Ah0,  Lr_h = -A0h Ahh^-1,
             // c0 = a00 - A0h Ahh^-1 Ah0.  Everything but D is constant: keep R(Ahh^-1), R(Lc_h), R(Lr_h), R(c0) as ONE b x b image
             // (additive rank-2 update on the device: no cancellation, unlike a Woodbury correction of the full inverse).
-            std::vector<cd> Ah((size_t)Hh * Hh), Bh((size_t)Hh * Hh, cd(0.0, 0.0));
+            // (in-place complex Gauss-Jordan with partial pivoting in plain re / im arithmetic: std::complex products go through the
+            //  checked library routine, several times slower -- this inversion is what the set-up of a 10 000-bus model spends its time in)
+            std::vector<double> ar((size_t)Hh * Hh), ai((size_t)Hh * Hh);
+            std::vector<int> pv(Hh > 0 ? Hh : 1, 0);
             for (int q = 0; q < Hh; ++q)
-                for (int p2 = 0; p2 < Hh; ++p2) Ah[(size_t)q * Hh + p2] = Yc[(size_t)(q + 1) * Hn + p2 + 1];
-            for (int q = 0; q < Hh; ++q) Bh[(size_t)q * Hh + q] = cd(1.0, 0.0);
+                for (int p2 = 0; p2 < Hh; ++p2) {
+                    ar[(size_t)q * Hh + p2] = Yc[(size_t)(q + 1) * Hn + p2 + 1].real();
+                    ai[(size_t)q * Hh + p2] = Yc[(size_t)(q + 1) * Hn + p2 + 1].imag();
+                }
             bool ok = true;
-            for (int col = 0; col < Hh && ok; ++col) {                // complex Gauss-Jordan with partial pivoting
+            for (int col = 0; col < Hh && ok; ++col) {
                 int piv = col;
-                for (int r2 = col + 1; r2 < Hh; ++r2)
-                    if (std::abs(Ah[(size_t)r2 * Hh + col]) > std::abs(Ah[(size_t)piv * Hh + col])) piv = r2;
-                if (std::abs(Ah[(size_t)piv * Hh + col]) == 0.0) {
+                double best = -1.0;
+                for (int r2 = col; r2 < Hh; ++r2) {
+                    const double xr = ar[(size_t)r2 * Hh + col], xi = ai[(size_t)r2 * Hh + col], mg = xr * xr + xi * xi;
+                    if (mg > best) {
+                        best = mg;
+                        piv = r2;
+                    }
+                }
+                if (best == 0.0 || !(best == best)) {
                     ok = false;
                     break;
                 }
-                if (piv != col)
+                pv[col] = piv;
+                double* __restrict__ cr = &ar[(size_t)col * Hh];
+                double* __restrict__ ci = &ai[(size_t)col * Hh];
+                if (piv != col) {
+                    double* __restrict__ qr = &ar[(size_t)piv * Hh];
+                    double* __restrict__ qi = &ai[(size_t)piv * Hh];
                     for (int c2 = 0; c2 < Hh; ++c2) {
-                        std::swap(Ah[(size_t)piv * Hh + c2], Ah[(size_t)col * Hh + c2]);
-                        std::swap(Bh[(size_t)piv * Hh + c2], Bh[(size_t)col * Hh + c2]);
+                        std::swap(cr[c2], qr[c2]);
+                        std::swap(ci[c2], qi[c2]);
                     }
-                const cd ip = cd(1.0, 0.0) / Ah[(size_t)col * Hh + col];
+                }
+                const cd ip = cd(1.0, 0.0) / cd(cr[col], ci[col]);
+                const double pr = ip.real(), pi = ip.imag();
+                cr[col] = 1.0;
+                ci[col] = 0.0;
                 for (int c2 = 0; c2 < Hh; ++c2) {
-                    Ah[(size_t)col * Hh + c2] *= ip;
-                    Bh[(size_t)col * Hh + c2] *= ip;
+                    const double xr = cr[c2], xi = ci[c2];
+                    cr[c2] = xr * pr - xi * pi;
+                    ci[c2] = xr * pi + xi * pr;
                 }
                 for (int r2 = 0; r2 < Hh; ++r2) {
                     if (r2 == col) continue;
-                    const cd fct = Ah[(size_t)r2 * Hh + col];
-                    if (fct == cd(0.0, 0.0)) continue;
-                    for (int c2 = 0; c2 < Hh; ++c2) {
-                        Ah[(size_t)r2 * Hh + c2] -= fct * Ah[(size_t)col * Hh + c2];
-                        Bh[(size_t)r2 * Hh + c2] -= fct * Bh[(size_t)col * Hh + c2];
-                    }
+                    double* __restrict__ rr = &ar[(size_t)r2 * Hh];
+                    double* __restrict__ ri = &ai[(size_t)r2 * Hh];
+                    const double fr = rr[col], fi = ri[col];
+                    if (fr == 0.0 && fi == 0.0) continue;
+                    rr[col] = 0.0;
+                    ri[col] = 0.0;
+                    cplx_row_axpy(rr, ri, cr, ci, fr, fi, Hh);
                 }
+            }
+            std::vector<cd> Bh((size_t)Hh * Hh);
+            if (ok) {
+                for (int col = Hh - 1; col >= 0; --col)               // undo the row exchanges: columns of the inverse, in reverse
+                    if (pv[col] != col)
+                        for (int r2 = 0; r2 < Hh; ++r2) {
+                            std::swap(ar[(size_t)r2 * Hh + col], ar[(size_t)r2 * Hh + pv[col]]);
+                            std::swap(ai[(size_t)r2 * Hh + col], ai[(size_t)r2 * Hh + pv[col]]);
+                        }
+                for (size_t e = 0; e < Bh.size(); ++e) Bh[e] = cd(ar[e], ai[e]);
             }
             if (!ok) return false;                                   // singular constant part: leave the bus on the general path
             img.assign((size_t)Hn * Hn, cd(0.0, 0.0));               // complex image: [c0 Lr_h; Lc_h Ahh^-1]
@@ -1605,25 +1676,59 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
             img[0] = c0;
             return true;
         };
+        // the leaves' constant images (one complex (Hn-1) x (Hn-1) inversion each) are independent of each other: host threads
+        struct LeafPre {
+            std::vector<cd> Yc, geff, heff, img;
+            bool ok = false;
+        };
+        std::vector<int> leaf_pos(n, -1);
+        std::vector<LeafPre> pre;
+        {
+            std::vector<int> cand;
+            for (int pos = 0; pos < T.n_dense; ++pos) {
+                const int k = T.lvl_nodes[pos];
+                if (k < d->m || dchild_ptr[k + 1] != dchild_ptr[k] || d->dev_of_bus[k] < 0) continue;
+                leaf_pos[k] = (int)cand.size();
+                cand.push_back(k);
+            }
+            pre.resize(cand.size());
+            unsigned nth = host_threads();
+            if ((size_t)nth > cand.size() / 8 + 1) nth = (unsigned)(cand.size() / 8 + 1);
+            auto work = [&](unsigned t0) {
+                for (size_t ci = t0; ci < cand.size(); ci += nth) {
+                    LeafPre& lp = pre[ci];
+                    build_Yc(cand[ci], lp.Yc, lp.geff, lp.heff);
+                    lp.ok = border_image(lp.Yc, lp.img);
+                }
+            };
+            std::vector<std::thread> pool;
+            for (unsigned t0 = 1; t0 < nth; ++t0) pool.emplace_back(work, t0);
+            work(0);
+            for (std::thread& th : pool) th.join();
+        }
+        // slots in elimination order, then the images of all leaves at once (host threads again: 100 KB of image per leaf at b = 100)
+        std::vector<int> leaf_list;
         for (int pos = 0; pos < T.n_dense; ++pos) {
             const int k = T.lvl_nodes[pos];
-            if (k < d->m || dchild_ptr[k + 1] != dchild_ptr[k] || d->dev_of_bus[k] < 0) continue;
-            std::vector<cd> Yc, geff, heff, img;
-            build_Yc(k, Yc, geff, heff);
-            if (!border_image(Yc, img)) continue;
+            if (leaf_pos[k] < 0 || !pre[leaf_pos[k]].ok) continue;
             cleaf_of[k] = T.n_cleaf++;
-            minv.resize((size_t)T.n_cleaf * CTc, 0.0);
+            leaf_list.push_back(k);
+        }
+        minv.assign((size_t)T.n_cleaf * CTc, 0.0);
+        const int NTRl = (BWc + 15) / 16, KSl = (BWc + 3) / 4, SZl = NTRl * KSl * 64 + 2 * BWc + 4;
+        if (BWc <= 52) lbimg.assign((size_t)T.n_cleaf * SZl, 0.0);
+        auto fill_leaf = [&](int k) {
+            const std::vector<cd>& img = pre[leaf_pos[k]].img;
             double* Mt = &minv[(size_t)cleaf_of[k] * CTc];
             for (int row = 0; row < b; ++row)                          // (rows / columns beyond b: zeros)
                 for (int col = 0; col < b; ++col) {
                     const cd z = img[(size_t)(row >> 1) * Hn + (col >> 1)];
                     const int t = row & 1, t2 = col & 1;              // R(z) = [re -im; im re]
-                    const long long o = tile_off(row, col);
+                    const int o = toff_tab[(size_t)row * b + col];
                     if (o >= 0) Mt[o] = (t == t2) ? z.real() : (t ? z.imag() : -z.imag());
                 }
             if (BWc <= 52) {   // the same constants for k_leaf_batch: [0 Lr; 0 Ahh^-1] in MFMA A-operand layout, R(Lc), R(c0)
-                const int NTR = (BWc + 15) / 16, KS = (BWc + 3) / 4, SZ = NTR * KS * 64 + 2 * BWc + 4;
-                lbimg.resize((size_t)T.n_cleaf * SZ, 0.0);
+                const int NTR = NTRl, KS = KSl, SZ = SZl;
                 double* L = &lbimg[(size_t)cleaf_of[k] * SZ];
                 auto Rz = [](cd z, int t, int t2) { return (t == t2) ? z.real() : (t ? z.imag() : -z.imag()); };
                 for (int w2 = 0; w2 < NTR; ++w2)
@@ -1642,6 +1747,20 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
                 double* C0 = Lc + 2 * BWc;
                 C0[0] = img[0].real(); C0[1] = -img[0].imag(); C0[2] = img[0].imag(); C0[3] = img[0].real();
             }
+        };
+        {
+            unsigned nth = host_threads();
+            if ((size_t)nth > leaf_list.size() / 8 + 1) nth = (unsigned)(leaf_list.size() / 8 + 1);
+            auto work = [&](unsigned t0) {
+                for (size_t li = t0; li < leaf_list.size(); li += nth) fill_leaf(leaf_list[li]);
+            };
+            std::vector<std::thread> pool;
+            for (unsigned t0 = 1; t0 < nth; ++t0) pool.emplace_back(work, t0);
+            work(0);
+            for (std::thread& th : pool) th.join();
+        }
+        for (int k : leaf_list) {
+            const std::vector<cd>&geff = pre[leaf_pos[k]].geff, &heff = pre[leaf_pos[k]].heff, &img = pre[leaf_pos[k]].img;
             const int pk = pard[k];                                   // dense parent, directly or through a contracted chain
             const bool direct = chain_of[k] < 0;
             if (lazy_on && (direct || lazy_mode >= 2) && pk >= (d->c > 1 ? d->c : 1) && (int)lazy_of[pk].size() < LZ_MAX) {
@@ -2239,6 +2358,8 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
             fclose(fp);
         }
     }
+    T.plan_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    if (getenv("HPF_TREE_INFO")) fprintf(stderr, "hpf tree (%s): planned on the host in %.1f ms\n", contract ? "contracted" : "plain", T.plan_ms);
     int r;
     if ((r = upload(h, &T.d_parent, T.parent))) return r;
     if ((r = upload(h, &T.d_lvl_nodes, T.lvl_nodes))) return r;
@@ -2723,6 +2844,11 @@ int tree_find_ties(hpf_handle* h, const hpf_desc* d) {
 //   pass 2: x = J_t^-1 (f - E_T g), one more sweep in the first virtual slot.
 // Nothing of Z = J_t^-1 E_T is kept, so m is bounded by the dense border system only.  Called with the launch context on h->stream
 // over real slots.
+int ensure_blas(hpf_handle* h) {
+    if (h->blas) return HPF_OK;
+    return rocblas_create_handle(&h->blas) == rocblas_status_success ? HPF_OK : HPF_E_ROCSOLVER;
+}
+
 int border_slots(const hpf_handle* h) { return h->m_border + 1 < 256 ? h->m_border + 1 : 256; }
 
 int tree_newton_step_bordered(hpf_handle* h, bool only_active) {
@@ -2769,7 +2895,7 @@ int tree_newton_step_bordered(hpf_handle* h, bool only_active) {
             hipLaunchKernelGGL(k_border_build, dim3((unsigned)((m + 255) / 256), (unsigned)V), dim3(256), 0, st, h->M, BW, b, r, v0, c0, m,
                                h->d_tb_bus, h->d_tb_ptr, h->d_tb_adj, h->d_U, h->d_E, h->d_x, h->d_bM, h->d_brhs);
         }
-        if (rocblas_set_stream(h->blas, st) != rocblas_status_success) return HPF_E_ROCSOLVER;
+        if (ensure_blas(h) || rocblas_set_stream(h->blas, st) != rocblas_status_success) return HPF_E_ROCSOLVER;
         if (rocsolver_dgetrf(h->blas, m, m, h->d_bM, m, h->d_bipiv, h->d_binfo) != rocblas_status_success ||
             rocsolver_dgetrs(h->blas, rocblas_operation_none, m, 1, h->d_bM, m, h->d_bipiv, h->d_brhs, m) != rocblas_status_success)
             return HPF_E_ROCSOLVER;

@@ -118,6 +118,7 @@ struct Tree {
     int n_comp = 0;
     std::vector<int> comp_v, comp_c;
     int* d_comp_child = nullptr;      // [n_comp] c of compress step i (k_back_q: x_v needs x_c)
+    double plan_ms = 0.0;             // host time of tree_build_into up to the uploads
     double flops_per_solve = 0.0;     // factor sweep + back sweep
     double flops_factor = 0.0;        // factor sweep only (k_tree_factor, all levels)
     double bytes_back = 0.0;          // algorithmic HBM bytes of the dense back sweep, one scenario and step
@@ -216,6 +217,7 @@ struct hpf_handle {
     hipStream_t gstream[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t fork_ev = nullptr, join_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     rocblas_handle blas = nullptr;
+    double setup_ms[4] = {0, 0, 0, 0}; // hpf_create: total | tree planning on the host | tree uploads | per-scenario allocation
     int timing = 0;                   // hpf_timing_enable: 1 HIP-event spans + device stamps, 2 device stamps only (no event packets between kernels)
     std::vector<hpf::TimedSpan> spans;
     double t_ms[hpf::T_COUNT] = {0, 0, 0, 0, 0, 0, 0};
@@ -256,6 +258,7 @@ int tree_alloc_scenarios(hpf_handle* h);
 int tree_fund_step(hpf_handle* h, bool only_active);     // fundamental pf Newton step on the tree (2x2 blocks)
 int tree_newton_step(hpf_handle* h, bool only_active);   // assembles, eliminates, back-substitutes -> d_f holds the step
 int tree_newton_step_bordered(hpf_handle* h, bool only_active);   // the same for a network with loop-closing lines (h->n_ties > 0)
+int ensure_blas(hpf_handle* h);                                   // rocBLAS handle on first use (dense LU, border system)
 int border_slots(const hpf_handle* h);                            // virtual scenario slots of the bordered step (behind the S_max real ones)
 
 }  // namespace hpf

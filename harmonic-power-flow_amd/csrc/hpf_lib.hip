@@ -12,6 +12,7 @@
 //   k_mismatch   HBM: 16*Hn*nnz (Y) + 16*Hn*n (U) + 8*N (f) + pattern;   k_jac_*  HBM: Y + U,E + 32*E_cplx written;
 //   dense solve  FP64 matrix pipe: 2/3 N^3 + 2 N^2 flop (rocSOLVER getrf/getrs).
 #include <math.h>
+#include <chrono>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -636,6 +637,7 @@ int launch_jacobian_dense(hpf_handle* h, const int* active) {
 int dense_solve(hpf_handle* h, int Nsys) {
     ScopedTimer t(h, T_SOLVE);
     if (Nsys <= 0) return HPF_OK;
+    if (ensure_blas(h)) return HPF_E_ROCSOLVER;
     BLASCHK(rocblas_set_stream(h->blas, h->stream));
     if ((long long)Nsys * Nsys >= (1ll << 31)) {
         // beyond 32-bit element offsets (N > 46 340, e.g. the 1 000-bus x 26-harmonic feeder as a dense system: 21.6 GB per scenario):
@@ -998,6 +1000,7 @@ int hpf_create(hpf_handle** out, const hpf_desc* d) {
     }
     hpf_handle* h = new (std::nothrow) hpf_handle();
     if (!h) return HPF_E_NOMEM;
+    const auto t_create = std::chrono::steady_clock::now();
     int r = HPF_OK;
     auto fail = [&](int code) {
         free_all(h);
@@ -1025,7 +1028,8 @@ int hpf_create(hpf_handle** out, const hpf_desc* d) {
     }
     if (hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming) != hipSuccess) return fail(HPF_E_HIP);
     set_ctx(h, h->stream, 0, 0);
-    if (rocblas_create_handle(&h->blas) != rocblas_status_success) return fail(HPF_E_ROCSOLVER);
+    // (the rocBLAS handle is created on first use, ensure_blas: the radial block-tree path never needs it and its creation costs
+    //  more than the whole set-up of a 10 000-bus model)
     h->S_alloc = h->S_max;
     if (d->solver == HPF_SOLVER_BLOCK_TREE) {
         // loop-closing lines of a meshed network: the bordered Newton step needs 1 + m virtual scenario slots behind the real ones
@@ -1079,9 +1083,15 @@ int hpf_create(hpf_handle** out, const hpf_desc* d) {
     M.rowptr = h->d_rowptr; M.col = h->d_col; M.diag = h->d_diag; M.Y = h->d_Y; M.dev = h->d_dev;
     M.YN = h->d_YN; M.IN = h->d_IN; M.YNt = h->d_YNt;
     if (d->solver == HPF_SOLVER_BLOCK_TREE) {
+        const auto t_tree = std::chrono::steady_clock::now();
         if ((r = tree_build(h, d))) return fail(r);
+        h->setup_ms[1] = h->tree.plan_ms + h->ctree.plan_ms;
+        h->setup_ms[2] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_tree).count() - h->setup_ms[1];
+        const auto t_al = std::chrono::steady_clock::now();
         if ((r = tree_alloc_scenarios(h))) return fail(r);
+        h->setup_ms[3] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_al).count();
     }
+    h->setup_ms[0] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_create).count();
     *out = h;
     return HPF_OK;
 }
@@ -1463,6 +1473,12 @@ int hpf_tree_census(const hpf_handle* h, int* counts, int n_counts) {
     const Tree& T = active_tree(const_cast<hpf_handle*>(h));
     const int fused = (h->fuse_levels && h->gj_mode == 1 && 2 * h->Hn <= 52) ? 1 : 0;
     for (int i = 0; i < n_counts; ++i) counts[i] = i < 8 ? T.census[i] : (i == 8 ? h->n_ties : (i == 9 ? fused : (i == 10 ? T.n_comp : 0)));
+    return HPF_OK;
+}
+
+int hpf_setup_times(const hpf_handle* h, double* ms, int n_ms) {
+    if (!h || !ms || n_ms < 0) return HPF_E_ARG;
+    for (int i = 0; i < n_ms; ++i) ms[i] = i < 4 ? h->setup_ms[i] : 0.0;
     return HPF_OK;
 }
 

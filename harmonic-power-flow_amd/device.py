@@ -222,6 +222,12 @@ class DeviceModel:
             out[name] = (ms.value, cnt.value)
         return out
 
+    def setup_times(self):
+        """Milliseconds hpf_create spent: total, tree planning on the host, tree uploads, per-scenario allocation (hpf_setup_times)."""
+        ms = (C.c_double * 4)()
+        self._chk(self.lib.hpf_setup_times(self._h, ms, 4), "hpf_setup_times")
+        return dict(zip(("create_ms", "tree_plan_ms", "tree_upload_ms", "alloc_ms"), (float(v) for v in ms)))
+
     def scenario_groups(self, live):
         """Scenario groups (streams) a step of `live` running scenarios is split into (hpf_scenario_groups)."""
         return int(self.lib.hpf_scenario_groups(self._h, int(live)))

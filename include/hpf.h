@@ -231,6 +231,10 @@ int  hpf_kernel_model(const hpf_handle* h, int which, double* bytes, double* flo
  * [10] compress steps (Gauss-Jordan buses eliminated before their tallest dense child: levels counts the shortened chain).
  * HPF_E_STATE for DENSE. */
 int  hpf_tree_census(const hpf_handle* h, int* counts, int n_counts);
+/* Wall-clock milliseconds hpf_create spent: ms[0] total, [1] planning the elimination trees on the host (classification of the buses,
+ * per-model constant images: complex inversions on host threads, env HPF_HOST_THREADS), [2] uploading them, [3] allocating the
+ * per-scenario state.  (The host-side ingest and admittance build happen before hpf_create, in the Python layer.) */
+int  hpf_setup_times(const hpf_handle* h, double* ms, int n_ms);
 /* Number of scenario groups (independent pipelines on separate HIP streams) a Newton step of `live` running scenarios is split into:
  * option "scenario_groups" bounded by a minimum group size; 1 for DENSE and for meshed networks. */
 int  hpf_scenario_groups(const hpf_handle* h, int live);

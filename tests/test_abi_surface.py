@@ -40,15 +40,14 @@ def test_create_rejects_bad_arguments_without_gpu():
     assert lib.hpf_solve(None, 1e-4, 50, None, None, None) == -1
 
 
-def test_dense_solver_size_limit_is_refused_on_the_host():
-    """rocSOLVER addresses the dense Jacobian with 32-bit element offsets: N*N >= 2^31 must be refused before any HIP
-    call (it would fault the GPU), by the C ABI and by the Python host."""
-    import ctypes as C
+def test_dense_solver_memory_limit_is_refused_on_the_host():
+    """Dense systems beyond N*N = 2^31 run through rocSOLVER's 64-bit entry points since round 3 (GPU test
+    test_dense_solver_beyond_32_bit_offsets_matches_the_block_tree_step); what the Python host still refuses before any HIP call is a
+    dense model whose Jacobians cannot fit the GPU (8 N^2 bytes per scenario)."""
     import numpy as np
     import pytest
-    from harmonic_power_flow_amd import _lib
     from harmonic_power_flow_amd.device import DeviceModel
-    n, Hn = 1000, 26                                            # N = 51 998
+    n, Hn = 1000, 26                                            # N = 51 998: 21.6 GB per scenario
     rows = [[i - 1, i, i + 1] for i in range(n)]
     rows[0], rows[-1] = [0, 1], [n - 2, n - 1]
     rowptr = np.cumsum([0] + [len(r) for r in rows]).astype(np.int32)
@@ -58,14 +57,7 @@ def test_dense_solver_size_limit_is_refused_on_the_host():
     dev[650:] = 0
     YN, IN = np.zeros((1, Hn, Hn), dtype=np.complex128), np.zeros((1, Hn), dtype=np.complex128)
     with pytest.raises(ValueError, match="block_tree"):
-        DeviceModel(n, 650, 1, list(range(1, 2 * Hn, 2)), rowptr, col, Yval, dev, YN, IN, 1, True, solver="dense")
-    d = _lib.hpf_desc()
-    d.n, d.m, d.c, d.Hn, d.nnz, d.n_dev, d.coupled, d.solver, d.device, d.max_scenarios = n, 650, 1, Hn, len(col), 1, 1, 0, 0, 1
-    dp = lambda a: a.view(np.float64).ctypes.data_as(_lib.c_dbl_p)
-    d.rowptr, d.col = rowptr.ctypes.data_as(_lib.c_int_p), col.ctypes.data_as(_lib.c_int_p)
-    d.Yval, d.dev_of_bus, d.Y_N, d.I_N = dp(Yval), dev.ctypes.data_as(_lib.c_int_p), dp(YN), dp(IN)
-    h = C.c_void_p()
-    assert _lib.load().hpf_create(C.byref(h), C.byref(d)) == -1
+        DeviceModel(n, 650, 1, list(range(1, 2 * Hn, 2)), rowptr, col, Yval, dev, YN, IN, 1, True, solver="dense", max_scenarios=16)
 
 
 def test_every_environment_switch_of_the_library_is_documented_in_the_header():
