@@ -11,6 +11,8 @@
 #pragma once
 
 constexpr int LB_SB = 16;      // scenarios per workgroup
+constexpr int LBP = LB_SB + 1; // row stride of the [row][scenario] arrays in LDS (odd: a wave's 16 rows x 4 scenarios spread over the banks
+                               // instead of meeting in one bank pair -- LDS bank conflicts per LDS instruction 6.9 -> see profiles/r03)
 
 // per-leaf constants (Tree::d_lbimg): A-operand image [NTR][KS][64] | Lc as real b x 2 | c0 2x2
 template <int B>
@@ -29,7 +31,7 @@ struct SleafImg {
     static constexpr bool QB_ROWS = 16 * NTR - B >= 10;
 };
 
-constexpr int LEAF_BATCH_LDS = 2 * 64 * LB_SB + LB_SB * 4 + LB_SB * 2;      // doubles
+constexpr int LEAF_BATCH_LDS = 2 * 64 * LBP + LB_SB * 4 + LB_SB * 2;      // doubles
 
 template <int B>
 __device__ __forceinline__ void leaf_batch_body(
@@ -63,8 +65,8 @@ __device__ __forceinline__ void leaf_batch_body(
     const double* c0img = lcimg + 2 * B;
 
     double* Y = smem_;                                       // right-hand sides [row][scenario]
-    double* V = Y + 64 * LB_SB;                              // [0 Lr; 0 Ahh^-1] y
-    double* DL = V + 64 * LB_SB;                             // Delta_polar per scenario
+    double* V = Y + 64 * LBP;                              // [0 Lr; 0 Ahh^-1] y
+    double* DL = V + 64 * LBP;                             // Delta_polar per scenario
     double* UK = DL + LB_SB * 4;                             // u = K (y0 + V0)
     constexpr int QI = (H2 + 15) / 16;                       // harmonics per thread of a scenario's 16
     double sir[QI][4], glr[QI][4];                           // S_q^-1 and A(parent, k) of the thread's harmonics (same mapping in R2, K, F)
@@ -130,7 +132,7 @@ __device__ __forceinline__ void leaf_batch_body(
 #pragma unroll
         for (int pz = 0; pz < 4; ++pz) {
             const int row = l16 + 16 * pz;
-            Y[row * LB_SB + sc] = ok[pz] ? fy[pz] + ay[pz] - ey[pz] : 0.0;
+            Y[row * LBP + sc] = ok[pz] ? fy[pz] + ay[pz] - ey[pz] : 0.0;
             if (row < 2) {
                 DL[sc * 4 + row * 2] = ok[pz] ? a0[pz] - e0[pz] : 0.0;
                 DL[sc * 4 + row * 2 + 1] = ok[pz] ? a1[pz] - e1[pz] : 0.0;
@@ -196,11 +198,11 @@ __device__ __forceinline__ void leaf_batch_body(
 #pragma unroll 4
         for (int ks = 0; ks < KS; ++ks) {
             const double a = ia[(size_t)ks * 64];
-            const double bop = Y[(4 * ks + lg) * LB_SB + jj];
+            const double bop = Y[(4 * ks + lg) * LBP + jj];
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bop, acc, 0, 0, 0);
         }
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) V[(16 * wv + 4 * reg + lg) * LB_SB + jj] = acc[reg];
+        for (int reg = 0; reg < 4; ++reg) V[(16 * wv + 4 * reg + lg) * LBP + jj] = acc[reg];
     }
     __syncthreads();
     // ---- K. per scenario: K = (c0 + Delta_polar S_0^-1)^-1, u = K (y0 + V0) --------------------------------------------------------
@@ -211,7 +213,7 @@ __device__ __forceinline__ void leaf_batch_body(
         const double q10 = c0img[2] + fma(dl[3], si[2], dl[2] * si[0]), q11 = c0img[3] + fma(dl[3], si[3], dl[2] * si[1]);
         double k00, k01, k10, k11;
         inv2(q00, q01, q10, q11, k00, k01, k10, k11);
-        const double r0 = Y[sc] + V[sc], r1 = Y[LB_SB + sc] + V[LB_SB + sc];
+        const double r0 = Y[sc] + V[sc], r1 = Y[LBP + sc] + V[LBP + sc];
         UK[sc * 2] = fma(k01, r1, k00 * r0);
         UK[sc * 2 + 1] = fma(k11, r1, k10 * r0);
         if (live) {
@@ -232,8 +234,8 @@ __device__ __forceinline__ void leaf_batch_body(
             double x0 = u0, x1 = u1;
             if (q > 0) {
                 const double* lc = lcimg + (2 * q) * 2;
-                x0 = V[(2 * q) * LB_SB + sc] + fma(lc[1], u1, lc[0] * u0);
-                x1 = V[(2 * q + 1) * LB_SB + sc] + fma(lc[3], u1, lc[2] * u0);
+                x0 = V[(2 * q) * LBP + sc] + fma(lc[1], u1, lc[0] * u0);
+                x1 = V[(2 * q + 1) * LBP + sc] + fma(lc[3], u1, lc[2] * u0);
             }
             const double* si = sir[it];
             const bool in = 2 * q < b;
@@ -297,8 +299,8 @@ __global__ __launch_bounds__(256) void k_leaf_back_batch(
     const double* img = lbimg + (size_t)slot * LeafBatchImg<B>::SZ;
     const double* lcimg = img + NTR * KS * 64;
 
-    __shared__ double TT[64 * LB_SB];                        // t = A(k,parent) x_parent, [row][scenario]
-    __shared__ double V[64 * LB_SB];
+    __shared__ double TT[64 * LBP];                        // t = A(k,parent) x_parent, [row][scenario]
+    __shared__ double V[64 * LBP];
     __shared__ double UK[LB_SB * 2];
 
     // one round trip for everything addressed by the record: the lane's image column, K, and Lc / S^-1 / w of the thread's harmonics
@@ -340,23 +342,23 @@ __global__ __launch_bounds__(256) void k_leaf_back_batch(
             t0 = fma(hk[1], xp.y, hk[0] * xp.x);
             t1 = fma(hk[3], xp.y, hk[2] * xp.x);
         }
-        TT[(2 * q) * LB_SB + sc] = t0;
-        TT[(2 * q + 1) * LB_SB + sc] = t1;
+        TT[(2 * q) * LBP + sc] = t0;
+        TT[(2 * q + 1) * LBP + sc] = t1;
     }
     __syncthreads();
     if (wv < NTR) {
         d4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const double bop = TT[(4 * ks + lg) * LB_SB + jj];
+            const double bop = TT[(4 * ks + lg) * LBP + jj];
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ia[ks], bop, acc, 0, 0, 0);
         }
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) V[(16 * wv + 4 * reg + lg) * LB_SB + jj] = acc[reg];
+        for (int reg = 0; reg < 4; ++reg) V[(16 * wv + 4 * reg + lg) * LBP + jj] = acc[reg];
     }
     __syncthreads();
     if (l16 == 0) {
-        const double r0 = TT[sc] + V[sc], r1 = TT[LB_SB + sc] + V[LB_SB + sc];                      // [I Lr] t
+        const double r0 = TT[sc] + V[sc], r1 = TT[LBP + sc] + V[LBP + sc];                      // [I Lr] t
         UK[sc * 2] = fma(k4[1], r1, k4[0] * r0);
         UK[sc * 2 + 1] = fma(k4[3], r1, k4[2] * r0);
     }
@@ -369,8 +371,8 @@ __global__ __launch_bounds__(256) void k_leaf_back_batch(
             if (q >= H2) continue;
             double x0 = u0, x1 = u1;
             if (q > 0) {
-                x0 = V[(2 * q) * LB_SB + sc] + fma(lc4[it][1], u1, lc4[it][0] * u0);
-                x1 = V[(2 * q + 1) * LB_SB + sc] + fma(lc4[it][3], u1, lc4[it][2] * u0);
+                x0 = V[(2 * q) * LBP + sc] + fma(lc4[it][1], u1, lc4[it][0] * u0);
+                x1 = V[(2 * q + 1) * LBP + sc] + fma(lc4[it][3], u1, lc4[it][2] * u0);
             }
             const double d0 = fma(si4[it][1], x1, si4[it][0] * x0), d1 = fma(si4[it][3], x1, si4[it][2] * x0);
             *reinterpret_cast<double2*>(xs + (size_t)k * B + 2 * q) = double2{w4[it][0] - d0, w4[it][1] - d1};
@@ -422,10 +424,10 @@ __global__ __launch_bounds__(256) void k_sleaf_back_batch(
     double* xs = xall + (size_t)s * n * B;
     const double* tk = Zall + ((size_t)s * n + k) * CT;         // T^-1 [10][10] | W_k^-1 [4]
 
-    __shared__ double TT[64 * LB_SB];                           // v = Wd^-1 t, [row][scenario]
-    __shared__ double V[64 * LB_SB];
-    __shared__ double RR[16 * LB_SB];                           // r = Qb v, then y = T^-1 r, [border unknown][scenario]
-    __shared__ double YY[16 * LB_SB];
+    __shared__ double TT[64 * LBP];                           // v = Wd^-1 t, [row][scenario]
+    __shared__ double V[64 * LBP];
+    __shared__ double RR[16 * LBP];                           // r = Qb v, then y = T^-1 r, [border unknown][scenario]
+    __shared__ double YY[16 * LBP];
 
     // every operand whose address comes from the record alone is requested here, in one round trip with A(k,parent) and x_parent:
     // the image column of the lane's MFMAs, the thread's row of T^-1, S^-1 and w of its harmonics
@@ -468,22 +470,22 @@ __global__ __launch_bounds__(256) void k_sleaf_back_batch(
                 t1 = fma(tk[103], c2, tk[102] * a);
             }
         }
-        TT[(2 * q) * LB_SB + sc] = t0;
-        TT[(2 * q + 1) * LB_SB + sc] = t1;
+        TT[(2 * q) * LBP + sc] = t0;
+        TT[(2 * q + 1) * LBP + sc] = t1;
     }
     __syncthreads();
     d4_t acc = {0.0, 0.0, 0.0, 0.0};
     if (wv < NTR) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const double bop = TT[(4 * ks + lg) * LB_SB + jj];
+            const double bop = TT[(4 * ks + lg) * LBP + jj];
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ia[ks], bop, acc, 0, 0, 0);
         }
         if (QBR && wv == NTR - 1) {                             // rows B.. of the last row tile: r = Qb v
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int j = 16 * (NTR - 1) + 4 * reg + lg - B;
-                if (j >= 0 && j < 16) RR[j * LB_SB + jj] = acc[reg];
+                if (j >= 0 && j < 16) RR[j * LBP + jj] = acc[reg];
             }
         }
     }
@@ -491,26 +493,26 @@ __global__ __launch_bounds__(256) void k_sleaf_back_batch(
         double r = 0.0;                                         // r_j = Qb[j][:] v   (thread (scenario, j))
         if (l16 < m) {
             const double* qr = qbm + (size_t)l16 * b;
-            for (int col = 0; col < b; ++col) r = fma(qr[col], TT[col * LB_SB + sc], r);
+            for (int col = 0; col < b; ++col) r = fma(qr[col], TT[col * LBP + sc], r);
         }
-        RR[l16 * LB_SB + sc] = r;
+        RR[l16 * LBP + sc] = r;
     }
     __syncthreads();
     {
         double y = 0.0;                                         // y_i = T^-1[i][:] r
 #pragma unroll
-        for (int j = 0; j < 10; ++j) y = fma(trow[j], (j < m ? RR[j * LB_SB + sc] : 0.0), y);
-        YY[l16 * LB_SB + sc] = (live && l16 < m) ? y : 0.0;
+        for (int j = 0; j < 10; ++j) y = fma(trow[j], (j < m ? RR[j * LBP + sc] : 0.0), y);
+        YY[l16 * LBP + sc] = (live && l16 < m) ? y : 0.0;
     }
     __syncthreads();
     if (wv < NTR) {                                             // V = [0 0; 0 Ahh^-1] v + Pb y
 #pragma unroll
         for (int kp = 0; kp < KP; ++kp) {
-            const double bop = YY[(4 * kp + lg) * LB_SB + jj];
+            const double bop = YY[(4 * kp + lg) * LBP + jj];
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[kp], bop, acc, 0, 0, 0);
         }
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) V[(16 * wv + 4 * reg + lg) * LB_SB + jj] = acc[reg];
+        for (int reg = 0; reg < 4; ++reg) V[(16 * wv + 4 * reg + lg) * LBP + jj] = acc[reg];
     }
     __syncthreads();
     if (live) {
@@ -518,7 +520,7 @@ __global__ __launch_bounds__(256) void k_sleaf_back_batch(
         for (int it = 0; it < QI; ++it) {
             const int q = l16 + 16 * it;
             if (q >= H2) continue;
-            const double x0 = V[(2 * q) * LB_SB + sc], x1 = V[(2 * q + 1) * LB_SB + sc];
+            const double x0 = V[(2 * q) * LBP + sc], x1 = V[(2 * q + 1) * LBP + sc];
             const double d0 = fma(si4[it][1], x1, si4[it][0] * x0), d1 = fma(si4[it][3], x1, si4[it][2] * x0);
             *reinterpret_cast<double2*>(xs + (size_t)k * B + 2 * q) = double2{w4[it][0] - d0, w4[it][1] - d1};
         }
@@ -543,7 +545,7 @@ int launch_sleaf_back_batch(hpf_handle* h, const int* nodes, int count, const in
 // Roles as in k_leaf_batch (plus the power-row diagonal of a linear bus and the G w of its lazy leaves), T assembled and inverted
 // per scenario by the scenario's 16 threads (thread r owns row r; the pivot row goes through LDS), the Ahh^-1 part on the matrix
 // cores.  nodes: Tree::d_fdesc records (int 39: slot of the bus's image in Tree::d_sbimg).
-constexpr int SLEAF_BATCH_LDS = 2 * 64 * LB_SB + LB_SB * 100 + LB_SB * 10 + 3 * LB_SB * 4 + 2 * 16 * LB_SB;      // doubles
+constexpr int SLEAF_BATCH_LDS = 2 * 64 * LBP + LB_SB * 100 + LB_SB * 10 + 3 * LB_SB * 4 + 2 * 16 * LBP;      // doubles
 
 template <int B>
 __device__ __forceinline__ void sleaf_batch_body(
@@ -591,14 +593,14 @@ __device__ __forceinline__ void sleaf_batch_body(
     const bool linear_k = k < M.m;
 
     double* Y = smem_;                                           // v = Wd^-1 y, [row][scenario]
-    double* V = Y + 64 * LB_SB;
-    double* AUG = V + 64 * LB_SB;                                // T, then T^-1, per scenario [10][10]
+    double* V = Y + 64 * LBP;
+    double* AUG = V + 64 * LBP;                                // T, then T^-1, per scenario [10][10]
     double* PR = AUG + LB_SB * 100;                              // pivot row of the step
     double* DL = PR + LB_SB * 10;
     double* S0 = DL + LB_SB * 4;
     double* WI = S0 + LB_SB * 4;
     double* RR = WI + LB_SB * 4;
-    double* YY = RR + 16 * LB_SB;
+    double* YY = RR + 16 * LBP;
 
     // ---- R1. rows --------------------------------------------------------------------------------------------------------------
     {
@@ -668,7 +670,7 @@ __device__ __forceinline__ void sleaf_batch_body(
 #pragma unroll
         for (int pz = 0; pz < 4; ++pz) {
             const int row = l16 + 16 * pz;
-            Y[row * LB_SB + sc] = ok[pz] ? fy[pz] + ay[pz] - ey[pz] : 0.0;
+            Y[row * LBP + sc] = ok[pz] ? fy[pz] + ay[pz] - ey[pz] : 0.0;
             if (row < 2) {
                 DL[sc * 4 + row * 2] = ok[pz] ? a0[pz] - e0[pz] : 0.0;
                 DL[sc * 4 + row * 2 + 1] = ok[pz] ? a1[pz] - e1[pz] : 0.0;
@@ -760,9 +762,9 @@ __device__ __forceinline__ void sleaf_batch_body(
             aug[1] += fma(wi[1], e11, wi[0] * e01);
             aug[10] += fma(wi[3], e10, wi[2] * e00);
             aug[11] += fma(wi[3], e11, wi[2] * e01);
-            const double y0 = Y[sc], y1 = Y[LB_SB + sc];                  // right-hand side rows 0 / 1: W_k^-1
+            const double y0 = Y[sc], y1 = Y[LBP + sc];                  // right-hand side rows 0 / 1: W_k^-1
             Y[sc] = fma(wi[1], y1, wi[0] * y0);
-            Y[LB_SB + sc] = fma(wi[3], y1, wi[2] * y0);
+            Y[LBP + sc] = fma(wi[3], y1, wi[2] * y0);
         } else if (l16 <= L && live) {
             const int i = l16 - 1, bc = 2 + 2 * i;
             const int leaf = i == 0 ? lzA.z : (i == 1 ? lzA.w : (i == 2 ? lzB.x : lzB.y));
@@ -872,14 +874,14 @@ __device__ __forceinline__ void sleaf_batch_body(
 #pragma unroll 4
         for (int ks = 0; ks < KS; ++ks) {
             const double a = ia[(size_t)ks * 64];
-            const double bop = Y[(4 * ks + lg) * LB_SB + jj];
+            const double bop = Y[(4 * ks + lg) * LBP + jj];
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bop, acc, 0, 0, 0);
         }
         if (QBR && wv == NTR - 1) {
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int j = 16 * (NTR - 1) + 4 * reg + lg - B;
-                if (j >= 0 && j < 16) RR[j * LB_SB + jj] = acc[reg];
+                if (j >= 0 && j < 16) RR[j * LBP + jj] = acc[reg];
             }
         }
     }
@@ -887,18 +889,18 @@ __device__ __forceinline__ void sleaf_batch_body(
         double r = 0.0;
         if (l16 < m) {
             const double* qr = qbm + (size_t)l16 * b;
-            for (int col = 0; col < b; ++col) r = fma(qr[col], Y[col * LB_SB + sc], r);
+            for (int col = 0; col < b; ++col) r = fma(qr[col], Y[col * LBP + sc], r);
         }
-        RR[l16 * LB_SB + sc] = r;
+        RR[l16 * LBP + sc] = r;
     }
     __syncthreads();
     {
         double y = 0.0;
         if (l16 < m) {
             const double* tr = AUG + sc * 100 + l16 * 10;
-            for (int j = 0; j < m; ++j) y = fma(tr[j], RR[j * LB_SB + sc], y);
+            for (int j = 0; j < m; ++j) y = fma(tr[j], RR[j * LBP + sc], y);
         }
-        YY[l16 * LB_SB + sc] = y;
+        YY[l16 * LBP + sc] = y;
     }
     __syncthreads();
     if (wv < NTR) {                                              // ... + Pb y: three more rank-4 steps on the same accumulators
@@ -906,11 +908,11 @@ __device__ __forceinline__ void sleaf_batch_body(
 #pragma unroll
         for (int kp = 0; kp < KP; ++kp) {
             const double a = pa[(size_t)kp * 64];
-            const double bop = YY[(4 * kp + lg) * LB_SB + jj];
+            const double bop = YY[(4 * kp + lg) * LBP + jj];
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bop, acc, 0, 0, 0);
         }
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) V[(16 * wv + 4 * reg + lg) * LB_SB + jj] = acc[reg];
+        for (int reg = 0; reg < 4; ++reg) V[(16 * wv + 4 * reg + lg) * LBP + jj] = acc[reg];
     }
     __syncthreads();
     HPF_SLSTAMP(6);
@@ -922,7 +924,7 @@ __device__ __forceinline__ void sleaf_batch_body(
         for (int it = 0; it < QI; ++it) {
             const int q = l16 + 16 * it;
             if (q >= H2) continue;
-            const double x0 = V[(2 * q) * LB_SB + sc], x1 = V[(2 * q + 1) * LB_SB + sc];
+            const double x0 = V[(2 * q) * LBP + sc], x1 = V[(2 * q + 1) * LBP + sc];
             const double* si = sir[it];
             const bool in = 2 * q < b;
             const double w0 = in ? fma(si[1], x1, si[0] * x0) : 0.0, w1 = in ? fma(si[3], x1, si[2] * x0) : 0.0;
