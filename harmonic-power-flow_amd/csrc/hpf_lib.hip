@@ -587,7 +587,7 @@ static int tree_bst(const hpf_handle* h) { const int b = 2 * h->Hn; return b <= 
 
 // stacked: also write the mismatch in the reference's stacked order (C ABI, dense solver, single-wave / generic tree kernels)
 template <bool FUND>
-int launch_mismatch(hpf_handle* h, const int* active, bool stacked = true) {
+int launch_mismatch(hpf_handle* h, const int* active, bool stacked = true, const cplx* Uover = nullptr) {
     ScopedTimer t(h, T_MISMATCH);
     const int count = FUND ? h->n : h->n * h->Hn;
     const int N = FUND ? h->Nf : h->N;
@@ -607,7 +607,7 @@ int launch_mismatch(hpf_handle* h, const int* active, bool stacked = true) {
             if (lds > 160 * 1024) return HPF_E_ARG;
         }
         hipLaunchKernelGGL((k_mismatch<FUND>), dim3(xcd_grid(nbx, h->cur_S)), dim3(TPB), lds, h->cur_stream, h->M, count, N, Nc,
-                           active, h->d_U, h->d_P, h->d_Q, (stacked || !img) ? h->d_f : nullptr, h->d_errbits, h->d_I0,
+                           active, Uover ? Uover : h->d_U, h->d_P, h->d_Q, (stacked || !img) ? h->d_f : nullptr, h->d_errbits, h->d_I0,
                            img ? h->d_fb : nullptr, tree_bst(h), h->cur_s0, h->cur_S, nbx);
         HIPCHK(hipGetLastError());
     }
@@ -753,15 +753,32 @@ int nr_pass(hpf_handle* h, double thresh, int max_iter, const int* mask) {
     // c - 1 while chunk c is already queued (pinned double buffer + events), so the device never drains between chunks.
     const bool pipelined = !FUND && h->solver == HPF_SOLVER_BLOCK_TREE && !trace && h->n_ties == 0;
     const int chunk = pipelined ? (S >= 8 ? 4 : 2) : 1;
+    // Folded state update (hpf_internal.hpp, d_U2): the back-substitution kernels of a step write the new U / E into the second copy and
+    // the mismatch of the new state reads them there; the host swaps the two copies per iteration.  A group's body enqueues all its
+    // iterations before the next group's: every body starts from the chunk's pointers and leaves them swapped `todo` times.
+    const bool folded = !FUND && h->fold_update && fold_update_possible(h);
     auto enqueue = [&](int todo, int slots) -> int {
+        cplx *const U0 = h->d_U, *const E0 = h->d_E, *const U20 = h->d_U2, *const E20 = h->d_E2;
         auto body = [&]() -> int {
             int rr;
+            h->d_U = U0;
+            h->d_E = E0;
+            h->d_U2 = U20;
+            h->d_E2 = E20;
             for (int j = 0; j < todo; ++j) {
                 if (!FUND && h->keep_prev && h->d_Vmp)
                     hipLaunchKernelGGL(k_keep_prev, grid2(h->n * h->Hn, h->cur_S), dim3(TPB), 0, h->cur_stream, h->n * h->Hn,
                                        h->d_active, h->d_Vm, h->d_Va, h->d_Vmp, h->d_Vap, h->cur_s0);
-                if ((rr = newton_step<FUND>(h, h->d_active))) return rr;
-                if ((rr = launch_update<FUND>(h, h->d_active))) return rr;
+                h->fold_step = folded ? 1 : 0;
+                rr = newton_step<FUND>(h, h->d_active);
+                h->fold_step = 0;
+                if (rr) return rr;
+                if (folded) {
+                    std::swap(h->d_U, h->d_U2);
+                    std::swap(h->d_E, h->d_E2);
+                } else if ((rr = launch_update<FUND>(h, h->d_active))) {
+                    return rr;
+                }
                 if ((rr = launch_mismatch<FUND>(h, h->d_active, false))) return rr;
                 hipLaunchKernelGGL(k_finalize, dim3((h->cur_S + 63) / 64), dim3(64), 0, h->cur_stream, h->cur_S, 0, thresh,
                                    max_iter, h->hist_cap, hist_off, h->d_errbits, h->d_err, h->d_niter, h->d_active,
@@ -928,7 +945,7 @@ int nr_loop(hpf_handle* h, double thresh, int max_iter, int* n_iter, double* err
 void free_all(hpf_handle* h) {
     void* ptrs[] = {h->d_rowptr, h->d_col, h->d_diag, h->d_erow, h->d_dev, h->d_Y, h->d_YN, h->d_YNt, h->d_IN, h->d_P, h->d_Q,
                     h->d_Vm, h->d_Va, h->d_U, h->d_E, h->d_I0, h->d_f, h->d_errbits, h->d_err, h->d_niter, h->d_active,
-                    h->d_nactive, h->d_pivflag, h->d_mask, h->d_Vm0, h->d_Va0, h->d_Vmp, h->d_Vap, h->d_tstamp, h->d_hist, h->d_stats, h->d_J, h->d_ipiv, h->d_info, h->d_Z, h->d_w, h->d_x, h->d_linA, h->d_C, h->d_dbg, h->d_H, h->d_chG, h->d_chH, h->d_chD, h->d_chy, h->d_chZ, h->d_lfK, h->d_lfS, h->d_fb, h->d_F, h->d_H2};
+                    h->d_nactive, h->d_pivflag, h->d_mask, h->d_Vm0, h->d_Va0, h->d_Vmp, h->d_Vap, h->d_tstamp, h->d_hist, h->d_stats, h->d_J, h->d_ipiv, h->d_info, h->d_Z, h->d_w, h->d_x, h->d_linA, h->d_C, h->d_dbg, h->d_H, h->d_chG, h->d_chH, h->d_chD, h->d_chy, h->d_chZ, h->d_lfK, h->d_lfS, h->d_fb, h->d_F, h->d_H2, h->d_U2, h->d_E2};
     for (void* p : ptrs)
         if (p) hipFree(p);
     tree_free(h);
@@ -1018,6 +1035,7 @@ int hpf_create(hpf_handle** out, const hpf_desc* d) {
     if (const char* gm = getenv("HPF_GJ_MODE")) h->gj_mode = atoi(gm) ? 1 : 0;
     if (const char* lb = getenv("HPF_LEAFBATCH")) h->leafbatch = atoi(lb) ? 1 : 0;
     if (const char* fl = getenv("HPF_FUSELEVEL")) h->fuse_levels = atoi(fl) ? 1 : 0;
+    if (const char* fu = getenv("HPF_FOLDUPDATE")) h->fold_update = atoi(fu) ? 1 : 0;
     if (hipSetDevice(d->device) != hipSuccess) return fail(HPF_E_HIP);
     if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) return fail(HPF_E_HIP);
     h->stream = h->own_stream;
@@ -1068,6 +1086,10 @@ int hpf_create(hpf_handle** out, const hpf_desc* d) {
     if ((r = dev_alloc(h, &h->d_Va, S * HnN))) return fail(r);
     if ((r = dev_alloc(h, &h->d_U, S * HnN))) return fail(r);
     if ((r = dev_alloc(h, &h->d_E, S * HnN))) return fail(r);
+    if (d->solver == HPF_SOLVER_BLOCK_TREE && h->n_ties == 0 && h->fold_update) {     // second copy of U / E: folded state update (hpf_internal.hpp)
+        if ((r = dev_alloc(h, &h->d_U2, S * HnN))) return fail(r);
+        if ((r = dev_alloc(h, &h->d_E2, S * HnN))) return fail(r);
+    }
     if ((r = dev_alloc(h, &h->d_I0, S * (size_t)h->n))) return fail(r);
     if ((r = dev_alloc(h, &h->d_f, S * (size_t)(h->N > h->Nf ? h->N : h->Nf)))) return fail(r);
     if ((r = dev_alloc(h, &h->d_errbits, S))) return fail(r);
@@ -1254,16 +1276,24 @@ static int iterate_enqueue(hpf_handle* h, int iters) {
         HIPCHK(hipEventRecord(h->fork_ev, h->stream));
         for (int g = 0; g < G; ++g) HIPCHK(hipStreamWaitEvent(h->gstream[g], h->fork_ev, 0));
     }
+    const bool folded = h->fold_update && fold_update_possible(h);      // (the state update inside the back-substitution kernels, nr_pass)
+    auto bound = [&](int g) { return g >= G ? h->S : (int)(16 * (((long long)h->S * g / G + 8) / 16)); };   // (tile-aligned groups, for_groups)
     for (int it = 0; it < iters && r == HPF_OK; ++it) {
         for (int g = 0; g < G && r == HPF_OK; ++g) {
             if (G > 1)
-                set_ctx(h, h->gstream[g], (int)((long long)h->S * g / G),
-                        (int)((long long)h->S * (g + 1) / G) - (int)((long long)h->S * g / G));
+                set_ctx(h, h->gstream[g], bound(g), bound(g + 1) - bound(g));
             else
                 full_ctx(h);
-            if ((r = newton_step<false>(h, nullptr))) break;
-            if ((r = launch_update<false>(h, nullptr))) break;
-            r = launch_mismatch<false>(h, nullptr, false);
+            h->fold_step = folded ? 1 : 0;
+            r = newton_step<false>(h, nullptr);
+            h->fold_step = 0;
+            if (r) break;
+            if (!folded && (r = launch_update<false>(h, nullptr))) break;
+            r = launch_mismatch<false>(h, nullptr, false, folded ? h->d_U2 : nullptr);
+        }
+        if (folded) {
+            std::swap(h->d_U, h->d_U2);
+            std::swap(h->d_E, h->d_E2);
         }
     }
     if (G > 1) {
