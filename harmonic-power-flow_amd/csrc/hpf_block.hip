@@ -2764,7 +2764,12 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
         if (T.n_lin_bundles2 > 0) {
             const dim3 g2((unsigned)T.n_lin_bundles2, (unsigned)h->cur_S);
 #define HPF_LB_B(NP_)                                                                                                                \
-    hipLaunchKernelGGL((k_lin_bundle_back<NP_>), g2, dim3(256), 0, h->cur_stream, h->M, T.d_lb2rec, (const int2*)T.d_lb2x, T.d_lb2ptr, \
+    if (td.fold.on)                                                                                                                  \
+        hipLaunchKernelGGL((k_lin_bundle_back<NP_, true>), g2, dim3(256), 0, h->cur_stream, h->M, T.d_lb2rec, (const int2*)T.d_lb2x, T.d_lb2ptr, \
+                           T.n_lin_heights, Bst, active, h->d_U, h->d_E, h->d_linA, h->d_w, h->d_x, h->cur_s0,                             \
+                           T.chains_bundled ? T.d_lb2cptr : (const int*)nullptr, T.d_lb2clist, T.d_crec, T.d_cnode, h->d_chZ, td.fold);    \
+    else                                                                                                                             \
+    hipLaunchKernelGGL((k_lin_bundle_back<NP_, false>), g2, dim3(256), 0, h->cur_stream, h->M, T.d_lb2rec, (const int2*)T.d_lb2x, T.d_lb2ptr, \
                        T.n_lin_heights, Bst, active, h->d_U, h->d_E, h->d_linA, h->d_w, h->d_x, h->cur_s0,                                 \
                        T.chains_bundled ? T.d_lb2cptr : (const int*)nullptr, T.d_lb2clist, T.d_crec, T.d_cnode, h->d_chZ, td.fold)
             if (T.lin_np == 1) HPF_LB_B(1);

@@ -139,7 +139,7 @@ __device__ __forceinline__ cplx norton_injection_lds(const Model& M, int d, cons
 // f: the reference's stacked real layout (HG:388; dense solver, C ABI) or nullptr; fb: bus-major image [bus][2q + (Re|Im)] with
 // stride Bst and zeros where there is no equation (tree kernels) or nullptr.
 template <bool FUND>
-__global__ void k_mismatch(Model M, int count, int N, int Nc, const int* __restrict__ active, const cplx* __restrict__ U,
+__global__ __launch_bounds__(TPB, 8) void k_mismatch(Model M, int count, int N, int Nc, const int* __restrict__ active, const cplx* __restrict__ U,
                            const double* __restrict__ P, const double* __restrict__ Q, double* __restrict__ f,
                            unsigned long long* __restrict__ errbits, cplx* __restrict__ I0, double* __restrict__ fb, int Bst,
                            int s0, int S_cnt, int nbx) {

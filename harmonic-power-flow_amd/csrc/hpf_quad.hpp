@@ -1839,8 +1839,14 @@ __global__ __launch_bounds__(128) void k_chain_back2(Model M, TreeDev T, const i
 // the back sweep walks the chains first.  cbptr / cblist: chains per bundle (null: chains have their own launches).
 // Records: Rec8 with cbeg = first child slot of the bus; xrec[record] = (own slot or -1 for a subtree root, local index of the parent
 // inside the bundle or -1); bptr: nh + 1 record offsets per bundle (heights ascending).
+#ifndef HPF_LBF_OCC
+#define HPF_LBF_OCC 3       // waves per SIMD the one-round-trip 2x2 kernels (NP = 1) are compiled for (factor / back)
+#endif
+#ifndef HPF_LBB_OCC
+#define HPF_LBB_OCC 4
+#endif
 template <int NP>
-__global__ __launch_bounds__(256) void k_lin_bundle_factor(Model M, const int* __restrict__ rec, const int2* __restrict__ xrec,
+__global__ __launch_bounds__(256, NP == 1 ? HPF_LBF_OCC : 1) void k_lin_bundle_factor(Model M, const int* __restrict__ rec, const int2* __restrict__ xrec,
                                                            const int* __restrict__ bptr, int nh, int Bst, const int* __restrict__ active,
                                                            const cplx* __restrict__ Uall, const cplx* __restrict__ Eall,
                                                            const double* __restrict__ fall, double* linAall, double* wall,
@@ -1965,8 +1971,8 @@ __global__ __launch_bounds__(256) void k_lin_bundle_factor(Model M, const int* _
 
 // ... and its back sweep: x_k = w_k - D_k^-1 (A(k,par) x_par).  D^-1, w, A(k,par) of every item in one round trip (a subtree root
 // also fetches x of its dense / chain parent), then the heights top-down with x_par through LDS.
-template <int NP>
-__global__ __launch_bounds__(256) void k_lin_bundle_back(Model M, const int* __restrict__ rec, const int2* __restrict__ xrec,
+template <int NP, bool FOLD>
+__global__ __launch_bounds__(256, NP == 1 ? HPF_LBB_OCC : 1) void k_lin_bundle_back(Model M, const int* __restrict__ rec, const int2* __restrict__ xrec,
                                                          const int* __restrict__ bptr, int nh, int Bst, const int* __restrict__ active,
                                                          const cplx* __restrict__ Uall, const cplx* __restrict__ Eall,
                                                          const double* __restrict__ linAall, const double* __restrict__ wall,
@@ -2017,7 +2023,7 @@ __global__ __launch_bounds__(256) void k_lin_bundle_back(Model M, const int* __r
         const int c0 = cbptr[blockIdx.x], nc2 = cbptr[blockIdx.x + 1] - c0;
         if (nc2 > 0) {
             for (int t = threadIdx.x; t < nc2 * Hn; t += 256)
-                chain_back_item(M, crec, cnode, cblist[c0 + t / Hn], t % Hn, s, 0, 0, Bst, Uall, Eall, linAall, wall, xall, nullptr, chZ, &fold);
+                chain_back_item(M, crec, cnode, cblist[c0 + t / Hn], t % Hn, s, 0, 0, Bst, Uall, Eall, linAall, wall, xall, nullptr, chZ, FOLD ? &fold : nullptr);
             __syncthreads();
         }
     }
@@ -2054,7 +2060,7 @@ __global__ __launch_bounds__(256) void k_lin_bundle_back(Model M, const int* __r
             const double x1 = wkv[p].y - fma(i23[p].y, t1, i23[p].x * t0);
             *reinterpret_cast<double2*>(xl + ((size_t)lbv[p] * Hn + q) * 2) = double2{x0, x1};
             *reinterpret_cast<double2*>(xs + (size_t)r0v[p].x * Bst + 2 * q) = double2{x0, x1};
-            if (fold.on) fold_update(fold, n, Hn, c, s, r0v[p].x, q, x0, x1);
+            if (FOLD && fold.on) fold_update(fold, n, Hn, c, s, r0v[p].x, q, x0, x1);
         }
     }
 }
