@@ -124,22 +124,25 @@ def add_ties(fl, n, k, seed=42):
     return out
 
 
-def mesh():
-    """gen(1000, seed 0) + 5 loop-closing lines (add_ties seed 42), harmonics 1..51, coupled: N = 51 998 unknowns, beyond the dense
-    rocSOLVER limit -> the bordered block-tree step is the only GPU path; oracle = SuperLU on the meshed Jacobian."""
+def mesh(k=5):
+    """gen(1000, seed 0) + k loop-closing lines (add_ties seed 42; k = 5, and k = 20 since round 3: 40 endpoint buses, m = 2 080 border
+    unknowns), harmonics 1..51, coupled: N = 51 998 unknowns; oracle = SuperLU on the meshed Jacobian."""
     synth = _synth()
     tmp = tempfile.mkdtemp()
     fb, fl = synth.gen(1000, seed=0, outdir=tmp)
-    ties = add_ties(fl, 1000, 5)
+    ties = add_ties(fl, 1000, k)
     H = o.harmonics_upto(51)
     r, stop, fix, r2 = run(o.init_network(fb, fl), H)
     print("meshed syn1000 + ties %s: %d it err %.3e; fixed point +%d it err %.3e" % (ties, r["n_iter_h"], r["err_h"], r2["n_iter_h"], r2["err_h"]), flush=True)
     idx = np.arange(0, stop[0].size, 7)
     Uf = fix[0] * np.exp(1j * fix[1])
-    np.savez_compressed(os.path.join(GOLD, "syn1000_H51_mesh5.npz"), ties=np.array(ties), n_iter=r["n_iter_h"], err_hist=r["err_hist"],
+    np.savez_compressed(os.path.join(GOLD, "syn1000_H51_mesh%d.npz" % k), ties=np.array(ties), n_iter=r["n_iter_h"], err_hist=r["err_hist"],
                         idx=idx, V_stop_sample=np.stack([stop[0][idx], stop[1][idx]], 1), V_fix_sample=np.stack([fix[0][idx], fix[1][idx]], 1),
                         seed_fund=np.stack(r["seed"], 1)[:1000], U_fix_abs_per_harmonic=np.abs(Uf).reshape(len(H), 1000).sum(1))
 
 
 if __name__ == "__main__":
-    {"scen": scen, "cfg5": cfg5, "mesh": mesh}[sys.argv[1]]()
+    if sys.argv[1] == "mesh" and len(sys.argv) > 2:
+        mesh(int(sys.argv[2]))
+    else:
+        {"scen": scen, "cfg5": cfg5, "mesh": mesh}[sys.argv[1]]()
