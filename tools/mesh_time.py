@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Time per Newton iteration of the bordered block-tree step on the headline feeder with k loop-closing lines:  python tools/mesh_time.py [k ...]  (GPU)"""
+import importlib.util
+import os
+import sys
+import tempfile
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import harmonic_power_flow_amd as hp              # noqa: E402
+from harmonic_power_flow_amd import api, synth    # noqa: E402
+
+INPUTS = os.path.join(REPO, "tests", "golden", "inputs")
+spec = importlib.util.spec_from_file_location("mgb", os.path.join(REPO, "oracle", "make_golden_bench.py"))
+for k in [int(a) for a in sys.argv[1:]] or [5, 20]:
+    tmp = tempfile.mkdtemp()
+    fb, fl = synth.gen(1000, seed=0, outdir=tmp)
+    rows = open(fl).read().splitlines()
+    # (the tie generator of the fixtures, restated here so that the tool does not import test infrastructure)
+    import numpy as np
+    have = {(min(int(c.split(";")[1]), int(c.split(";")[2])), max(int(c.split(";")[1]), int(c.split(";")[2]))) for c in rows[1:]}
+    rng = np.random.default_rng(42)
+    pal = [(0.5, 0.5), (1, 4), (0.5, 1)]
+    lid, out = len(rows), []
+    while len(out) < k:
+        a, b = int(rng.integers(2, 1001)), int(rng.integers(2, 1001))
+        if a == b or (min(a, b), max(a, b)) in have:
+            continue
+        have.add((min(a, b), max(a, b)))
+        r, x = pal[int(rng.integers(0, len(pal)))]
+        rows.append("%d;%d;%d;%.10g;%.10g;0;0" % (lid, a, b, r * 20.0 / 1000, x * 20.0 / 1000))
+        lid += 1
+        out.append((a, b))
+    open(fl, "w").write("\n".join(rows) + "\n")
+    st = hp.Settings(H_MAX=51)
+    buses, lines, m, n, c = hp.init_network(fb, fl, settings=st)
+    Y = hp.build_admittance_matrices(buses, lines, st.HARMONICS)
+    NE = hp.import_Norton_Equivalents(buses, True, st, INPUTS)
+    dm = api._device_model(buses, Y, NE, True, st.HARMONICS, solver="block_tree")
+    dm.set_loads(buses["P"].to_numpy(float), buses["Q"].to_numpy(float))
+    dm.set_state(None, None, n_scen=1)
+    dm.fund_pf(1e-6, 30)
+    seed = dm.get_state()
+    dm.solve(1e-4, 3)
+    dm.set_state(*seed)
+    t0 = time.perf_counter()
+    it, err, _ = dm.solve(1e-4, 50)
+    t = time.perf_counter() - t0
+    print("syn1000 + %d ties: census %s; %d iterations in %.3f s = %.2f ms per iteration (err %.1e)" % (k, dm.tree_census()["ties"], it[0], t, 1e3 * t / it[0], err[0]))
+    dm.close()
