@@ -240,6 +240,29 @@ def test_compress_steps_shorten_the_level_chain_and_keep_the_newton_step(n, hmax
     assert np.abs(Uc - Uf).max() < TOL_V
 
 
+def test_compress_steps_default_follows_the_handle_capacity(tmp_path, monkeypatch):
+    """Compress steps pay while the elimination levels do not fill the chip: on by default for handles of up to 256 scenarios, off above
+    (measured crossover between 256 and 384 live scenarios); HPF_COMPRESS=1 / 0 force them."""
+    hp = _hp()
+    from harmonic_power_flow_amd import api
+    st, buses, Y, NE, _ = _feeder(hp, 1000, 51, tmp_path, seed=0)
+    monkeypatch.delenv("HPF_COMPRESS", raising=False)
+    got = {}
+    for S, env in ((256, None), (257, None), (257, "1"), (8, "0")):
+        if env is None:
+            monkeypatch.delenv("HPF_COMPRESS", raising=False)
+        else:
+            monkeypatch.setenv("HPF_COMPRESS", env)
+        dm = api._device_model(buses, Y, NE, True, st.HARMONICS, solver="block_tree", max_scenarios=S)
+        try:
+            got[(S, env)] = dm.tree_census()
+        finally:
+            dm.close()
+    assert got[(256, None)]["compress_steps"] > 0 and got[(256, None)]["levels"] == 10
+    assert got[(257, None)]["compress_steps"] == 0 and got[(257, None)]["levels"] == 15
+    assert got[(257, "1")]["compress_steps"] > 0 and got[(8, "0")]["compress_steps"] == 0
+
+
 # (n, H_MAX, share of nonlinear buses, PV buses, generator seed, iterations of the ORACLE [50 = the reference's own Newton iteration
 #  does not converge on this feeder: measured with oracle/hpf_oracle.py, err stays at 1e2..1e4])
 FUZZ = [(347, 35, 0.85, 0, 880227, 50), (377, 51, 0.60, 2, 318146, 31), (118, 27, 0.85, 2, 867892, 50), (384, 59, 0.15, 0, 569402, 26),
