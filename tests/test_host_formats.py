@@ -6,6 +6,8 @@ import numpy as np
 import pandas as pd
 
 from conftest import INPUTS
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 import harmonic_power_flow_amd as hp
 from harmonic_power_flow_amd import ingest, sweep
 from harmonic_power_flow_amd.settings import Settings
@@ -66,3 +68,31 @@ def test_sweep_summary_reports_thd_percentiles():
     assert s["thd_max"] == ok.max()
     for q in (50, 95, 99):
         assert s["thd_p%d" % q] == np.percentile(ok, q)
+
+
+def test_bench_reports_counter_traffic_only_for_the_running_library(tmp_path, monkeypatch):
+    """bench.py's `roofline.traffic` comes from committed PMC passes (profiles/pmc_traffic_latest.json); it must be `null` unless that file
+    was collected with the very libhpf.so that is running (sha256 recorded by tools/pmc_traffic.py) and on the default workload."""
+    import argparse
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(REPO, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    args = argparse.Namespace(buses=1000, hmax=51, solver="block_tree")
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "REPO", str(tmp_path))
+    lib_dir = tmp_path / "harmonic-power-flow_amd"
+    lib_dir.mkdir()
+    (lib_dir / "libhpf.so").write_bytes(b"not really a library")
+    sha = bench.lib_sha16()
+    good = {"format": 2, "lib_sha16": sha, "note": "n", "command": "c", "per_launch_bytes": {"k_factor_q_general": {"fetch": 3.0, "write": 4.0}},
+            "per_step_bytes": {"k": {"fetch": 10.0, "write": 5.0}}}
+    (prof / "pmc_traffic_latest.json").write_text(json.dumps(good))
+    t, note, src = bench.pmc_traffic(args, 128)
+    assert t == 7.0 and src["lib_sha16"] == sha and bench.pmc_step_traffic(args, 128) == 15.0
+    assert bench.pmc_traffic(args, 64)[0] is None                      # another workload
+    (prof / "pmc_traffic_latest.json").write_text(json.dumps(dict(good, lib_sha16="0" * 16)))
+    t, note, src = bench.pmc_traffic(args, 128)
+    assert t is None and src is None and "another build" in note and bench.pmc_step_traffic(args, 128) is None
