@@ -267,7 +267,8 @@ def test_compress_steps_default_follows_the_handle_capacity(tmp_path, monkeypatc
 #  does not converge on this feeder: measured with oracle/hpf_oracle.py, err stays at 1e2..1e4])
 FUZZ = [(347, 35, 0.85, 0, 880227, 50), (377, 51, 0.60, 2, 318146, 31), (118, 27, 0.85, 2, 867892, 50), (384, 59, 0.15, 0, 569402, 26),
         (200, 35, 0.60, 2, 422784, 23), (262, 25, 0.85, 0, 438186, 22), (54, 27, 0.15, 0, 657433, 14), (403, 11, 0.35, 2, 522250, 22),
-        (296, 25, 0.85, 1, 644436, 28), (161, 19, 0.35, 1, 692459, 50)]
+        (296, 25, 0.85, 1, 644436, 28), (161, 19, 0.35, 1, 692459, 50),
+        (125, 75, 0.60, 2, 128047, 50)]       # (round 3: the one outlier of 300 fuzz cases, first step 6.5e-6 off -- the reference's iteration diverges here too)
 
 
 @pytest.mark.parametrize("n,hmax,frac,n_pv,seed,it_oracle", FUZZ)
