@@ -43,6 +43,9 @@ SYMBOLS = {
     "hpf_mismatch": (C.c_int, [_H, c_dbl_p, c_dbl_p]),
     "hpf_jacobian": (C.c_int, [_H, C.c_int, c_dbl_p]),
     "hpf_jacobian_last": (C.c_int, [_H, C.c_int, c_dbl_p]),
+    "hpf_jacobian_nnz": (C.c_int, [_H, C.POINTER(C.c_int64)]),
+    "hpf_jacobian_csr": (C.c_int, [_H, C.c_int, c_int_p, c_int_p, c_dbl_p]),
+    "hpf_jacobian_csr_last": (C.c_int, [_H, C.c_int, c_int_p, c_int_p, c_dbl_p]),
     "hpf_fund_mismatch": (C.c_int, [_H, c_dbl_p, c_dbl_p]),
     "hpf_fund_jacobian": (C.c_int, [_H, C.c_int, c_dbl_p]),
     "hpf_fund_pf": (C.c_int, [_H, C.c_double, C.c_int, c_int_p, c_dbl_p, c_dbl_p]),

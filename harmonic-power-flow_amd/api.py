@@ -79,7 +79,7 @@ def _frame(Vm, Va, harmonics, n):
     return pd.DataFrame({"V_m": np.asarray(Vm), "V_a": np.asarray(Va)}, index=idx)
 
 
-def _device_model(buses, Y, NE, coupled, harmonics, solver="auto", max_scenarios=1, device=0):
+def _device_model(buses, Y, NE, coupled, harmonics, solver="auto", max_scenarios=1, device=0, assembly_only=False):
     m, n, c = ingest.network_constants(buses)
     Hn = len(harmonics)
     if NE is None:
@@ -91,7 +91,7 @@ def _device_model(buses, Y, NE, coupled, harmonics, solver="auto", max_scenarios
     else:
         dev, Y_N, I_N, n_dev = ingest.norton_arrays(buses, NE, coupled, Hn)
     return DeviceModel(n, m, c, harmonics, Y.rowptr, Y.col, Y.Yval, dev, Y_N, I_N, n_dev, coupled,
-                       solver=solver, device=device, max_scenarios=max_scenarios)
+                       solver=solver, device=device, max_scenarios=max_scenarios, assembly_only=assembly_only)
 
 
 def pf(Y, buses, thresh_f=1e-6, max_iter_f=30, plt_convergence=False, settings=None, verbose=True, _model=None):
@@ -134,16 +134,13 @@ def _postprocess(Vm, Va):
     return Vm, Va
 
 
-def _jac_to_csr(Jd):
-    return sp.csr_matrix(Jd)
-
-
 def hpf(buses, lines, coupled, thresh_h=1e-4, max_iter_h=50, plt_convergence=False, settings=None, ne_dir=None,
         solver="auto", verbose=True, return_jacobian=True, details=None, extra_iters=0):
     """HG:511-560 -> (V, err_h, n_iter_h, J).
 
-    `J` is the Jacobian of the last iteration as scipy CSR like the reference (only materialised for N <= 4096,
-    else None).  `details`, if a dict, receives err_hist, the pf seed, n_iter_f, solver name and device stats.
+    `J` is the Jacobian of the last iteration as scipy CSR like the reference (HG:537,560), at every size: the device writes
+    the CSR arrays directly (hpf_jacobian_csr_last; 1.2 M entries at 1 000 buses x 26 harmonics).  return_jacobian=False skips it;
+    J is None only when the loop took no iteration (the reference would raise NameError there, HG:560).  `details`, if a dict, receives err_hist, the pf seed, n_iter_f, solver name and device stats.
     `extra_iters` (not in the reference, default 0 = the reference's behaviour): Newton iterations taken AFTER the stop rule.
     The reference stops at err_h <= 1e-4, up to 4e-7 p.u. away from the fixed point, and where exactly below the
     threshold the last iterate lands depends on the rounding of the linear solver; one or two more iterations put the result on
@@ -167,7 +164,7 @@ def hpf(buses, lines, coupled, thresh_h=1e-4, max_iter_h=50, plt_convergence=Fal
             else:
                 print("Warning! Maximum of " + str(int(nf[0])) + " iterations reached.")
         # (block-tree: hpf_solve itself watches the static pivot order and repeats a flagged scenario with partial pivoting)
-        want_J = return_jacobian and dm.N <= 4096
+        want_J = bool(return_jacobian)
         if want_J:
             dm.set_option("keep_previous_state", 1)
         n_iter, err, hist = dm.solve(thresh_h, max_iter_h)                        # HG:530-542
@@ -185,8 +182,8 @@ def hpf(buses, lines, coupled, thresh_h=1e-4, max_iter_h=50, plt_convergence=Fal
         J = None
         if want_J and n_iter_h > 0:
             # the reference returns the Jacobian built in its last iteration, i.e. at the state before the last update: the solve
-            # kept that state on the device (small systems only: J is handed back as a dense column-major copy)
-            J = _jac_to_csr(dm.jacobian_last(0))
+            # kept that state on the device
+            J = dm.jacobian_csr(0, last=True)
         if details is not None:
             details.update(err_hist=hist[0, :n_iter_h + 1].copy(), seed=(seed[0][0].copy(), seed[1][0].copy()),
                            n_iter_f=int(nf[0]), err_f=hf[0, :int(nf[0])].copy(), solver=dm.solver,
@@ -219,7 +216,7 @@ def harmonic_mismatch(V, Y, buses, NE, settings=None):
     harmonics = list(dict.fromkeys(V.index.get_level_values(0)))
     Y = _as_admittance(Y, harmonics, n)
     coupled = np.asarray(next(iter(NE.values()))[1]).shape[0] > 1 if NE else False
-    dm = _device_model(buses, Y, NE, coupled, harmonics, solver="dense")
+    dm = _device_model(buses, Y, NE, coupled, harmonics, solver="dense", assembly_only=True)
     try:
         dm.set_loads(buses["P"].to_numpy(dtype=float), buses["Q"].to_numpy(dtype=float))
         dm.set_state(*_state_arrays(V))
@@ -237,14 +234,14 @@ def build_harmonic_jacobian(V, Y, NE, coupled, buses=None):
     n = len(buses)
     harmonics = list(dict.fromkeys(V.index.get_level_values(0)))
     Y = _as_admittance(Y, harmonics, n)
-    dm = _device_model(buses, Y, NE, coupled, harmonics, solver="dense")
+    dm = _device_model(buses, Y, NE, coupled, harmonics, solver="dense", assembly_only=True)
     try:
         dm.set_loads(buses["P"].to_numpy(dtype=float), buses["Q"].to_numpy(dtype=float))
         dm.set_state(*_state_arrays(V))
-        J = dm.jacobian(0)
+        J = dm.jacobian_csr(0)
     finally:
         dm.close()
-    return _jac_to_csr(J)
+    return J
 
 
 def harmonic_state_vector(V, c=None, buses=None):

@@ -322,6 +322,103 @@ struct DenseEmit {
     }
 };
 
+// ---- The Jacobian as the reference returns it: the stacked real matrix of HG:469-472 in CSR form (scipy.sparse.csr_matrix) ---------
+// Real row r: r < Nc -> Re part of complex row k = r + 1; else Im part of k = r - Nc + c.  The columns of a row, ascending: the theta
+// columns (kc - 1) of its complex entries, then the V columns (Nc + kc - c); the complex entries of row k = q*n + i in ascending
+// stacked column kc = p*n + j: for p < q the Norton cross term (p, i) of a nonlinear bus (HG:425-435), at p = q the stored
+// admittance entries of row i (HG:403-411 / power rows HG:451-462), for p > q the cross terms again.
+// Which entries EXIST follows the reference's construction: `block_diag` of the dense per-harmonic admittance arrays keeps the
+// non-zero values only (HG:407), the diagonal of a power row comes from `diags(...)` (HG:454-459: always stored), the diagonal of a
+// nonlinear bus and its cross terms from the `-=` on the lil_matrix (HG:432-435: stored unless the product is exactly zero, i.e.
+// unless Y_N[q,p] is).  State-dependent exact cancellations are not tracked: the pattern is a property of the model.
+struct JRow {
+    int k, t, q, i;
+    bool power, cross;
+};
+
+HPF_HD JRow jcsr_row(const Model& M, int Nc, int r) {
+    JRow R;
+    R.t = r < Nc ? 0 : 1;
+    R.k = R.t ? r - Nc + M.c : r + 1;
+    R.q = R.k / M.n;
+    R.i = R.k - R.q * M.n;
+    R.power = R.q == 0 && R.i < M.m;
+    R.cross = M.coupled && R.i >= M.m;
+    return R;
+}
+
+HPF_HD bool jcsr_has_entry(const Model& M, const JRow& R, int e, int j) {
+    if (j == R.i && (R.power || R.i >= M.m)) return true;
+    const cplx y = M.Y[M.yi(R.q, e)];
+    return y.re != 0.0 || y.im != 0.0;
+}
+
+HPF_HD bool jcsr_has_cross(const Model& M, const JRow& R, int p) {
+    const cplx y = M.YN[((size_t)M.dev[R.i] * M.Hn + R.q) * M.Hn + p];
+    return y.re != 0.0 || y.im != 0.0;
+}
+
+// visit the complex entries of row R in ascending stacked column order: f(kc, e, j, p) with e >= 0 for an admittance entry (i, j),
+// e = -1 for the Norton cross term of harmonic position p
+template <class F>
+HPF_HD void jcsr_walk(const Model& M, const JRow& R, F& f) {
+    for (int p = R.cross ? 0 : R.q; p < (R.cross ? M.Hn : R.q + 1); ++p) {
+        if (p == R.q) {
+            for (int e = M.rowptr[R.i]; e < M.rowptr[R.i + 1]; ++e) {
+                const int j = M.col[e];
+                if (jcsr_has_entry(M, R, e, j)) f(p * M.n + j, e, j, p);
+            }
+        } else if (jcsr_has_cross(M, R, p)) {
+            f(p * M.n + R.i, -1, R.i, p);
+        }
+    }
+}
+
+struct JCount {
+    int c, n_theta, n_v;
+    HPF_HD void operator()(int kc, int, int, int) {
+        n_theta += kc >= 1;
+        n_v += kc >= c;
+    }
+};
+
+// stored entries of real row r (theta columns, V columns)
+HPF_HD JCount jcsr_count_row(const Model& M, int Nc, int r) {
+    const JRow R = jcsr_row(M, Nc, r);
+    JCount cnt{M.c, 0, 0};
+    jcsr_walk(M, R, cnt);
+    return cnt;
+}
+
+struct JFill {
+    const Model& M;
+    const cplx *U, *E;
+    JRow R;
+    int Nc;
+    int* col;
+    double* val;
+    long long pos_t, pos_v;
+    HPF_HD void operator()(int kc, int e, int j, int p) {
+        const Blk2 b = e >= 0 ? (R.power ? jac_power_entry<false>(M, U, E, R.i, j, e) : jac_current_entry(M, U, E, R.q, R.i, j, e))
+                              : jac_norton_cross(M, U, E, R.q, p, R.i);
+        if (kc >= 1) {
+            if (col) col[pos_t] = kc - 1;
+            val[pos_t++] = R.t ? b.dA.im : b.dA.re;
+        }
+        if (kc >= M.c) {
+            if (col) col[pos_v] = Nc + kc - M.c;
+            val[pos_v++] = R.t ? b.dV.im : b.dV.re;
+        }
+    }
+};
+
+// write real row r: its entries start at `start` (= indptr[r]); col may be nullptr (values only)
+HPF_HD void jcsr_fill_row(const Model& M, const cplx* U, const cplx* E, int Nc, int r, long long start, int* col, double* val) {
+    const JCount cnt = jcsr_count_row(M, Nc, r);
+    JFill fl{M, U, E, jcsr_row(M, Nc, r), Nc, col, val, start, start + cnt.n_theta};
+    jcsr_walk(M, fl.R, fl);
+}
+
 // Real mismatch vector layout f = [Re f_c ; Im f_c[c-1:]] (HG:388).
 HPF_HD void store_mismatch(double* f, int Nc, int c, int k, cplx v) {
     f[k - 1] = v.re;

@@ -187,6 +187,11 @@ struct hpf_handle {
     int* d_ipiv = nullptr;
     int* d_info = nullptr;
     bool info64 = false;              // the last dense factorisation went through rocSOLVER's 64-bit entry points (int64 pivots / info)
+    // CSR export of the Jacobian (hpf_jacobian_csr): indptr [N+1] (built once per handle), column indices / values of one scenario
+    int* d_jptr = nullptr;
+    int* d_jcol = nullptr;
+    double* d_jval = nullptr;
+    long long jnnz = 0;
     // block-tree solver
     hpf::Tree tree;                   // elimination tree as the network gives it (single-wave / generic kernels, pf)
     hpf::Tree ctree;                  // the same with pass-through buses contracted (multi-wave kernels, gj_mode 1)

@@ -13,6 +13,7 @@
 //   dense solve  FP64 matrix pipe: 2/3 N^3 + 2 N^2 flop (rocSOLVER getrf/getrs).
 #include <math.h>
 #include <chrono>
+#include <functional>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -239,6 +240,51 @@ __global__ void k_jac_cross_dense(Model M, int total, int N, int Nc, size_t J_st
     DenseEmit em{J + (size_t)s * J_stride, N, Nc, M.c};
     const size_t so = (size_t)s * M.n * M.Hn;
     jac_cross(M, U + so, E + so, q, p, i, em);
+}
+
+// The Jacobian in CSR form (HG:469-472 as the reference returns it, hpf_jacobian_csr): one thread per real row.  k_jcsr_count leaves
+// the row lengths, k_jcsr_scan turns them into indptr (one workgroup: chunk sums, LDS scan of the 1 024 partials, chunk prefixes),
+// k_jcsr_fill writes column indices and values of scenario `s` behind indptr[r] (per-entry arithmetic: hpf_assembly.hpp, the same
+// functions as the dense target).
+__global__ void k_jcsr_count(Model M, int N, int Nc, int* __restrict__ cnt) {
+    const int r = blockIdx.x * TPB + threadIdx.x;
+    if (r >= N) return;
+    const JCount c = jcsr_count_row(M, Nc, r);
+    cnt[r] = c.n_theta + c.n_v;
+}
+
+__global__ __launch_bounds__(1024) void k_jcsr_scan(int N, int* __restrict__ indptr, long long* __restrict__ total) {
+    __shared__ long long part[1024];
+    const int tid = threadIdx.x;
+    const int chunk = (N + 1023) / 1024;
+    const int b = tid * chunk < N ? tid * chunk : N, e = b + chunk < N ? b + chunk : N;
+    long long s = 0;
+    for (int i = b; i < e; ++i) s += indptr[i];
+    part[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const long long v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    long long base = tid ? part[tid - 1] : 0;
+    for (int i = b; i < e; ++i) {
+        const int c = indptr[i];
+        indptr[i] = (int)base;
+        base += c;
+    }
+    if (tid == 1023) {
+        *total = part[1023];
+        indptr[N] = part[1023] < 0x7fffffffll ? (int)part[1023] : 0x7fffffff;
+    }
+}
+
+__global__ void k_jcsr_fill(Model M, int N, int Nc, const int* __restrict__ indptr, const cplx* __restrict__ U,
+                            const cplx* __restrict__ E, int* __restrict__ col, double* __restrict__ val) {
+    const int r = blockIdx.x * TPB + threadIdx.x;
+    if (r >= N) return;
+    jcsr_fill_row(M, U, E, Nc, r, indptr[r], col, val);
 }
 
 // x <- x - step, scattered back into (Va, Vm) (HG:478,484-485 / HG:229,234-235), then refresh U, E of the entry.
@@ -945,7 +991,7 @@ int nr_loop(hpf_handle* h, double thresh, int max_iter, int* n_iter, double* err
 void free_all(hpf_handle* h) {
     void* ptrs[] = {h->d_rowptr, h->d_col, h->d_diag, h->d_erow, h->d_dev, h->d_Y, h->d_YN, h->d_YNt, h->d_IN, h->d_P, h->d_Q,
                     h->d_Vm, h->d_Va, h->d_U, h->d_E, h->d_I0, h->d_f, h->d_errbits, h->d_err, h->d_niter, h->d_active,
-                    h->d_nactive, h->d_pivflag, h->d_mask, h->d_Vm0, h->d_Va0, h->d_Vmp, h->d_Vap, h->d_tstamp, h->d_hist, h->d_stats, h->d_J, h->d_ipiv, h->d_info, h->d_Z, h->d_w, h->d_x, h->d_linA, h->d_C, h->d_dbg, h->d_H, h->d_chG, h->d_chH, h->d_chD, h->d_chy, h->d_chZ, h->d_lfK, h->d_lfS, h->d_fb, h->d_F, h->d_H2, h->d_U2, h->d_E2};
+                    h->d_nactive, h->d_pivflag, h->d_mask, h->d_Vm0, h->d_Va0, h->d_Vmp, h->d_Vap, h->d_tstamp, h->d_hist, h->d_stats, h->d_J, h->d_ipiv, h->d_info, h->d_Z, h->d_w, h->d_x, h->d_linA, h->d_C, h->d_dbg, h->d_H, h->d_chG, h->d_chH, h->d_chD, h->d_chy, h->d_chZ, h->d_lfK, h->d_lfS, h->d_fb, h->d_F, h->d_H2, h->d_U2, h->d_E2, h->d_jptr, h->d_jcol, h->d_jval};
     for (void* p : ptrs)
         if (p) hipFree(p);
     tree_free(h);
@@ -1225,15 +1271,79 @@ static int jacobian_impl(hpf_handle* h, bool fund, int scen, double* J) {
 
 int hpf_jacobian(hpf_handle* h, int scen, double* J) { return jacobian_impl(h, false, scen, J); }
 
-int hpf_jacobian_last(hpf_handle* h, int scen, double* J) {
-    if (!h || !J || scen < 0 || scen >= h->S) return HPF_E_ARG;
+// indptr of the CSR Jacobian (a property of the model): built on the device at the first request, kept for the handle's life
+static int jcsr_pattern(hpf_handle* h) {
+    if (h->d_jptr) return HPF_OK;
+    int r;
+    int* ptr = nullptr;
+    long long* tot = nullptr;
+    if ((r = dev_alloc(h, &ptr, (size_t)h->N + 1))) return r;
+    if ((r = dev_alloc(h, &tot, (size_t)1))) {
+        hipFree(ptr);
+        return r;
+    }
+    hipLaunchKernelGGL(k_jcsr_count, dim3((unsigned)((h->N + TPB - 1) / TPB)), dim3(TPB), 0, h->stream, h->M, h->N, h->Nc, ptr);
+    hipLaunchKernelGGL(k_jcsr_scan, dim3(1), dim3(1024), 0, h->stream, h->N, ptr, tot);
+    long long nnz = 0;
+    hipError_t e = hipMemcpyAsync(&nnz, tot, sizeof(long long), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipFree(tot);
+    if (e != hipSuccess) {
+        hipFree(ptr);
+        h->last_detail = (int)e;
+        return HPF_E_HIP;
+    }
+    if (nnz >= 0x7fffffffll) {           // 32-bit column indices / offsets, like scipy's default index type
+        hipFree(ptr);
+        return HPF_E_ARG;
+    }
+    h->d_jptr = ptr;
+    h->jnnz = nnz;
+    return HPF_OK;
+}
+
+static int jacobian_csr_impl(hpf_handle* h, int scen, int32_t* indptr, int32_t* indices, double* data) {
+    if (!h || !data || scen < 0 || scen >= h->S) return HPF_E_ARG;
+    if (!h->loads_set || !h->state_set) return HPF_E_STATE;
+    int r;
+    if ((r = jcsr_pattern(h))) return r;
+    if (!h->d_jval) {
+        if ((r = dev_alloc(h, &h->d_jval, (size_t)h->jnnz))) return r;
+        if ((r = dev_alloc(h, &h->d_jcol, (size_t)h->jnnz))) return r;
+    }
+    if ((r = launch_polar<false>(h))) return r;
+    const size_t so = (size_t)scen * h->n * h->Hn;
+    hipLaunchKernelGGL(k_jcsr_fill, dim3((unsigned)((h->N + TPB - 1) / TPB)), dim3(TPB), 0, h->stream, h->M, h->N, h->Nc, h->d_jptr,
+                       h->d_U + so, h->d_E + so, indices ? h->d_jcol : (int*)nullptr, h->d_jval);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (indptr) HIPCHK(hipMemcpy(indptr, h->d_jptr, sizeof(int32_t) * ((size_t)h->N + 1), hipMemcpyDeviceToHost));
+    if (indices) HIPCHK(hipMemcpy(indices, h->d_jcol, sizeof(int32_t) * (size_t)h->jnnz, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(data, h->d_jval, sizeof(double) * (size_t)h->jnnz, hipMemcpyDeviceToHost));
+    return HPF_OK;
+}
+
+int hpf_jacobian_nnz(hpf_handle* h, int64_t* nnz) {
+    if (!h || !nnz) return HPF_E_ARG;
+    const int r = jcsr_pattern(h);
+    if (r) return r;
+    *nnz = (int64_t)h->jnnz;
+    return HPF_OK;
+}
+
+int hpf_jacobian_csr(hpf_handle* h, int scen, int32_t* indptr, int32_t* indices, double* data) {
+    return jacobian_csr_impl(h, scen, indptr, indices, data);
+}
+
+// run fn() with the voltages of option "keep_previous_state" in place of the current ones, then put the current state back
+static int with_previous_state(hpf_handle* h, int scen, const std::function<int()>& fn) {
+    if (!h || scen < 0 || scen >= h->S) return HPF_E_ARG;
     if (!h->keep_prev || !h->d_Vmp || !h->state_set) return HPF_E_STATE;
     {   // the kept state exists for scenarios that took at least one Newton step in the last hpf_solve
         int ni = 0;
         HIPCHK(hipMemcpy(&ni, h->d_niter + scen, sizeof(int), hipMemcpyDeviceToHost));
         if (ni <= 0 || !h->prev_valid) return HPF_E_STATE;
     }
-    // assemble at the kept state, then put the current one back (the swap goes through the repeat-pass buffers' siblings)
     const size_t cnt = (size_t)h->S * h->n * h->Hn;
     double *tm = nullptr, *ta = nullptr;
     int r;
@@ -1246,7 +1356,7 @@ int hpf_jacobian_last(hpf_handle* h, int scen, double* J) {
     hipMemcpyAsync(ta, h->d_Va, sizeof(double) * cnt, hipMemcpyDeviceToDevice, h->stream);
     hipMemcpyAsync(h->d_Vm, h->d_Vmp, sizeof(double) * cnt, hipMemcpyDeviceToDevice, h->stream);
     hipMemcpyAsync(h->d_Va, h->d_Vap, sizeof(double) * cnt, hipMemcpyDeviceToDevice, h->stream);
-    r = jacobian_impl(h, false, scen, J);
+    r = fn();
     hipMemcpyAsync(h->d_Vm, tm, sizeof(double) * cnt, hipMemcpyDeviceToDevice, h->stream);
     hipMemcpyAsync(h->d_Va, ta, sizeof(double) * cnt, hipMemcpyDeviceToDevice, h->stream);
     if (!r) r = launch_polar<false>(h);
@@ -1254,6 +1364,16 @@ int hpf_jacobian_last(hpf_handle* h, int scen, double* J) {
     hipFree(tm);
     hipFree(ta);
     return r;
+}
+
+int hpf_jacobian_last(hpf_handle* h, int scen, double* J) {
+    if (!J) return HPF_E_ARG;
+    return with_previous_state(h, scen, [&]() { return jacobian_impl(h, false, scen, J); });
+}
+
+int hpf_jacobian_csr_last(hpf_handle* h, int scen, int32_t* indptr, int32_t* indices, double* data) {
+    if (!data) return HPF_E_ARG;
+    return with_previous_state(h, scen, [&]() { return jacobian_csr_impl(h, scen, indptr, indices, data); });
 }
 int hpf_fund_jacobian(hpf_handle* h, int scen, double* J) { return jacobian_impl(h, true, scen, J); }
 

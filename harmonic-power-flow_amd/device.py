@@ -35,7 +35,7 @@ def is_radial(n, rowptr, col):
 
 class DeviceModel:
     def __init__(self, n, m, c, harmonics, rowptr, col, Yval, dev_of_bus, Y_N, I_N, n_dev, coupled,
-                 solver="auto", device=0, max_scenarios=1):
+                 solver="auto", device=0, max_scenarios=1, assembly_only=False):
         lib = _lib.load()
         self.lib = lib
         self.n, self.m, self.c = int(n), int(m), int(c)
@@ -60,7 +60,8 @@ class DeviceModel:
         if solver == "block_tree_or_dense":
             solver = "block_tree"
         self.solver = solver
-        if solver == "dense" and 8 * N * N * int(max_scenarios) > 240e9:
+        # (assembly_only: a handle used for hpf_mismatch / hpf_jacobian_csr alone never allocates the dense Jacobian)
+        if solver == "dense" and not assembly_only and 8 * N * N * int(max_scenarios) > 240e9:
             raise ValueError("dense solver: N = %d unknowns x %d scenarios need %.0f GB for the Jacobians alone; radial feeders and feeders "
                              "with loop-closing lines of this size use solver='block_tree'" % (N, max_scenarios, 8e-9 * N * N * max_scenarios))
         d = _lib.hpf_desc()
@@ -156,6 +157,24 @@ class DeviceModel:
         J = np.empty((self.N, self.N), order="F")
         self._chk(self.lib.hpf_jacobian_last(self._h, int(scen), J.ctypes.data_as(_lib.c_dbl_p)), "hpf_jacobian_last")
         return J
+
+    def jacobian_nnz(self):
+        nnz = C.c_int64()
+        self._chk(self.lib.hpf_jacobian_nnz(self._h, C.byref(nnz)), "hpf_jacobian_nnz")
+        return int(nnz.value)
+
+    def jacobian_csr(self, scen=0, last=False):
+        """build_harmonic_jacobian (HG:401-473) as the reference returns it: scipy CSR of the stacked real matrix (HG:469-472), assembled
+        on the device straight into the CSR arrays (hpf_jacobian_csr; no dense N x N).  last=True: at the state the scenario's last
+        Newton step started from (what hpf() returns, HG:537,560; needs set_option("keep_previous_state", 1) before the solve)."""
+        import scipy.sparse as sp
+        nnz = self.jacobian_nnz()
+        indptr = np.empty(self.N + 1, dtype=np.int32)
+        indices = np.empty(nnz, dtype=np.int32)
+        data = np.empty(nnz, dtype=np.float64)
+        fn = self.lib.hpf_jacobian_csr_last if last else self.lib.hpf_jacobian_csr
+        self._chk(fn(self._h, int(scen), _ip(indptr), _ip(indices), _dp(data)), "hpf_jacobian_csr")
+        return sp.csr_matrix((data, indices, indptr), shape=(self.N, self.N))
 
     def fund_pf(self, thresh=1e-6, max_iter=30):
         n_iter = np.zeros(self.S, dtype=np.int32)

@@ -32,7 +32,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference"
 REF_HPF = os.path.join(REF, "Harmonic Power Flow")
 GOLD = os.path.join(REPO, "tests", "golden")
-SCRATCH = "/tmp/hpf_oracle_scratch"
+SCRATCH = os.environ.get("HPF_ORACLE_SCRATCH", "/tmp/hpf_oracle_scratch")
 
 
 def _setup_scratch():
@@ -79,11 +79,16 @@ def _import_reference():
     return g
 
 
-def run_case(g, buses_csv, lines_csv, h_max, coupled, full=True):
-    """Run the reference on one case, recording the NR trajectory through wrappers."""
+def run_case(g, buses_csv, lines_csv, h_max, coupled, full=True, load_scale=None):
+    """Run the reference on one case, recording the NR trajectory through wrappers.
+    `load_scale` (per-bus multipliers of P and Q, applied to the p.u. columns after the reference's own ingest): a Monte-Carlo
+    load scenario of BASELINE config 4 -- a sweep is repeated `hpf()` calls with other `buses.P/Q` (HG:197, HG:372)."""
     g.HARMONICS = [h for h in range(1, h_max + 1, 2)]
     g.HARMONICS_FREQ = [g.NET_FREQ * i for i in g.HARMONICS]
     g.buses, g.lines, g.m, g.n, g.c = g.init_network(buses_csv, lines_csv)
+    if load_scale is not None:
+        g.buses.loc[:, "P"] = g.buses.P.to_numpy() * load_scale
+        g.buses.loc[:, "Q"] = g.buses.Q.to_numpy() * load_scale
     rec = {"err": [], "V": [], "f0": None, "J0": None, "Y": None, "NE": None, "Vpf": None,
            "n_iter_f": None, "err_f": None, "t_jac": 0.0, "t_mis": 0.0, "t_sol": 0.0}
     o_mis, o_jac, o_pf, o_ne, o_y, o_upd = (g.harmonic_mismatch, g.build_harmonic_jacobian, g.pf,
@@ -228,6 +233,20 @@ def main(argv):
         summary[name] = (out["n_iter_h"], out["err_h"], out["n_iter_f"], out["loop_s"],
                          out["t_jac"], out["t_mis"], out["t_sol"])
         print(name, summary[name], flush=True)
+    for w in sorted(what):
+        # config 4 evidence held by the reference itself: Monte-Carlo scenario s of the 128-scenario share (synth.scenario_scale),
+        # `scenref<s>` -> tests/golden/syn1000_H51_scenref<s>.npz (about 25 min each: 5 min admittances + 27..35 NR iterations)
+        if w.startswith("scenref"):
+            s_id = int(w[len("scenref"):])
+            fb, fl = synth.gen(1000, seed=0, outdir=work)
+            out = run_case(g, os.path.basename(fb), os.path.basename(fl), 51, True, full=False,
+                           load_scale=synth.scenario_scale(1000, s_id))
+            out["scenario"] = s_id
+            for k in ("J0_matvec", "J0_rmatvec", "J0_absrowsum", "f0", "I_N", "Y_N"):      # keep the fixture small
+                out.pop(k, None)
+            np.savez_compressed(os.path.join(GOLD, "syn1000_H51_scenref%d.npz" % s_id), **out)
+            summary[w] = (out["n_iter_h"], out["err_h"], out["n_iter_f"], out["loop_s"])
+            print(w, summary[w], flush=True)
     if "hf" in what:
         # hcne_based_on_fuchs.py (HF) is a script: run it in the scratch cwd (it writes V_log/I_log.json there)
         hf_dir = os.path.join(SCRATCH, "hf")

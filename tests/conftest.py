@@ -1,6 +1,7 @@
 import os
 import sys
 
+import numpy as np
 import pytest
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -32,3 +33,12 @@ def gold_dir():
 @pytest.fixture(scope="session")
 def inputs_dir():
     return INPUTS
+
+
+def check_jacobian_checksums(J, g, rtol=1e-12):
+    """the reference's own J0 of a synthetic feeder (oracle/make_golden.py run_case, full=False): nnz, J w, J^T w, row sums of |J|"""
+    assert J.shape == tuple(g["J0_shape"])
+    assert J.nnz == int(g["J0_nnz"]), (J.nnz, int(g["J0_nnz"]))
+    w = np.cos(np.arange(J.shape[1]) * 0.37) + 1.5
+    for ours, ref in ((J @ w, g["J0_matvec"]), (J.T @ w, g["J0_rmatvec"]), (np.asarray(abs(J).sum(axis=1)).ravel(), g["J0_absrowsum"])):
+        assert np.abs(ours - ref).max() <= rtol * np.abs(ref).max()

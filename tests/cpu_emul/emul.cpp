@@ -64,4 +64,23 @@ void emul_jacobian(int fund, int n, int m, int c, int Hn, int nnz, int n_dev, in
                 for (int p = 0; p < Hn; ++p)
                     if (p != q) jac_cross(M, (const cplx*)U, (const cplx*)E, q, p, i, em);
 }
+
+// The CSR form (hpf_jacobian_csr): indptr by a serial count + prefix sum, then the same per-row fill as k_jcsr_fill.
+// indptr [N+1]; indices / data may be NULL (size query): returns nnz.
+long long emul_jacobian_csr(int n, int m, int c, int Hn, int nnz, int n_dev, int coupled, const int* rowptr,
+                            const int* col, const int* diag, const double* Y, const int* dev, const double* YN,
+                            const double* IN, const double* U, const double* E, int* indptr, int* indices, double* data) {
+    Model M = mk(n, m, c, Hn, nnz, n_dev, coupled, rowptr, col, diag, Y, dev, YN, IN);
+    const int Nc = n * Hn - 1, N = 2 * Nc - (c - 1);
+    long long tot = 0;
+    for (int r = 0; r < N; ++r) {
+        indptr[r] = (int)tot;
+        const JCount k = jcsr_count_row(M, Nc, r);
+        tot += k.n_theta + k.n_v;
+    }
+    indptr[N] = (int)tot;
+    if (data)
+        for (int r = 0; r < N; ++r) jcsr_fill_row(M, (const cplx*)U, (const cplx*)E, Nc, r, indptr[r], indices, data);
+    return tot;
+}
 }

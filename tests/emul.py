@@ -67,3 +67,17 @@ class Emul:
         J = np.zeros((N, N), order="F")
         self.lib.emul_jacobian(int(fund), *self._model_args(), _p(U.view(np.float64)), _p(E.view(np.float64)), _p(J))
         return J
+
+    def jacobian_csr(self, Vm, Va):
+        """the CSR form (hpf_jacobian_csr) -> scipy.sparse.csr_matrix"""
+        import scipy.sparse as sp
+        U, E = self.polar(Vm, Va)
+        N = 2 * (self.n * self.Hn - 1) - (self.c - 1)
+        indptr = np.zeros(N + 1, np.int32)
+        self.lib.emul_jacobian_csr.restype = C.c_longlong
+        nnz = self.lib.emul_jacobian_csr(*self._model_args(), _p(U.view(np.float64)), _p(E.view(np.float64)),
+                                         _p(indptr, C.c_int32), None, None)
+        indices, data = np.zeros(nnz, np.int32), np.zeros(nnz)
+        self.lib.emul_jacobian_csr(*self._model_args(), _p(U.view(np.float64)), _p(E.view(np.float64)),
+                                   _p(indptr, C.c_int32), _p(indices, C.c_int32), _p(data))
+        return sp.csr_matrix((data, indices, indptr), shape=(N, N))

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import hpf_oracle as o
-from conftest import GOLD, INPUTS
+from conftest import GOLD, INPUTS, check_jacobian_checksums
 from emul import Emul
 
 import harmonic_power_flow_amd as hp
@@ -96,3 +96,59 @@ def test_fundamental_arithmetic_on_host(name):
                         [np.asarray(dSdA[c:, 1:].imag), np.asarray(dSdV[c:, c:].imag)]])
         J_e = em.jacobian(Vm, Va, fund=True)
         assert np.abs(J_e - J_o).max() <= 1e-14 * np.abs(J_o).max()
+
+
+def _sorted_coo(rows, cols, data):
+    o_ = np.lexsort((cols, rows))
+    return rows[o_], cols[o_], data[o_]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_csr_jacobian_pattern_and_values_equal_the_reference(name):
+    """hpf_jacobian_csr's per-row walk (jcsr_* in csrc/hpf_assembly.hpp, executed on the host): the STORED ENTRIES are exactly the
+    reference's (HG:469-472 as scipy built it: same nnz, same (row, column) set), columns ascending inside every row, values equal
+    to the dense target's bit for bit and to the reference's J0 at 1e-13."""
+    st, buses, Y, em, net, mdl, _ = _setup(name)
+    g = np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=True)
+    traj = g["V_traj"]
+    Vm, Va = traj[0][:, 0].copy(), traj[0][:, 1].copy()
+    J = em.jacobian_csr(Vm, Va)
+    assert J.shape == tuple(g["J0_shape"])
+    for r in range(J.shape[0]):
+        assert np.all(np.diff(J.indices[J.indptr[r]:J.indptr[r + 1]]) > 0), r
+    rr, cc, dd = _sorted_coo(g["J0_row"], g["J0_col"], g["J0_data"])
+    C = J.tocoo()
+    r2, c2, d2 = _sorted_coo(C.row, C.col, C.data)
+    assert J.nnz == len(dd), (J.nnz, len(dd))
+    assert np.array_equal(r2, rr) and np.array_equal(c2, cc)
+    assert np.abs(d2 - dd).max() <= 1e-13 * np.abs(dd).max()
+    Jd = em.jacobian(Vm, Va)
+    assert np.array_equal(J.toarray(), Jd)
+    # ... and along the trajectory against the oracle's CSR (pattern and values)
+    it = len(traj) // 2
+    Vm, Va = traj[it][:, 0].copy(), traj[it][:, 1].copy()
+    Jo = o.build_harmonic_jacobian(mdl, Vm.copy(), Va.copy()).tocsr()
+    Je = em.jacobian_csr(Vm, Va)
+    fin = np.isfinite(Jo.toarray())
+    assert np.abs(Je.toarray()[fin] - Jo.toarray()[fin]).max() <= 1e-13 * np.abs(Jo.toarray()[fin]).max()
+
+
+def _syn_emul(n, hmax, tmp_path):
+    from harmonic_power_flow_amd import synth
+    fb, fl = synth.gen(n, seed=0, outdir=str(tmp_path))
+    st = hp.Settings(H_MAX=hmax)
+    buses, lines, m, nn, c = hp.init_network(fb, fl, settings=st)
+    Y = hp.build_admittance_matrices(buses, lines, st.HARMONICS)
+    NE = hp.import_Norton_Equivalents(buses, True, st, INPUTS)
+    dev, Y_N, I_N, n_dev = ingest.norton_arrays(buses, NE, True, len(st.HARMONICS))
+    return Emul(nn, m, c, len(st.HARMONICS), Y.rowptr, Y.col, Y.Yval, dev, Y_N, I_N, n_dev, True)
+
+
+@pytest.mark.parametrize("n,hmax", [(100, 11), (200, 11), (1000, 51)])
+def test_csr_jacobian_checksums_of_the_synthetic_feeders_vs_reference(n, hmax, tmp_path):
+    """syn100 / syn200 (K = 5) and the HEADLINE shape syn1000 (K = 25: N = 51 998, nnz 1 221 740): the reference's first Jacobian
+    (at its post-pf state V_it0) is held as checksums; the CSR walk reproduces nnz exactly and the sums at 1e-12."""
+    g = np.load(os.path.join(GOLD, f"syn{n}_H{hmax}_c.npz"), allow_pickle=True)
+    em = _syn_emul(n, hmax, tmp_path)
+    J = em.jacobian_csr(g["V_it0"][:, 0].copy(), g["V_it0"][:, 1].copy())
+    check_jacobian_checksums(J, g)
