@@ -45,7 +45,7 @@ FP64_PEAK_TFLOPS = 78.6      # MI355X FP64 vector = matrix peak (spec; SURVEY.md
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -60,7 +60,33 @@ def parse():
     ap.add_argument("--sweep-1gpu", type=int, default=1024, help="(N = 1) scenarios of the single-GPU sweep leg (0 = skip)")
     ap.add_argument("--single", action="store_true", help="(default on rank 0 at N=1) also time a single-scenario solve: BASELINE config 3")
     ap.add_argument("--no-single", action="store_true", help="skip the single-scenario latency leg")
-    return ap.parse_args()
+    ap.add_argument("--repeats", type=int, default=5, help="the timed block of `steps` iterations is run this many times (each from the pf "
+                                                           "seed, each bracketed by barrier + synchronize); value = the median block")
+    return ap.parse_args(argv)
+
+
+def launch_plan(args, env):
+    """`python bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment): the command that starts N ranks of this
+    script, one per GPU -- or None when this process is itself a rank (or N = 1).  The children are FRESH processes started before
+    this one imports torch or touches the GPU; nothing is re-executed in place."""
+    if args.gpus <= 1 or "WORLD_SIZE" in env:
+        return None
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+
+
+def run_launcher(cmd):
+    """Start the ranks, relay rank 0's JSON line (the only line a rank prints on stdout) and the launcher's exit code."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    for line in p.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return p.wait()
 
 
 def build_inputs(args, hp):
@@ -129,9 +155,15 @@ def cpu_baseline_start(args):
 
 def main():
     args = parse()
+    cmd = launch_plan(args, os.environ)
+    if cmd is not None:
+        raise SystemExit(run_launcher(cmd))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (one rank per GPU: start it as `python bench.py --gpus N` or under "
+                         "torch.distributed.run with --nproc-per-node N)" % (args.gpus, world))
     cpu = cpu_baseline_start(args) if rank == 0 else None      # rank 0 of every world size; child processes, before any GPU initialisation
     import torch
     import torch.distributed as dist
@@ -174,18 +206,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    dm.iterate(args.warmup)
-    dm.sync()
-    barrier()
-    t0 = time.perf_counter()
-    dm.iterate(args.steps)
-    dm.sync()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # R timed blocks of exactly K steps, each from the pf seed (W warm-up steps first), each bracketed by barrier + synchronize on both
+    # sides and reduced with MAX over the ranks; the reported block is the median one
+    blocks = []
+    for rep in range(max(args.repeats, 1)):
+        if rep:
+            dm.set_state(seed[0], seed[1])
+            dm.mismatch(want_f=False)
+        dm.iterate(args.warmup)
+        dm.sync()
+        barrier()
+        t0 = time.perf_counter()
+        dm.iterate(args.steps)
+        dm.sync()
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        blocks.append(el)
+    elapsed = float(np.median(blocks))
     # per-kernel HIP-event timing (on the streams the kernels run on) over K more steps of the same configuration, continued
     # from the state the timed region left; kept out of the headline region because every span costs two event records
     Kt = min(args.steps, 20)                     # steps of each timing leg (bounded: every span is a pair of event records)
@@ -221,9 +262,14 @@ def main():
         sweep["solve_wall_s_rank0"] = t_sw        # hpf_solve of this rank's scenarios with the reference's stop rule (untimed leg)
         sweep["iters_per_s_rank0"] = float(n_iter.sum()) / t_sw
 
-    if rank != 0:
+    def leave():
+        # no rank tears its communicator down while another still works: rank 0 runs the single-GPU legs below before it gets here
         if world > 1:
+            dist.barrier()
             dist.destroy_process_group()
+
+    if rank != 0:
+        leave()
         return
 
     K = args.steps
@@ -280,6 +326,11 @@ def main():
                    "buses": n, "harmonics": Hn - 1, "unknowns_per_scenario": dm.N, "scenarios_per_gpu": S,
                    "solver": dm.solver, "step": "one NR iteration of every scenario (HG:537-540)",
                    "pf_iterations": int(nf.max())},
+        "repeats": len(blocks), "repeat_ms_per_step": [1e3 * b / K for b in blocks],
+        "repeat_note": "R timed blocks of exactly `steps` iterations, each from the pf seed after `warmup` iterations, each bracketed by "
+                       "barrier + synchronize and MAX-reduced over the ranks; ms_per_step / value are the MEDIAN block's",
+        "backend": backend if world > 1 else None,
+        "rccl_ranks": (dist.get_world_size() if (world > 1 and backend == "nccl") else None),
         "ms_per_iter_per_scenario": ms_step / S,
         "setup_ms": setup["model_setup_ms"], "setup": setup,
         "roofline": {"bound": "hbm",
@@ -303,7 +354,8 @@ def main():
                              "the kernel during the timing leg, %d launches) = what rocprofv3 --kernel-trace --stats averages for this "
                              "kernel (profiles/); avg_ms_hip_event_spans is the same launches bracketed by HIP events on their streams, "
                              "which adds the event packets and queue gaps around a ~25 us kernel.  The launches of the %d scenario groups "
-                             "overlap on separate streams, so a launch shares the chip with the other groups' kernels.  arithmetic intensity %.2f flop/B "
+                             "overlap on separate streams, so a launch shares the chip with the other groups' kernels: avg_ms, achieved and frac are "
+                             "SHARED-CHIP figures per launch (the sum of the launches of a step exceeds the step's wall time).  arithmetic intensity %.2f flop/B "
                              "< ridge %.1f: HBM-bound by the roofline, in practice bound by workgroup latency (DESIGN.md §5)"
                              % (gj_n, G, fl_gj / max(by_gj, 1.0), FP64_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS)},
         "roofline_factor_sweep": {"bound": "hbm", "kernels": "all factor kernels of a step (k_level, or k_leaf_batch + k_sleaf_batch + k_factor_q)",
@@ -352,9 +404,8 @@ def main():
         out["setup_warm_ms"] = (out["setup"]["ingest_csv_ms"] + out["setup"]["admittance_ms"] + out["setup"]["norton_ms"] +
                                 out["setup"]["create_warm_ms"])
     out["cpu_baseline"] = cpu
-    print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    print(json.dumps(out), flush=True)
+    leave()
 
 
 def lib_sha16():

@@ -96,3 +96,22 @@ def test_bench_reports_counter_traffic_only_for_the_running_library(tmp_path, mo
     (prof / "pmc_traffic_latest.json").write_text(json.dumps(dict(good, lib_sha16="0" * 16)))
     t, note, src = bench.pmc_traffic(args, 128)
     assert t is None and src is None and "another build" in note and bench.pmc_step_traffic(args, 128) is None
+
+
+def test_bench_gpus_flag_starts_one_rank_per_gpu(monkeypatch):
+    """`python bench.py --gpus N` without a launcher must start N ranks itself (fresh child processes through torch.distributed.run on
+    127.0.0.1, before anything touches the GPU); under a launcher (WORLD_SIZE set) or at N = 1 the process is a rank and runs the bench."""
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(REPO, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7", "--warmup", "2"])
+    args = bench.parse(["--gpus", "4", "--steps", "7", "--warmup", "2"])
+    cmd = bench.launch_plan(args, {})
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"] and cmd[-7].endswith("bench.py")
+    assert bench.launch_plan(args, {"WORLD_SIZE": "4", "RANK": "0"}) is None           # already a rank
+    assert bench.launch_plan(bench.parse(["--gpus", "1"]), {}) is None
+    assert bench.parse([]).gpus == 1 and bench.parse([]).repeats >= 5
