@@ -187,6 +187,7 @@ def hpf(buses, lines, coupled, thresh_h=1e-4, max_iter_h=50, plt_convergence=Fal
         if details is not None:
             details.update(err_hist=hist[0, :n_iter_h + 1].copy(), seed=(seed[0][0].copy(), seed[1][0].copy()),
                            n_iter_f=int(nf[0]), err_f=hf[0, :int(nf[0])].copy(), solver=dm.solver,
+                           tree=(dm.tree_census() if dm.solver == "block_tree" else None),
                            stats=stats, Vm_raw=Vm_raw[0].copy(), Va_raw=Va_raw[0].copy(), N=dm.N)
     finally:
         dm.close()

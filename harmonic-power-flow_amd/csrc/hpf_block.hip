@@ -898,6 +898,11 @@ __global__ __launch_bounds__(256, HPF_Q_OCC) void k_level(
             if (threadIdx.x == 0) atomicMax(tstamp + 1, (unsigned long long)wall_clock64());
         }
     } else {
+        // Blocks of 12 / 28: the factor body runs on NT < 4 wavefronts of this 256-thread workgroup and the others END here, before the
+        // body's workgroup barriers.  That relies on the gfx9 barrier rule -- s_barrier releases when every wavefront of the workgroup that
+        // has not terminated has arrived (s_endpgm takes a wavefront out of the count) --, not on anything HIP promises for a divergent
+        // __syncthreads().  Only levels that have batched workgroups come here at these sizes (level_is_fused); covered on the GPU by
+        // test_tree_build_variants_take_the_same_newton_steps (K = 5 / 13 against HPF_FUSELEVEL=0, bit for bit).
         if (64 * ((B + 16) / 16) < 256 && (int)threadIdx.x >= 64 * ((B + 16) / 16)) return;
         const int i = (int)blockIdx.x - nbb;
         factor_q_body<B, false>(FqLds<B>::carve(smem), i % ngen, i / ngen, M, T, nodes + FDESC * (size_t)nbatch, b, N, Nc, active, Uall, Eall, fall, Zall, wall,
@@ -2373,8 +2378,10 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
     if (getenv("HPF_TREE_INFO"))
         fprintf(stderr, "hpf tree (%s): %d buses, %d dense in %d levels, %d chains, %d constant-inverse leaves, %d lazy under %d parents\n",
                 contract ? "contracted" : "plain", n, T.n_dense, T.n_levels, T.n_chains, T.n_cleaf, T.n_lazy_leaves, T.n_lazy_parents);
-    if (const char* dump_path = getenv("HPF_TREE_DUMP")) {     // host-side plan of the dense tree (tools/tree_plan.py): one line per dense bus
+    // host-side plan of the dense tree (tools/tree_plan.py): one line per dense bus -- to the file hpf_tree_plan names, or env HPF_TREE_DUMP
+    if (const char* dump_path = h->plan_path ? h->plan_path : getenv("HPF_TREE_DUMP")) {
         if (FILE* fp = fopen(dump_path, contract ? "w" : "a")) {
+            h->plan_written = true;
             fprintf(fp, "# %s tree: k pard height depth kind(0 gauss-jordan, 1 constant-inverse leaf, 2 bordered) vector_only hbm_children via_chain compress_role\n",
                     contract ? "contracted" : "plain");
             for (int pos = 0; pos < T.n_dense; ++pos) {
@@ -2388,6 +2395,7 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
     }
     T.plan_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     if (getenv("HPF_TREE_INFO")) fprintf(stderr, "hpf tree (%s): planned on the host in %.1f ms\n", contract ? "contracted" : "plain", T.plan_ms);
+    if (h->plan_only) return HPF_OK;            // hpf_tree_plan: host-only, nothing goes to a device
     int r;
     if ((r = upload(h, &T.d_parent, T.parent))) return r;
     if ((r = upload(h, &T.d_lvl_nodes, T.lvl_nodes))) return r;
@@ -2454,14 +2462,19 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
     return HPF_OK;
 }
 
-// host-only: runs the tree planning of a radial model and writes the HPF_TREE_DUMP file; the uploads fail without a device, which is fine
-int tree_plan_dump(const hpf_desc* d) {
+// host-only: runs the tree planning of a radial model exactly as hpf_create would for a handle of d->max_scenarios scenarios (the compress
+// steps are a default of handles of up to 256) and writes the plan to `path`; returns before anything would go to a device
+int tree_plan_dump(const hpf_desc* d, const char* path) {
     hpf_handle tmp;
     tmp.n = d->n; tmp.m = d->m; tmp.c = d->c; tmp.Hn = d->Hn; tmp.nnz = d->nnz; tmp.coupled = d->coupled;
+    tmp.S_max = d->max_scenarios;
+    tmp.plan_path = path;
+    tmp.plan_only = true;
     Tree T;
     const int r = tree_build_into(&tmp, d, T, true);
     tree_free_one_fwd(T);
-    return r;
+    if (r) return r;
+    return tmp.plan_written ? HPF_OK : HPF_E_ARG;       // (the file could not be opened)
 }
 
 int tree_build(hpf_handle* h, const hpf_desc* d) {
@@ -2470,6 +2483,34 @@ int tree_build(hpf_handle* h, const hpf_desc* d) {
     h->has_ctree = wave_block_size(2 * d->Hn) != 0;
     if (h->has_ctree) r = tree_build_into(h, d, h->ctree, true);
     return r;
+}
+
+// the batched workgroups of elimination level l (lazy leaves at level 0, vector-only bordered buses above: 16 scenarios each);
+// kind 1 / 2 / 0 (none) -- the one place the factor sweep and the census take it from
+static int level_batched(const hpf_handle* h, const Tree& T, int l, int* kind) {
+    int nbatch = (l == 0 && h->leafbatch && h->has_ctree && T.lvl_all_leaf[0]) ? T.n_lazy_level0 : 0;
+    const bool slbatch = l > 0 && h->leafbatch && h->has_ctree && l < (int)T.lvl_nbatch.size() && T.lvl_nbatch[l] > 0;
+    if (slbatch) nbatch = T.lvl_nbatch[l];
+    if (kind) *kind = nbatch > 0 ? (slbatch ? 2 : 1) : 0;
+    return nbatch;
+}
+
+// elimination level l of the current mode is ONE launch of k_level<BW> (else: k_leaf_batch / k_sleaf_batch + k_factor_q, or k_factor_q
+// alone): blocks of 52 always, smaller blocks only where the level has batched workgroups to put next to the per-scenario ones
+static bool level_is_fused(const hpf_handle* h, const Tree& T, int l, int BW) {
+    if (h->gj_mode != 1 || !h->fuse_levels || (BW != 12 && BW != 28 && BW != 52)) return false;
+    return BW == 52 || level_batched(h, T, l, nullptr) > 0;
+}
+
+// hpf_tree_census[9] / hpf_kernel_model: every elimination level of the factor sweep is one k_level launch
+bool tree_levels_fused(hpf_handle* h) {
+    if (h->solver != HPF_SOLVER_BLOCK_TREE) return false;
+    const Tree& T = active_tree(h);
+    const int BW = wave_block_size(2 * h->Hn);
+    if (T.n_levels == 0) return false;
+    for (int l = 0; l < T.n_levels; ++l)
+        if (T.lvl_ptr[l + 1] > T.lvl_ptr[l] && !level_is_fused(h, T, l, BW)) return false;
+    return true;
 }
 
 // the tree the Newton step of the current mode runs on
@@ -2632,14 +2673,13 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
             const int* nodes = T.d_lvl_nodes + T.lvl_ptr[l];
             int r;
             // level 0 of the contracted tree: its lazy leaves come first and go 16 scenarios per workgroup (k_leaf_batch)
-            const int leafbatch = h->leafbatch;                 // 0: one workgroup per (leaf, scenario)
-            int nbatch = (l == 0 && leafbatch && h->has_ctree && T.lvl_all_leaf[0]) ? T.n_lazy_level0 : 0;
-            const bool slbatch = l > 0 && leafbatch && h->has_ctree && l < (int)T.lvl_nbatch.size() && T.lvl_nbatch[l] > 0;
-            if (slbatch) nbatch = T.lvl_nbatch[l];
+            int bkind = 0;                                      // (h->leafbatch == 0: one workgroup per (leaf, scenario), no batched ones)
+            const int nbatch = level_batched(h, T, l, &bkind);
+            const bool slbatch = bkind == 2;
             switch (BW) {                       // (timing spans: one per kernel launch, inside the launch helpers)
 #define HPF_FACTOR_CASE(BB_)                                                                                  \
     case BB_:                                                                                                 \
-        if (h->gj_mode == 1 && h->fuse_levels && (nbatch > 0 || BB_ == 52)) {     /* one launch per level: batched and per-scenario workgroups   \
+        if (level_is_fused(h, T, l, BB_)) {                 /* one launch per level: batched and per-scenario workgroups                          \
                                                       side by side (small blocks without batched workgroups: k_factor_q's own grid and LDS) */ \
             r = launch_level<BB_>(h, td, T.d_fdesc + FDESC * (size_t)T.lvl_ptr[l], nbatch > 0 ? (slbatch ? 2 : 1) : 0, nbatch,       \
                                   cnt - nbatch, active);                                                      \

@@ -145,6 +145,9 @@ struct hpf_handle {
     int N = 0, Nc = 0, Nf = 0;
     bool loads_set = false, state_set = false, mismatch_valid = false;
     int last_detail = 0;
+    const char* plan_path = nullptr;  // hpf_tree_plan: file the planning run writes (instead of env HPF_TREE_DUMP) ...
+    bool plan_only = false;           // ... and it stops before the uploads
+    bool plan_written = false;
     int gj_mode = 1;                  // BLOCK_TREE block inversion: 0 pivoted wave Gauss-Jordan (VALU, uncontracted tree), 1 MFMA static 4x4 blocks, NT waves per bus (hpf_quad.hpp)
     double piv_limit = 1e10;          // static pivot order: amplification of a 4x4 pivot block's inverse beyond which a scenario is repeated with partial pivoting
     int fuse_levels = 1;              // HPF_FUSELEVEL (read by hpf_create): 0 = separate launches for the batched and the per-scenario workgroups of a level
@@ -262,8 +265,9 @@ struct ScopedTimer {
 // block-tree solver (hpf_block.hip)
 int tree_find_ties(hpf_handle* h, const hpf_desc* d);    // spanning tree + loop-closing lines of the pattern (before any allocation)
 int tree_build(hpf_handle* h, const hpf_desc* d);
-int tree_plan_dump(const hpf_desc* d);                    // host-only planning run (HPF_TREE_DUMP), no device needed
+int tree_plan_dump(const hpf_desc* d, const char* path);  // host-only planning run (hpf_tree_plan), no device touched
 hpf::Tree& active_tree(hpf_handle* h);
+bool tree_levels_fused(hpf_handle* h);                   // every elimination level of the current mode is one k_level launch
 void tree_free(hpf_handle* h);
 int tree_alloc_scenarios(hpf_handle* h);
 int tree_fund_step(hpf_handle* h, bool only_active);     // fundamental pf Newton step on the tree (2x2 blocks)

@@ -645,12 +645,9 @@ int launch_mismatch(hpf_handle* h, const int* active, bool stacked = true, const
         const size_t lds = (!FUND && h->coupled && h->n > h->m)
                                ? sizeof(cplx) * ((size_t)h->Hn * h->Hn + (size_t)(TPB / h->Hn + 2) * h->Hn) : 0;
         if (lds > 64 * 1024) {                      // Hn >= 62 (H_MAX >= 123): beyond the default dynamic-LDS limit of a kernel
-            static bool attr_set = false;
-            if (!attr_set) {
-                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mismatch<FUND>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                attr_set = true;
-            }
             if (lds > 160 * 1024) return HPF_E_ARG;
+            // (per launch: the attribute belongs to the device the handle runs on, and the call costs nothing next to the launch)
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mismatch<FUND>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         }
         hipLaunchKernelGGL((k_mismatch<FUND>), dim3(xcd_grid(nbx, h->cur_S)), dim3(TPB), lds, h->cur_stream, h->M, count, N, Nc,
                            active, Uover ? Uover : h->d_U, h->d_P, h->d_Q, (stacked || !img) ? h->d_f : nullptr, h->d_errbits, h->d_I0,
@@ -1595,7 +1592,7 @@ int hpf_kernel_model(const hpf_handle* h, int which, double* bytes, double* flop
     int ln = 0;
     if (h->solver == HPF_SOLVER_BLOCK_TREE) {
         const Tree& T = active_tree(const_cast<hpf_handle*>(h));
-        if (which == T_GJ && h->fuse_levels && 2 * h->Hn <= 52) {      // k_level: every dense bus, one launch per level
+        if (which == T_GJ && tree_levels_fused(const_cast<hpf_handle*>(h))) {      // k_level: every dense bus, one launch per level
             by = T.bytes_factor; fl = T.flops_factor; ln = T.n_levels;
         } else if (which == T_GJ) {
             by = T.bytes_gj; fl = T.flops_gj; ln = T.n_gj_launches;
@@ -1621,7 +1618,7 @@ int hpf_tree_census(const hpf_handle* h, int* counts, int n_counts) {
     if (!h || !counts || n_counts < 0) return HPF_E_ARG;
     if (h->solver != HPF_SOLVER_BLOCK_TREE) return HPF_E_STATE;
     const Tree& T = active_tree(const_cast<hpf_handle*>(h));
-    const int fused = (h->fuse_levels && h->gj_mode == 1 && 2 * h->Hn <= 52) ? 1 : 0;
+    const int fused = tree_levels_fused(const_cast<hpf_handle*>(h)) ? 1 : 0;
     for (int i = 0; i < n_counts; ++i) counts[i] = i < 8 ? T.census[i] : (i == 8 ? h->n_ties : (i == 9 ? fused : (i == 10 ? T.n_comp : 0)));
     return HPF_OK;
 }
@@ -1640,13 +1637,9 @@ int hpf_scenario_groups(const hpf_handle* h, int live) {
 int hpf_tree_plan(const hpf_desc* d, const char* path) {
     if (!d || !path || d->n < 1 || !d->rowptr || !d->col || !d->Yval || !d->dev_of_bus) return HPF_E_ARG;
     if (d->nnz != d->n + 2 * (d->n - 1)) return HPF_E_TOPOLOGY;           // radial models only
-    setenv("HPF_TREE_DUMP", path, 1);
-    tree_plan_dump(d);                                                      // (its uploads fail without a device: ignored)
-    unsetenv("HPF_TREE_DUMP");
-    FILE* fp = fopen(path, "r");
-    if (!fp) return HPF_E_ARG;
-    fclose(fp);
-    return HPF_OK;
+    if (d->max_scenarios < 1) return HPF_E_ARG;
+    remove(path);                                                           // (a stale file of an earlier run must not pass for this one)
+    return tree_plan_dump(d, path);
 }
 
 double hpf_back_bytes(const hpf_handle* h) {

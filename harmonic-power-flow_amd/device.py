@@ -34,6 +34,12 @@ def is_radial(n, rowptr, col):
 
 
 class DeviceModel:
+    """One libhpf handle.  `max_scenarios` is the handle's capacity AND a build parameter of the block tree: handles of up to 256
+    scenarios eliminate the Gauss-Jordan skeleton with compress steps (fewer, wider elimination levels), larger ones
+    strictly leaves first.  Both orders take the same Newton steps up to rounding, so a solver-sensitive case can take a different
+    iteration count in a handle of another capacity class; within a class results are bit-identical across batch sizes.
+    `tree_census()["compress_steps"]` / `solve` details report which one a handle uses; env HPF_COMPRESS=0/1 forces it."""
+
     def __init__(self, n, m, c, harmonics, rowptr, col, Yval, dev_of_bus, Y_N, I_N, n_dev, coupled,
                  solver="auto", device=0, max_scenarios=1, assembly_only=False):
         lib = _lib.load()

@@ -241,7 +241,8 @@ int  hpf_kernel_model(const hpf_handle* h, int which, double* bytes, double* flo
  * block (the rest lives in the 2x2 algebra of the linear subtrees / contracted chains), Gauss-Jordan buses (k_factor_q<B,false>),
  * constant-inverse leaves, of which lazy (vector-only, k_leaf_batch), bordered buses (super-leaves, m x m core), of which nested
  * (bordered children below them), elimination levels, back-sweep depths, tie lines of a meshed network, [9] 1 if every elimination
- * level is ONE launch (k_level: scenario-batched and per-scenario workgroups in one grid; timing class 5 then covers it),
+ * level is ONE launch (k_level: scenario-batched and per-scenario workgroups in one grid; timing class 5 then covers it) -- blocks of 52
+ * in the default mode; smaller blocks only when every level has scenario-batched workgroups (levels without them run k_factor_q's own grid),
  * [10] compress steps (Gauss-Jordan buses eliminated before their tallest dense child: levels counts the shortened chain).
  * HPF_E_STATE for DENSE. */
 int  hpf_tree_census(const hpf_handle* h, int* counts, int n_counts);
@@ -252,9 +253,12 @@ int  hpf_setup_times(const hpf_handle* h, double* ms, int n_ms);
 /* Number of scenario groups (independent pipelines on separate HIP streams) a Newton step of `live` running scenarios is split into:
  * option "scenario_groups" bounded by a minimum group size; 1 for DENSE and for meshed networks. */
 int  hpf_scenario_groups(const hpf_handle* h, int live);
-/* Host-only planning run of the BLOCK_TREE elimination tree of a radial model (no device, no handle): builds the contracted tree
- * exactly as hpf_create would and writes one line per dense bus (bus, dense parent, elimination level, back-sweep depth, kind, ...)
- * to `path` (the file env HPF_TREE_DUMP would name; tools/tree_plan.py reads it).  Returns HPF_OK when the plan was written. */
+/* Host-only planning run of the BLOCK_TREE elimination tree of a radial model (no device is touched, no handle, the process environment
+ * is not modified): builds the contracted tree exactly as hpf_create would for a handle of d->max_scenarios scenarios (compress steps
+ * are the default up to 256) and writes one line per dense bus (bus, dense parent, elimination level, back-sweep depth, kind, ...)
+ * to `path` (replaced if it exists; tools/tree_plan.py reads it).  Returns the planning status: HPF_OK when the plan was written,
+ * HPF_E_TOPOLOGY for a meshed model, HPF_E_ARG when the file cannot be written.  (env HPF_TREE_DUMP=<file> makes hpf_create itself
+ * write the same dump.) */
 int  hpf_tree_plan(const hpf_desc* d, const char* path);
 
 #ifdef __cplusplus

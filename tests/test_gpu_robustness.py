@@ -258,8 +258,8 @@ def test_compress_steps_default_follows_the_handle_capacity(tmp_path, monkeypatc
             got[(S, env)] = dm.tree_census()
         finally:
             dm.close()
-    assert got[(256, None)]["compress_steps"] > 0 and got[(256, None)]["levels"] == 10
-    assert got[(257, None)]["compress_steps"] == 0 and got[(257, None)]["levels"] == 15
+    assert got[(256, None)]["compress_steps"] > 0 and got[(257, None)]["compress_steps"] == 0
+    assert got[(256, None)]["levels"] < got[(257, None)]["levels"]                     # the steps shorten the level chain (10 vs 15 here)
     assert got[(257, "1")]["compress_steps"] > 0 and got[(8, "0")]["compress_steps"] == 0
 
 

@@ -18,7 +18,7 @@ from harmonic_power_flow_amd import _lib, ingest, synth   # noqa: E402
 INPUTS = os.path.join(REPO, "tests", "golden", "inputs")
 
 
-def plan(nb, hmax, seed=0):
+def plan(nb, hmax, seed=0, max_scenarios=1):
     tmp = tempfile.mkdtemp(prefix="hpf_plan_")
     fb, fl = synth.gen(nb, seed=seed, outdir=tmp)
     st = hp.Settings(H_MAX=hmax)
@@ -34,7 +34,7 @@ def plan(nb, hmax, seed=0):
     Y_N = np.ascontiguousarray(Y_N, dtype=np.complex128)
     I_N = np.ascontiguousarray(I_N, dtype=np.complex128)
     d.n, d.m, d.c, d.Hn, d.nnz = n, m, c, len(st.HARMONICS), len(col)
-    d.n_dev, d.coupled, d.solver, d.device, d.max_scenarios = int(n_dev), 1, 1, 0, 1
+    d.n_dev, d.coupled, d.solver, d.device, d.max_scenarios = int(n_dev), 1, 1, 0, int(max_scenarios)
     d.rowptr, d.col = rowptr.ctypes.data_as(_lib.c_int_p), col.ctypes.data_as(_lib.c_int_p)
     d.Yval = Yv.view(np.float64).ctypes.data_as(_lib.c_dbl_p)
     d.dev_of_bus = dev.ctypes.data_as(_lib.c_int_p)
