@@ -181,3 +181,31 @@ def test_oracle_syn1000_headline_shape(tmp_path):
     assert np.abs(Uo - Ug).max() < 1e-8
     # survey checksums of the reference run
     assert abs(r["Vm"].sum() - 11436.6393011143) < 1e-6 and abs(r["Va"].sum() - 71429.0720178031) < 1e-5
+
+
+def test_config4_scenarios_held_by_the_reference_itself(tmp_path):
+    """BASELINE config 4 (Monte-Carlo load scenarios of the 1 000-bus x 25-harmonic feeder): the unmodified reference was run on scenarios 0
+    and 127 of the 128-scenario share (oracle/make_golden.py scenref<s>: 32 / 30 iterations, about 20 min each).  The oracle -- run live
+    on scenario 127 -- reproduces that run bit for bit (pf seed, every entry of the mismatch history, the final voltages), and so do the
+    oracle fixtures the GPU tests compare against (tests/golden/syn1000_H51_scen.npz) for both scenarios."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "synth", os.path.join(os.path.dirname(GOLD), "..", "harmonic-power-flow_amd", "synth.py"))
+    synth = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(synth)
+    f = np.load(os.path.join(GOLD, "syn1000_H51_scen.npz"))
+    for s, n_it in ((0, 32), (127, 30)):
+        g = np.load(os.path.join(GOLD, "syn1000_H51_scenref%d.npz" % s), allow_pickle=True)
+        assert int(g["n_iter_h"]) == n_it == int(f["n_iter_%d" % s]) and int(g["scenario"]) == s
+        assert np.array_equal(g["err_hist"], f["err_hist_%d" % s])
+        assert np.array_equal(g["V_pf"][:1000], f["seed_fund_%d" % s])
+        Vm, Va = o.postprocess(f["V_stop_%d" % s][:, 0].copy(), f["V_stop_%d" % s][:, 1].copy())
+        assert np.array_equal(Vm, g["V_final"][:, 0]) and np.array_equal(Va, g["V_final"][:, 1])
+    fb, fl = synth.gen(1000, seed=0, outdir=str(tmp_path))
+    net = o.init_network(fb, fl)
+    u = synth.scenario_scale(1000, 127)
+    net.P, net.Q = net.P * u, net.Q * u
+    r = o.hpf(net, o.harmonics_upto(51), True, INPUTS)
+    g = np.load(os.path.join(GOLD, "syn1000_H51_scenref127.npz"), allow_pickle=True)
+    assert r["n_iter_h"] == 30 and np.array_equal(np.asarray(r["err_hist"]), g["err_hist"])
+    assert np.array_equal(r["Vm"], g["V_final"][:, 0]) and np.array_equal(r["Va"], g["V_final"][:, 1])
