@@ -50,6 +50,7 @@ SYMBOLS = {
     "hpf_fund_jacobian": (C.c_int, [_H, C.c_int, c_dbl_p]),
     "hpf_fund_pf": (C.c_int, [_H, C.c_double, C.c_int, c_int_p, c_dbl_p, c_dbl_p]),
     "hpf_solve": (C.c_int, [_H, C.c_double, C.c_int, c_int_p, c_dbl_p, c_dbl_p]),
+    "hpf_solve_queue": (C.c_int, [_H, C.c_int, c_dbl_p, c_dbl_p, C.c_double, C.c_int, C.c_double, C.c_int, C.POINTER(hpf_stat), c_dbl_p, c_dbl_p]),
     "hpf_set_trace": (C.c_int, [_H, c_dbl_p, c_dbl_p, C.c_int]),
     "hpf_iterate": (C.c_int, [_H, C.c_int]),
     "hpf_get_stats": (C.c_int, [_H, C.POINTER(hpf_stat)]),

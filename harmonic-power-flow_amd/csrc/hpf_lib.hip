@@ -487,6 +487,156 @@ __global__ void k_stats(int n, int Hn, double thresh, int max_iter, const double
     }
 }
 
+
+// ---- hpf_solve_queue: a sweep of more scenarios than the handle has slots -------------------------------------------------------------
+// Slot storage s in [0, S_max) holds scenario slot_scen[s] (global id, -1: free).  Between two chunks of iterations (after k_compact:
+// running storages in front of the slot list, their count in *count): every storage that is not running and still holds a scenario has
+// met the stop rule -> harvest list; every free storage takes the next pending scenario -> new list, appended to the slot list.
+// One workgroup; the storage table sits in LDS and one thread walks it in order (deterministic assignment).
+__global__ __launch_bounds__(1024) void k_queue_refill(int S_max, int n_total, int* __restrict__ active, int* __restrict__ count,
+                                                        int* __restrict__ slot_scen, int* __restrict__ next, int* __restrict__ hlist,
+                                                        int* __restrict__ hg, int* __restrict__ newlist, int* __restrict__ base_out) {
+    extern __shared__ int q_lds[];                      // [S_max] busy | [S_max] scenario of the storage
+    int* busy = q_lds;
+    int* scen = q_lds + S_max;
+    const int tid = threadIdx.x, cnt = *count;
+    for (int s = tid; s < S_max; s += 1024) {
+        busy[s] = 0;
+        scen[s] = slot_scen[s];
+        hlist[s] = -1;
+        newlist[s] = -1;
+    }
+    __syncthreads();
+    for (int i = tid; i < cnt; i += 1024) busy[active[i]] = 1;
+    __syncthreads();
+    if (tid == 0) {
+        int nh = 0, nn = 0, nx = *next;
+        for (int s = 0; s < S_max; ++s) {
+            if (busy[s]) continue;
+            if (scen[s] >= 0) {
+                hlist[nh] = s;
+                hg[nh] = scen[s];
+                ++nh;
+                scen[s] = -1;
+            }
+            if (nx < n_total) {
+                scen[s] = nx++;
+                newlist[nn] = s;
+                active[cnt + nn] = s;
+                ++nn;
+            }
+        }
+        *next = nx;
+        *base_out = cnt;
+        *count = cnt + nn;
+    }
+    __syncthreads();
+    for (int s = tid; s < S_max; s += 1024) slot_scen[s] = scen[s];
+}
+
+// result record (k_stats) and, if asked for, the raw voltages in the ABI's stacked order q*n + i of every harvested storage -> the
+// per-scenario outputs of the sweep
+__global__ void k_queue_harvest(int n, int Hn, double thresh, int max_iter, const int* __restrict__ hlist, const int* __restrict__ hg,
+                                const double* __restrict__ Vm, const double* __restrict__ Va, const double* __restrict__ err,
+                                const int* __restrict__ niter, const int* __restrict__ pivflag, hpf_stat* __restrict__ qstats,
+                                double* __restrict__ qVm, double* __restrict__ qVa) {
+    const int s = hlist[blockIdx.x];
+    if (s < 0) return;
+    const int g = hg[blockIdx.x];
+    const double* V = Vm + (size_t)s * n * Hn;
+    const double* A = Va + (size_t)s * n * Hn;
+    double best = 0.0;
+    bool nan = false;
+    for (int b = threadIdx.x; b < n; b += TPB) {
+        double hs = 0.0;
+        for (int q = 1; q < Hn; ++q) hs = hs + V[(size_t)b * Hn + q] * V[(size_t)b * Hn + q];
+        const double t = sqrt(hs) / fabs(V[(size_t)b * Hn]);
+        if (t != t) nan = true;
+        best = t > best ? t : best;
+    }
+    unsigned long long bits = nan ? 0x7ff8000000000000ull : (unsigned long long)__double_as_longlong(best);
+    bits = wave_max_u64(bits);
+    __shared__ unsigned long long red[TPB / 64];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = bits;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long r = red[0];
+        for (int w = 1; w < TPB / 64; ++w) r = red[w] > r ? red[w] : r;
+        hpf_stat st;
+        st.n_iter = niter[s];
+        const double e = err[s];
+        st.err = e;
+        const int pf = pivflag[s];
+        st.flags = (e <= thresh ? 1 : 0) | ((niter[s] >= max_iter && !(e <= thresh)) ? 2 : 0) | ((e != e || isinf(e)) ? 4 : 0) |
+                   ((pf & 1) ? 8 : 0) | ((pf & 4) ? 32 : 0);
+        st.thd_max = __longlong_as_double((long long)r);
+        qstats[g] = st;
+    }
+    if (qVm) {
+        double* om = qVm + (size_t)g * n * Hn;
+        double* oa = qVa + (size_t)g * n * Hn;
+        for (int k = threadIdx.x; k < n * Hn; k += TPB) {       // k = q*n + i (coalesced stores), source bus-major
+            const int q = k / n, i = k - q * n;
+            om[k] = V[(size_t)i * Hn + q];
+            oa[k] = A[(size_t)i * Hn + q];
+        }
+    }
+}
+
+// a new scenario moves into every storage of the new list: loads, the reference's start (HG:174-184) with the fundamental entries from
+// its power-flow seed, U / E, counters
+__global__ void k_queue_init(int n, int Hn, const int* __restrict__ newlist, const int* __restrict__ slot_scen, const double* __restrict__ qP,
+                             const double* __restrict__ qQ, const double* __restrict__ seedVm, const double* __restrict__ seedVa,
+                             double* __restrict__ P, double* __restrict__ Q, double* __restrict__ Vm, double* __restrict__ Va,
+                             cplx* __restrict__ U, cplx* __restrict__ E, unsigned long long* __restrict__ errbits, int* __restrict__ niter,
+                             int* __restrict__ pivflag) {
+    const int s = newlist[blockIdx.y];
+    if (s < 0) return;
+    const int g = slot_scen[s];
+    const int k = blockIdx.x * TPB + threadIdx.x;
+    if (k >= n * Hn) return;
+    const int i = k / Hn, q = k - i * Hn;
+    const size_t o = (size_t)s * n * Hn + k;
+    const double vm = q == 0 ? seedVm[(size_t)g * n + i] : 0.1, va = q == 0 ? seedVa[(size_t)g * n + i] : 0.0;
+    Vm[o] = vm;
+    Va[o] = va;
+    cplx u, e;
+    polar<false>(vm, va, u, e);
+    U[o] = u;
+    E[o] = e;
+    if (q == 0) {
+        P[(size_t)s * n + i] = qP[(size_t)g * n + i];
+        Q[(size_t)s * n + i] = qQ[(size_t)g * n + i];
+    }
+    if (k == 0) {
+        errbits[s] = 0ull;
+        niter[s] = 0;
+        pivflag[s] = 0;
+    }
+}
+
+// the initial mismatch of the new scenarios against the stop rule (HG:531,536): a scenario that meets it at once leaves the slot list
+__global__ void k_queue_first(int S_max, double thresh, int max_iter, const int* __restrict__ newlist, const int* __restrict__ base,
+                              const unsigned long long* __restrict__ errbits, double* __restrict__ err, int* __restrict__ active) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= S_max) return;
+    const int s = newlist[idx];
+    if (s < 0) return;
+    const double e = __longlong_as_double((long long)errbits[s]);
+    err[s] = e;
+    if (!((e > thresh) && (0 < max_iter))) active[*base + idx] = -1;
+}
+
+// fundamental entries (harmonic position 0) of the first S scenarios' voltages -> seed arrays of scenarios g0 .. g0 + S - 1
+__global__ void k_queue_keep_seed(int n, int Hn, int g0, const double* __restrict__ Vm, const double* __restrict__ Va,
+                                  double* __restrict__ seedVm, double* __restrict__ seedVa) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    const size_t o = (size_t)blockIdx.y * n * Hn + (size_t)i * Hn;
+    seedVm[(size_t)(g0 + blockIdx.y) * n + i] = Vm[o];
+    seedVa[(size_t)(g0 + blockIdx.y) * n + i] = Va[o];
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------------
@@ -985,6 +1135,129 @@ int nr_loop(hpf_handle* h, double thresh, int max_iter, int* n_iter, double* err
     return HPF_OK;
 }
 
+// hpf_solve_queue on the fast path (radial BLOCK_TREE, static-pivot kernels): all scenarios' loads and power-flow seeds resident in
+// HBM, the harmonic NR runs in chunks of iterations over the slot list; between chunks finished scenarios are harvested and their
+// storages refilled (k_queue_*).  The host looks at the counters one chunk late (pinned double buffer + events, as in nr_pass).
+int solve_queue_fast(hpf_handle* h, int n_total, const double* P, const double* Q, double thresh_f, int max_iter_f, double thresh,
+                     int max_iter, hpf_stat* stats, double* Vm, double* Va) {
+    int r = HPF_OK;
+    const int n = h->n, Hn = h->Hn, S_max = h->S_max;
+    const size_t count = (size_t)n * Hn;
+    double *qP = nullptr, *qQ = nullptr, *sVm = nullptr, *sVa = nullptr, *qVm = nullptr, *qVa = nullptr;
+    hpf_stat* qst = nullptr;
+    int* qi = nullptr;                                   // slot_scen [S_max] | hlist | hg | newlist | next, base
+    auto cleanup = [&](int code) {
+        hipStreamSynchronize(h->stream);
+        void* ptrs[] = {qP, qQ, sVm, sVa, qVm, qVa, qst, qi};
+        for (void* q : ptrs)
+            if (q) hipFree(q);
+        return code;
+    };
+    if ((r = dev_alloc(h, &qP, (size_t)n_total * n)) || (r = dev_alloc(h, &qQ, (size_t)n_total * n)) ||
+        (r = dev_alloc(h, &sVm, (size_t)n_total * n)) || (r = dev_alloc(h, &sVa, (size_t)n_total * n)) ||
+        (r = dev_alloc(h, &qst, (size_t)n_total)) || (r = dev_alloc(h, &qi, (size_t)4 * S_max + 2)))
+        return cleanup(r);
+    if (Vm && ((r = dev_alloc(h, &qVm, (size_t)n_total * count)) || (r = dev_alloc(h, &qVa, (size_t)n_total * count)))) return cleanup(r);
+    int *slot_scen = qi, *hlist = qi + S_max, *hg = qi + 2 * S_max, *newlist = qi + 3 * S_max, *next = qi + 4 * S_max, *base = next + 1;
+    if (hipMemcpyAsync(qP, P, sizeof(double) * (size_t)n_total * n, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+        hipMemcpyAsync(qQ, Q, sizeof(double) * (size_t)n_total * n, hipMemcpyHostToDevice, h->stream) != hipSuccess)
+        return cleanup(HPF_E_HIP);
+    // ---- fundamental power flow (HG:244-275) of every scenario from the reference's start, in waves of S_max; only the fundamental
+    //      entries are kept (the harmonic rows of the seed are the constants of HG:181-183)
+    for (int g0 = 0; g0 < n_total; g0 += S_max) {
+        const int S = n_total - g0 < S_max ? n_total - g0 : S_max;
+        h->S = S;
+        hipMemcpyAsync(h->d_P, qP + (size_t)g0 * n, sizeof(double) * (size_t)S * n, hipMemcpyDeviceToDevice, h->stream);
+        hipMemcpyAsync(h->d_Q, qQ + (size_t)g0 * n, sizeof(double) * (size_t)S * n, hipMemcpyDeviceToDevice, h->stream);
+        hipLaunchKernelGGL(k_init_voltages, grid2((int)count, S), dim3(TPB), 0, h->stream, Hn, (int)count, h->d_Vm, h->d_Va);
+        h->loads_set = h->state_set = true;
+        if ((r = nr_loop<true>(h, thresh_f, max_iter_f, nullptr, nullptr, nullptr))) return cleanup(r);
+        hipLaunchKernelGGL(k_queue_keep_seed, grid2(n, S), dim3(TPB), 0, h->stream, n, Hn, g0, h->d_Vm, h->d_Va, sVm, sVa);
+    }
+    // ---- harmonic NR with refill -------------------------------------------------------------------------------------------------
+    const int S_used = n_total < S_max ? n_total : S_max;
+    h->S = S_used;
+    h->mismatch_valid = false;
+    h->prev_valid = false;
+    {
+        std::vector<int> init((size_t)4 * S_max + 2, -1);
+        init[(size_t)4 * S_max] = 0;                    // next
+        init[(size_t)4 * S_max + 1] = 0;                // base
+        if (hipMemcpyAsync(qi, init.data(), sizeof(int) * init.size(), hipMemcpyHostToDevice, h->stream) != hipSuccess) return cleanup(HPF_E_HIP);
+        if (hipStreamSynchronize(h->stream) != hipSuccess) return cleanup(HPF_E_HIP);      // (init is a local)
+    }
+    if (hipMemsetAsync(h->d_nactive, 0, sizeof(int), h->stream) != hipSuccess) return cleanup(HPF_E_HIP);
+    if (hipMemsetAsync(h->d_pivflag, 0, sizeof(int) * S_max, h->stream) != hipSuccess) return cleanup(HPF_E_HIP);
+    hipLaunchKernelGGL(k_set_int, dim3((unsigned)((S_max + TPB - 1) / TPB)), dim3(TPB), 0, h->stream, h->d_active, S_max, -1);   // (empty slot list)
+    if (!h->h_act[0]) {
+        for (int i = 0; i < 2; ++i) {
+            if (hipHostMalloc((void**)&h->h_act[i], sizeof(int) * 4, hipHostMallocDefault) != hipSuccess) return cleanup(HPF_E_HIP);
+            if (hipEventCreateWithFlags(&h->poll_ev[i], hipEventDisableTiming) != hipSuccess) return cleanup(HPF_E_HIP);
+        }
+    }
+    const size_t q_lds = sizeof(int) * 2 * (size_t)S_max;
+    // one round between two chunks: compact -> harvest / refill -> initial mismatch of the new scenarios -> counters to the host
+    auto round = [&](int buf) -> int {
+        full_ctx(h);
+        hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, h->stream, S_max, h->d_active, h->d_nactive);
+        hipLaunchKernelGGL(k_queue_refill, dim3(1), dim3(1024), q_lds, h->stream, S_max, n_total, h->d_active, h->d_nactive, slot_scen, next,
+                           hlist, hg, newlist, base);
+        hipLaunchKernelGGL(k_queue_harvest, dim3((unsigned)S_max), dim3(TPB), 0, h->stream, n, Hn, thresh, max_iter, hlist, hg, h->d_Vm,
+                           h->d_Va, h->d_err, h->d_niter, h->d_pivflag, qst, qVm, qVa);
+        hipLaunchKernelGGL(k_queue_init, grid2((int)count, S_max), dim3(TPB), 0, h->stream, n, Hn, newlist, slot_scen, qP, qQ, sVm, sVa,
+                           h->d_P, h->d_Q, h->d_Vm, h->d_Va, h->d_U, h->d_E, h->d_errbits, h->d_niter, h->d_pivflag);
+        set_ctx(h, h->stream, 0, S_max);
+        int rr = launch_mismatch<false>(h, newlist, false);
+        full_ctx(h);
+        if (rr) return rr;
+        hipLaunchKernelGGL(k_queue_first, dim3((unsigned)((S_max + 63) / 64)), dim3(64), 0, h->stream, S_max, thresh, max_iter, newlist, base,
+                           h->d_errbits, h->d_err, h->d_active);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(h->h_act[buf], h->d_nactive, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(h->h_act[buf] + 1, next, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipEventRecord(h->poll_ev[buf], h->stream));
+        return HPF_OK;
+    };
+    auto enqueue = [&](int todo, int slots) -> int {
+        auto body = [&]() -> int {
+            int rr;
+            for (int j = 0; j < todo; ++j) {
+                if ((rr = newton_step<false>(h, h->d_active))) return rr;
+                if ((rr = launch_update<false>(h, h->d_active))) return rr;
+                if ((rr = launch_mismatch<false>(h, h->d_active, false))) return rr;
+                hipLaunchKernelGGL(k_finalize, dim3((h->cur_S + 63) / 64), dim3(64), 0, h->cur_stream, h->cur_S, 0, thresh, max_iter, 1, 0,
+                                   h->d_errbits, h->d_err, h->d_niter, h->d_active, h->d_nactive, (double*)nullptr, h->cur_s0, (const int*)nullptr);
+            }
+            return HPF_OK;
+        };
+        return for_groups(h, slots, body);
+    };
+    const int chunk = h->queue_chunk > 0 ? h->queue_chunk : 2;
+    int c = 0, n_ub = S_used;
+    if ((r = round(0))) return cleanup(r);
+    const long long max_rounds = ((long long)(n_total + S_used - 1) / S_used + 2) * ((max_iter + chunk - 1) / chunk + 2) + 8;
+    for (long long rd = 0; rd < max_rounds; ++rd) {
+        // queue the next chunk BEFORE looking at what the previous round left (the device never drains between chunks)
+        if (n_ub > 0 && (r = enqueue(chunk, n_ub))) return cleanup(r);
+        if ((r = round((c + 1) & 1))) return cleanup(r);
+        if (hipEventSynchronize(h->poll_ev[c & 1]) != hipSuccess) return cleanup(HPF_E_HIP);
+        const int cnt = h->h_act[c & 1][0], nxt = h->h_act[c & 1][1];
+        ++c;
+        if (cnt == 0 && nxt >= n_total) break;           // nothing was running and nothing was pending: every scenario is harvested
+        n_ub = nxt < n_total ? S_used : cnt;             // pending scenarios: every storage may be running after the next refill
+    }
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return cleanup(HPF_E_HIP);
+    if (h->h_act[c & 1][0] != 0 || h->h_act[c & 1][1] < n_total) return cleanup(HPF_E_STATE);     // (round cap hit: cannot happen)
+    if (stats && hipMemcpy(stats, qst, sizeof(hpf_stat) * (size_t)n_total, hipMemcpyDeviceToHost) != hipSuccess) return cleanup(HPF_E_HIP);
+    if (Vm && (hipMemcpy(Vm, qVm, sizeof(double) * (size_t)n_total * count, hipMemcpyDeviceToHost) != hipSuccess ||
+               hipMemcpy(Va, qVa, sizeof(double) * (size_t)n_total * count, hipMemcpyDeviceToHost) != hipSuccess))
+        return cleanup(HPF_E_HIP);
+    // the handle is left without a defined batch: loads and state have to be set again before the per-batch entry points
+    h->loads_set = h->state_set = false;
+    h->S = 0;
+    return cleanup(HPF_OK);
+}
+
 void free_all(hpf_handle* h) {
     void* ptrs[] = {h->d_rowptr, h->d_col, h->d_diag, h->d_erow, h->d_dev, h->d_Y, h->d_YN, h->d_YNt, h->d_IN, h->d_P, h->d_Q,
                     h->d_Vm, h->d_Va, h->d_U, h->d_E, h->d_I0, h->d_f, h->d_errbits, h->d_err, h->d_niter, h->d_active,
@@ -1384,6 +1657,29 @@ int hpf_solve(hpf_handle* h, double thresh, int max_iter, int* n_iter, double* e
     return nr_loop<false>(h, thresh, max_iter, n_iter, err, err_hist);
 }
 
+int hpf_solve_queue(hpf_handle* h, int n_total, const double* P, const double* Q, double thresh_f, int max_iter_f, double thresh,
+                    int max_iter, hpf_stat* stats, double* Vm, double* Va) {
+    if (!h || !P || !Q || n_total < 1 || max_iter < 0 || max_iter_f < 0 || (Vm == nullptr) != (Va == nullptr)) return HPF_E_ARG;
+    const bool fast = h->solver == HPF_SOLVER_BLOCK_TREE && h->n_ties == 0 && h->has_ctree && h->gj_mode == 1 && !h->fold_update &&
+                      bus_images(h) && h->S_max <= 8192 && !h->trace_Vm;
+    if (fast) return solve_queue_fast(h, n_total, P, Q, thresh_f, max_iter_f, thresh, max_iter, stats, Vm, Va);
+    // every other handle (dense solver, meshed network, pivoted mode): waves of up to S_max scenarios through the per-batch entry points
+    const size_t cnt = (size_t)h->n * h->Hn;
+    for (int g0 = 0; g0 < n_total; g0 += h->S_max) {
+        const int S = n_total - g0 < h->S_max ? n_total - g0 : h->S_max;
+        int r;
+        if ((r = hpf_set_loads(h, S, P + (size_t)g0 * h->n, Q + (size_t)g0 * h->n))) return r;
+        if ((r = hpf_set_state(h, S, nullptr, nullptr))) return r;
+        if ((r = hpf_fund_pf(h, thresh_f, max_iter_f, nullptr, nullptr, nullptr))) return r;
+        if ((r = hpf_solve(h, thresh, max_iter, nullptr, nullptr, nullptr))) return r;
+        if (stats && (r = hpf_get_stats(h, stats + g0))) return r;
+        if (Vm && (r = hpf_get_state(h, Vm + (size_t)g0 * cnt, Va + (size_t)g0 * cnt))) return r;
+    }
+    h->loads_set = h->state_set = false;                 // (as on the queued path: the handle is left without a defined batch)
+    h->S = 0;
+    return HPF_OK;
+}
+
 // `iters` unconditional iterations of every scenario, enqueued group by group on the group streams (fork / join with h->stream)
 static int iterate_enqueue(hpf_handle* h, int iters) {
     // iteration-major enqueue order (all groups' step i before any group's step i+1) keeps the group pipelines in phase
@@ -1476,6 +1772,11 @@ int hpf_set_option(hpf_handle* h, const char* name, int value) {
             if ((rr = dev_alloc(h, &h->d_Vmp, (size_t)h->S_alloc * h->n * h->Hn))) return rr;
             if ((rr = dev_alloc(h, &h->d_Vap, (size_t)h->S_alloc * h->n * h->Hn))) return rr;
         }
+        return HPF_OK;
+    }
+    if (!strcmp(name, "queue_chunk")) {             // hpf_solve_queue: Newton iterations between two harvest / refill rounds
+        if (value < 1 || value > 16) return HPF_E_ARG;
+        h->queue_chunk = value;
         return HPF_OK;
     }
     if (!strcmp(name, "auto_repivot")) {            // 0: flagged scenarios are only reported (flags bit 3), not repeated

@@ -210,6 +210,25 @@ class DeviceModel:
             return n_iter, err, hist, Vt, At
         return n_iter, err, hist
 
+    def solve_queue(self, P, Q, thresh_f=1e-6, max_iter_f=30, thresh=1e-4, max_iter=50, want_voltages=False):
+        """hpf_solve_queue: every row of P, Q [n_scen][n] is one scenario (reference start, pf, harmonic NR); the handle's S_max slots are
+        refilled with pending scenarios as running ones meet the stop rule.  -> records (n_iter, flags, err, thd_max) [n_scen]
+        [, raw Vm, Va [n_scen][Hn*n]].  Leaves the handle without a batch (set_loads / set_state before the per-batch calls)."""
+        P = np.ascontiguousarray(np.atleast_2d(P), dtype=np.float64)
+        Q = np.ascontiguousarray(np.atleast_2d(Q), dtype=np.float64)
+        assert P.shape == Q.shape and P.shape[1] == self.n
+        n_scen = P.shape[0]
+        st = (_lib.hpf_stat * n_scen)()
+        Vm = Va = None
+        if want_voltages:
+            Vm = np.empty((n_scen, self.n * self.Hn))
+            Va = np.empty_like(Vm)
+        self._chk(self.lib.hpf_solve_queue(self._h, n_scen, _dp(P), _dp(Q), float(thresh_f), int(max_iter_f), float(thresh), int(max_iter),
+                                           st, _dp(Vm) if want_voltages else None, _dp(Va) if want_voltages else None), "hpf_solve_queue")
+        self.S = 0
+        rec = np.frombuffer(st, dtype=[("n_iter", "<i4"), ("flags", "<i4"), ("err", "<f8"), ("thd_max", "<f8")]).copy()
+        return (rec, Vm, Va) if want_voltages else rec
+
     def iterate(self, iters):
         self._chk(self.lib.hpf_iterate(self._h, int(iters)), "hpf_iterate")
 

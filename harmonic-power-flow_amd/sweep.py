@@ -25,14 +25,18 @@ def gather_stats(rec, world):
     return torch.stack(parts, dim=1).reshape(-1, rec.shape[1])
 
 
-def solve_scenarios(dm, P, Q, thresh_f=1e-6, max_iter_f=30, thresh_h=1e-4, max_iter_h=50, want_voltages=False):
+def solve_scenarios(dm, P, Q, thresh_f=1e-6, max_iter_f=30, thresh_h=1e-4, max_iter_h=50, want_voltages=False, refill=True):
     """Monte-Carlo / what-if sweep on ONE GPU: every row of P, Q [n_scen][n] (p.u. loads, HG:197,372) is one scenario of the
-    network `dm` (a DeviceModel) holds.  The scenarios run in waves of up to `dm.S_max` live scenarios (size the model for as many
-    as fit: 72 MB of solver state per scenario of the 1 000-bus x 25-harmonic feeder, i.e. 1 024 scenarios = 74 GB of the 288 GB;
-    larger waves amortise the latency-bound upper tree levels: 107 k NR it/s at 128 live scenarios, 150 k at 1 024).  Per wave:
-    reference start (HG:174-184), fundamental pf (HG:244), harmonic NR with the reference's stop rule (HG:536) -- per-scenario
-    freeze, running scenarios compacted between chunks of iterations.  -> structured array of per-scenario records
-    (n_iter, flags, err, thd_max: the 24-byte record of the multi-GPU gather) [+ raw Vm, Va [n_scen][Hn*n]]."""
+    network `dm` (a DeviceModel) holds -- the reference's counterpart is one hpf() call per load case (HG:511).  Per scenario:
+    reference start (HG:174-184), fundamental pf (HG:244), harmonic NR with the reference's stop rule (HG:536).
+    refill=True (default): `hpf_solve_queue` -- the `dm.S_max` slots of the model stay full: scenarios that meet the stop rule are
+    harvested between chunks of Newton iterations and their slots take the next pending scenarios, so a sweep of many more scenarios
+    than slots runs at the lock-step rate of a full handle instead of paying every wave's convergence tail (size the model for as
+    many live scenarios as fit: 72 MB of solver state per scenario of the 1 000-bus x 25-harmonic feeder; larger batches amortise the
+    latency-bound upper tree levels).  A scenario the static-pivot monitor flags is solved again on its own with partial pivoting.
+    refill=False: fixed waves of up to S_max scenarios (each through fund_pf + solve).
+    -> structured array of per-scenario records (n_iter, flags, err, thd_max: the 24-byte record of the multi-GPU gather)
+    [+ raw Vm, Va [n_scen][Hn*n]]; every record and voltage is bit-identical to the scenario solved alone."""
     P = np.ascontiguousarray(np.atleast_2d(P), dtype=np.float64)
     Q = np.ascontiguousarray(np.atleast_2d(Q), dtype=np.float64)
     n_scen = P.shape[0]
@@ -41,8 +45,8 @@ def solve_scenarios(dm, P, Q, thresh_f=1e-6, max_iter_f=30, thresh_h=1e-4, max_i
     if want_voltages:
         Vm = np.empty((n_scen, dm.n * dm.Hn))
         Va = np.empty_like(Vm)
-    for a in range(0, n_scen, dm.S_max):
-        b = min(a + dm.S_max, n_scen)
+
+    def wave(a, b):
         dm.set_loads(P[a:b], Q[a:b])
         dm.set_state(None, None, n_scen=b - a)
         dm.fund_pf(thresh_f, max_iter_f)
@@ -52,6 +56,24 @@ def solve_scenarios(dm, P, Q, thresh_f=1e-6, max_iter_f=30, thresh_h=1e-4, max_i
             out[k][a:b] = st[k]
         if want_voltages:
             Vm[a:b], Va[a:b] = dm.get_state()
+
+    if not refill:
+        for a in range(0, n_scen, dm.S_max):
+            wave(a, min(a + dm.S_max, n_scen))
+        return (out, Vm, Va) if want_voltages else out
+    # the device keeps the voltages of a whole call: bound a call by ~8 GB of result buffers when they are asked for
+    per_call = n_scen if not want_voltages else max(dm.S_max, int(8e9 // (16 * dm.n * dm.Hn)))
+    for a in range(0, n_scen, per_call):
+        b = min(a + per_call, n_scen)
+        res = dm.solve_queue(P[a:b], Q[a:b], thresh_f, max_iter_f, thresh_h, max_iter_h, want_voltages=want_voltages)
+        if want_voltages:
+            rec, Vm[a:b], Va[a:b] = res
+        else:
+            rec = res
+        for k in STAT_DTYPE.names:
+            out[k][a:b] = rec[k]
+    for s in np.nonzero((out["flags"] & 8) != 0)[0]:        # static pivot order flagged: the scenario alone, hpf_solve repeats it pivoted
+        wave(int(s), int(s) + 1)
     return (out, Vm, Va) if want_voltages else out
 
 

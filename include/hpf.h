@@ -146,6 +146,18 @@ int  hpf_fund_pf(hpf_handle* h, double thresh, int max_iter, int* n_iter, double
  * DENSE: rocSOLVER info > 0, BLOCK_TREE: the pivoted wave Gauss-Jordan. */
 int  hpf_solve(hpf_handle* h, double thresh, int max_iter, int* n_iter, double* err, double* err_hist);
 
+/* A sweep of n_total scenarios through the handle's S_max slots -- the reference's counterpart is one hpf() call per load case (HG:511:
+ * other buses.P / buses.Q, HG:197,372).  P, Q [n_total][n] in p.u.  Every scenario: the reference's start (HG:174-184), pf (HG:244-275) with
+ * (thresh_f, max_iter_f), the harmonic NR of hpf_solve with (thresh, max_iter).  Radial BLOCK_TREE handles keep all loads and pf seeds in HBM
+ * and, between chunks of Newton iterations (option "queue_chunk", default 2), harvest the scenarios that met the stop rule and put the next
+ * pending scenarios into the freed slots, so the handle stays full until the queue drains; every scenario's result is bit-identical to its
+ * solve alone (the arithmetic of a scenario does not depend on its slot).  Other handles (DENSE, meshed networks, pivoted mode) run waves of
+ * S_max scenarios.  Outputs (host, may be NULL; Vm and Va together): stats [n_total], raw voltages Vm, Va [n_total][Hn*n] (stacked order,
+ * signed / un-wrapped like hpf_get_state).  In the queued mode a scenario flagged by the static-pivot monitor (flags bit 3) is reported,
+ * not repeated: solve it again with hpf_solve.  Afterwards the handle holds no batch: set loads and state before per-batch calls. */
+int  hpf_solve_queue(hpf_handle* h, int n_total, const double* P, const double* Q, double thresh_f, int max_iter_f, double thresh,
+                     int max_iter, hpf_stat* stats, double* Vm, double* Va);
+
 /* Per-iteration state dump for trajectory diffing against the oracle / the reference (the reference's analogue is the JSON log of
  * every iterate, hcne_based_on_fuchs.py:186,370-372): while set, hpf_solve writes the voltages after iteration k (k = 0: the
  * state it was entered with) of every scenario to Vm_traj / Va_traj [S][cap][Hn*n] (caller-owned host arrays, stacked order
@@ -181,6 +193,7 @@ int  hpf_debug_stamps(hpf_handle* h, long long* out, int count);
  * (a lower bound of its condition number) exceeds 10^value; "auto_repivot" (default 1): hpf_solve repeats flagged scenarios
  * with partial pivoting (0: they are only reported in hpf_stat.flags).
  * "keep_previous_state" (default 0): hpf_solve keeps per scenario the state its last Newton step started from (hpf_jacobian_last).
+ * "queue_chunk" (1..16, default 2): Newton iterations between two harvest / refill rounds of hpf_solve_queue.
  * "scenario_groups" (1..8, default 3 -- with the host framework's own streams a fourth busy queue is a cliff --; at least 32 running scenarios per group): independent scenario pipelines on separate HIP streams.
  * Environment read by hpf_create (diagnostics, A/B runs): HPF_LAZY=0 builds the elimination tree without lazy leaves (every
  * leaf writes its Schur complement; 1: only leaves directly under their dense parent), HPF_SLEAF=0 sends the nonlinear buses

@@ -165,9 +165,11 @@ def test_config5_full_size_vs_oracle_fixture(tmp_path):
     assert d_sum < n * TOL_V * 1e-2
 
 
-def test_sweep_in_waves_equals_single_scenario_solves(tmp_path):
-    """sweep.solve_scenarios: 75 scenarios through a model sized for 32 live scenarios (waves of 32 + 32 + 11, two groups / one
-    group) -- every record and every voltage bit-identical to the scenario solved alone."""
+@pytest.mark.parametrize("refill", [True, False])
+def test_sweep_in_waves_equals_single_scenario_solves(tmp_path, refill):
+    """sweep.solve_scenarios: 75 scenarios through a model sized for 32 live scenarios -- refill=True: hpf_solve_queue (finished scenarios
+    harvested between chunks of iterations, their slots refilled from the queue until it drains); refill=False: waves of 32 + 32 + 11 --
+    every record and every voltage bit-identical to the scenario solved alone."""
     hp = _hp()
     from harmonic_power_flow_amd import api, sweep, synth
     st, buses, Y, NE = _feeder(hp, 200, 27, tmp_path, seed=3)
@@ -176,13 +178,53 @@ def test_sweep_in_waves_equals_single_scenario_solves(tmp_path):
     scale = np.stack([synth.scenario_scale(n, s) for s in range(75)])
     dm = api._device_model(buses, Y, NE, True, st.HARMONICS, solver="block_tree", max_scenarios=32)
     try:
-        rec, Vm, Va = sweep.solve_scenarios(dm, P0 * scale, Q0 * scale, want_voltages=True)
+        rec, Vm, Va = sweep.solve_scenarios(dm, P0 * scale, Q0 * scale, want_voltages=True, refill=refill)
+        rec_nv = sweep.solve_scenarios(dm, P0 * scale, Q0 * scale, refill=refill)                 # records only, same handle again
+        few, Vm_few, Va_few = sweep.solve_scenarios(dm, (P0 * scale)[40:45], (Q0 * scale)[40:45], want_voltages=True, refill=refill)   # fewer scenarios than slots
     finally:
         dm.close()
     assert rec.shape == (75,) and ((rec["flags"] & 1) == 1).all()
+    assert np.array_equal(rec.view(np.uint8), rec_nv.view(np.uint8))
+    assert np.array_equal(few.view(np.uint8), rec[40:45].view(np.uint8)) and np.array_equal(Vm_few, Vm[40:45]) and np.array_equal(Va_few, Va[40:45])
     summ = sweep.summarize(rec.view(np.uint8).reshape(75, 24))
     assert summ["scenarios"] == 75 and summ["converged"] == 75 and summ["iters_total"] == int(rec["n_iter"].sum())
-    for s in (0, 31, 32, 63, 64, 74):
+    assert len(set(rec["n_iter"])) > 1                       # (the scenarios do finish at different times: slots are refilled mid-sweep)
+    for s in (0, 31, 32, 40, 63, 64, 74):
         it1, err1, Vm1, Va1, _, st1 = _run(hp, st, buses, Y, NE, [s])
         assert rec["n_iter"][s] == it1[0] and rec["err"][s] == err1[0] and rec["thd_max"][s] == st1["thd_max"][0]
+        assert rec["flags"][s] == st1["flags"][0]
         assert np.array_equal(Vm[s], Vm1[0]) and np.array_equal(Va[s], Va1[0])
+
+
+def test_solve_queue_edge_cases(tmp_path):
+    """hpf_solve_queue: one scenario in a one-slot handle, a scenario that hits max_iter (reported, its slot is refilled), a queue through a
+    DENSE handle (waves), and the handle's per-batch entry points after a queued sweep."""
+    hp = _hp()
+    from harmonic_power_flow_amd import api, synth
+    st, buses, Y, NE = _feeder(hp, 100, 11, tmp_path, seed=1)
+    n = len(buses)
+    P0, Q0 = buses["P"].to_numpy(float), buses["Q"].to_numpy(float)
+    scale = np.stack([synth.scenario_scale(n, s) for s in range(9)])
+    ref = {}
+    for solver, S_max in (("block_tree", 1), ("block_tree", 4), ("dense", 4)):
+        dm = api._device_model(buses, Y, NE, True, st.HARMONICS, solver=solver, max_scenarios=S_max)
+        try:
+            rec, Vm, Va = dm.solve_queue(P0 * scale, Q0 * scale, want_voltages=True)
+            short = dm.solve_queue(P0 * scale, Q0 * scale, max_iter=5)
+            with pytest.raises(Exception):
+                dm.solve(1e-4, 50)                           # no batch in the handle after a queued sweep
+            dm.set_loads(P0 * scale[:1], Q0 * scale[:1])     # ... and the per-batch path works again
+            dm.set_state(None, None, n_scen=1)
+            dm.fund_pf(1e-6, 30)
+            it1, err1, _ = dm.solve(1e-4, 50)
+        finally:
+            dm.close()
+        assert ((rec["flags"] & 1) == 1).all() and it1[0] == rec["n_iter"][0]
+        if solver == "block_tree":                           # (DENSE: rocSOLVER's batched and single LU round differently)
+            assert err1[0] == rec["err"][0]
+        assert (short["n_iter"] == 5).all() and ((short["flags"] & 2) == 2).all() and ((short["flags"] & 1) == 0).all()
+        ref[(solver, S_max)] = (rec, Vm, Va)
+    a, b, d = ref[("block_tree", 1)], ref[("block_tree", 4)], ref[("dense", 4)]
+    assert np.array_equal(a[0].view(np.uint8), b[0].view(np.uint8)) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert np.abs(a[0]["n_iter"] - d[0]["n_iter"]).max() <= 4                                # (solver-sensitive counts on this feeder)
+    assert np.abs(a[1] * np.exp(1j * a[2]) - d[1] * np.exp(1j * d[2])).max() < 5e-5        # (dense vs block tree, each at ITS stop: the stop rule is 1e-4)
