@@ -388,6 +388,19 @@ def main():
     if sweep is not None:
         out["sweep"] = sweep
         out["sweep_iters_per_s"] = sweep["iters_per_s_rank0"] * world
+    if args.sweep_1gpu > 0 and bt and world == 1:
+        # the same 1 024-scenario sweep through THIS handle's 128 slots: hpf_solve_queue keeps the slots full (finished scenarios are
+        # harvested between chunks of iterations, their slots refilled from the queue); end to end incl. uploads and the pf of all scenarios
+        from harmonic_power_flow_amd.sweep import solve_scenarios
+        scale_q = np.stack([synth.scenario_scale(n, s) for s in range(args.sweep_1gpu)])
+        solve_scenarios(dm, P0 * scale_q[:2 * S], Q0 * scale_q[:2 * S])                         # warm (pinned buffers)
+        t0 = time.perf_counter()
+        rec_q = solve_scenarios(dm, P0 * scale_q, Q0 * scale_q)
+        t_q = time.perf_counter() - t0
+        out["sweep_queue_1gpu"] = {"scenarios": int(args.sweep_1gpu), "slots": S, "converged": int(((rec_q["flags"] & 1) != 0).sum()),
+                                   "iters_total": int(rec_q["n_iter"].sum()), "wall_s": t_q, "iters_per_s": float(rec_q["n_iter"].sum()) / t_q,
+                                   "note": "hpf_solve_queue (sweep.solve_scenarios): more scenarios than slots, the handle stays full until the "
+                                           "queue drains; wall time includes the upload of all loads and the fundamental pf of every scenario"}
     if args.sweep_1gpu > 0 and bt:               # rank 0 of every world size: the whole sweep on ONE GPU, the strong-scaling comparator
         dm.close()
         dm = None

@@ -1143,6 +1143,9 @@ int solve_queue_fast(hpf_handle* h, int n_total, const double* P, const double* 
     int r = HPF_OK;
     const int n = h->n, Hn = h->Hn, S_max = h->S_max;
     const size_t count = (size_t)n * Hn;
+    const bool info = getenv("HPF_QUEUE_INFO") != nullptr;
+    const auto t_0 = std::chrono::steady_clock::now();
+    auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
     double *qP = nullptr, *qQ = nullptr, *sVm = nullptr, *sVa = nullptr, *qVm = nullptr, *qVa = nullptr;
     hpf_stat* qst = nullptr;
     int* qi = nullptr;                                   // slot_scen [S_max] | hlist | hg | newlist | next, base
@@ -1174,6 +1177,11 @@ int solve_queue_fast(hpf_handle* h, int n_total, const double* P, const double* 
         if ((r = nr_loop<true>(h, thresh_f, max_iter_f, nullptr, nullptr, nullptr))) return cleanup(r);
         hipLaunchKernelGGL(k_queue_keep_seed, grid2(n, S), dim3(TPB), 0, h->stream, n, Hn, g0, h->d_Vm, h->d_Va, sVm, sVa);
     }
+    if (info) {
+        hipStreamSynchronize(h->stream);
+        fprintf(stderr, "hpf queue: %d scenarios, %d slots: uploads + pf of all scenarios %.2f ms\n", n_total, S_max, ms_since(t_0));
+    }
+    const auto t_1 = std::chrono::steady_clock::now();
     // ---- harmonic NR with refill -------------------------------------------------------------------------------------------------
     const int S_used = n_total < S_max ? n_total : S_max;
     h->S = S_used;
@@ -1247,6 +1255,7 @@ int solve_queue_fast(hpf_handle* h, int n_total, const double* P, const double* 
         n_ub = nxt < n_total ? S_used : cnt;             // pending scenarios: every storage may be running after the next refill
     }
     if (hipStreamSynchronize(h->stream) != hipSuccess) return cleanup(HPF_E_HIP);
+    if (info) fprintf(stderr, "hpf queue: harmonic NR with refill %.2f ms (%d rounds of %d iterations)\n", ms_since(t_1), c, chunk);
     if (h->h_act[c & 1][0] != 0 || h->h_act[c & 1][1] < n_total) return cleanup(HPF_E_STATE);     // (round cap hit: cannot happen)
     if (stats && hipMemcpy(stats, qst, sizeof(hpf_stat) * (size_t)n_total, hipMemcpyDeviceToHost) != hipSuccess) return cleanup(HPF_E_HIP);
     if (Vm && (hipMemcpy(Vm, qVm, sizeof(double) * (size_t)n_total * count, hipMemcpyDeviceToHost) != hipSuccess ||

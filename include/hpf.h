@@ -211,6 +211,7 @@ int  hpf_debug_stamps(hpf_handle* h, long long* out, int count);
  * height, HPF_CHAINBUNDLE=0 gives the contracted chains their own launches, HPF_COMPRESS=0 eliminates the Gauss-Jordan buses strictly
  * leaves first (no compress steps: one elimination level per unit of tree height; the default for handles of more than 256 scenarios,
  * whose levels fill the chip -- HPF_COMPRESS=1 forces the compress steps there too), HPF_TREE_INFO=1 prints the tree statistics to stderr,
+ * HPF_QUEUE_INFO=1 prints the phase times of hpf_solve_queue to stderr,
  * HPF_GROUPS=n presets "scenario_groups".  Every switch selects a path with the same Newton steps (tests/test_gpu_robustness.py). */
 int  hpf_set_option(hpf_handle* h, const char* name, int value);
 
