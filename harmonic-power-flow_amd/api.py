@@ -271,16 +271,22 @@ def update_harmonic_state_vec(J, x, f, device=0):
 
 
 def get_THD(V):
-    """HG:563-572 -> DataFrame[THD_F, THD_R] per bus (harmonic labels >= 3 are the non-fundamental rows)."""
+    """HG:563-572 -> DataFrame[THD_F, THD_R] per bus (harmonic labels >= 3 are the non-fundamental rows).  One pass over the [Hn][n]
+    magnitudes; the per-bus sums run over the harmonics in ascending order like the reference's Python `sum` (HG:567-570), so the values
+    are the reference's to the last bit."""
     harmonics = list(dict.fromkeys(V.index.get_level_values(0)))
     n = len(V) // len(harmonics)
     Vm = V["V_m"].to_numpy(dtype=float).reshape(len(harmonics), n)
-    THD = pd.DataFrame(np.zeros((n, 2)), columns=["THD_F", "THD_R"])
-    for b in range(n):
-        hs = sum(Vm[1:, b] ** 2)
-        THD.loc[b, "THD_F"] = np.sqrt(hs) / Vm[0, b]
-        THD.loc[b, "THD_R"] = np.sqrt(hs) / np.sqrt(sum(Vm[:, b] ** 2))
-    return THD
+    hs = np.zeros(n)
+    for q in range(1, len(harmonics)):               # sequential over harmonics, vectorised over buses
+        hs = hs + Vm[q] ** 2
+    tot = Vm[0] ** 2
+    for q in range(1, len(harmonics)):
+        tot = tot + Vm[q] ** 2
+    with np.errstate(divide="ignore", invalid="ignore"):
+        thd_f = np.sqrt(hs) / Vm[0]
+        thd_r = np.sqrt(hs) / np.sqrt(tot)
+    return pd.DataFrame({"THD_F": thd_f, "THD_R": thd_r})
 
 
 def solve(filename_buses, filename_lines, coupled=True, settings=None, ne_dir=None, solver="auto", verbose=False, extra_iters=0):

@@ -115,3 +115,26 @@ def test_bench_gpus_flag_starts_one_rank_per_gpu(monkeypatch):
     assert bench.launch_plan(args, {"WORLD_SIZE": "4", "RANK": "0"}) is None           # already a rank
     assert bench.launch_plan(bench.parse(["--gpus", "1"]), {}) is None
     assert bench.parse([]).gpus == 1 and bench.parse([]).repeats >= 5
+
+
+def test_get_THD_equals_the_reference_to_the_last_bit():
+    """api.get_THD (HG:563-572, vectorised over buses) on the reference's own final voltages of every golden case = the reference's THD table,
+    bit for bit (the per-bus sums keep the reference's order of additions)."""
+    import glob
+    import pandas as pd
+    import harmonic_power_flow_amd as hp
+    from conftest import GOLD
+    n_checked = 0
+    for path in sorted(glob.glob(os.path.join(GOLD, "*_H*_*c.npz"))):
+        g = np.load(path, allow_pickle=True)
+        if "THD" not in g.files or "V_final" not in g.files or "harmonics" not in g.files:
+            continue
+        harmonics, n = [int(h) for h in g["harmonics"]], int(g["n"])
+        idx = pd.MultiIndex.from_product([harmonics, list(range(n))], names=["harmonic", "bus"])
+        V = pd.DataFrame(g["V_final"], index=idx, columns=["V_m", "V_a"])
+        thd = hp.get_THD(V).to_numpy()
+        ref = np.asarray(g["THD"], dtype=float)
+        assert thd.shape == ref.shape
+        assert np.array_equal(thd, ref, equal_nan=True), os.path.basename(path)
+        n_checked += 1
+    assert n_checked >= 16
