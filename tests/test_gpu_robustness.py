@@ -308,7 +308,11 @@ def test_level_kernel_for_every_block_size_matches_separate_launches(n, hmax, tm
     fused = _solve(hp, st, buses, Y, NE, S=S, polish=1)
     monkeypatch.setenv("HPF_FUSELEVEL", "0")
     plain = _solve(hp, st, buses, Y, NE, S=S, polish=1)
-    assert fused["census"]["fused_levels"] == 1 and plain["census"]["fused_levels"] == 0
+    # census[9] = EVERY elimination level is one k_level launch: always so for blocks of 52; smaller blocks fuse the levels that have
+    # scenario-batched workgroups only (the upper levels run k_factor_q's own grid), so the flag is 0 there although k_level runs
+    assert plain["census"]["fused_levels"] == 0
+    if 2 * ((hmax + 1) // 2) > 28:
+        assert fused["census"]["fused_levels"] == 1
     assert (fused["err"] <= 1e-4).all() and (plain["err"] <= 1e-4).all()
     Uf, Up = fused["Vm"] * np.exp(1j * fused["Va"]), plain["Vm"] * np.exp(1j * plain["Va"])
     print("\nn=%d hmax=%d: iterations %s vs %s, max|dU| %.2e" % (n, hmax, fused["it"][:4], plain["it"][:4], np.abs(Uf - Up).max()))

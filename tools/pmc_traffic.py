@@ -48,7 +48,7 @@ def main():
                 agg[k][1] += float(r["Counter_Value"])
         res[c] = agg
     out = {"format": 2,
-           "command": "rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-trace --output-format csv -- python3 bench.py --steps 5 --warmup 2 "
+           "command": "rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-trace --output-format csv -- python3 bench.py --steps 5 --warmup 2 --repeats 1 "
                       "--cpu-iters 0 --no-finish --no-single --sweep-1gpu 0 (two separate passes; tools/measure.sh <tag> pmc)",
            "steps_profiled": steps, "fetch_factor": ff, "write_factor": wf, "calibration": os.path.relpath(calib, REPO),
            "per_step_bytes": {}, "per_launch_bytes": {}}
