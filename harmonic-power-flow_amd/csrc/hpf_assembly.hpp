@@ -169,9 +169,7 @@ HPF_HD cplx norton_injection(const Model& M, const cplx* U, int q, int i) {
 // Iout (optional): receives the network current I of a power row -- the Jacobian's diagonal power entries (HG:451-459) need
 // the same sum again, and the block-tree kernels read it back instead of re-walking the admittance row.
 template <bool FUND>
-HPF_HD cplx mismatch_row(const Model& M, const cplx* U, const double* P, const double* Q, int k, cplx* Iout = nullptr) {
-    const int q = FUND ? 0 : k / M.n;
-    const int i = FUND ? k : k - q * M.n;
+HPF_HD cplx mismatch_row_qi(const Model& M, const cplx* U, const double* P, const double* Q, int q, int i, cplx* Iout = nullptr) {
     const cplx I = FUND ? row_current_fund(M, U, i) : row_current(M, U, q, i);
     if (FUND || (q == 0 && i < M.m)) {
         if (Iout) Iout[i] = I;
@@ -181,6 +179,13 @@ HPF_HD cplx mismatch_row(const Model& M, const cplx* U, const double* P, const d
     }
     if (i >= M.m) return cadd(I, norton_injection(M, U, q, i));   // HG:351,354
     return I;
+}
+
+template <bool FUND>
+HPF_HD cplx mismatch_row(const Model& M, const cplx* U, const double* P, const double* Q, int k, cplx* Iout = nullptr) {
+    const int q = FUND ? 0 : k / M.n;
+    const int i = FUND ? k : k - q * M.n;
+    return mismatch_row_qi<FUND>(M, U, P, Q, q, i, Iout);
 }
 
 // ---- Jacobian ---------------------------------------------------------------------------------------------

@@ -70,19 +70,25 @@ __global__ void k_polar(int count, int stride, int Hn, const double* __restrict_
 // gathered again by the neighbours' rows and by the Norton rows of the same bus -- are fetched into one L2 instead of eight.
 // With fewer than 8 scenarios that placement would leave XCDs empty (ONE scenario: the whole kernel on 32 of the 256 CUs -- 196 us
 // instead of 30 for the mismatch of the 10 000-bus x 49-harmonic feeder): the workgroups are then dealt over the whole chip.
-__device__ __forceinline__ bool xcd_map(int nbx, int S, int& bx, int& slot) {
-    const int id = blockIdx.x;
+// ... realised WITHOUT index arithmetic through a 3-D grid (the linear workgroup id is x + gx (y + gy z)): S >= 8: grid (8, nbx, ceil(S/8))
+// -> x = scenario mod 8 = the XCD, y = x block, z = scenario block; S < 8: grid (nbx, S, 1).  (The decode of a 1-D id took two integer
+// divisions by run-time values per workgroup: ~50 scalar instructions and two quarter-rate reciprocals in front of the first load.)
+__device__ __forceinline__ bool xcd_map(int S, int& bx, int& slot) {
     if (S < 8) {
-        bx = id % nbx;
-        slot = id / nbx;
-        return slot < S;
+        bx = blockIdx.x;
+        slot = blockIdx.y;
+        return true;
     }
-    const int l8 = id & 7, rest = id >> 3;
-    bx = rest % nbx;
-    slot = (rest / nbx) * 8 + l8;
+    bx = blockIdx.y;
+    slot = blockIdx.z * 8 + blockIdx.x;
     return slot < S;
 }
-__host__ inline unsigned xcd_grid(int nbx, int S) { return (unsigned)((S < 8 ? S : 8 * ((S + 7) / 8)) * nbx); }
+__host__ inline dim3 xcd_grid(int nbx, int S) {
+    return S < 8 ? dim3((unsigned)nbx, (unsigned)S, 1) : dim3(8, (unsigned)nbx, (unsigned)((S + 7) / 8));
+}
+// unsigned division of t < 2^32 / d by a run-time d through its reciprocal m = floor(2^32 / d) + 1 (host: div_magic): exact there
+__device__ __forceinline__ int div_by(int t, unsigned magic) { return (int)__umulhi((unsigned)t, magic); }
+__host__ inline unsigned div_magic(int d) { return d <= 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)d + 1ull); }
 
 // ||.||_inf with NaN propagation: |x| as its IEEE bit pattern is monotone for non-negative doubles, and every NaN
 // pattern compares above +inf, so an unsigned max reproduces np.linalg.norm(f, inf) including its NaN result
@@ -107,12 +113,31 @@ __device__ __forceinline__ cplx norton_injection_lds(const Model& M, int d, cons
     const int Hn = M.Hn;
     const cplx in = M.IN[(size_t)d * Hn + q];
     cplx acc = {0.0, 0.0};
+    const cplx* yq = ynl + q;
     if (q < (Hn & ~3)) {
-        for (int p0 = 0; p0 < Hn; p0 += 4) {
+        int p0 = 0;
+        for (; p0 + 4 <= Hn; p0 += 4) {                  // a full group: its eight LDS reads first, then the four FMA chains
+            cplx y4[4], u4[4];
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) {
+                y4[pp] = yq[(p0 + pp) * Hn];
+                u4[pp] = ul[p0 + pp];
+            }
             double rr = 0, ii = 0, ri = 0, ir = 0;
-            const int p1 = p0 + 4 < Hn ? p0 + 4 : Hn;
-            for (int p = p0; p < p1; ++p) {
-                const cplx u = ul[p], y = ynl[p * Hn + q];
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) {
+                rr = fma(y4[pp].re, u4[pp].re, rr);
+                ri = fma(y4[pp].re, u4[pp].im, ri);
+                ii = fma(y4[pp].im, u4[pp].im, ii);
+                ir = fma(y4[pp].im, u4[pp].re, ir);
+            }
+            acc.re += rr - ii;
+            acc.im += ri + ir;
+        }
+        if (p0 < Hn) {                                   // the last, shorter group
+            double rr = 0, ii = 0, ri = 0, ir = 0;
+            for (int p = p0; p < Hn; ++p) {
+                const cplx u = ul[p], y = yq[p * Hn];
                 rr = fma(y.re, u.re, rr);
                 ri = fma(y.re, u.im, ri);
                 ii = fma(y.im, u.im, ii);
@@ -123,7 +148,7 @@ __device__ __forceinline__ cplx norton_injection_lds(const Model& M, int d, cons
         }
     } else {
         for (int p = 0; p < Hn; ++p) {
-            const cplx u = ul[p], y = ynl[p * Hn + q];
+            const cplx u = ul[p], y = yq[p * Hn];
             acc.re += fma(y.re, u.re, -(y.im * u.im));
             acc.im += fma(y.re, u.im, y.im * u.re);
         }
@@ -143,19 +168,19 @@ template <bool FUND>
 __global__ __launch_bounds__(TPB, 8) void k_mismatch(Model M, int count, int N, int Nc, const int* __restrict__ active, const cplx* __restrict__ U,
                            const double* __restrict__ P, const double* __restrict__ Q, double* __restrict__ f,
                            unsigned long long* __restrict__ errbits, cplx* __restrict__ I0, double* __restrict__ fb, int Bst,
-                           int s0, int S_cnt, int nbx) {
+                           int s0, int S_cnt, unsigned hn_magic) {
     extern __shared__ cplx mm_lds[];                    // [Hn*Hn] Y_N^T of the tile's first device type | [tile buses][Hn] voltages
     int bx, slot;
-    if (!xcd_map(nbx, S_cnt, bx, slot)) return;
+    if (!xcd_map(S_cnt, bx, slot)) return;
     const int s = active ? active[slot + s0] : slot + s0;   // slot -> scenario (active list; -1: frozen / empty slot)
     if (s < 0) return;
     const int t = bx * TPB + threadIdx.x;
     const cplx* Us = U + (size_t)s * M.n * M.Hn;
+    const int Hn = M.Hn;
     int d0 = -1, i_first = 0;
     if (!FUND && M.coupled && M.YNt) {
-        const int Hn = M.Hn;
-        i_first = (bx * TPB) / Hn;
-        int i_last = (bx * TPB + TPB - 1) / Hn;
+        i_first = div_by(bx * TPB, hn_magic);
+        int i_last = div_by(bx * TPB + TPB - 1, hn_magic);
         if (i_last > M.n - 1) i_last = M.n - 1;
         if (i_last >= M.m) {                            // the tile holds nonlinear buses (they come last in the bus order, HG:83)
             d0 = M.dev[i_first > M.m ? i_first : M.m];
@@ -169,16 +194,16 @@ __global__ __launch_bounds__(TPB, 8) void k_mismatch(Model M, int count, int N, 
     }
     unsigned long long b = 0;
     if (t < count) {
-        const int i = FUND ? t : t / M.Hn, q = FUND ? 0 : t - i * M.Hn;
+        const int i = FUND ? t : div_by(t, hn_magic), q = FUND ? 0 : t - i * Hn;
         const int k = q * M.n + i;
         cplx v = {0.0, 0.0};
         if (k >= 1) {
             if (!FUND && d0 >= 0 && i >= M.m && M.dev[i] == d0) {
                 // current-balance row of a nonlinear bus (HG:351,354): network current + Norton injection out of LDS
                 const cplx I = row_current(M, Us, q, i);
-                v = cadd(I, norton_injection_lds(M, d0, mm_lds, mm_lds + M.Hn * M.Hn + (i - i_first) * M.Hn, q));
+                v = cadd(I, norton_injection_lds(M, d0, mm_lds, mm_lds + Hn * Hn + (i - i_first) * Hn, q));
             } else {
-                v = mismatch_row<FUND>(M, Us, P + (size_t)s * M.n, Q + (size_t)s * M.n, k, I0 ? I0 + (size_t)s * M.n : nullptr);
+                v = mismatch_row_qi<FUND>(M, Us, P + (size_t)s * M.n, Q + (size_t)s * M.n, q, i, I0 ? I0 + (size_t)s * M.n : nullptr);
             }
             if (f) store_mismatch(f + (size_t)s * N, Nc, M.c, k, v);
             b = abs_bits(v.re);
@@ -799,9 +824,9 @@ int launch_mismatch(hpf_handle* h, const int* active, bool stacked = true, const
             // (per launch: the attribute belongs to the device the handle runs on, and the call costs nothing next to the launch)
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mismatch<FUND>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         }
-        hipLaunchKernelGGL((k_mismatch<FUND>), dim3(xcd_grid(nbx, h->cur_S)), dim3(TPB), lds, h->cur_stream, h->M, count, N, Nc,
+        hipLaunchKernelGGL((k_mismatch<FUND>), xcd_grid(nbx, h->cur_S), dim3(TPB), lds, h->cur_stream, h->M, count, N, Nc,
                            active, Uover ? Uover : h->d_U, h->d_P, h->d_Q, (stacked || !img) ? h->d_f : nullptr, h->d_errbits, h->d_I0,
-                           img ? h->d_fb : nullptr, tree_bst(h), h->cur_s0, h->cur_S, nbx);
+                           img ? h->d_fb : nullptr, tree_bst(h), h->cur_s0, h->cur_S, div_magic(h->Hn));
         HIPCHK(hipGetLastError());
     }
     return HPF_OK;
