@@ -174,36 +174,91 @@ __global__ __launch_bounds__(TPB, 8) void k_mismatch(Model M, int count, int N, 
     if (!xcd_map(S_cnt, bx, slot)) return;
     const int s = active ? active[slot + s0] : slot + s0;   // slot -> scenario (active list; -1: frozen / empty slot)
     if (s < 0) return;
-    const int t = bx * TPB + threadIdx.x;
+    const int tid = threadIdx.x;
+    const int t = bx * TPB + tid;
     const cplx* Us = U + (size_t)s * M.n * M.Hn;
     const int Hn = M.Hn;
+    const bool live = t < count;
+    const int i = live ? (FUND ? t : div_by(t, hn_magic)) : M.n - 1, q = (FUND || !live) ? 0 : t - i * Hn;
+    // The kernel is bound by the chain of dependent fetches of a wavefront, so the harmonic variant issues them in BATCHES of independent,
+    // branch-free loads (indices clamped into the row, values masked afterwards): A = the row bounds, Y_N^T and the tile's bus voltages
+    // (for LDS); B = col and Y of the row's first PF entries; C = the neighbours' voltages.  Longer rows finish in a loop.  Same
+    // operations in the same order as mismatch_row / row_current: bit-identical results.
+    constexpr int PF = 3;                               // (a feeder row holds 3 entries on average)
     int d0 = -1, i_first = 0;
-    if (!FUND && M.coupled && M.YNt) {
+    int e0 = 0, e1 = 0;
+    cplx yv[PF], ug[PF];
+    if (!FUND) {
+        e0 = M.rowptr[i];
+        e1 = M.rowptr[i + 1];
+        const bool has_nl = M.coupled && M.YNt;
         i_first = div_by(bx * TPB, hn_magic);
         int i_last = div_by(bx * TPB + TPB - 1, hn_magic);
         if (i_last > M.n - 1) i_last = M.n - 1;
-        if (i_last >= M.m) {                            // the tile holds nonlinear buses (they come last in the bus order, HG:83)
+        const bool stage = has_nl && i_last >= M.m;     // the tile holds nonlinear buses (they come last in the bus order, HG:83)
+        const int nyn = Hn * Hn, nv = (i_last - i_first + 1) * Hn;          // nv <= 2 TPB
+        double2 tv0 = {0.0, 0.0}, tv1 = {0.0, 0.0};
+        if (stage) {
             d0 = M.dev[i_first > M.m ? i_first : M.m];
-            const cplx* src = M.YNt + (size_t)d0 * Hn * Hn;
-            for (int e = threadIdx.x; e < Hn * Hn; e += TPB) mm_lds[e] = src[e];
-            cplx* ul = mm_lds + Hn * Hn;
-            const int nv = (i_last - i_first + 1) * Hn;
-            for (int e = threadIdx.x; e < nv; e += TPB) ul[e] = Us[(size_t)i_first * Hn + e];
+            const double2* Ut = reinterpret_cast<const double2*>(Us + (size_t)i_first * Hn);
+            tv0 = Ut[tid < nv ? tid : 0];
+            tv1 = Ut[tid + TPB < nv ? tid + TPB : 0];
+            const double2* src = reinterpret_cast<const double2*>(M.YNt + (size_t)d0 * nyn);
+            double2* dst = reinterpret_cast<double2*>(mm_lds);
+            for (int base = tid; base < nyn; base += 4 * TPB) {                 // (26 harmonics: one pass of three loads in flight)
+                const double2 y0 = src[base], y1 = src[base + TPB < nyn ? base + TPB : 0], y2 = src[base + 2 * TPB < nyn ? base + 2 * TPB : 0],
+                              y3 = src[base + 3 * TPB < nyn ? base + 3 * TPB : 0];
+                dst[base] = y0;
+                if (base + TPB < nyn) dst[base + TPB] = y1;
+                if (base + 2 * TPB < nyn) dst[base + 2 * TPB] = y2;
+                if (base + 3 * TPB < nyn) dst[base + 3 * TPB] = y3;
+            }
         }
-        __syncthreads();
+        int jc[PF];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int e = e0 + u < e1 ? e0 + u : e1 - 1;
+            jc[u] = M.col[e];
+            yv[u] = M.Y[(size_t)e * Hn + q];
+        }
+#pragma unroll
+        for (int u = 0; u < PF; ++u) ug[u] = Us[(size_t)jc[u] * Hn + q];
+        if (stage) {
+            double2* ul = reinterpret_cast<double2*>(mm_lds + nyn);
+            if (tid < nv) ul[tid] = tv0;
+            if (tid + TPB < nv) ul[tid + TPB] = tv1;
+        }
+        if (has_nl) __syncthreads();
     }
     unsigned long long b = 0;
-    if (t < count) {
-        const int i = FUND ? t : div_by(t, hn_magic), q = FUND ? 0 : t - i * Hn;
+    if (live) {
         const int k = q * M.n + i;
         cplx v = {0.0, 0.0};
         if (k >= 1) {
-            if (!FUND && d0 >= 0 && i >= M.m && M.dev[i] == d0) {
-                // current-balance row of a nonlinear bus (HG:351,354): network current + Norton injection out of LDS
-                const cplx I = row_current(M, Us, q, i);
-                v = cadd(I, norton_injection_lds(M, d0, mm_lds, mm_lds + Hn * Hn + (i - i_first) * Hn, q));
+            if (FUND) {
+                v = mismatch_row_qi<true>(M, Us, P + (size_t)s * M.n, Q + (size_t)s * M.n, 0, i, I0 ? I0 + (size_t)s * M.n : nullptr);   // (pf's tree kernels read the row currents back)
             } else {
-                v = mismatch_row_qi<FUND>(M, Us, P + (size_t)s * M.n, Q + (size_t)s * M.n, q, i, I0 ? I0 + (size_t)s * M.n : nullptr);
+                cplx I = {0.0, 0.0};                    // row_current: ascending columns, every product and sum rounded (csr_matvec)
+#pragma unroll
+                for (int u = 0; u < PF; ++u) {
+                    const cplx nx = cadd(I, cmul_unf(yv[u], ug[u]));
+                    const bool has = e0 + u < e1;       // (component selects: a select of the struct goes through scratch)
+                    I.re = has ? nx.re : I.re;
+                    I.im = has ? nx.im : I.im;
+                }
+                for (int e = e0 + PF; e < e1; ++e) I = cadd(I, cmul_unf(M.Y[(size_t)e * Hn + q], Us[(size_t)M.col[e] * Hn + q]));
+                if (q == 0 && i < M.m) {                // power row (HG:372-380)
+                    if (I0) I0[(size_t)s * M.n + i] = I;
+                    const cplx sl = cmul_npy(Us[(size_t)i * Hn], cconj(I));
+                    v = {P[(size_t)s * M.n + i] + sl.re, Q[(size_t)s * M.n + i] + sl.im};
+                } else if (d0 >= 0 && i >= M.m && M.dev[i] == d0) {
+                    // current-balance row of a nonlinear bus (HG:351,354): network current + Norton injection out of LDS
+                    v = cadd(I, norton_injection_lds(M, d0, mm_lds, mm_lds + Hn * Hn + (i - i_first) * Hn, q));
+                } else if (i >= M.m) {
+                    v = cadd(I, norton_injection(M, Us, q, i));
+                } else {
+                    v = I;
+                }
             }
             if (f) store_mismatch(f + (size_t)s * N, Nc, M.c, k, v);
             b = abs_bits(v.re);
@@ -214,15 +269,14 @@ __global__ __launch_bounds__(TPB, 8) void k_mismatch(Model M, int count, int N, 
         }
         if (!FUND && fb) {
             double* o = fb + ((size_t)s * M.n + i) * Bst + 2 * q;
-            o[0] = k >= 1 ? v.re : 0.0;
-            o[1] = k >= M.c ? v.im : 0.0;
+            *reinterpret_cast<double2*>(o) = double2{k >= 1 ? v.re : 0.0, k >= M.c ? v.im : 0.0};
         }
     }
     b = wave_max_u64(b);
     __shared__ unsigned long long red[TPB / 64];
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = b;
+    if ((tid & 63) == 0) red[tid >> 6] = b;
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         unsigned long long r = red[0];
 #pragma unroll
         for (int w = 1; w < TPB / 64; ++w) r = red[w] > r ? red[w] : r;
