@@ -1,0 +1,51 @@
+"""Sanitizer runs of everything of the product that executes on the HOST (no GPU; GPU AddressSanitizer is not available on the pool):
+  * csrc/hpf_assembly.hpp executed serially (mismatch rows, dense and CSR Jacobian targets) under ASan + UBSan (g++);
+  * an ASan + UBSan HOST build of libhpf.so (hipcc -fsanitize=address,undefined -fno-gpu-sanitize): hpf_create's argument validation and the
+    elimination-tree planner (hpf_tree_plan = tree_build_into up to the uploads: ~1 400 lines of index bookkeeping) on random feeders of every
+    block-size class.
+tests/cpu_emul/sanitize_main.cpp is the driver; an out-of-bounds access or undefined behaviour aborts it."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+from conftest import REPO
+
+SRC = os.path.join(REPO, "tests", "cpu_emul", "sanitize_main.cpp")
+CSRC = os.path.join(REPO, "harmonic-power-flow_amd", "csrc")
+OUT = os.path.join(REPO, "tests", "cpu_emul")
+FLAGS = ["-O1", "-g", "-std=c++17", "-ffp-contract=off", "-mfma", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"]
+
+
+def _newer(target, deps):
+    return os.path.exists(target) and all(os.path.getmtime(target) >= os.path.getmtime(d) for d in deps)
+
+
+def test_device_arithmetic_on_host_under_asan_ubsan():
+    exe = os.path.join(OUT, "sanitize_emul.bin")
+    if not _newer(exe, [SRC, os.path.join(CSRC, "hpf_assembly.hpp")]):
+        subprocess.check_call(["g++"] + FLAGS + ["-I", CSRC, SRC, "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "12 cases clean" in r.stdout
+
+
+def test_host_side_of_libhpf_under_asan_ubsan():
+    hipcc, clang = "/opt/rocm/bin/hipcc", "/opt/rocm/lib/llvm/bin/clang++"
+    if not (os.path.exists(hipcc) and os.path.exists(clang)):
+        pytest.skip("ROCm toolchain not present")
+    lib = os.path.join(OUT, "libhpf_asan.so")
+    srcs = [os.path.join(CSRC, f) for f in ("hpf_lib.hip", "hpf_block.hip")]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(REPO, "include", "hpf.h")]
+    if not _newer(lib, deps):
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value", "-w", "-fPIC",
+                               "-shared", "-fsanitize=address,undefined", "-fno-gpu-sanitize", "-fno-sanitize-recover=undefined"] + srcs +
+                              ["-o", lib, "-L/opt/rocm/lib", "-lrocsolver", "-lrocblas", "-Wl,-rpath,/opt/rocm/lib"])
+    exe = os.path.join(OUT, "sanitize_lib.bin")
+    if not _newer(exe, [SRC, lib]):
+        subprocess.check_call([clang] + FLAGS + ["-DWITH_LIBHPF", "-I", CSRC, SRC, "-o", exe, lib, "-Wl,-rpath," + OUT, "-Wl,-rpath,/opt/rocm/lib"])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")      # (the HIP runtime's start-up allocations are not ours to free)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "20 cases clean" in r.stdout
