@@ -2531,7 +2531,7 @@ static void tree_free_one(Tree& T) {
 void tree_free(hpf_handle* h) {
     tree_free_one(h->tree);
     tree_free_one(h->ctree);
-    void* bp[] = {h->d_tb_bus, h->d_tb_ptr, h->d_tb_adj, h->d_bM, h->d_brhs, h->d_bipiv, h->d_binfo};
+    void* bp[] = {h->d_tb_bus, h->d_tb_ptr, h->d_tb_adj, h->d_bM, h->d_brhs, h->d_bipiv, h->d_binfo, h->d_bM0, h->d_brhs0};
     for (void* q2 : bp)
         if (q2) hipFree(q2);
 }
@@ -2907,7 +2907,8 @@ int tree_find_ties(hpf_handle* h, const hpf_desc* d) {
     if ((r = upload(h, &h->d_tb_adj, tb_adj))) return r;
     const size_t m = (size_t)h->m_border;
     if (hipMalloc((void**)&h->d_bM, sizeof(double) * m * m) != hipSuccess || hipMalloc((void**)&h->d_brhs, sizeof(double) * m) != hipSuccess ||
-        hipMalloc((void**)&h->d_bipiv, sizeof(int) * m) != hipSuccess || hipMalloc((void**)&h->d_binfo, sizeof(int)) != hipSuccess)
+        hipMalloc((void**)&h->d_bipiv, sizeof(int) * m) != hipSuccess || hipMalloc((void**)&h->d_binfo, sizeof(int)) != hipSuccess ||
+        hipMalloc((void**)&h->d_bM0, sizeof(double) * m * m) != hipSuccess || hipMalloc((void**)&h->d_brhs0, sizeof(double) * (m + 2)) != hipSuccess)
         return HPF_E_NOMEM;
     return HPF_OK;
 }
@@ -2937,6 +2938,28 @@ int ensure_blas(hpf_handle* h) {
 }
 
 int border_slots(const hpf_handle* h) { return h->m_border + 1 < 256 ? h->m_border + 1 : 256; }
+
+// max |v_i| of a vector (NaN-propagating) -> *out; one workgroup
+__global__ __launch_bounds__(1024) void k_border_absmax(int m, const double* __restrict__ v, double* __restrict__ out) {
+    __shared__ double red[1024];
+    double a = 0.0;
+    bool nan = false;
+    for (int i = threadIdx.x; i < m; i += 1024) {
+        const double x = fabs(v[i]);
+        nan = nan || x != x;
+        a = x > a ? x : a;
+    }
+    red[threadIdx.x] = nan ? NAN : a;
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            const double p = red[threadIdx.x], q = red[threadIdx.x + off];
+            red[threadIdx.x] = (p != p || q != q) ? NAN : (q > p ? q : p);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = red[0];
+}
 
 int tree_newton_step_bordered(hpf_handle* h, bool only_active) {
     const int m = h->m_border, VC = border_slots(h), v0 = h->S_max;
@@ -2983,13 +3006,43 @@ int tree_newton_step_bordered(hpf_handle* h, bool only_active) {
                                h->d_tb_bus, h->d_tb_ptr, h->d_tb_adj, h->d_U, h->d_E, h->d_x, h->d_bM, h->d_brhs);
         }
         if (ensure_blas(h) || rocblas_set_stream(h->blas, st) != rocblas_status_success) return HPF_E_ROCSOLVER;
-        if (rocsolver_dgetrf(h->blas, m, m, h->d_bM, m, h->d_bipiv, h->d_binfo) != rocblas_status_success ||
-            rocsolver_dgetrs(h->blas, rocblas_operation_none, m, 1, h->d_bM, m, h->d_bipiv, h->d_brhs, m) != rocblas_status_success)
-            return HPF_E_ROCSOLVER;
+        // Border system (I + Q^T Z) g = Q^T y.  rocSOLVER's pivoted getrf spends most of its time in thousands of tiny pivot-search / swap
+        // kernels at these sizes (m = 520: a third of the whole bordered iteration, m = 2 080: 10 ms), so the LU runs WITHOUT pivoting first
+        // (getrf_npvt + two triangular solves) and its solution is checked against a kept copy of the system: a residual above 1e-10 of the
+        // right-hand side (pivot growth), a zero pivot or a non-finite entry sends the system through the pivoted LU.
+        double* res = h->d_brhs0 + m;                     // [2]: max |rhs - M g|, max |rhs|
         int info = 0;
-        if (hipMemcpyAsync(&info, h->d_binfo, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+        double hres[2] = {0.0, 0.0};
+        hipMemcpyAsync(h->d_bM0, h->d_bM, sizeof(double) * (size_t)m * m, hipMemcpyDeviceToDevice, st);
+        hipMemcpyAsync(h->d_brhs0, h->d_brhs, sizeof(double) * m, hipMemcpyDeviceToDevice, st);
+        const double one = 1.0, neg = -1.0;
+        if (rocsolver_dgetrf_npvt(h->blas, m, m, h->d_bM, m, h->d_binfo) != rocblas_status_success ||
+            rocblas_dtrsv(h->blas, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_unit, m, h->d_bM, m, h->d_brhs, 1) != rocblas_status_success ||
+            rocblas_dtrsv(h->blas, rocblas_fill_upper, rocblas_operation_none, rocblas_diagonal_non_unit, m, h->d_bM, m, h->d_brhs, 1) != rocblas_status_success)
+            return HPF_E_ROCSOLVER;
+        hipLaunchKernelGGL(k_border_absmax, dim3(1), dim3(1024), 0, st, m, (const double*)h->d_brhs0, res + 1);
+        if (rocblas_dgemv(h->blas, rocblas_operation_none, m, m, &neg, h->d_bM0, m, h->d_brhs, 1, &one, h->d_brhs0, 1) != rocblas_status_success)
+            return HPF_E_ROCSOLVER;                       // brhs0 <- rhs - M g
+        hipLaunchKernelGGL(k_border_absmax, dim3(1), dim3(1024), 0, st, m, (const double*)h->d_brhs0, res);
+        if (hipMemcpyAsync(&info, h->d_binfo, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipMemcpyAsync(hres, res, sizeof(double) * 2, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
             h->last_detail = (int)hipGetLastError();
             return HPF_E_HIP;
+        }
+        if (h->border_pivoting || info != 0 || !(hres[0] <= 1e-10 * hres[1]) || !(hres[1] < INFINITY)) {
+            // (brhs0 was overwritten by the residual: the right-hand side is residual + M g; rebuild it from the kept matrix)
+            if (rocblas_dgemv(h->blas, rocblas_operation_none, m, m, &one, h->d_bM0, m, h->d_brhs, 1, &one, h->d_brhs0, 1) != rocblas_status_success)
+                return HPF_E_ROCSOLVER;
+            hipMemcpyAsync(h->d_bM, h->d_bM0, sizeof(double) * (size_t)m * m, hipMemcpyDeviceToDevice, st);
+            hipMemcpyAsync(h->d_brhs, h->d_brhs0, sizeof(double) * m, hipMemcpyDeviceToDevice, st);
+            ++h->border_repivots;
+            if (rocsolver_dgetrf(h->blas, m, m, h->d_bM, m, h->d_bipiv, h->d_binfo) != rocblas_status_success ||
+                rocsolver_dgetrs(h->blas, rocblas_operation_none, m, 1, h->d_bM, m, h->d_bipiv, h->d_brhs, m) != rocblas_status_success)
+                return HPF_E_ROCSOLVER;
+            if (hipMemcpyAsync(&info, h->d_binfo, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+                h->last_detail = (int)hipGetLastError();
+                return HPF_E_HIP;
+            }
         }
         if (info != 0) {                                  // exactly singular border system (rocSOLVER info > 0)
             h->last_detail = r;

@@ -141,6 +141,9 @@ struct hpf_handle {
     int *d_tb_adj = nullptr;          // per (endpoint i, tie (i,j)): j, CSR entry (i,j), 0
     double *d_bM = nullptr, *d_brhs = nullptr;   // border system (m x m column-major, m)
     int *d_bipiv = nullptr, *d_binfo = nullptr;
+    double *d_bM0 = nullptr, *d_brhs0 = nullptr;   // kept copy of the border system (residual check of the unpivoted LU) | copy of its right-hand side + 2 check words
+    int border_pivoting = 0;          // option "border_pivoting": 1 = every border system through the pivoted LU (A/B, tests)
+    int border_repivots = 0;          // border systems that went through the pivoted LU after the residual check
     std::vector<int> host_act;        // the slot list as the host last saw it (the bordered step walks the running scenarios)
     int N = 0, Nc = 0, Nf = 0;
     bool loads_set = false, state_set = false, mismatch_valid = false;

@@ -1862,6 +1862,10 @@ int hpf_set_option(hpf_handle* h, const char* name, int value) {
         }
         return HPF_OK;
     }
+    if (!strcmp(name, "border_pivoting")) {         // meshed BLOCK_TREE handles: 1 = the border system always through the pivoted LU
+        h->border_pivoting = value ? 1 : 0;
+        return HPF_OK;
+    }
     if (!strcmp(name, "queue_chunk")) {             // hpf_solve_queue: Newton iterations between two harvest / refill rounds
         if (value < 1 || value > 16) return HPF_E_ARG;
         h->queue_chunk = value;
@@ -2008,7 +2012,7 @@ int hpf_tree_census(const hpf_handle* h, int* counts, int n_counts) {
     if (h->solver != HPF_SOLVER_BLOCK_TREE) return HPF_E_STATE;
     const Tree& T = active_tree(const_cast<hpf_handle*>(h));
     const int fused = tree_levels_fused(const_cast<hpf_handle*>(h)) ? 1 : 0;
-    for (int i = 0; i < n_counts; ++i) counts[i] = i < 8 ? T.census[i] : (i == 8 ? h->n_ties : (i == 9 ? fused : (i == 10 ? T.n_comp : 0)));
+    for (int i = 0; i < n_counts; ++i) counts[i] = i < 8 ? T.census[i] : (i == 8 ? h->n_ties : (i == 9 ? fused : (i == 10 ? T.n_comp : (i == 11 ? h->border_repivots : 0))));
     return HPF_OK;
 }
 

@@ -193,6 +193,10 @@ int  hpf_debug_stamps(hpf_handle* h, long long* out, int count);
  * (a lower bound of its condition number) exceeds 10^value; "auto_repivot" (default 1): hpf_solve repeats flagged scenarios
  * with partial pivoting (0: they are only reported in hpf_stat.flags).
  * "keep_previous_state" (default 0): hpf_solve keeps per scenario the state its last Newton step started from (hpf_jacobian_last).
+ * "border_pivoting" (meshed BLOCK_TREE handles, default 0): the m x m border system of a bordered Newton step is factored WITHOUT pivoting
+ * first (rocSOLVER's pivoted LU spends a third of such a step in tiny pivot-search kernels) and its solution checked against a kept copy of
+ * the system; a relative residual above 1e-10, a zero pivot or a non-finite entry repeats it with partial pivoting (hpf_tree_census[11]
+ * counts those).  1 = always the pivoted LU.
  * "queue_chunk" (1..16, default 2): Newton iterations between two harvest / refill rounds of hpf_solve_queue.
  * "scenario_groups" (1..8, default 3 -- with the host framework's own streams a fourth busy queue is a cliff --; at least 32 running scenarios per group): independent scenario pipelines on separate HIP streams.
  * Environment read by hpf_create (diagnostics, A/B runs): HPF_LAZY=0 builds the elimination tree without lazy leaves (every
@@ -257,7 +261,8 @@ int  hpf_kernel_model(const hpf_handle* h, int which, double* bytes, double* flo
  * (bordered children below them), elimination levels, back-sweep depths, tie lines of a meshed network, [9] 1 if every elimination
  * level is ONE launch (k_level: scenario-batched and per-scenario workgroups in one grid; timing class 5 then covers it) -- blocks of 52
  * in the default mode; smaller blocks only when every level has scenario-batched workgroups (levels without them run k_factor_q's own grid),
- * [10] compress steps (Gauss-Jordan buses eliminated before their tallest dense child: levels counts the shortened chain).
+ * [10] compress steps (Gauss-Jordan buses eliminated before their tallest dense child: levels counts the shortened chain),
+ * [11] border systems of a meshed network that were repeated with the pivoted LU since hpf_create (option "border_pivoting").
  * HPF_E_STATE for DENSE. */
 int  hpf_tree_census(const hpf_handle* h, int* counts, int n_counts);
 /* Wall-clock milliseconds hpf_create spent: ms[0] total, [1] planning the elimination trees on the host (classification of the buses,

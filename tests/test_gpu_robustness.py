@@ -402,6 +402,52 @@ def test_meshed_feeder_bordered_block_tree_vs_dense(n, hmax, k, tmp_path):
     assert np.abs(Ud - Ub).max() < TOL_V
 
 
+def test_border_system_unpivoted_lu_with_residual_check_vs_pivoted(tmp_path):
+    """The m x m border system of a bordered Newton step: unpivoted LU + residual check (default; a failed check repeats it pivoted) against
+    option "border_pivoting" = 1 (always rocSOLVER's pivoted LU): same Newton steps to 1e-9 of the step, same fixed point; the census counts the
+    systems that went through the pivoted LU."""
+    hp = _hp()
+    from harmonic_power_flow_amd import api, synth
+    n, hmax, k = 260, 51, 6
+    fb, fl = synth.gen(n, seed=4, outdir=str(tmp_path))
+    _add_ties(fl, n, k)
+    st = hp.Settings(H_MAX=hmax)
+    buses, lines, m, nn, c = hp.init_network(fb, fl, settings=st)
+    Y = hp.build_admittance_matrices(buses, lines, st.HARMONICS)
+    NE = hp.import_Norton_Equivalents(buses, True, st, INPUTS)
+    out = {}
+    for piv in (0, 1):
+        dm = api._device_model(buses, Y, NE, True, st.HARMONICS, solver="block_tree")
+        try:
+            dm.set_option("border_pivoting", piv)
+            dm.set_loads(buses["P"].to_numpy(float), buses["Q"].to_numpy(float))
+            dm.set_state(None, None, n_scen=1)
+            dm.fund_pf(1e-6, 30)
+            v0 = dm.get_state()
+            dm.mismatch(want_f=False)
+            dm.iterate(1)
+            dm.sync()
+            v1 = dm.get_state()
+            dm.set_state(*v0)
+            n_iter, err, _ = dm.solve(1e-4, 50)
+            dm.mismatch(want_f=False)
+            dm.iterate(2)
+            dm.sync()
+            out[piv] = (v0, v1, dm.get_state(), int(n_iter[0]), float(err[0]), dm.tree_census())
+        finally:
+            dm.close()
+    (v0a, v1a, vfa, ita, ea, ca), (v0b, v1b, vfb, itb, eb, cb) = out[0], out[1]
+    step = max(np.abs(v1b[0] - v0b[0]).max(), np.abs(v1b[1] - v0b[1]).max())
+    d1 = max(np.abs(v1a[0] - v1b[0]).max(), np.abs(v1a[1] - v1b[1]).max())
+    Ua, Ub = vfa[0][0] * np.exp(1j * vfa[1][0]), vfb[0][0] * np.exp(1j * vfb[1][0])
+    print("\nborder LU: unpivoted + check %d it (repeated pivoted: %d), always pivoted %d it (%d systems); first step %.1e, deviation %.1e; "
+          "fixed points differ by %.2e" % (ita, ca["border_repivots"], itb, cb["border_repivots"], step, d1, np.abs(Ua - Ub).max()))
+    assert ca["ties"] == k and cb["border_repivots"] >= itb + 3 and ca["border_repivots"] <= cb["border_repivots"]
+    assert d1 <= 1e-9 * max(1.0, step)
+    assert ea <= 1e-4 and eb <= 1e-4
+    assert np.abs(Ua - Ub).max() < TOL_V
+
+
 def test_meshed_handle_refuses_the_pivoted_mode(tmp_path):
     """The bordered Newton step of a meshed network exists in the bus-image layout of the static-pivot kernels only: asking such a handle
     for partial pivoting (option block_pivoting = 1) is refused with HPF_E_STATE instead of taking silently wrong steps, and env
