@@ -1977,7 +1977,7 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
         // push of the pending child), which pays while the levels do not fill the chip (measured crossover between 256 and 384 live
         // scenarios on the headline feeder, tools/groups_sweep.py); HPF_COMPRESS=1 / 0 force it on / off
         const bool compress_on = contract && d->coupled && BWc != 0 && BWc <= 100 && T.n_dense > 2 &&
-                                 (cp_env ? atoi(cp_env) != 0 : h->S_max <= 256);
+                                 (cp_env ? atoi(cp_env) != 0 : h->S_max + (h->n_ties > 0 ? border_slots(h) : 0) <= 256);   // (live slots incl. the virtual ones of a meshed handle)
         auto is_gj = [&](int k2) { return kept(k2) && cleaf_of[k2] < 0 && sl_off[k2] < 0; };
         std::vector<int> cc(n, -1), isc(n, 0), keptl;
         for (int i = 0; i < n; ++i)
@@ -2937,7 +2937,13 @@ int ensure_blas(hpf_handle* h) {
     return rocblas_create_handle(&h->blas) == rocblas_status_success ? HPF_OK : HPF_E_ROCSOLVER;
 }
 
-int border_slots(const hpf_handle* h) { return h->m_border + 1 < 256 ? h->m_border + 1 : 256; }
+// virtual scenario slots of the bordered step: all 1 + m right-hand sides at once up to 256, above that chunks of up to 1 024 (a chunk
+// runs in the throughput regime of the tree kernels: 6.5 us per scenario-step at 256 live slots, 5.5 at 1 024; 72 MB of state per slot)
+int border_slots(const hpf_handle* h) {
+    static const int cap = getenv("HPF_BORDER_SLOTS") ? atoi(getenv("HPF_BORDER_SLOTS")) : 1024;
+    const int c = cap < 16 ? 16 : cap;
+    return h->m_border + 1 < 256 ? h->m_border + 1 : (h->m_border + 1 < c ? ((h->m_border + 1 + 15) / 16) * 16 : c);
+}
 
 // max |v_i| of a vector (NaN-propagating) -> *out; one workgroup
 __global__ __launch_bounds__(1024) void k_border_absmax(int m, const double* __restrict__ v, double* __restrict__ out) {
