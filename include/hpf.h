@@ -36,7 +36,7 @@ enum {
     HPF_SOLVER_BLOCK_TREE = 1  /* bus-major 2Hn x 2Hn block elimination along the feeder tree.  Radial networks directly; meshed
                                   networks as BFS spanning tree + k loop-closing lines, solved as a bordered system on top of the
                                   same tree factorisation (m + 2 right-hand sides per scenario and Newton step, m = 2Hn x number
-                                  of distinct endpoint buses of the loop-closing lines, in chunks of up to 256 virtual scenarios;
+                                  of distinct endpoint buses of the loop-closing lines, in chunks of up to 1 024 virtual scenarios;
                                   m x m border system on rocSOLVER); m <= 16 384 and 2Hn <= 100, else HPF_E_TOPOLOGY */
 };
 
@@ -215,7 +215,8 @@ int  hpf_debug_stamps(hpf_handle* h, long long* out, int count);
  * height, HPF_CHAINBUNDLE=0 gives the contracted chains their own launches, HPF_COMPRESS=0 eliminates the Gauss-Jordan buses strictly
  * leaves first (no compress steps: one elimination level per unit of tree height; the default for handles of more than 256 scenarios,
  * whose levels fill the chip -- HPF_COMPRESS=1 forces the compress steps there too), HPF_TREE_INFO=1 prints the tree statistics to stderr,
- * HPF_QUEUE_INFO=1 prints the phase times of hpf_solve_queue to stderr,
+ * HPF_QUEUE_INFO=1 prints the phase times of hpf_solve_queue to stderr, HPF_BORDER_SLOTS=n caps the virtual scenario slots a meshed handle
+ * allocates for its bordered step (default 1 024, at least 16: the m + 1 right-hand sides run in chunks of that many),
  * HPF_GROUPS=n presets "scenario_groups".  Every switch selects a path with the same Newton steps (tests/test_gpu_robustness.py). */
 int  hpf_set_option(hpf_handle* h, const char* name, int value);
 
