@@ -43,33 +43,6 @@ namespace {
 
 constexpr int FDESC = 48;   // ints per node record of the multi-wave factor kernel (Tree::d_fdesc)
 
-// State update folded into the back-substitution kernels (round 3): the kernel that produces the Newton step of a bus also applies it
-// (HG:478,484-485: x <- x - step, scattered into V_a / V_m) and refreshes the bus's U, E -- into the OTHER copy of the U / E arrays,
-// because the 2x2 kernels at the end of the back sweep still form coupling blocks from the old voltages; the host swaps the two
-// copies after the step.  Same arithmetic as k_update.
-struct FoldUpd {
-    double* Vm;
-    double* Va;
-    cplx* Un;
-    cplx* En;
-    unsigned long long* errbits;
-    int on;
-};
-__device__ __forceinline__ void fold_update(const FoldUpd& F, int n, int Hn, int c, int s, int k, int q, double dx0, double dx1) {
-    const int kst = q * n + k;
-    const size_t o = ((size_t)s * n + k) * Hn + q;
-    double va = F.Va[o], vm = F.Vm[o];
-    if (kst >= 1) va = va - dx0;
-    if (kst >= c) vm = vm - dx1;
-    F.Va[o] = va;
-    F.Vm[o] = vm;
-    cplx u, e;
-    polar<false>(vm, va, u, e);
-    F.Un[o] = u;
-    F.En[o] = e;
-    if (kst == 0) F.errbits[s] = 0ull;
-}
-
 struct TreeDev {
     const int* parent;
     const int* child_ptr;
@@ -90,7 +63,6 @@ struct TreeDev {
     double* cH2;
     const int* comp_child;
     int n_comp;
-    FoldUpd fold;           // state update inside the back-substitution kernels (on = 0: k_update does it)
 };
 
 // validity of local index l = 2q+t of bus i as an unknown / equation (same rule for both, see hpf_assembly.hpp)
@@ -2614,8 +2586,7 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
     Tree& T = active_tree(h);
     const int* active = only_active ? h->d_active : nullptr;
     const TreeDev td{T.d_parent, T.d_child_ptr, T.d_child, T.d_e_up, T.d_e_dn, T.d_child_mid, T.d_lin_ptr, T.d_lin_post, T.d_child3, T.d_dchild, T.d_chain_ptr, T.d_chain_nodes, T.d_chain_ch, T.d_lzrec, T.d_lzimg,
-                     h->d_F, h->d_H2, T.d_comp_child, T.n_comp,
-                     FoldUpd{h->d_Vm, h->d_Va, h->d_U2, h->d_E2, h->d_errbits, (h->fold_step && fold_update_possible(h)) ? 1 : 0}};
+                     h->d_F, h->d_H2, T.d_comp_child, T.n_comp};
     const int b = 2 * h->Hn;
     const int R = (b + 15) / 16;
     const int BW = wave_block_size(b);
@@ -2776,9 +2747,9 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
                 const int b0 = T.bsleaf_ptr[gi], bc2 = T.bsleaf_ptr[gi + 1] - b0;
                 if (bc2 <= 0) continue;
                 switch (BW) {
-                    case 12: r = launch_sleaf_back_batch<12>(h, T.d_bsleaf + 8 * (size_t)b0, bc2, active, td.fold); break;
-                    case 28: r = launch_sleaf_back_batch<28>(h, T.d_bsleaf + 8 * (size_t)b0, bc2, active, td.fold); break;
-                    case 52: r = launch_sleaf_back_batch<52>(h, T.d_bsleaf + 8 * (size_t)b0, bc2, active, td.fold); break;
+                    case 12: r = launch_sleaf_back_batch<12>(h, T.d_bsleaf + 8 * (size_t)b0, bc2, active); break;
+                    case 28: r = launch_sleaf_back_batch<28>(h, T.d_bsleaf + 8 * (size_t)b0, bc2, active); break;
+                    case 52: r = launch_sleaf_back_batch<52>(h, T.d_bsleaf + 8 * (size_t)b0, bc2, active); break;
                     default: break;
                 }
             }
@@ -2787,9 +2758,9 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
         if (leafbatch_e && h->has_ctree && h->gj_mode == 1 && T.n_bleaf > 0) {
             int r = HPF_OK;
             switch (BW) {
-                case 12: r = launch_leaf_back_batch<12>(h, T.d_bleaf, T.n_bleaf, active, td.fold); break;
-                case 28: r = launch_leaf_back_batch<28>(h, T.d_bleaf, T.n_bleaf, active, td.fold); break;
-                case 52: r = launch_leaf_back_batch<52>(h, T.d_bleaf, T.n_bleaf, active, td.fold); break;
+                case 12: r = launch_leaf_back_batch<12>(h, T.d_bleaf, T.n_bleaf, active); break;
+                case 28: r = launch_leaf_back_batch<28>(h, T.d_bleaf, T.n_bleaf, active); break;
+                case 52: r = launch_leaf_back_batch<52>(h, T.d_bleaf, T.n_bleaf, active); break;
                 default: break;
             }
             if (r) return r;
@@ -2804,14 +2775,9 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
         if (T.n_lin_bundles2 > 0) {
             const dim3 g2((unsigned)T.n_lin_bundles2, (unsigned)h->cur_S);
 #define HPF_LB_B(NP_)                                                                                                                \
-    if (td.fold.on)                                                                                                                  \
-        hipLaunchKernelGGL((k_lin_bundle_back<NP_, true>), g2, dim3(256), 0, h->cur_stream, h->M, T.d_lb2rec, (const int2*)T.d_lb2x, T.d_lb2ptr, \
-                           T.n_lin_heights, Bst, active, h->d_U, h->d_E, h->d_linA, h->d_w, h->d_x, h->cur_s0,                             \
-                           T.chains_bundled ? T.d_lb2cptr : (const int*)nullptr, T.d_lb2clist, T.d_crec, T.d_cnode, h->d_chZ, td.fold);    \
-    else                                                                                                                             \
-    hipLaunchKernelGGL((k_lin_bundle_back<NP_, false>), g2, dim3(256), 0, h->cur_stream, h->M, T.d_lb2rec, (const int2*)T.d_lb2x, T.d_lb2ptr, \
+    hipLaunchKernelGGL((k_lin_bundle_back<NP_>), g2, dim3(256), 0, h->cur_stream, h->M, T.d_lb2rec, (const int2*)T.d_lb2x, T.d_lb2ptr, \
                        T.n_lin_heights, Bst, active, h->d_U, h->d_E, h->d_linA, h->d_w, h->d_x, h->cur_s0,                                 \
-                       T.chains_bundled ? T.d_lb2cptr : (const int*)nullptr, T.d_lb2clist, T.d_crec, T.d_cnode, h->d_chZ, td.fold)
+                       T.chains_bundled ? T.d_lb2cptr : (const int*)nullptr, T.d_lb2clist, T.d_crec, T.d_cnode, h->d_chZ)
             if (T.lin_np == 1) HPF_LB_B(1);
             else if (T.lin_np == 2) HPF_LB_B(2);
             else HPF_LB_B(4);
@@ -2919,19 +2885,6 @@ int tree_find_ties(hpf_handle* h, const hpf_desc* d) {
 //   pass 2: x = J_t^-1 (f - E_T g), one more sweep in the first virtual slot.
 // Nothing of Z = J_t^-1 E_T is kept, so m is bounded by the dense border system only.  Called with the launch context on h->stream
 // over real slots.
-// The folded update needs every bus of the model in one of the kernels that apply it: the multi-wave kernels of the contracted tree
-// (k_back_q, k_leaf_back_batch, k_sleaf_back_batch) and the one-round-trip 2x2 kernel with the chains inside it; radial networks only
-// (the virtual scenarios of the bordered step must not move the state).
-bool fold_update_possible(const hpf_handle* h) {
-    if (h->solver != HPF_SOLVER_BLOCK_TREE || !h->has_ctree || h->gj_mode != 1 || h->n_ties > 0 || !h->d_U2) return false;
-    const Tree& T = h->ctree;
-    const int bw = wave_block_size(2 * h->Hn);
-    if (bw == 0) return false;
-    const bool has2x2 = T.n_lin_roots > 0 || T.n_chains > 0;
-    if (has2x2 && (T.n_lin_bundles2 <= 0 || (T.n_chains > 0 && !T.chains_bundled))) return false;
-    return true;
-}
-
 int ensure_blas(hpf_handle* h) {
     if (h->blas) return HPF_OK;
     return rocblas_create_handle(&h->blas) == rocblas_status_success ? HPF_OK : HPF_E_ROCSOLVER;

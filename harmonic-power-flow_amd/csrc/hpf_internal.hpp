@@ -163,12 +163,6 @@ struct hpf_handle {
     // per-scenario state (device)
     double *d_P = nullptr, *d_Q = nullptr, *d_Vm = nullptr, *d_Va = nullptr;
     hpf::cplx *d_U = nullptr, *d_E = nullptr;
-    hpf::cplx *d_U2 = nullptr, *d_E2 = nullptr;   // second copy for the folded state update (the back-substitution kernels write the new U / E
-                                                  // there; swapped with d_U / d_E after the step).  During a solve U / E are valid for the RUNNING
-                                                  // scenarios only; every other consumer refreshes them from V_m / V_a (launch_polar)
-    int fold_step = 0;                // this Newton step applies the state update inside its back-substitution kernels (set per step by the NR loop)
-    int fold_update = 0;              // HPF_FOLDUPDATE (read by hpf_create): 1 = the state update inside the back-substitution kernels instead of the
-                                      // separate k_update launch (measured slower: it moves one wide launch's work into ten narrow, latency-bound ones)
     double* d_f = nullptr;            // [S][N]  mismatch, overwritten by the Newton step during a solve
     hpf::cplx* d_I0 = nullptr;            // [S][n]  network current of the power rows, kept by the harmonic mismatch kernel
     unsigned long long* d_errbits = nullptr;   // [S]
@@ -277,7 +271,6 @@ int tree_alloc_scenarios(hpf_handle* h);
 int tree_fund_step(hpf_handle* h, bool only_active);     // fundamental pf Newton step on the tree (2x2 blocks)
 int tree_newton_step(hpf_handle* h, bool only_active);   // assembles, eliminates, back-substitutes -> d_f holds the step
 int tree_newton_step_bordered(hpf_handle* h, bool only_active);   // the same for a network with loop-closing lines (h->n_ties > 0)
-bool fold_update_possible(const hpf_handle* h);                   // every bus of the model sits in a kernel that can apply the state update
 int ensure_blas(hpf_handle* h);                                   // rocBLAS handle on first use (dense LU, border system)
 int border_slots(const hpf_handle* h);                            // virtual scenario slots of the bordered step (behind the S_max real ones)
 

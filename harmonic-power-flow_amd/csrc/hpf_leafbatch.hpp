@@ -283,7 +283,7 @@ template <int B>
 __global__ __launch_bounds__(256) void k_leaf_back_batch(
     Model M, const int* __restrict__ nodes, int b, const int* __restrict__ active, int S_cnt, const double* __restrict__ wall,
     double* __restrict__ xall, const double* __restrict__ Hall, const double* __restrict__ lbimg, const double* __restrict__ lfK,
-    const double* __restrict__ lfS, int s0, FoldUpd fold) {
+    const double* __restrict__ lfS, int s0) {
     constexpr int NTR = LeafBatchImg<B>::NTR, KS = LeafBatchImg<B>::KS, H2 = B / 2, QI = (H2 + 15) / 16;
     const int4 kp = reinterpret_cast<const int4*>(nodes)[blockIdx.x];
     const int k = kp.x, par = kp.y, slot = kp.z - 1;
@@ -376,16 +376,15 @@ __global__ __launch_bounds__(256) void k_leaf_back_batch(
             }
             const double d0 = fma(si4[it][1], x1, si4[it][0] * x0), d1 = fma(si4[it][3], x1, si4[it][2] * x0);
             *reinterpret_cast<double2*>(xs + (size_t)k * B + 2 * q) = double2{w4[it][0] - d0, w4[it][1] - d1};
-            if (fold.on && q < Hn) fold_update(fold, n, Hn, M.c, s, k, q, w4[it][0] - d0, w4[it][1] - d1);
         }
     }
 }
 
 template <int B>
-int launch_leaf_back_batch(hpf_handle* h, const int* nodes, int count, const int* active, const FoldUpd& fold) {
+int launch_leaf_back_batch(hpf_handle* h, const int* nodes, int count, const int* active) {
     const dim3 grid((unsigned)count, (unsigned)((h->cur_S + LB_SB - 1) / LB_SB));
     hipLaunchKernelGGL((k_leaf_back_batch<B>), grid, dim3(256), 0, h->cur_stream, h->M, nodes, 2 * h->Hn, active, h->cur_S, h->d_w,
-                       h->d_x, h->d_H, active_tree(h).d_lbimg, h->d_lfK, h->d_lfS, h->cur_s0, fold);
+                       h->d_x, h->d_H, active_tree(h).d_lbimg, h->d_lfK, h->d_lfS, h->cur_s0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         h->last_detail = (int)e;
@@ -403,7 +402,7 @@ template <int B>
 __global__ __launch_bounds__(256) void k_sleaf_back_batch(
     Model M, const int* __restrict__ nodes, int b, const int* __restrict__ active, int S_cnt, const double* __restrict__ wall,
     double* __restrict__ xall, const double* __restrict__ Hall, const double* __restrict__ sbimg, const double* __restrict__ lzimg,
-    const double* __restrict__ Zall, const double* __restrict__ lfS, int s0, FoldUpd fold) {
+    const double* __restrict__ Zall, const double* __restrict__ lfS, int s0) {
     constexpr int NT = (B + 16) / 16;
     constexpr size_t CT = (size_t)NT * NT * 256;
     constexpr int NTR = SleafImg<B>::NTR, KS = SleafImg<B>::KS, KP = SleafImg<B>::KP, H2 = B / 2, QI = (H2 + 15) / 16;
@@ -524,16 +523,15 @@ __global__ __launch_bounds__(256) void k_sleaf_back_batch(
             const double x0 = V[(2 * q) * LBP + sc], x1 = V[(2 * q + 1) * LBP + sc];
             const double d0 = fma(si4[it][1], x1, si4[it][0] * x0), d1 = fma(si4[it][3], x1, si4[it][2] * x0);
             *reinterpret_cast<double2*>(xs + (size_t)k * B + 2 * q) = double2{w4[it][0] - d0, w4[it][1] - d1};
-            if (fold.on && q < M.Hn) fold_update(fold, M.n, M.Hn, M.c, s, k, q, w4[it][0] - d0, w4[it][1] - d1);
         }
     }
 }
 
 template <int B>
-int launch_sleaf_back_batch(hpf_handle* h, const int* nodes, int count, const int* active, const FoldUpd& fold) {
+int launch_sleaf_back_batch(hpf_handle* h, const int* nodes, int count, const int* active) {
     const dim3 grid((unsigned)count, (unsigned)((h->cur_S + LB_SB - 1) / LB_SB));
     hipLaunchKernelGGL((k_sleaf_back_batch<B>), grid, dim3(256), 0, h->cur_stream, h->M, nodes, 2 * h->Hn, active, h->cur_S, h->d_w,
-                       h->d_x, h->d_H, active_tree(h).d_sbimg, active_tree(h).d_lzimg, h->d_Z, h->d_lfS, h->cur_s0, fold);
+                       h->d_x, h->d_H, active_tree(h).d_sbimg, active_tree(h).d_lzimg, h->d_Z, h->d_lfS, h->cur_s0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         h->last_detail = (int)e;

@@ -371,12 +371,12 @@ template <bool FUND>
 __global__ void k_update(int n, int Hn, int c, int count, int stride, int N, int Nc, const int* __restrict__ active,
                          const double* __restrict__ step, double* __restrict__ Vm, double* __restrict__ Va,
                          cplx* __restrict__ U, cplx* __restrict__ E, unsigned long long* __restrict__ errbits,
-                         const double* __restrict__ xbus, int Bst, int s0) {
+                         const double* __restrict__ xbus, int Bst, int s0, unsigned hn_magic) {
     const int s = active ? active[blockIdx.y + s0] : (int)blockIdx.y + s0;   // slot -> scenario (active list; -1: frozen / empty slot)
     if (s < 0) return;
     const int t = blockIdx.x * TPB + threadIdx.x;
     if (t >= count) return;
-    const int i = FUND ? t : t / Hn, q = FUND ? 0 : t - i * Hn;          // thread t = i*Hn + q: bus-major state arrays
+    const int i = FUND ? t : div_by(t, hn_magic), q = FUND ? 0 : t - i * Hn;          // thread t = i*Hn + q: bus-major state arrays
     const int k = q * n + i;                                             // stacked index (HG:139-143)
     const size_t o = (size_t)s * stride + (size_t)i * Hn + q;
     double va = Va[o], vm = Vm[o];
@@ -862,7 +862,7 @@ static int tree_bst(const hpf_handle* h) { const int b = 2 * h->Hn; return b <= 
 
 // stacked: also write the mismatch in the reference's stacked order (C ABI, dense solver, single-wave / generic tree kernels)
 template <bool FUND>
-int launch_mismatch(hpf_handle* h, const int* active, bool stacked = true, const cplx* Uover = nullptr) {
+int launch_mismatch(hpf_handle* h, const int* active, bool stacked = true) {
     ScopedTimer t(h, T_MISMATCH);
     const int count = FUND ? h->n : h->n * h->Hn;
     const int N = FUND ? h->Nf : h->N;
@@ -879,7 +879,7 @@ int launch_mismatch(hpf_handle* h, const int* active, bool stacked = true, const
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mismatch<FUND>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         }
         hipLaunchKernelGGL((k_mismatch<FUND>), xcd_grid(nbx, h->cur_S), dim3(TPB), lds, h->cur_stream, h->M, count, N, Nc,
-                           active, Uover ? Uover : h->d_U, h->d_P, h->d_Q, (stacked || !img) ? h->d_f : nullptr, h->d_errbits, h->d_I0,
+                           active, h->d_U, h->d_P, h->d_Q, (stacked || !img) ? h->d_f : nullptr, h->d_errbits, h->d_I0,
                            img ? h->d_fb : nullptr, tree_bst(h), h->cur_s0, h->cur_S, div_magic(h->Hn));
         HIPCHK(hipGetLastError());
     }
@@ -950,7 +950,7 @@ int launch_update(hpf_handle* h, const int* active) {
     const int bw = tree_bst(h);
     hipLaunchKernelGGL((k_update<FUND>), grid2(count, h->cur_S), dim3(TPB), 0, h->cur_stream, h->n, h->Hn, h->c, count,
                        h->n * h->Hn, N, Nc, active, h->d_f, h->d_Vm, h->d_Va, h->d_U, h->d_E, h->d_errbits,
-                       busx ? h->d_x : nullptr, bw, h->cur_s0);
+                       busx ? h->d_x : nullptr, bw, h->cur_s0, div_magic(h->Hn));
     HIPCHK(hipGetLastError());
     return HPF_OK;
 }
@@ -1025,32 +1025,15 @@ int nr_pass(hpf_handle* h, double thresh, int max_iter, const int* mask) {
     // c - 1 while chunk c is already queued (pinned double buffer + events), so the device never drains between chunks.
     const bool pipelined = !FUND && h->solver == HPF_SOLVER_BLOCK_TREE && !trace && h->n_ties == 0;
     const int chunk = pipelined ? (S >= 8 ? 4 : 2) : 1;
-    // Folded state update (hpf_internal.hpp, d_U2): the back-substitution kernels of a step write the new U / E into the second copy and
-    // the mismatch of the new state reads them there; the host swaps the two copies per iteration.  A group's body enqueues all its
-    // iterations before the next group's: every body starts from the chunk's pointers and leaves them swapped `todo` times.
-    const bool folded = !FUND && h->fold_update && fold_update_possible(h);
     auto enqueue = [&](int todo, int slots) -> int {
-        cplx *const U0 = h->d_U, *const E0 = h->d_E, *const U20 = h->d_U2, *const E20 = h->d_E2;
         auto body = [&]() -> int {
             int rr;
-            h->d_U = U0;
-            h->d_E = E0;
-            h->d_U2 = U20;
-            h->d_E2 = E20;
             for (int j = 0; j < todo; ++j) {
                 if (!FUND && h->keep_prev && h->d_Vmp)
                     hipLaunchKernelGGL(k_keep_prev, grid2(h->n * h->Hn, h->cur_S), dim3(TPB), 0, h->cur_stream, h->n * h->Hn,
                                        h->d_active, h->d_Vm, h->d_Va, h->d_Vmp, h->d_Vap, h->cur_s0);
-                h->fold_step = folded ? 1 : 0;
-                rr = newton_step<FUND>(h, h->d_active);
-                h->fold_step = 0;
-                if (rr) return rr;
-                if (folded) {
-                    std::swap(h->d_U, h->d_U2);
-                    std::swap(h->d_E, h->d_E2);
-                } else if ((rr = launch_update<FUND>(h, h->d_active))) {
-                    return rr;
-                }
+                if ((rr = newton_step<FUND>(h, h->d_active))) return rr;
+                if ((rr = launch_update<FUND>(h, h->d_active))) return rr;
                 if ((rr = launch_mismatch<FUND>(h, h->d_active, false))) return rr;
                 hipLaunchKernelGGL(k_finalize, dim3((h->cur_S + 63) / 64), dim3(64), 0, h->cur_stream, h->cur_S, 0, thresh,
                                    max_iter, h->hist_cap, hist_off, h->d_errbits, h->d_err, h->d_niter, h->d_active,
@@ -1349,7 +1332,7 @@ int solve_queue_fast(hpf_handle* h, int n_total, const double* P, const double* 
 void free_all(hpf_handle* h) {
     void* ptrs[] = {h->d_rowptr, h->d_col, h->d_diag, h->d_erow, h->d_dev, h->d_Y, h->d_YN, h->d_YNt, h->d_IN, h->d_P, h->d_Q,
                     h->d_Vm, h->d_Va, h->d_U, h->d_E, h->d_I0, h->d_f, h->d_errbits, h->d_err, h->d_niter, h->d_active,
-                    h->d_nactive, h->d_pivflag, h->d_mask, h->d_Vm0, h->d_Va0, h->d_Vmp, h->d_Vap, h->d_tstamp, h->d_hist, h->d_stats, h->d_J, h->d_ipiv, h->d_info, h->d_Z, h->d_w, h->d_x, h->d_linA, h->d_C, h->d_dbg, h->d_H, h->d_chG, h->d_chH, h->d_chD, h->d_chy, h->d_chZ, h->d_lfK, h->d_lfS, h->d_fb, h->d_F, h->d_H2, h->d_U2, h->d_E2, h->d_jptr, h->d_jcol, h->d_jval};
+                    h->d_nactive, h->d_pivflag, h->d_mask, h->d_Vm0, h->d_Va0, h->d_Vmp, h->d_Vap, h->d_tstamp, h->d_hist, h->d_stats, h->d_J, h->d_ipiv, h->d_info, h->d_Z, h->d_w, h->d_x, h->d_linA, h->d_C, h->d_dbg, h->d_H, h->d_chG, h->d_chH, h->d_chD, h->d_chy, h->d_chZ, h->d_lfK, h->d_lfS, h->d_fb, h->d_F, h->d_H2, h->d_jptr, h->d_jcol, h->d_jval};
     for (void* p : ptrs)
         if (p) hipFree(p);
     tree_free(h);
@@ -1439,7 +1422,6 @@ int hpf_create(hpf_handle** out, const hpf_desc* d) {
     if (const char* gm = getenv("HPF_GJ_MODE")) h->gj_mode = atoi(gm) ? 1 : 0;
     if (const char* lb = getenv("HPF_LEAFBATCH")) h->leafbatch = atoi(lb) ? 1 : 0;
     if (const char* fl = getenv("HPF_FUSELEVEL")) h->fuse_levels = atoi(fl) ? 1 : 0;
-    if (const char* fu = getenv("HPF_FOLDUPDATE")) h->fold_update = atoi(fu) ? 1 : 0;
     if (hipSetDevice(d->device) != hipSuccess) return fail(HPF_E_HIP);
     if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) return fail(HPF_E_HIP);
     h->stream = h->own_stream;
@@ -1490,10 +1472,6 @@ int hpf_create(hpf_handle** out, const hpf_desc* d) {
     if ((r = dev_alloc(h, &h->d_Va, S * HnN))) return fail(r);
     if ((r = dev_alloc(h, &h->d_U, S * HnN))) return fail(r);
     if ((r = dev_alloc(h, &h->d_E, S * HnN))) return fail(r);
-    if (d->solver == HPF_SOLVER_BLOCK_TREE && h->n_ties == 0 && h->fold_update) {     // second copy of U / E: folded state update (hpf_internal.hpp)
-        if ((r = dev_alloc(h, &h->d_U2, S * HnN))) return fail(r);
-        if ((r = dev_alloc(h, &h->d_E2, S * HnN))) return fail(r);
-    }
     if ((r = dev_alloc(h, &h->d_I0, S * (size_t)h->n))) return fail(r);
     if ((r = dev_alloc(h, &h->d_f, S * (size_t)(h->N > h->Nf ? h->N : h->Nf)))) return fail(r);
     if ((r = dev_alloc(h, &h->d_errbits, S))) return fail(r);
@@ -1748,7 +1726,7 @@ int hpf_solve(hpf_handle* h, double thresh, int max_iter, int* n_iter, double* e
 int hpf_solve_queue(hpf_handle* h, int n_total, const double* P, const double* Q, double thresh_f, int max_iter_f, double thresh,
                     int max_iter, hpf_stat* stats, double* Vm, double* Va) {
     if (!h || !P || !Q || n_total < 1 || max_iter < 0 || max_iter_f < 0 || (Vm == nullptr) != (Va == nullptr)) return HPF_E_ARG;
-    const bool fast = h->solver == HPF_SOLVER_BLOCK_TREE && h->n_ties == 0 && h->has_ctree && h->gj_mode == 1 && !h->fold_update &&
+    const bool fast = h->solver == HPF_SOLVER_BLOCK_TREE && h->n_ties == 0 && h->has_ctree && h->gj_mode == 1 &&
                       bus_images(h) && h->S_max <= 8192 && !h->trace_Vm;
     if (fast) return solve_queue_fast(h, n_total, P, Q, thresh_f, max_iter_f, thresh, max_iter, stats, Vm, Va);
     // every other handle (dense solver, meshed network, pivoted mode): waves of up to S_max scenarios through the per-batch entry points
@@ -1777,7 +1755,6 @@ static int iterate_enqueue(hpf_handle* h, int iters) {
         HIPCHK(hipEventRecord(h->fork_ev, h->stream));
         for (int g = 0; g < G; ++g) HIPCHK(hipStreamWaitEvent(h->gstream[g], h->fork_ev, 0));
     }
-    const bool folded = h->fold_update && fold_update_possible(h);      // (the state update inside the back-substitution kernels, nr_pass)
     auto bound = [&](int g) { return g >= G ? h->S : (int)(16 * (((long long)h->S * g / G + 8) / 16)); };   // (tile-aligned groups, for_groups)
     for (int it = 0; it < iters && r == HPF_OK; ++it) {
         for (int g = 0; g < G && r == HPF_OK; ++g) {
@@ -1785,16 +1762,9 @@ static int iterate_enqueue(hpf_handle* h, int iters) {
                 set_ctx(h, h->gstream[g], bound(g), bound(g + 1) - bound(g));
             else
                 full_ctx(h);
-            h->fold_step = folded ? 1 : 0;
-            r = newton_step<false>(h, nullptr);
-            h->fold_step = 0;
-            if (r) break;
-            if (!folded && (r = launch_update<false>(h, nullptr))) break;
-            r = launch_mismatch<false>(h, nullptr, false, folded ? h->d_U2 : nullptr);
-        }
-        if (folded) {
-            std::swap(h->d_U, h->d_U2);
-            std::swap(h->d_E, h->d_E2);
+            if ((r = newton_step<false>(h, nullptr))) break;
+            if ((r = launch_update<false>(h, nullptr))) break;
+            r = launch_mismatch<false>(h, nullptr, false);
         }
     }
     if (G > 1) {

@@ -1397,10 +1397,6 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16)) void k_back_q(
         }
         if (tid < B) x -= acc;
     }
-    if (T.fold.on) {                           // state update of this bus (fold_update): the even row's thread takes the pair (2q, 2q + 1)
-        const double xo = __shfl_down(x, 1);
-        if (tid < b && !(tid & 1)) fold_update(T.fold, n, Hn, c, s, k, tid >> 1, x, xo);
-    }
     if (tid < B) {
         xs[(size_t)k * B + tid] = x;
         if (step && tid < b) {                 // (nullptr: the update kernel reads the bus-major image xs instead)
@@ -1770,7 +1766,7 @@ __global__ __launch_bounds__(128) void k_chain_factor2(Model M, TreeDev T, const
 __device__ __forceinline__ void chain_back_item(const Model& M, const int* __restrict__ crec, const int* __restrict__ cnode, int r, int q, int s,
                                                 int N, int Nc, int Bst, const cplx* __restrict__ Uall, const cplx* __restrict__ Eall,
                                                 const double* __restrict__ linAall, const double* __restrict__ wall, double* xall,
-                                                double* step, const double* __restrict__ chZ, const FoldUpd* fold = nullptr) {
+                                                double* step, const double* __restrict__ chZ) {
     const int n = M.n, c = M.c, Hn = M.Hn;
     const size_t so = (size_t)s * n * Hn;
     const cplx* U = Uall + so;
@@ -1803,7 +1799,6 @@ __device__ __forceinline__ void chain_back_item(const Model& M, const int* __res
         double* xk = xs + (size_t)k * Bst + 2 * q;
         xk[0] = x0;
         xk[1] = x1;
-        if (fold && fold->on) fold_update(*fold, n, Hn, c, s, k, q, x0, x1);
         if (step) {
             const int kst = q * n + k;
             if (kst >= 1) st[kst - 1] = x0;
@@ -1971,14 +1966,14 @@ __global__ __launch_bounds__(256, NP == 1 ? HPF_LBF_OCC : 1) void k_lin_bundle_f
 
 // ... and its back sweep: x_k = w_k - D_k^-1 (A(k,par) x_par).  D^-1, w, A(k,par) of every item in one round trip (a subtree root
 // also fetches x of its dense / chain parent), then the heights top-down with x_par through LDS.
-template <int NP, bool FOLD>
+template <int NP>
 __global__ __launch_bounds__(256, NP == 1 ? HPF_LBB_OCC : 1) void k_lin_bundle_back(Model M, const int* __restrict__ rec, const int2* __restrict__ xrec,
                                                          const int* __restrict__ bptr, int nh, int Bst, const int* __restrict__ active,
                                                          const cplx* __restrict__ Uall, const cplx* __restrict__ Eall,
                                                          const double* __restrict__ linAall, const double* __restrict__ wall,
                                                          double* xall, int s0, const int* __restrict__ cbptr,
                                                          const int* __restrict__ cblist, const int* __restrict__ crec,
-                                                         const int* __restrict__ cnode, const double* __restrict__ chZ, FoldUpd fold) {
+                                                         const int* __restrict__ cnode, const double* __restrict__ chZ) {
     const int s = active ? active[blockIdx.y + s0] : (int)blockIdx.y + s0;
     if (s < 0) return;
     __shared__ double xl[256 * NP * 2];
@@ -2023,7 +2018,7 @@ __global__ __launch_bounds__(256, NP == 1 ? HPF_LBB_OCC : 1) void k_lin_bundle_b
         const int c0 = cbptr[blockIdx.x], nc2 = cbptr[blockIdx.x + 1] - c0;
         if (nc2 > 0) {
             for (int t = threadIdx.x; t < nc2 * Hn; t += 256)
-                chain_back_item(M, crec, cnode, cblist[c0 + t / Hn], t % Hn, s, 0, 0, Bst, Uall, Eall, linAall, wall, xall, nullptr, chZ, FOLD ? &fold : nullptr);
+                chain_back_item(M, crec, cnode, cblist[c0 + t / Hn], t % Hn, s, 0, 0, Bst, Uall, Eall, linAall, wall, xall, nullptr, chZ);
             __syncthreads();
         }
     }
@@ -2060,7 +2055,6 @@ __global__ __launch_bounds__(256, NP == 1 ? HPF_LBB_OCC : 1) void k_lin_bundle_b
             const double x1 = wkv[p].y - fma(i23[p].y, t1, i23[p].x * t0);
             *reinterpret_cast<double2*>(xl + ((size_t)lbv[p] * Hn + q) * 2) = double2{x0, x1};
             *reinterpret_cast<double2*>(xs + (size_t)r0v[p].x * Bst + 2 * q) = double2{x0, x1};
-            if (FOLD && fold.on) fold_update(fold, n, Hn, c, s, r0v[p].x, q, x0, x1);
         }
     }
 }

@@ -208,9 +208,6 @@ int  hpf_debug_stamps(hpf_handle* h, long long* out, int count);
  * faster build up to about 24 live scenarios), HPF_SLNEST=0 keeps bordered buses below bordered buses on the
  * Gauss-Jordan path, HPF_FUSELEVEL=0 launches the scenario-batched
  * and the per-scenario workgroups of an elimination level separately (k_leaf_batch / k_sleaf_batch + k_factor_q instead of k_level),
- * HPF_FOLDUPDATE=1 applies the Newton step inside the back-substitution kernels (second copy of U / E, swapped per iteration) instead
- * of the separate k_update launch -- bit-identical, measured 2-4 % slower (the update's work moves from one wide launch into the
- * narrow, latency-bound launches of the back sweep), kept as an A/B switch,
  * HPF_LINBUNDLE=0 / HPF_LINTREE=0 run the 2x2 algebra of the linear subtrees height by height in one launch / in one launch per
  * height, HPF_CHAINBUNDLE=0 gives the contracted chains their own launches, HPF_COMPRESS=0 eliminates the Gauss-Jordan buses strictly
  * leaves first (no compress steps: one elimination level per unit of tree height; the default for handles of more than 256 scenarios,
