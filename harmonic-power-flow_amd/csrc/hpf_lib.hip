@@ -1302,7 +1302,7 @@ int solve_queue_fast(hpf_handle* h, int n_total, const double* P, const double* 
         };
         return for_groups(h, slots, body);
     };
-    const int chunk = h->queue_chunk > 0 ? h->queue_chunk : 2;
+    const int chunk = h->queue_chunk > 0 ? h->queue_chunk : 4;
     int c = 0, n_ub = S_used;
     if ((r = round(0))) return cleanup(r);
     const long long max_rounds = ((long long)(n_total + S_used - 1) / S_used + 2) * ((max_iter + chunk - 1) / chunk + 2) + 8;

@@ -149,7 +149,7 @@ int  hpf_solve(hpf_handle* h, double thresh, int max_iter, int* n_iter, double* 
 /* A sweep of n_total scenarios through the handle's S_max slots -- the reference's counterpart is one hpf() call per load case (HG:511:
  * other buses.P / buses.Q, HG:197,372).  P, Q [n_total][n] in p.u.  Every scenario: the reference's start (HG:174-184), pf (HG:244-275) with
  * (thresh_f, max_iter_f), the harmonic NR of hpf_solve with (thresh, max_iter).  Radial BLOCK_TREE handles keep all loads and pf seeds in HBM
- * and, between chunks of Newton iterations (option "queue_chunk", default 2), harvest the scenarios that met the stop rule and put the next
+ * and, between chunks of Newton iterations (option "queue_chunk", default 4), harvest the scenarios that met the stop rule and put the next
  * pending scenarios into the freed slots, so the handle stays full until the queue drains; every scenario's result is bit-identical to its
  * solve alone (the arithmetic of a scenario does not depend on its slot).  Other handles (DENSE, meshed networks, pivoted mode) run waves of
  * S_max scenarios.  Outputs (host, may be NULL; Vm and Va together): stats [n_total], raw voltages Vm, Va [n_total][Hn*n] (stacked order,
@@ -197,7 +197,7 @@ int  hpf_debug_stamps(hpf_handle* h, long long* out, int count);
  * first (rocSOLVER's pivoted LU spends a third of such a step in tiny pivot-search kernels) and its solution checked against a kept copy of
  * the system; a relative residual above 1e-10, a zero pivot or a non-finite entry repeats it with partial pivoting (hpf_tree_census[11]
  * counts those).  1 = always the pivoted LU.
- * "queue_chunk" (1..16, default 2): Newton iterations between two harvest / refill rounds of hpf_solve_queue.
+ * "queue_chunk" (1..16, default 4): Newton iterations between two harvest / refill rounds of hpf_solve_queue.
  * "scenario_groups" (1..8, default 3 -- with the host framework's own streams a fourth busy queue is a cliff --; at least 32 running scenarios per group): independent scenario pipelines on separate HIP streams.
  * Environment read by hpf_create (diagnostics, A/B runs): HPF_LAZY=0 builds the elimination tree without lazy leaves (every
  * leaf writes its Schur complement; 1: only leaves directly under their dense parent), HPF_SLEAF=0 sends the nonlinear buses

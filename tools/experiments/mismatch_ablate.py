@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
-"""Timing-only ablation of k_mismatch<false> (a library built with an `ablate` argument: tools/bin/libhpf_ablate.so; HPF_DEBUG_ABLATE bits
-8..11: 1 no Norton rows, 2 no row walk at all, 4 no LDS staging, 8 no reduction / atomics).  One scenario group, per-launch HIP-event spans."""
+"""Timing-only ablation of k_mismatch<false>, one scenario group, per-launch HIP-event spans.  Needs a DIAGNOSTIC build of the library whose
+kernel takes an `ablate` argument (HPF_DEBUG_ABLATE >> 8: 1 no Norton rows, 2 no row walk, 4 no LDS staging, 8 no reduction / atomic); round 4
+built it by patching the round-3 kernel text (four uniform branches) into tools/bin/libhpf_ablate.so -- the product kernel has no such argument:
+a run-time flag in front of its load batches changes the code it times (the patched round-4 kernel measured 50 us where the real one takes 38).
+Without HPF_LIB_PATH the script times the product kernel (every `ablate` value then reads the same).  Results of round 4: DESIGN.md section 5."""
 import os, sys, time
 import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,7 +15,7 @@ inp = bench.build_inputs(bench.parse([]), hp)
 n = inp["n"]
 P0, Q0 = inp["buses"]["P"].to_numpy(float), inp["buses"]["Q"].to_numpy(float)
 for rep in range(2):
-    for abl in (0, 1, 2, 4, 8, 1 | 4, 2 | 4 | 8):
+    for abl in (0, 1, 2, 8, 1 | 4, 1 | 4 | 8, 1 | 2 | 4, 1 | 2 | 4 | 8):
         os.environ["HPF_DEBUG_ABLATE"] = str(abl << 8)
         dm = hp.DeviceModel(n, inp["m"], inp["c"], inp["st"].HARMONICS, inp["Y"].rowptr, inp["Y"].col, inp["Y"].Yval, inp["dev"],
                             inp["Y_N"], inp["I_N"], inp["n_dev"], True, solver="block_tree", max_scenarios=S)
