@@ -1727,7 +1727,7 @@ int hpf_solve_queue(hpf_handle* h, int n_total, const double* P, const double* Q
                     int max_iter, hpf_stat* stats, double* Vm, double* Va) {
     if (!h || !P || !Q || n_total < 1 || max_iter < 0 || max_iter_f < 0 || (Vm == nullptr) != (Va == nullptr)) return HPF_E_ARG;
     const bool fast = h->solver == HPF_SOLVER_BLOCK_TREE && h->n_ties == 0 && h->has_ctree && h->gj_mode == 1 &&
-                      bus_images(h) && h->S_max <= 8192 && !h->trace_Vm;
+                      bus_images(h) && h->S_max <= 4096 && !h->trace_Vm;      // (k_queue_refill keeps its storage table in LDS: 8 B per slot)
     if (fast) return solve_queue_fast(h, n_total, P, Q, thresh_f, max_iter_f, thresh, max_iter, stats, Vm, Va);
     // every other handle (dense solver, meshed network, pivoted mode): waves of up to S_max scenarios through the per-batch entry points
     const size_t cnt = (size_t)h->n * h->Hn;
