@@ -2874,7 +2874,7 @@ int tree_find_ties(hpf_handle* h, const hpf_desc* d) {
     const size_t m = (size_t)h->m_border;
     if (hipMalloc((void**)&h->d_bM, sizeof(double) * m * m) != hipSuccess || hipMalloc((void**)&h->d_brhs, sizeof(double) * m) != hipSuccess ||
         hipMalloc((void**)&h->d_bipiv, sizeof(int) * m) != hipSuccess || hipMalloc((void**)&h->d_binfo, sizeof(int)) != hipSuccess ||
-        hipMalloc((void**)&h->d_bM0, sizeof(double) * m * m) != hipSuccess || hipMalloc((void**)&h->d_brhs0, sizeof(double) * (m + 2)) != hipSuccess)
+        hipMalloc((void**)&h->d_bM0, sizeof(double) * m * m) != hipSuccess || hipMalloc((void**)&h->d_brhs0, sizeof(double) * (2 * m + 2)) != hipSuccess)
         return HPF_E_NOMEM;
     return HPF_OK;
 }
@@ -2969,30 +2969,29 @@ int tree_newton_step_bordered(hpf_handle* h, bool only_active) {
         // kernels at these sizes (m = 520: a third of the whole bordered iteration, m = 2 080: 10 ms), so the LU runs WITHOUT pivoting first
         // (getrf_npvt + two triangular solves) and its solution is checked against a kept copy of the system: a residual above 1e-10 of the
         // right-hand side (pivot growth), a zero pivot or a non-finite entry sends the system through the pivoted LU.
-        double* res = h->d_brhs0 + m;                     // [2]: max |rhs - M g|, max |rhs|
+        double* rwork = h->d_brhs0 + m;                   // [m] residual rhs - M g (d_brhs0[0, m) keeps the right-hand side itself)
+        double* res = h->d_brhs0 + 2 * (size_t)m;         // [2]: max |rhs - M g|, max |rhs|
         int info = 0;
         double hres[2] = {0.0, 0.0};
         hipMemcpyAsync(h->d_bM0, h->d_bM, sizeof(double) * (size_t)m * m, hipMemcpyDeviceToDevice, st);
         hipMemcpyAsync(h->d_brhs0, h->d_brhs, sizeof(double) * m, hipMemcpyDeviceToDevice, st);
+        hipMemcpyAsync(rwork, h->d_brhs, sizeof(double) * m, hipMemcpyDeviceToDevice, st);
         const double one = 1.0, neg = -1.0;
         if (rocsolver_dgetrf_npvt(h->blas, m, m, h->d_bM, m, h->d_binfo) != rocblas_status_success ||
             rocblas_dtrsv(h->blas, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_unit, m, h->d_bM, m, h->d_brhs, 1) != rocblas_status_success ||
             rocblas_dtrsv(h->blas, rocblas_fill_upper, rocblas_operation_none, rocblas_diagonal_non_unit, m, h->d_bM, m, h->d_brhs, 1) != rocblas_status_success)
             return HPF_E_ROCSOLVER;
         hipLaunchKernelGGL(k_border_absmax, dim3(1), dim3(1024), 0, st, m, (const double*)h->d_brhs0, res + 1);
-        if (rocblas_dgemv(h->blas, rocblas_operation_none, m, m, &neg, h->d_bM0, m, h->d_brhs, 1, &one, h->d_brhs0, 1) != rocblas_status_success)
-            return HPF_E_ROCSOLVER;                       // brhs0 <- rhs - M g
-        hipLaunchKernelGGL(k_border_absmax, dim3(1), dim3(1024), 0, st, m, (const double*)h->d_brhs0, res);
+        if (rocblas_dgemv(h->blas, rocblas_operation_none, m, m, &neg, h->d_bM0, m, h->d_brhs, 1, &one, rwork, 1) != rocblas_status_success)
+            return HPF_E_ROCSOLVER;                       // rwork <- rhs - M g
+        hipLaunchKernelGGL(k_border_absmax, dim3(1), dim3(1024), 0, st, m, (const double*)rwork, res);
         if (hipMemcpyAsync(&info, h->d_binfo, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipMemcpyAsync(hres, res, sizeof(double) * 2, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
             h->last_detail = (int)hipGetLastError();
             return HPF_E_HIP;
         }
         if (h->border_pivoting || info != 0 || !(hres[0] <= 1e-10 * hres[1]) || !(hres[1] < INFINITY)) {
-            // (brhs0 was overwritten by the residual: the right-hand side is residual + M g; rebuild it from the kept matrix)
-            if (rocblas_dgemv(h->blas, rocblas_operation_none, m, m, &one, h->d_bM0, m, h->d_brhs, 1, &one, h->d_brhs0, 1) != rocblas_status_success)
-                return HPF_E_ROCSOLVER;
-            hipMemcpyAsync(h->d_bM, h->d_bM0, sizeof(double) * (size_t)m * m, hipMemcpyDeviceToDevice, st);
+            hipMemcpyAsync(h->d_bM, h->d_bM0, sizeof(double) * (size_t)m * m, hipMemcpyDeviceToDevice, st);       // the kept system, untouched
             hipMemcpyAsync(h->d_brhs, h->d_brhs0, sizeof(double) * m, hipMemcpyDeviceToDevice, st);
             ++h->border_repivots;
             if (rocsolver_dgetrf(h->blas, m, m, h->d_bM, m, h->d_bipiv, h->d_binfo) != rocblas_status_success ||

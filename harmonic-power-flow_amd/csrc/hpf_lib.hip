@@ -1367,7 +1367,7 @@ const char* hpf_strerror(int code) {
         case HPF_OK: return "success";
         case HPF_E_ARG: return "invalid argument";
         case HPF_E_STATE: return "call order violated (loads/state/mismatch not set)";
-        case HPF_E_TOPOLOGY: return "BLOCK_TREE solver: network not connected from bus 0, pattern not symmetric, or too many loop-closing lines (border > 1024 unknowns)";
+        case HPF_E_TOPOLOGY: return "BLOCK_TREE solver: network not connected from bus 0, pattern not symmetric, or too many loop-closing lines (border > 16 384 unknowns)";
         case HPF_E_NOMEM: return "out of device memory";
         case HPF_E_HIP: return "HIP runtime error";
         case HPF_E_ROCSOLVER: return "rocBLAS/rocSOLVER error";
