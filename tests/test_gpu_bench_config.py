@@ -228,3 +228,58 @@ def test_solve_queue_edge_cases(tmp_path):
     assert np.array_equal(a[0].view(np.uint8), b[0].view(np.uint8)) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
     assert np.abs(a[0]["n_iter"] - d[0]["n_iter"]).max() <= 4                                # (solver-sensitive counts on this feeder)
     assert np.abs(a[1] * np.exp(1j * a[2]) - d[1] * np.exp(1j * d[2])).max() < 5e-5        # (dense vs block tree, each at ITS stop: the stop rule is 1e-4)
+
+
+def test_queue_at_the_benchmark_configuration_equals_the_batch_solve(tmp_path):
+    """BASELINE config 4's per-GPU share through hpf_solve_queue: the 128 Monte-Carlo scenarios of the 1 000-bus x 25-harmonic feeder through a
+    handle of 48 slots (three scenario groups, slots refilled as scenarios converge) -- every record and every voltage bit-identical to the same
+    scenarios solved together in one 128-scenario handle (hpf_solve)."""
+    hp = _hp()
+    from harmonic_power_flow_amd import api, sweep, synth
+    st, buses, Y, NE = _feeder(hp, 1000, 51, tmp_path)
+    n, S = len(buses), 128
+    P0, Q0 = buses["P"].to_numpy(float), buses["Q"].to_numpy(float)
+    scale = np.stack([synth.scenario_scale(n, s) for s in range(S)])
+    it, err, Vm, Va, seed, stats = _run(hp, st, buses, Y, NE, list(range(S)))
+    dm = api._device_model(buses, Y, NE, True, st.HARMONICS, solver="block_tree", max_scenarios=48)
+    try:
+        rec, Vq, Aq = sweep.solve_scenarios(dm, P0 * scale, Q0 * scale, want_voltages=True)
+    finally:
+        dm.close()
+    assert np.array_equal(rec["n_iter"], it) and np.array_equal(rec["err"], err)
+    assert np.array_equal(rec["flags"], stats["flags"]) and np.array_equal(rec["thd_max"], stats["thd_max"])
+    assert np.array_equal(Vq, Vm) and np.array_equal(Aq, Va)
+
+
+def test_queue_reports_flagged_scenarios_and_the_sweep_resolves_them_with_pivoting(tmp_path):
+    """With the pivot-growth limit at 10^0 every scenario is flagged by the static-pivot monitor: hpf_solve_queue reports it (flags bit 3, not
+    repeated), sweep.solve_scenarios then solves each flagged scenario alone through hpf_solve, which repeats it with partial pivoting (bit 4) --
+    the results equal an explicit block_pivoting = 1 solve bit for bit."""
+    hp = _hp()
+    from harmonic_power_flow_amd import api, sweep, synth
+    st, buses, Y, NE = _feeder(hp, 100, 27, tmp_path, seed=1)
+    n, S = len(buses), 7
+    P0, Q0 = buses["P"].to_numpy(float), buses["Q"].to_numpy(float)
+    scale = np.stack([synth.scenario_scale(n, s) for s in range(S)])
+    dm = api._device_model(buses, Y, NE, True, st.HARMONICS, solver="block_tree", max_scenarios=3)
+    try:
+        dm.set_option("pivot_growth_limit_log10", 0)
+        raw = dm.solve_queue(P0 * scale, Q0 * scale)
+        rec, Vq, Aq = sweep.solve_scenarios(dm, P0 * scale, Q0 * scale, want_voltages=True)
+    finally:
+        dm.close()
+    assert ((raw["flags"] & 8) == 8).all() and ((raw["flags"] & 16) == 0).all()
+    assert ((rec["flags"] & (8 | 16)) == (8 | 16)).all() and ((rec["flags"] & 1) == 1).all()
+    for s in (0, 3, 6):
+        dm1 = api._device_model(buses, Y, NE, True, st.HARMONICS, solver="block_tree", max_scenarios=1)
+        try:
+            dm1.set_option("block_pivoting", 1)
+            dm1.set_loads(P0 * scale[s], Q0 * scale[s])
+            dm1.set_state(None, None, n_scen=1)
+            dm1.fund_pf(1e-6, 30)
+            it1, err1, _ = dm1.solve(1e-4, 50)
+            Vm1, Va1 = dm1.get_state()
+        finally:
+            dm1.close()
+        assert it1[0] == rec["n_iter"][s] and err1[0] == rec["err"][s]
+        assert np.array_equal(Vm1[0], Vq[s]) and np.array_equal(Va1[0], Aq[s])
