@@ -138,6 +138,10 @@ __device__ __forceinline__ void lz_aop(const double* p, double (&a)[NT]) {
     }
 }
 
+// orders the LDS accesses of ONE wavefront (writes of some lanes before reads of others) where no workgroup barrier does: waits for the
+// wave's outstanding LDS operations and keeps the compiler from moving memory accesses across
+#define HPF_WAVE_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
 #ifndef HPF_Q_OCC
 #define HPF_Q_OCC 4        // waves per SIMD the B = 52 factor kernel is compiled for (register budget 512 / HPF_Q_OCC)
 #endif
@@ -1015,8 +1019,82 @@ __device__ __forceinline__ void factor_q_body(
     // ---- C. blocked Gauss-Jordan, static 4x4 pivot blocks (hpf_gj_mfma.hpp), tile columns spread over the waves ------------
     // (all B/4 block steps are always performed: rows / columns beyond b are identity-padded, their steps are no-ops in
     //  exact arithmetic, and a step count known at compile time keeps the accumulators in place -- no copies between steps)
+    // Columns 0 .. 16 NB16 - 1 go in BLOCKS of 16 (round 4): the wave that owns diagonal tile T inverts it ALONE -- the same four 4 x 4 pivot
+    // sub-steps, inside the tile, ordered by wave-level LDS fences instead of workgroup barriers -- and puts W16 = D^-1 and its column panel
+    // A_iP into LDS (row-major 16 x 16 images, row stride 17: the A-operand reads of 16 rows hit 16 banks); after ONE barrier every wave forms
+    // its new pivot rows R = W16 R and the rank-16 update A_i -= A_iP R as K = 16 MFMA chains (the owner: A_iP <- -A_iP W16).  Block
+    // Gauss-Jordan with the same pivot order: the result differs from the 13-step form at rounding level (1e-17 on the test matrices of
+    // tools/experiments/gj16_micro.hip), with 4 workgroup barriers instead of 13 at b = 52 (7 instead of 25 at b = 100).  The images live in
+    // the assembly's arrays (Y_N, tab, dgb, cc: dead from here on -- the barrier below ends their last readers).
+    constexpr int NB16 = B / 16;
+    if constexpr (NB16 > 0) {
+        constexpr int WS = 17, NBUF = NB16 > 1 ? 2 : 1;
+        static_assert(2 * (B / 2) * (B / 2) + (B / 2) * 8 + RP * 3 + NT * RP * 3 >= NBUF * NT * 16 * WS, "block images fit the dead assembly arrays");
+        double* const img = lds_.pbuf;
+        double* const pcol = &panel[1][0];               // owner-private: pivot columns of the diagonal tile during its inversion
+        __syncthreads();
 #pragma unroll
-    for (int st = 0; st < B / 4; ++st) {
+        for (int T = 0; T < NB16; ++T) {
+            double* const im = img + (size_t)(NBUF > 1 ? (T & 1) : 0) * NT * 16 * WS;
+            if (wv == T) {
+#pragma unroll
+                for (int ss = 0; ss < 4; ++ss) {
+                    const int j0 = 4 * ss;
+                    const bool incol = jj >= j0 && jj < j0 + 4;
+                    if (incol) pv[0][lg * 4 + (jj - j0)] = ct[T][ss];
+                    HPF_WAVE_LDS_FENCE();                 // (one wave, no workgroup barrier: the other LANES' writes before this lane's reads)
+                    bool weak;
+                    const double wji = inv4_cofactor_lane(pv[0], lane, piv_limit, weak);
+                    if (incol) {
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) pcol[(lg + 4 * reg) * 4 + (jj - j0)] = ct[T][reg];
+                    }
+                    if (weak && lane < 16) atomicOr(pivflag + s, 1);      // static pivot order under watch (see the 4 x 4 steps below)
+                    if (lane < 16) wl[0][(lane & 3) * 4 + (lane >> 2)] = wji;
+                    HPF_WAVE_LDS_FENCE();
+                    const double vcol = pcol[jj * 4 + lg];
+                    const double aopl = incol ? 0.0 : vcol;
+                    const double aw = jj < 4 ? wl[0][jj * 4 + lg] : 0.0;
+                    const d4_t z = {0.0, 0.0, 0.0, 0.0};
+                    const d4_t d = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, ct[T][ss], z, 0, 0, 0);
+                    double rfin = d[0];
+                    if (incol) {
+                        rfin = wl[0][lg * 4 + (jj - j0)];
+                        ct[T] = d4_t{0.0, 0.0, 0.0, 0.0};
+                    }
+                    ct[T] = __builtin_amdgcn_mfma_f64_16x16x4f64(aopl, -rfin, ct[T], 0, 0, 0);
+                    ct[T][ss] = rfin;
+                    HPF_WAVE_LDS_FENCE();                 // (the next sub-step overwrites pv / pcol / wl)
+                }
+#pragma unroll
+                for (int tr = 0; tr < NT; ++tr)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) im[tr * 16 * WS + (4 * reg + lg) * WS + jj] = ct[tr][reg];
+            }
+            __syncthreads();
+            d4_t Rn;                                      // -R (B operand of the rank-16 update), by row group
+            if (wv == T) {
+                Rn = -ct[T];
+            } else {
+                d4_t r4 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) r4 = __builtin_amdgcn_mfma_f64_16x16x4f64(im[T * 16 * WS + jj * WS + 4 * k4 + lg], ct[T][k4], r4, 0, 0, 0);
+                ct[T] = r4;
+                Rn = -r4;
+            }
+#pragma unroll
+            for (int tr = 0; tr < NT; ++tr) {
+                if (tr == T) continue;
+                d4_t a4 = ct[tr];
+                if (wv == T) a4 = d4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(im[tr * 16 * WS + jj * WS + 4 * k4 + lg], Rn[k4], a4, 0, 0, 0);
+                ct[tr] = a4;
+            }
+        }
+    }
+#pragma unroll
+    for (int st = 4 * NB16; st < B / 4; ++st) {
         {
             const int tP = st >> 2, rg = st & 3, j0 = 4 * (st & 3), buf = st & 1;
             const bool incol = jj >= j0 && jj < j0 + 4;
