@@ -249,7 +249,7 @@ __device__ __forceinline__ void factor_q_body(
         lzC = nd[9];                          // lazy super-leaf children: buses, their numbers of border unknowns (8 bits each)
     }
 #ifdef HPF_FACTOR_STAMPS
-    long long sd1 = 0, sd2 = 0, sd3 = 0;
+    long long sd1 = 0, sd2 = 0, sd3 = 0, se1 = 0, se2 = 0;
     {
         int kk = k;
         asm volatile("" : "+s"(kk));
@@ -515,10 +515,9 @@ __device__ __forceinline__ void factor_q_body(
     }
     // ---- B0. Schur complement of the FIRST dense child (accumulator layout, own tile column): the loads are issued here, after
     //      the role loads (loads return in order: a role must not wait behind them), and first touched after the assembly ----------
-    double sumc[NT * 4];
-#pragma unroll
-    for (int e = 0; e < NT * 4; ++e) sumc[e] = 0.0;
-    if (n_den > 0) TileIO<B>::load(Cs + (size_t)nd2.z * CT, wv, lg, jj, sumc);
+#ifdef HPF_FACTOR_STAMPS
+    se1 = __builtin_amdgcn_s_memtime();
+#endif
     // ---- L. lazy leaves (Tree::d_lzrec): the Schur complements of the constant-inverse leaves c hanging directly under this bus,
     //      sum_c A(k,c) D_c^-1 A(c,k) = [ R(sum_c C0_c) + sum_c Gc_c K_c Hr_c ] S_k,
     //      with per-model images (L2 / Infinity Cache) for the harmonics q >= 1 of the borders Gc (b x 2), Hr (2 x b) -- constant
@@ -589,9 +588,16 @@ __device__ __forceinline__ void factor_q_body(
 #pragma unroll
             for (int tr = 0; tr < NT; ++tr) xt[tr] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[tr], b1, xt[tr], 0, 0, 0);
         }
+#ifdef HPF_FACTOR_STAMPS
+        asm volatile("" : "+v"(xt[0]), "+v"(xt[NT - 1]));
+        se2 = __builtin_amdgcn_s_memtime();
+#endif
         // lazy super-leaf children (at most two): the same rebuild with the m x m core T^-1 the child left at the head of its
         // inverse slot, m <= 10 border unknowns in chunks of four; position 0 of the borders from the child's record
         // (G0 S_c^-1 on rows 0 / 1 of the first two unknowns, W_c^-1 H0 S_k^-1 on columns 0 / 1)
+        // Every load of a child is issued in ONE batch (one memory round trip per child instead of one per chunk): the child's T^-1 | W^-1
+        // (104 doubles, per scenario) goes through a per-wave LDS strip (slb is free in a Gauss-Jordan workgroup; its head holds the
+        // compress role's blocks), the image columns and A operands stay in registers.
         const double* simgs = himg + (size_t)np * NT * 2 * 64;
         for (int zc = 0; zc < 2; ++zc) {
             const int child = zc == 0 ? lzC.x : lzC.y;
@@ -601,33 +607,54 @@ __device__ __forceinline__ void factor_q_body(
             const double* zq = za + 3 * 64 * NT;
             const double* tk = Zall + ((size_t)s * n + child) * CT;                 // T^-1 [10][10] | W^-1 [4]
             const double* kc = lfK + ((size_t)s * n + child) * 12;
+            double* tl = slb + 2 * NT * 32 + (wv * 2 + zc) * 104;
+            double2 tke = {0.0, 0.0};
+            if (lane < 52) tke = reinterpret_cast<const double2*>(tk)[lane];
             double qh[10];
 #pragma unroll
             for (int j = 0; j < 10; ++j) qh[j] = (j < mz && col < b) ? zq[(size_t)j * B + col] : 0.0;
+            double h0 = 0.0, h1 = 0.0, g0 = 0.0;
+            if (col < 2) {
+                h0 = kc[8 + col];
+                h1 = kc[10 + col];
+            }
+            if (jj < 2 && lg < 2) g0 = kc[4 + jj * 2 + lg];                        // rows 0 / 1: (G0 S_c^-1)[jj][i], i = lg (first chunk)
+            double az[3][NT];
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+#pragma unroll
+                for (int tr = 0; tr < NT; ++tr) az[ch][tr] = 0.0;
+                if (4 * ch < mz) lz_aop<NT>(za + ((size_t)ch * 64 + lane) * NT, az[ch]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (lane < 52) *reinterpret_cast<double2*>(tl + 2 * lane) = tke;
+            HPF_WAVE_LDS_FENCE();                                                // (one wave: the other lanes' writes before this lane's reads)
             if (col < 2) {                                               // (W^-1 H0 S_k^-1)[j][col], j < 2
-                const double h0 = kc[8 + col], h1 = kc[10 + col];
-                qh[0] = fma(tk[101], h1, tk[100] * h0);
-                qh[1] = fma(tk[103], h1, tk[102] * h0);
+                qh[0] = fma(tl[101], h1, tl[100] * h0);
+                qh[1] = fma(tl[103], h1, tl[102] * h0);
             }
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
                 if (4 * ch < mz) {
                     const int i = 4 * ch + lg;
-                    const double* tr_ = tk + (i < mz ? i : 0) * 10;
+                    const double* tr_ = tl + (i < mz ? i : 0) * 10;
                     double bop = 0.0;
 #pragma unroll
                     for (int j = 0; j < 10; ++j)
                         if (j < mz) bop = fma(tr_[j], qh[j], bop);
                     bop = i < mz ? bop : 0.0;
-                    double az[NT];
-                    lz_aop<NT>(za + ((size_t)ch * 64 + lane) * NT, az);
-                    if (jj < 2) az[0] = i < 2 ? kc[4 + jj * 2 + i] : 0.0;                  // rows 0 / 1: (G0 S_c^-1)[jj][i]
+                    if (jj < 2) az[ch][0] = ch == 0 ? g0 : 0.0;
 #pragma unroll
-                    for (int tr = 0; tr < NT; ++tr) xt[tr] = __builtin_amdgcn_mfma_f64_16x16x4f64(az[tr], bop, xt[tr], 0, 0, 0);
+                    for (int tr = 0; tr < NT; ++tr) xt[tr] = __builtin_amdgcn_mfma_f64_16x16x4f64(az[ch][tr], bop, xt[tr], 0, 0, 0);
                 }
             }
+            HPF_WAVE_LDS_FENCE();
         }
     }
+    double sumc[NT * 4];
+#pragma unroll
+    for (int e = 0; e < NT * 4; ++e) sumc[e] = 0.0;
+    if (n_den > 0) TileIO<B>::load(Cs + (size_t)nd2.z * CT, wv, lg, jj, sumc);
     // super-leaf: stage the per-model constants and everything of T that does not depend on this bus's own roles (all of it but
     // the 2x2 term of the fundamental) while the roles' loads are in flight
     if (sleaf) {
@@ -1333,7 +1360,8 @@ __device__ __forceinline__ void factor_q_body(
         o[3] = st4 - st3;   // MFMA Gauss-Jordan
         o[5] = st6 - st5;   // Schur push
         o[6] = n_den + (sleaf ? 100 : 0);
-        o[7] = (k >= M.m) | ((lin_end - lin_beg) << 1);
+        o[7] = (k >= M.m) | ((lin_end - lin_beg) << 1) | ((((se1 - sd2) >> 4) & 0xffff) << 16) | ((((se2 ? se2 - se1 : 0) >> 4) & 0xffff) << 32) |
+               ((long long)(lzC.x >= 0) << 48) | ((long long)(lzC.y >= 0) << 49) | ((long long)lazy << 50);
     }
 #endif
 }

@@ -80,3 +80,24 @@ for label, sel in (("nonlinear leaf (0 dense children)", dense & (d[0, :, 6] == 
         print("      GJ split (wave 0, sums over the block steps): owner work of its 4 steps %6.0f   barrier waits %6.0f   post-barrier sections %6.0f"
               % tuple(np.median((gsp >> sh) & 0xfffff) * 16 for sh in (0, 20, 40)))
 
+
+# wave 0's pre-barrier phases by the number of 2x2-algebra children of the bus (o[7] >> 1)
+gj = dense & (d[0, :, 6] < 100)
+if gj.any() and (d[:, gj, 1].max() > (1 << 20)):
+    nl_ = (d[0, :, 7] >> 1) & 0x7fff
+    print("Gauss-Jordan buses by number of 2x2-algebra children: wave 0 base diagonal / children section / wait at barrier 1 (cycles, median)")
+    for v in sorted(set(nl_[gj])):
+        sel = gj & (nl_ == v)
+        osp = d[:, sel, 4].reshape(-1)
+        print("   %2d children  n=%3d   %6.0f  %6.0f  %6.0f" % ((v, sel.sum()) + tuple(np.median((osp >> sh) & 0xffff) * 16 for sh in (16, 32, 48))))
+    print("... by lazy children (lazy leaves | lazy bordered children): children loop / B0 issue + lazy loads + MFMA / rest up to barrier 1 (lazy bordered children)")
+    o7 = d[:, :, 7]
+    for lz in (0, 1):
+        for nz in (0, 1, 2):
+            sel = gj & (((d[0, :, 7] >> 50) & 1) == lz) & ((((d[0, :, 7] >> 48) & 1) + ((d[0, :, 7] >> 49) & 1)) == nz)
+            if not sel.any():
+                continue
+            a = np.median((o7[:, sel] >> 16) & 0xffff) * 16
+            bb = np.median((o7[:, sel] >> 32) & 0xffff) * 16
+            tot = np.median((d[:, sel, 4] >> 32) & 0xffff) * 16
+            print("   lazy %d  bordered children %d  n=%3d   %6.0f  %6.0f  %6.0f   (section %6.0f)" % (lz, nz, sel.sum(), a, bb, tot - a - bb, tot))
