@@ -14,12 +14,13 @@ import harmonic_power_flow_amd as hp  # noqa: E402
 from harmonic_power_flow_amd import synth  # noqa: E402
 
 Ss = [int(a) for a in sys.argv[1:]] or [1, 8, 32, 64, 128, 256, 512, 1024]
+GROUPS = tuple(int(g) for g in os.environ.get("HPF_SCALE_GROUPS", "1,3").split(","))     # scenario groups (streams) to compare
 args = bench.parse.__globals__["argparse"].Namespace(buses=1000, hmax=51)
 inp = bench.build_inputs(args, hp)
 n = inp["n"]
 P0, Q0 = inp["buses"]["P"].to_numpy(float), inp["buses"]["Q"].to_numpy(float)
 for S in Ss:
-    for groups in ((1, 3) if S >= 24 else (1,)):
+    for groups in (GROUPS if S >= 24 else (1,)):
         dm = hp.DeviceModel(n, inp["m"], inp["c"], inp["st"].HARMONICS, inp["Y"].rowptr, inp["Y"].col, inp["Y"].Yval, inp["dev"],
                             inp["Y_N"], inp["I_N"], inp["n_dev"], True, solver="block_tree", max_scenarios=S)
         dm.set_option("scenario_groups", groups)
