@@ -142,6 +142,9 @@ __device__ __forceinline__ void lz_aop(const double* p, double (&a)[NT]) {
 // wave's outstanding LDS operations and keeps the compiler from moving memory accesses across
 #define HPF_WAVE_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
+#ifndef HPF_Q100_OCC
+#define HPF_Q100_OCC 2     // the same for 52 < B <= 100 (7 waves per workgroup: 2 -> one workgroup per CU, 4 -> two)
+#endif
 #ifndef HPF_Q_OCC
 #define HPF_Q_OCC 4        // waves per SIMD the B = 52 factor kernel is compiled for (register budget 512 / HPF_Q_OCC)
 #endif
@@ -1063,6 +1066,9 @@ __device__ __forceinline__ void factor_q_body(
 #pragma unroll
         for (int T = 0; T < NB16; ++T) {
             double* const im = img + (size_t)(NBUF > 1 ? (T & 1) : 0) * NT * 16 * WS;
+#ifdef HPF_FACTOR_STAMPS
+            const long long g0_ = __builtin_amdgcn_s_memtime();
+#endif
             if (wv == T) {
 #pragma unroll
                 for (int ss = 0; ss < 4; ++ss) {
@@ -1098,7 +1104,13 @@ __device__ __forceinline__ void factor_q_body(
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) im[tr * 16 * WS + (4 * reg + lg) * WS + jj] = ct[tr][reg];
             }
+#ifdef HPF_FACTOR_STAMPS
+            const long long g1_ = __builtin_amdgcn_s_memtime();
+#endif
             __syncthreads();
+#ifdef HPF_FACTOR_STAMPS
+            const long long g2_ = __builtin_amdgcn_s_memtime();
+#endif
             d4_t Rn;                                      // -R (B operand of the rank-16 update), by row group
             if (wv == T) {
                 Rn = -ct[T];
@@ -1118,6 +1130,15 @@ __device__ __forceinline__ void factor_q_body(
                 for (int k4 = 0; k4 < 4; ++k4) a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(im[tr * 16 * WS + jj * WS + 4 * k4 + lg], Rn[k4], a4, 0, 0, 0);
                 ct[tr] = a4;
             }
+#ifdef HPF_FACTOR_STAMPS
+            {
+                asm volatile("" : "+v"(ct[0]), "+v"(ct[NT - 1]));
+                const long long g3_ = __builtin_amdgcn_s_memtime();
+                if (T == 0) gown += g1_ - g0_;            // wave 0: the block it owns (inversion of the diagonal tile + images)
+                gwait += g2_ - g1_;
+                gmf += g3_ - g2_;
+            }
+#endif
         }
     }
 #pragma unroll
@@ -1369,7 +1390,7 @@ __device__ __forceinline__ void factor_q_body(
 // LEAF: every bus of the launch is a constant-inverse leaf (elimination level 0 of the contracted tree): the general path
 // (assembly, child sums, Gauss-Jordan) is compiled out and with it most of the register budget -> more workgroups per CU.
 template <int B, bool LEAF>
-__global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 52 ? 2 : (B > 28 ? (LEAF ? 6 : HPF_Q_OCC) : 5))) void k_factor_q(
+__global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 52 ? (LEAF ? 2 : HPF_Q100_OCC) : (B > 28 ? (LEAF ? 6 : HPF_Q_OCC) : 5))) void k_factor_q(
     Model M, TreeDev T, const int* __restrict__ nodes, int b, int N, int Nc, const int* __restrict__ active,
     const cplx* __restrict__ Uall, const cplx* __restrict__ Eall, const double* __restrict__ fall, double* __restrict__ Zall,
     double* __restrict__ wall, const double* __restrict__ linAall, double* __restrict__ Call, double* __restrict__ Hall,

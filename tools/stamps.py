@@ -16,10 +16,12 @@ import harmonic_power_flow_amd as hp
 from harmonic_power_flow_amd import ingest, synth
 
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+NBUS = int(sys.argv[2]) if len(sys.argv) > 2 else 1000          # python tools/stamps.py 1 10000 99: config 5
+HMAX = int(sys.argv[3]) if len(sys.argv) > 3 else 51
 INPUTS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "inputs")
 tmp = tempfile.mkdtemp()
-fb, fl = synth.gen(1000, seed=0, outdir=tmp)
-st = hp.Settings(H_MAX=51)
+fb, fl = synth.gen(NBUS, seed=0, outdir=tmp)
+st = hp.Settings(H_MAX=HMAX)
 buses, lines, m, n, c = hp.init_network(fb, fl, settings=st)
 Y = hp.build_admittance_matrices(buses, lines, st.HARMONICS)
 NE = hp.import_Norton_Equivalents(buses, True, st, INPUTS)
