@@ -2934,12 +2934,12 @@ int tree_newton_step_bordered(hpf_handle* h, bool only_active) {
     const int cmax = n * BW;
     // the virtual scenarios of one chunk: slots [v0, v0 + V), scenario groups on their own streams as usual
     auto sweep = [&](int V) -> int {
-        const int G = V >= 96 ? (save_groups < 1 ? 1 : (save_groups > 3 ? 3 : save_groups)) : 1;
+        const int G = V >= 128 ? (save_groups < 1 ? 1 : (save_groups > 4 ? 4 : save_groups)) : (V >= 96 ? (save_groups > 3 ? 3 : (save_groups < 1 ? 1 : save_groups)) : 1);
         if (G > 1) hipEventRecord(h->fork_ev, st);
         int rc = HPF_OK;
         for (int g = 0; g < G && rc == HPF_OK; ++g) {
             const int a0 = (int)((long long)V * g / G), a1 = (int)((long long)V * (g + 1) / G);
-            hipStream_t gs = G > 1 ? h->gstream[g] : st;
+            hipStream_t gs = G > 1 ? group_stream(h, g) : st;
             if (G > 1) hipStreamWaitEvent(gs, h->fork_ev, 0);
             h->cur_stream = gs;
             h->cur_s0 = v0 + a0;

@@ -225,8 +225,8 @@ struct hpf_handle {
     // pipelines on their own streams so that the latency-bound upper tree levels of one group overlap the others)
     hipStream_t cur_stream = nullptr;
     int cur_s0 = 0, cur_S = 0;
-    int n_groups = 3;
-    hipStream_t gstream[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int n_groups = 4;
+    hipStream_t gstream[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // groups 1..7 (group 0: the handle's stream, group_stream)
     hipEvent_t fork_ev = nullptr, join_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     rocblas_handle blas = nullptr;
     double setup_ms[4] = {0, 0, 0, 0}; // hpf_create: total | tree planning on the host | tree uploads | per-scenario allocation
@@ -240,6 +240,10 @@ struct hpf_handle {
 };
 
 namespace hpf {
+
+// Stream of scenario group g: group 0 runs on the handle's stream itself, so a step of G groups keeps G hardware queues busy, not G + 1 (the
+// runtime maps streams onto four queues; a fifth busy stream shares one and serialises two groups: 1.25 instead of 0.90 ms per step at G = 4)
+inline hipStream_t group_stream(const hpf_handle* h, int g) { return g == 0 ? h->stream : h->gstream[g]; }
 
 struct ScopedTimer {
     hpf_handle* h;

@@ -835,10 +835,10 @@ int for_groups(hpf_handle* h, int count, F body) {
     auto bound = [&](int g) { return g >= G ? count : (int)(16 * (((long long)count * g / G + 8) / 16)); };
     for (int g = 0; g < G && rc == HPF_OK; ++g) {
         const int s0 = bound(g), s1 = bound(g + 1);
-        HIPCHK(hipStreamWaitEvent(h->gstream[g], h->fork_ev, 0));
-        set_ctx(h, h->gstream[g], s0, s1 - s0);
+        HIPCHK(hipStreamWaitEvent(group_stream(h, g), h->fork_ev, 0));
+        set_ctx(h, group_stream(h, g), s0, s1 - s0);
         rc = body();
-        HIPCHK(hipEventRecord(h->join_ev[g], h->gstream[g]));
+        HIPCHK(hipEventRecord(h->join_ev[g], group_stream(h, g)));
     }
     for (int g = 0; g < G; ++g) HIPCHK(hipStreamWaitEvent(h->stream, h->join_ev[g], 0));
     full_ctx(h);
@@ -1427,7 +1427,7 @@ int hpf_create(hpf_handle** out, const hpf_desc* d) {
     h->stream = h->own_stream;
     if (const char* gs = getenv("HPF_GROUPS")) h->n_groups = atoi(gs) < 1 ? 1 : (atoi(gs) > 8 ? 8 : atoi(gs));
     for (int g = 0; g < 8; ++g) {
-        if (hipStreamCreateWithFlags(&h->gstream[g], hipStreamNonBlocking) != hipSuccess) return fail(HPF_E_HIP);
+        if (g > 0 && hipStreamCreateWithFlags(&h->gstream[g], hipStreamNonBlocking) != hipSuccess) return fail(HPF_E_HIP);   // (group 0: group_stream)
         if (hipEventCreateWithFlags(&h->join_ev[g], hipEventDisableTiming) != hipSuccess) return fail(HPF_E_HIP);
     }
     if (hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming) != hipSuccess) return fail(HPF_E_HIP);
@@ -1753,13 +1753,13 @@ static int iterate_enqueue(hpf_handle* h, int iters) {
     int r = HPF_OK;
     if (G > 1) {
         HIPCHK(hipEventRecord(h->fork_ev, h->stream));
-        for (int g = 0; g < G; ++g) HIPCHK(hipStreamWaitEvent(h->gstream[g], h->fork_ev, 0));
+        for (int g = 0; g < G; ++g) HIPCHK(hipStreamWaitEvent(group_stream(h, g), h->fork_ev, 0));
     }
     auto bound = [&](int g) { return g >= G ? h->S : (int)(16 * (((long long)h->S * g / G + 8) / 16)); };   // (tile-aligned groups, for_groups)
     for (int it = 0; it < iters && r == HPF_OK; ++it) {
         for (int g = 0; g < G && r == HPF_OK; ++g) {
             if (G > 1)
-                set_ctx(h, h->gstream[g], bound(g), bound(g + 1) - bound(g));
+                set_ctx(h, group_stream(h, g), bound(g), bound(g + 1) - bound(g));
             else
                 full_ctx(h);
             if ((r = newton_step<false>(h, nullptr))) break;
@@ -1769,7 +1769,7 @@ static int iterate_enqueue(hpf_handle* h, int iters) {
     }
     if (G > 1) {
         for (int g = 0; g < G; ++g) {
-            HIPCHK(hipEventRecord(h->join_ev[g], h->gstream[g]));
+            HIPCHK(hipEventRecord(h->join_ev[g], group_stream(h, g)));
             HIPCHK(hipStreamWaitEvent(h->stream, h->join_ev[g], 0));
         }
     }

@@ -198,7 +198,10 @@ int  hpf_debug_stamps(hpf_handle* h, long long* out, int count);
  * the system; a relative residual above 1e-10, a zero pivot or a non-finite entry repeats it with partial pivoting (hpf_tree_census[11]
  * counts those).  1 = always the pivoted LU.
  * "queue_chunk" (1..16, default 4): Newton iterations between two harvest / refill rounds of hpf_solve_queue.
- * "scenario_groups" (1..8, default 3 -- with the host framework's own streams a fourth busy queue is a cliff --; at least 32 running scenarios per group): independent scenario pipelines on separate HIP streams.
+ * "scenario_groups" (1..8, default 4; at least 32 running scenarios per group): independent scenario pipelines on separate HIP streams -- group 0
+ * on the handle's own stream (hpf_set_stream), the others on streams of the handle.  The runtime maps streams onto FOUR hardware queues: with a fifth
+ * stream busy at the same time (the application's own work during a solve) two groups share a queue and serialise (1.25 instead of 0.90 ms per
+ * step at the benchmark shape) -- such an application sets 3.
  * Environment read by hpf_create (diagnostics, A/B runs): HPF_LAZY=0 builds the elimination tree without lazy leaves (every
  * leaf writes its Schur complement; 1: only leaves directly under their dense parent), HPF_SLEAF=0 sends the nonlinear buses
  * whose dense children are all lazy leaves (super-leaves: bordered low-rank inverse) through Gauss-Jordan like every other bus,

@@ -1,8 +1,8 @@
 """GPU parity tests AT THE BENCHMARK CONFIGURATIONS (run with -m gpu on an MI355X).
 
 BASELINE config 4, one GPU's share: gen(1000, seed 0) x harmonics 1..51, coupled, 128 Monte-Carlo load scenarios in ONE handle
--> three scenario groups on their own HIP streams (43 + 42 + 43 scenarios: scenario offsets 0 / 42 / 85), full and ragged
-16-scenario tiles in k_leaf_batch / k_sleaf_batch / k_*_back_batch.  Checked
+-> scenario groups on their own HIP streams (four groups of 32 by default, tile-aligned; three before round 4: the fixture's scenarios
+0 / 15 / 16 / 42 / 43 / 85 / 127 sit at tile and group boundaries of both splits), full and ragged 16-scenario tiles in k_leaf_batch / k_sleaf_batch / k_*_back_batch.  Checked
   (i)   bit for bit against single-scenario handles (one group, one scenario per tile) for scenarios at every tile / group
         boundary, and against the same batch run as ONE group;
   (ii)  against oracle fixtures (tests/golden/syn1000_H51_scen.npz, oracle/make_golden_bench.py): the iterate where the
@@ -104,7 +104,7 @@ def test_benchmark_configuration_128_scenarios_three_groups(tmp_path):
         worst_stop, worst_fix = max(worst_stop, d_stop), max(worst_fix, d_fix)
         assert d_stop < 1e-6
         assert d_fix < TOL_V and d_vm < TOL_V
-    print("\nS=128, 3 groups: max|dU| vs oracle at the stop rule %.2e, at the fixed point %.2e" % (worst_stop, worst_fix))
+    print("\nS=128, default groups: max|dU| vs oracle at the stop rule %.2e, at the fixed point %.2e" % (worst_stop, worst_fix))
     # (iii) the REFERENCE ITSELF on scenarios 0 and 127 (oracle/make_golden.py scenref<s>: the unmodified hcne_generalized.py with the
     # scenario's loads, 32 / 30 iterations): its final voltages lie 3.7e-10 / 2.7e-10 from the fixed point (it stops at err 4e-7), so
     # the product's fixed point must agree with the reference's own printed result within the north-star tolerance
