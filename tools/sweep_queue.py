@@ -25,7 +25,8 @@ for S in Ss:
     dm = hp.DeviceModel(n, inp["m"], inp["c"], inp["st"].HARMONICS, inp["Y"].rowptr, inp["Y"].col, inp["Y"].Yval, inp["dev"],
                         inp["Y_N"], inp["I_N"], inp["n_dev"], True, solver="block_tree", max_scenarios=S)
     base = None
-    for mode, chunk in (("waves", 0), ("queue", 1), ("queue", 2), ("queue", 4), ("waves", 0), ("queue", 2)):
+    CH = [int(c) for c in os.environ.get("HPF_QUEUE_CHUNKS", "1,2,4,2").split(",")]       # queue_chunk values to compare
+    for mode, chunk in [("waves", 0)] + [("queue", c) for c in CH] + [("waves", 0)]:
         if chunk:
             dm.set_option("queue_chunk", chunk)
         t0 = time.perf_counter()
