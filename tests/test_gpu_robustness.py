@@ -616,3 +616,37 @@ def test_many_scenarios_compaction_over_several_tiles(tmp_path):
             assert np.array_equal(Vm1[0], Vm[s]) and np.array_equal(Va1[0], Va[s])
     finally:
         dm1.close()
+
+
+def test_caller_stream_carries_scenario_group_0(tmp_path):
+    """hpf_set_stream: with a caller-provided HIP stream the four scenario groups of a 128-scenario solve run on that stream (group 0) and three
+    streams of the handle; records and voltages are bit-identical to the solve on the handle's own stream and to a one-group solve, work queued on the
+    caller's stream before the solve is ordered before it, and the handle goes back to its own stream with set_stream(None)."""
+    import torch
+    hp = _hp()
+    from harmonic_power_flow_amd import api, sweep, synth
+    st, buses, Y, NE, _ = _feeder(hp, 60, 11, tmp_path, seed=5, frac_nl=0.35)
+    n, S = len(buses), 128
+    P0, Q0 = buses["P"].to_numpy(float), buses["Q"].to_numpy(float)
+    scale = np.stack([synth.scenario_scale(n, s) for s in range(S)])
+    dm = api._device_model(buses, Y, NE, True, st.HARMONICS, solver="block_tree", max_scenarios=S)
+    try:
+        assert dm.scenario_groups(S) == 4 and dm.scenario_groups(127) == 3 and dm.scenario_groups(63) == 1
+        ref = sweep.solve_scenarios(dm, P0 * scale, Q0 * scale, want_voltages=True)
+        ts = torch.cuda.Stream()
+        dm.set_stream(ts.cuda_stream)
+        with torch.cuda.stream(ts):
+            busy = torch.ones(1 << 24, device="cuda")
+            for _ in range(20):
+                busy = busy * 1.0000001                           # work on the caller's stream ahead of the solve
+        got = sweep.solve_scenarios(dm, P0 * scale, Q0 * scale, want_voltages=True)
+        ts.synchronize()
+        dm.set_stream(None)
+        dm.set_option("scenario_groups", 1)
+        one = sweep.solve_scenarios(dm, P0 * scale, Q0 * scale, want_voltages=True)
+    finally:
+        dm.close()
+    for other in (got, one):
+        assert np.array_equal(ref[0].view(np.uint8), other[0].view(np.uint8))
+        assert np.array_equal(ref[1], other[1]) and np.array_equal(ref[2], other[2])
+    assert ((ref[0]["flags"] & 1) == 1).all()
