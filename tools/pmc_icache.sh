@@ -1,0 +1,27 @@
+#!/bin/bash
+# Instruction-cache counters of the bench kernels (one rocprofv3 --pmc pass per group, kernel-trace only):  bash tools/pmc_icache.sh <tag> [bench.py args...]
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+TAG=$1; shift
+ARGS="--steps 5 --warmup 2 --repeats 1 --cpu-iters 0 --no-finish --no-single --sweep-1gpu 0 $@"
+d=gpurun_out/${TAG}_ic; rm -rf $d; mkdir -p $d
+i=0
+for c in "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE" "SQ_IFETCH SQ_IFETCH_LEVEL SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQC_ICACHE_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVES SQ_INSTS_VALU"; do
+  mkdir -p $d/g$i
+  timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $d/g$i -- python3 bench.py $ARGS > $d/g$i/run.log 2>&1 || echo "group $i failed"
+  i=$((i+1))
+done
+python3 - "$d" > gpurun_out/${TAG}_icache.txt <<'PY'
+import collections, csv, glob, os, re, sys
+agg = collections.defaultdict(lambda: collections.defaultdict(float)); disp = collections.defaultdict(set)
+for f in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        m = re.search(r"(k_\w+)(<[^>]*>)?", r["Kernel_Name"])
+        if not m:
+            continue
+        k = m.group(1) + (m.group(2) or "").replace(" ", "")
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); disp[k].add(r.get("Dispatch_Id"))
+for k, c in sorted(agg.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0)):
+    print("%-26s dispatches %4d  " % (k, len(disp[k])) + "  ".join("%s %.4g" % (n, v) for n, v in sorted(c.items())))
+PY
+rm -rf $d
+cat gpurun_out/${TAG}_icache.txt
