@@ -952,6 +952,48 @@ int launch_factor(hpf_handle* h, const TreeDev& T, const int* nodes, int count, 
 }
 
 
+// Back sweep, one launch per depth (round 4): the scenario-batched workgroups of the depth's bordered buses and constant-inverse leaves (16 scenarios
+// each: k_sleaf_back_batch / k_leaf_back_batch bodies) share the grid with the per-scenario workgroups of its Gauss-Jordan buses (k_back_q body) --
+// a bordered bus or a leaf needs its dense parent's x only, so it belongs to its own depth instead of waiting for the last one (four more dependent
+// launches behind the depths' before).  Blocks of 52 only (the bodies of smaller blocks run on fewer wavefronts than the batched ones).
+template <int B>
+__global__ __launch_bounds__(256) void k_level_back(
+    Model M, TreeDev T, const int* __restrict__ sl_nodes, int n_sl, const int* __restrict__ lf_nodes, int n_lf, const int* __restrict__ gj_nodes, int n_gj,
+    int b, int N, int Nc, const int* __restrict__ active, int S_cnt, const double* __restrict__ Zall, const double* __restrict__ wall,
+    double* __restrict__ xall, const double* __restrict__ Hall, const double* __restrict__ Minv, const double* __restrict__ lbimg,
+    const double* __restrict__ sbimg, const double* __restrict__ lzimg, const double* __restrict__ lfK, const double* __restrict__ lfS, int s0) {
+    static_assert(64 * ((B + 16) / 16) == 256, "k_level_back: blocks of 52 rows (four wavefronts in every body)");
+    const int ytiles = (S_cnt + LB_SB - 1) / LB_SB, nb_sl = n_sl * ytiles, nb_lf = n_lf * ytiles;
+    const int bid = (int)blockIdx.x;
+    if (bid < nb_sl) {
+        sleaf_back_batch_body<B>(bid % n_sl, bid / n_sl, M, sl_nodes, b, active, S_cnt, wall, xall, Hall, sbimg, lzimg, Zall, lfS, s0);
+    } else if (bid < nb_sl + nb_lf) {
+        const int i = bid - nb_sl;
+        leaf_back_batch_body<B>(i % n_lf, i / n_lf, M, lf_nodes, b, active, S_cnt, wall, xall, Hall, lbimg, lfK, lfS, s0);
+    } else {
+        const int i = bid - nb_sl - nb_lf;
+        back_q_body<B>(i % n_gj, i / n_gj, M, T, gj_nodes, b, N, Nc, active, Zall, wall, xall, (double*)nullptr, Hall, Minv, lfK, lfS, s0);
+    }
+}
+
+template <int B>
+int launch_level_back(hpf_handle* h, const TreeDev& T, const int* sl_nodes, int n_sl, const int* lf_nodes, int n_lf, const int* gj_nodes, int n_gj,
+                      const int* active) {
+    const Tree& tr = active_tree(h);
+    const unsigned ytiles = (unsigned)((h->cur_S + LB_SB - 1) / LB_SB);
+    const unsigned grid = (unsigned)(n_sl + n_lf) * ytiles + (unsigned)n_gj * (unsigned)h->cur_S;
+    if (grid == 0) return HPF_OK;
+    hipLaunchKernelGGL((k_level_back<B>), dim3(grid), dim3(256), 0, h->cur_stream, h->M, T, sl_nodes, n_sl, lf_nodes, n_lf, gj_nodes, n_gj, 2 * h->Hn,
+                       h->N, h->Nc, active, h->cur_S, h->d_Z, h->d_w, h->d_x, h->d_H, tr.d_Minv, tr.d_lbimg, tr.d_sbimg, tr.d_lzimg, h->d_lfK, h->d_lfS,
+                       h->cur_s0);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        h->last_detail = (int)e;
+        return HPF_E_HIP;
+    }
+    return HPF_OK;
+}
+
 // =============================================================================================================
 // Meshed networks on the block-tree path: "bordered Newton step".
 // The admittance pattern = BFS spanning tree + k loop-closing lines (ties).  With J_t = the Jacobian without the ties' off-
@@ -2402,12 +2444,29 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
         }
         T.n_bsleaf = (int)bsleaf.size() / 8;
         if ((r = upload(h, &T.d_bsleaf, bsleaf))) return r;
+        // the same records by back-sweep depth (k_level_back: a bordered bus needs its dense parent's x only, i.e. the previous depth)
+        std::vector<int> bsd;
+        T.bsl_dep_ptr.assign(1, 0);
+        for (int dl = 0; dl < T.n_depths; ++dl) {
+            for (int pos = T.dep_ptr[dl]; pos < T.dep_ptr[dl + 1]; ++pos) {
+                const int kb = T.dep_nodes[pos];
+                if (sb_ord[kb] < 0 || sl_off[kb] < 0 || lz_idx[kb] < 0) continue;
+                const int rec[8] = {kb, pard[kb], sb_ord[kb], (int)(sl_base + sl_off[kb]), sb_m[kb], 0, 0, 0};
+                bsd.insert(bsd.end(), rec, rec + 8);
+            }
+            T.bsl_dep_ptr.push_back((int)bsd.size() / 8);
+        }
+        if ((r = upload(h, &T.d_bsleaf_dep, bsd))) return r;
         if ((r = upload(h, &T.d_sbimg, sbimg))) return r;
     }
     {
         std::vector<int> bleaf;
-        for (int pos = 0; pos < T.n_dense; ++pos)
-            if (bdesc[(size_t)pos * 4 + 2] > 0 && bdesc[(size_t)pos * 4 + 1] >= 0) bleaf.insert(bleaf.end(), &bdesc[(size_t)pos * 4], &bdesc[(size_t)pos * 4] + 4);
+        T.bleaf_dep_ptr.assign(1, 0);
+        for (int dl = 0; dl < T.n_depths; ++dl) {                // (bdesc is in depth order)
+            for (int pos = T.dep_ptr[dl]; pos < T.dep_ptr[dl + 1]; ++pos)
+                if (bdesc[(size_t)pos * 4 + 2] > 0 && bdesc[(size_t)pos * 4 + 1] >= 0) bleaf.insert(bleaf.end(), &bdesc[(size_t)pos * 4], &bdesc[(size_t)pos * 4] + 4);
+            T.bleaf_dep_ptr.push_back((int)bleaf.size() / 4);
+        }
         T.n_bleaf = (int)bleaf.size() / 4;
         if ((r = upload(h, &T.d_bleaf, bleaf))) return r;
     }
@@ -2494,7 +2553,7 @@ static void tree_free_one(Tree& T) {
     void* ptrs[] = {T.d_parent, T.d_lvl_nodes, T.d_dep_nodes, T.d_child_ptr, T.d_child, T.d_e_up, T.d_e_dn,
                     T.d_child_mid, T.d_lin, T.d_lin_ptr, T.d_lin_post, T.d_all_ptr, T.d_all_post, T.d_fdesc, T.d_child3,
                     T.d_bdesc, T.d_dchild, T.d_chain_ptr, T.d_chain_nodes, T.d_chain_ch, T.d_Minv, T.d_lrec, T.d_crec, T.d_cnode, T.d_arec,
-                    T.d_lzrec, T.d_lzimg, T.d_lbimg, T.d_bleaf, T.d_bsleaf, T.d_sbimg, T.d_lbrec, T.d_lbptr, T.d_lb2rec, T.d_lb2x, T.d_lb2ptr, T.d_lb2cptr, T.d_lb2clist,
+                    T.d_lzrec, T.d_lzimg, T.d_lbimg, T.d_bleaf, T.d_bsleaf, T.d_bsleaf_dep, T.d_sbimg, T.d_lbrec, T.d_lbptr, T.d_lb2rec, T.d_lb2x, T.d_lb2ptr, T.d_lb2cptr, T.d_lb2clist,
                     T.d_comp_child};
     for (void* p : ptrs)
         if (p) hipFree(p);
@@ -2690,6 +2749,15 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
         }
     }
     ScopedTimer tb(h, T_BACK);
+    // one launch per depth for all bus kinds (k_level_back) where the batched bodies exist and every body has four wavefronts
+    // (groups of up to 32 scenarios only: larger launches are throughput-bound, and k_back_q alone runs at twice the
+    //  occupancy of the fused kernel -- 5.2 vs 5.4 ms per step at 1 024 scenarios, 0.297 vs 0.288 ms at one)
+    static const int fuse_back_max = getenv("HPF_FUSEBACK_MAX") ? atoi(getenv("HPF_FUSEBACK_MAX")) : 32;
+    bool fused_back = h->fuse_back && h->cur_S <= fuse_back_max && h->leafbatch && h->has_ctree && h->gj_mode == 1 && BW == 52 &&
+                      (int)T.bsl_dep_ptr.size() == T.n_depths + 1 && (int)T.bleaf_dep_ptr.size() == T.n_depths + 1 && (int)T.dep_nleaf.size() >= T.n_depths;
+    for (int dl = 1; fused_back && dl < T.n_depths; ++dl)         // (a depth's batched records are exactly its leaves + bordered buses)
+        fused_back = T.bsl_dep_ptr[dl + 1] - T.bsl_dep_ptr[dl] + T.bleaf_dep_ptr[dl + 1] - T.bleaf_dep_ptr[dl] == T.dep_nleaf[dl];
+    if (fused_back && (T.bsl_dep_ptr[1] != 0 || T.bleaf_dep_ptr[1] != 0)) fused_back = false;
     for (int dl = 0; dl < T.n_depths; ++dl) {
         const int cnt = T.dep_ptr[dl + 1] - T.dep_ptr[dl];
         if (cnt == 0) continue;
@@ -2697,6 +2765,13 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
         int r = HPF_OK;
         const int leafbatch_b = h->leafbatch;
         const int nlb = (leafbatch_b && h->has_ctree && dl > 0 && dl < (int)T.dep_nleaf.size()) ? T.dep_nleaf[dl] : 0;
+        if (fused_back) {
+            const int n_sl = dl > 0 ? T.bsl_dep_ptr[dl + 1] - T.bsl_dep_ptr[dl] : 0, n_lf = dl > 0 ? T.bleaf_dep_ptr[dl + 1] - T.bleaf_dep_ptr[dl] : 0;
+            if ((r = launch_level_back<52>(h, td, T.d_bsleaf_dep + 8 * (size_t)T.bsl_dep_ptr[dl], n_sl, T.d_bleaf + 4 * (size_t)T.bleaf_dep_ptr[dl], n_lf,
+                                           T.d_bdesc + 4 * (size_t)(T.dep_ptr[dl] + nlb), cnt - nlb, active)))
+                return r;
+            continue;
+        }
         switch (BW) {
             case 12:
                 if (h->gj_mode == 1 && nlb > 0) {                    // (the leaves of this depth wait for the one batched launch below)
@@ -2740,7 +2815,7 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
     {
         // every constant-inverse leaf at once, 16 scenarios per workgroup: a leaf's x needs its parent's only, and nothing of the
         // dense tree hangs below a leaf (the 2x2 kernels that do come next)
-        const int leafbatch_e = h->leafbatch;
+        const int leafbatch_e = h->leafbatch && !fused_back;
         if (leafbatch_e && h->has_ctree && h->gj_mode == 1 && T.n_bsleaf > 0) {    // super-leaves first: leaves hang below them
             int r = HPF_OK;
             for (size_t gi = 0; gi + 1 < T.bsleaf_ptr.size() && !r; ++gi) {      // nested bordered buses first (by nesting order)

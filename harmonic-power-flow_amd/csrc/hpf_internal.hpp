@@ -107,6 +107,8 @@ struct Tree {
     int n_bsleaf = 0;
     int* d_bsleaf = nullptr;          // [n_bsleaf][8] back-sweep records of the super-leaves (k_sleaf_back_batch)
     double* d_sbimg = nullptr;        // [n_bsleaf][SleafImg<B>::SZ] their [0 0; 0 Ahh^-1] images (+ Qb rows) and Pb in MFMA A-operand layout
+    std::vector<int> bsl_dep_ptr, bleaf_dep_ptr;   // [n_depths + 1] the same records by back-sweep depth (d_bsleaf_dep: depth order; d_bleaf is in depth order): k_level_back
+    int* d_bsleaf_dep = nullptr;
     int n_bleaf = 0;
     int* d_bleaf = nullptr;           // [n_bleaf][4] back-sweep records of ALL constant-inverse leaves: one k_leaf_back_batch launch after the last depth
     double* d_lbimg = nullptr;        // [leaf slot][LeafBatchImg::SZ]: the leaf images in MFMA A-operand layout (16 scenarios per workgroup)
@@ -153,6 +155,7 @@ struct hpf_handle {
     bool plan_written = false;
     int gj_mode = 1;                  // BLOCK_TREE block inversion: 0 pivoted wave Gauss-Jordan (VALU, uncontracted tree), 1 MFMA static 4x4 blocks, NT waves per bus (hpf_quad.hpp)
     double piv_limit = 1e10;          // static pivot order: amplification of a 4x4 pivot block's inverse beyond which a scenario is repeated with partial pivoting
+    int fuse_back = 1;                // HPF_FUSEBACK (read by hpf_create): 0 = the back sweep's batched launches after the last depth instead of inside the depths' launches
     int fuse_levels = 1;              // HPF_FUSELEVEL (read by hpf_create): 0 = separate launches for the batched and the per-scenario workgroups of a level
     int leafbatch = 1;                // HPF_LEAFBATCH (read by hpf_create): 0 = one workgroup per (leaf, scenario) instead of 16 scenarios per workgroup
     int debug_ablate = 0;             // HPF_DEBUG_ABLATE: timing-only ablation of factor-kernel phases (results invalid)

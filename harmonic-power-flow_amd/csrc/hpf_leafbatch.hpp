@@ -280,18 +280,18 @@ int launch_leaf_batch(hpf_handle* h, const TreeDev& T, const int* nodes, int cou
 // Drect^-1 t = [u; Vh + Lc u],  V = [0 Lr; 0 Ahh^-1] t  (the same per-model image on the matrix cores),  u = K (t0 + V0).
 // nodes: Tree::d_bdesc records (bus, parent, leaf slot + 1, 0) of leaves only.
 template <int B>
-__global__ __launch_bounds__(256) void k_leaf_back_batch(
-    Model M, const int* __restrict__ nodes, int b, const int* __restrict__ active, int S_cnt, const double* __restrict__ wall,
+__device__ __forceinline__ void leaf_back_batch_body(
+    const int bx_, const int by_, const Model& M, const int* __restrict__ nodes, int b, const int* __restrict__ active, int S_cnt, const double* __restrict__ wall,
     double* __restrict__ xall, const double* __restrict__ Hall, const double* __restrict__ lbimg, const double* __restrict__ lfK,
     const double* __restrict__ lfS, int s0) {
     constexpr int NTR = LeafBatchImg<B>::NTR, KS = LeafBatchImg<B>::KS, H2 = B / 2, QI = (H2 + 15) / 16;
-    const int4 kp = reinterpret_cast<const int4*>(nodes)[blockIdx.x];
+    const int4 kp = reinterpret_cast<const int4*>(nodes)[bx_];
     const int k = kp.x, par = kp.y, slot = kp.z - 1;
     const int tid = threadIdx.x, lane = tid & 63, lg = lane >> 4, jj = lane & 15;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = M.n, Hn = M.Hn;
     const int sc = tid >> 4, l16 = tid & 15;
-    const int sl = blockIdx.y * LB_SB + sc;
+    const int sl = by_ * LB_SB + sc;
     const int ss = sl < S_cnt ? (active ? active[sl + s0] : sl + s0) : -1;      // slot -> scenario (active list; -1: frozen / empty slot)
     const bool live = ss >= 0;
     const int s = live ? ss : 0;
@@ -381,6 +381,14 @@ __global__ __launch_bounds__(256) void k_leaf_back_batch(
 }
 
 template <int B>
+__global__ __launch_bounds__(256) void k_leaf_back_batch(
+    Model M, const int* __restrict__ nodes, int b, const int* __restrict__ active, int S_cnt, const double* __restrict__ wall,
+    double* __restrict__ xall, const double* __restrict__ Hall, const double* __restrict__ lbimg, const double* __restrict__ lfK,
+    const double* __restrict__ lfS, int s0) {
+    leaf_back_batch_body<B>(blockIdx.x, blockIdx.y, M, nodes, b, active, S_cnt, wall, xall, Hall, lbimg, lfK, lfS, s0);
+}
+
+template <int B>
 int launch_leaf_back_batch(hpf_handle* h, const int* nodes, int count, const int* active) {
     const dim3 grid((unsigned)count, (unsigned)((h->cur_S + LB_SB - 1) / LB_SB));
     hipLaunchKernelGGL((k_leaf_back_batch<B>), grid, dim3(256), 0, h->cur_stream, h->M, nodes, 2 * h->Hn, active, h->cur_S, h->d_w,
@@ -399,15 +407,15 @@ int launch_leaf_back_batch(hpf_handle* h, const int* nodes, int count, const int
 // W_k^-1 were left by the factor kernel at the head of the bus's (otherwise unused) inverse slot.
 // nodes: records of 8 ints (bus, parent, slot in Tree::d_sbimg, offset of [Tc | Pb | Qb] in Tree::d_lzimg, m, 0, 0, 0).
 template <int B>
-__global__ __launch_bounds__(256) void k_sleaf_back_batch(
-    Model M, const int* __restrict__ nodes, int b, const int* __restrict__ active, int S_cnt, const double* __restrict__ wall,
+__device__ __forceinline__ void sleaf_back_batch_body(
+    const int bx_, const int by_, const Model& M, const int* __restrict__ nodes, int b, const int* __restrict__ active, int S_cnt, const double* __restrict__ wall,
     double* __restrict__ xall, const double* __restrict__ Hall, const double* __restrict__ sbimg, const double* __restrict__ lzimg,
     const double* __restrict__ Zall, const double* __restrict__ lfS, int s0) {
     constexpr int NT = (B + 16) / 16;
     constexpr size_t CT = (size_t)NT * NT * 256;
     constexpr int NTR = SleafImg<B>::NTR, KS = SleafImg<B>::KS, KP = SleafImg<B>::KP, H2 = B / 2, QI = (H2 + 15) / 16;
     constexpr bool QBR = SleafImg<B>::QB_ROWS;
-    const int4* rec = reinterpret_cast<const int4*>(nodes) + 2 * (size_t)blockIdx.x;
+    const int4* rec = reinterpret_cast<const int4*>(nodes) + 2 * (size_t)bx_;
     const int4 r0 = rec[0], r1 = rec[1];
     const int k = r0.x, par = r0.y, m = r1.x;
     const double* img = sbimg + (size_t)r0.z * SleafImg<B>::SZ;
@@ -417,7 +425,7 @@ __global__ __launch_bounds__(256) void k_sleaf_back_batch(
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = M.n, Hn = M.Hn;
     const int sc = tid >> 4, l16 = tid & 15;
-    const int sl = blockIdx.y * LB_SB + sc;
+    const int sl = by_ * LB_SB + sc;
     const int ss = sl < S_cnt ? (active ? active[sl + s0] : sl + s0) : -1;      // slot -> scenario (active list; -1: frozen / empty slot)
     const bool live = ss >= 0;
     const int s = live ? ss : 0;
@@ -525,6 +533,14 @@ __global__ __launch_bounds__(256) void k_sleaf_back_batch(
             *reinterpret_cast<double2*>(xs + (size_t)k * B + 2 * q) = double2{w4[it][0] - d0, w4[it][1] - d1};
         }
     }
+}
+
+template <int B>
+__global__ __launch_bounds__(256) void k_sleaf_back_batch(
+    Model M, const int* __restrict__ nodes, int b, const int* __restrict__ active, int S_cnt, const double* __restrict__ wall,
+    double* __restrict__ xall, const double* __restrict__ Hall, const double* __restrict__ sbimg, const double* __restrict__ lzimg,
+    const double* __restrict__ Zall, const double* __restrict__ lfS, int s0) {
+    sleaf_back_batch_body<B>(blockIdx.x, blockIdx.y, M, nodes, b, active, S_cnt, wall, xall, Hall, sbimg, lzimg, Zall, lfS, s0);
 }
 
 template <int B>

@@ -1422,6 +1422,7 @@ int hpf_create(hpf_handle** out, const hpf_desc* d) {
     if (const char* gm = getenv("HPF_GJ_MODE")) h->gj_mode = atoi(gm) ? 1 : 0;
     if (const char* lb = getenv("HPF_LEAFBATCH")) h->leafbatch = atoi(lb) ? 1 : 0;
     if (const char* fl = getenv("HPF_FUSELEVEL")) h->fuse_levels = atoi(fl) ? 1 : 0;
+    if (const char* fb = getenv("HPF_FUSEBACK")) h->fuse_back = atoi(fb) ? 1 : 0;
     if (hipSetDevice(d->device) != hipSuccess) return fail(HPF_E_HIP);
     if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) return fail(HPF_E_HIP);
     h->stream = h->own_stream;

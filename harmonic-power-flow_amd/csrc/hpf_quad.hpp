@@ -1418,16 +1418,16 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 52 ? (LEAF ? 2 : HPF_Q10
 // the partial row sums meet in LDS.  Constant-inverse leaves keep no inverse in HBM:  D^-1 t = S^-1 (M t - Mc K (Mr t))  with
 // the per-model M (tile layout, L2 / Infinity Cache), the Woodbury core K and S^-1 left by the factor kernel.
 template <int B>
-__global__ __launch_bounds__(64 * ((B + 16) / 16)) void k_back_q(
-    Model M, TreeDev T, const int* __restrict__ nodes, int b, int N, int Nc, const int* __restrict__ active,
+__device__ __forceinline__ void back_q_body(
+    const int bx_, const int by_, const Model& M, const TreeDev& T, const int* __restrict__ nodes, int b, int N, int Nc, const int* __restrict__ active,
     const double* __restrict__ Zall, const double* __restrict__ wall, double* __restrict__ xall, double* __restrict__ step,
     const double* __restrict__ Hall, const double* __restrict__ Minv, const double* __restrict__ lfK,
     const double* __restrict__ lfS, int s0) {
     constexpr int NT = (B + 16) / 16;
     constexpr size_t CT = (size_t)NT * NT * 256;
-    const int s = active ? active[blockIdx.y + s0] : (int)blockIdx.y + s0;   // slot -> scenario (active list; -1: frozen / empty slot)
+    const int s = active ? active[by_ + s0] : (int)by_ + s0;   // slot -> scenario (active list; -1: frozen / empty slot)
     if (s < 0) return;
-    const int4 kp = reinterpret_cast<const int4*>(nodes)[blockIdx.x];          // Tree::d_bdesc: (bus, parent, leaf slot + 1, 0)
+    const int4 kp = reinterpret_cast<const int4*>(nodes)[bx_];          // Tree::d_bdesc: (bus, parent, leaf slot + 1, 0)
     const int k = kp.x, par = kp.y, cleaf = kp.z;
     // compress steps (tree_build_into): role 1 = bus eliminated before its pending child c: x_k = w_k - D_k^-1 (A(k,p) x_p + A(k,c) x_c), it
     // comes AFTER c; role 2 = such a child: its coupling block with the parent p is the dense Hd = A'(k,p) the compress step left
@@ -1536,6 +1536,15 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16)) void k_back_q(
             }
         }
     }
+}
+
+template <int B>
+__global__ __launch_bounds__(64 * ((B + 16) / 16)) void k_back_q(
+    Model M, TreeDev T, const int* __restrict__ nodes, int b, int N, int Nc, const int* __restrict__ active,
+    const double* __restrict__ Zall, const double* __restrict__ wall, double* __restrict__ xall, double* __restrict__ step,
+    const double* __restrict__ Hall, const double* __restrict__ Minv, const double* __restrict__ lfK,
+    const double* __restrict__ lfS, int s0) {
+    back_q_body<B>(blockIdx.x, blockIdx.y, M, T, nodes, b, N, Nc, active, Zall, wall, xall, step, Hall, Minv, lfK, lfS, s0);
 }
 
 template <int B, bool LEAF>

@@ -217,6 +217,8 @@ int  hpf_debug_stamps(hpf_handle* h, long long* out, int count);
  * whose levels fill the chip -- HPF_COMPRESS=1 forces the compress steps there too), HPF_TREE_INFO=1 prints the tree statistics to stderr,
  * HPF_QUEUE_INFO=1 prints the phase times of hpf_solve_queue to stderr, HPF_BORDER_SLOTS=n caps the virtual scenario slots a meshed handle
  * allocates for its bordered step (default 1 024, at least 16: the m + 1 right-hand sides run in chunks of that many),
+ * HPF_FUSEBACK=0 launches the back sweep's scenario-batched workgroups (bordered buses, leaves) after the last depth instead of inside the
+ * depths' launches (k_level_back: groups of up to HPF_FUSEBACK_MAX = 32 scenarios, blocks of 52),
  * HPF_GROUPS=n presets "scenario_groups".  Every switch selects a path with the same Newton steps (tests/test_gpu_robustness.py). */
 int  hpf_set_option(hpf_handle* h, const char* name, int value);
 

@@ -170,7 +170,7 @@ def test_per_iteration_state_dump_follows_the_reference_trajectory(name, solver,
 @pytest.mark.parametrize("env", [{"HPF_LAZY": "0"}, {"HPF_LAZY": "1"}, {"HPF_SLEAF": "0"}, {"HPF_SLEAF": "1"},
                                  {"HPF_SLLAZY": "0"}, {"HPF_SLBACK": "0"}, {"HPF_LEAFBATCH": "0"}, {"HPF_GROUPS": "2"},
                                  {"HPF_SLNEST": "0"}, {"HPF_LINTREE": "0"}, {"HPF_FUSELEVEL": "0"}, {"HPF_LINBUNDLE": "0"}, {"HPF_CHAINBUNDLE": "0"},
-                                 {"HPF_COMPRESS": "0"}])
+                                 {"HPF_COMPRESS": "0"}, {"HPF_FUSEBACK": "0"}])
 def test_tree_build_variants_take_the_same_newton_steps(env, tmp_path, monkeypatch):
     """Every diagnostic switch of hpf_create (hpf.h) selects a more general path for some class of buses (no lazy leaves, no
     super-leaves, super-leaves that push their Schur complement / store their inverse, leaves one workgroup per scenario): the
@@ -182,7 +182,7 @@ def test_tree_build_variants_take_the_same_newton_steps(env, tmp_path, monkeypat
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     var = _solve(hp, st, buses, Y, NE, S=S, polish=1)
-    if "HPF_GROUPS" in env or "HPF_LINTREE" in env or "HPF_LINBUNDLE" in env or "HPF_CHAINBUNDLE" in env:   # same arithmetic, other launch shapes: bit-identical
+    if "HPF_GROUPS" in env or "HPF_LINTREE" in env or "HPF_LINBUNDLE" in env or "HPF_CHAINBUNDLE" in env or "HPF_FUSEBACK" in env:   # same arithmetic, other launch shapes: bit-identical
         assert np.array_equal(var["Vm"], base["Vm"]) and np.array_equal(var["Va"], base["Va"])
     Ub, Uv = base["Vm"] * np.exp(1j * base["Va"]), var["Vm"] * np.exp(1j * var["Va"])
     print("\n%s: iterations %s vs %s, max|dU| after one more iteration %.2e" % (env, var["it"][:4], base["it"][:4], np.abs(Ub - Uv).max()))
