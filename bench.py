@@ -206,11 +206,31 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Untimed probe of the stream configuration: four scenario groups use all four hardware queues of the runtime; if anything else in this
+    # process keeps a queue busy (another library's stream) two groups share one and the step is ~30 % slower -- then three groups are the
+    # better configuration for THIS process.  A few iterations of each, the default stays unless it is clearly on that cliff.
+    groups_probe = None
+    if args.solver == "block_tree" and dm.scenario_groups(S) >= 4:
+        def per_iter(k=4):
+            dm.sync()
+            t = time.perf_counter()
+            dm.iterate(k)
+            dm.sync()
+            return 1e3 * (time.perf_counter() - t) / k
+        dm.iterate(2)
+        t4 = min(per_iter(), per_iter())
+        dm.set_option("scenario_groups", 3)
+        dm.iterate(2)
+        t3 = min(per_iter(), per_iter())
+        keep4 = t4 <= 1.1 * t3
+        if keep4:
+            dm.set_option("scenario_groups", 4)
+        groups_probe = {"ms_per_step_4_groups": t4, "ms_per_step_3_groups": t3, "chosen": 4 if keep4 else 3}
     # R timed blocks of exactly K steps, each from the pf seed (W warm-up steps first), each bracketed by barrier + synchronize on both
     # sides and reduced with MAX over the ranks; the reported block is the median one
     blocks = []
     for rep in range(max(args.repeats, 1)):
-        if rep:
+        if rep or groups_probe:
             dm.set_state(seed[0], seed[1])
             dm.mismatch(want_f=False)
         dm.iterate(args.warmup)
@@ -329,6 +349,7 @@ def main():
         "repeats": len(blocks), "repeat_ms_per_step": [1e3 * b / K for b in blocks],
         "repeat_note": "R timed blocks of exactly `steps` iterations, each from the pf seed after `warmup` iterations, each bracketed by "
                        "barrier + synchronize and MAX-reduced over the ranks; ms_per_step / value are the MEDIAN block's",
+        "scenario_groups_probe": groups_probe,      # untimed: four groups (default) against three in this process; the default stays unless > 10 % slower
         "backend": backend if world > 1 else None,
         "rccl_ranks": (dist.get_world_size() if (world > 1 and backend == "nccl") else None),
         "ms_per_iter_per_scenario": ms_step / S,
