@@ -142,6 +142,9 @@ __device__ __forceinline__ void lz_aop(const double* p, double (&a)[NT]) {
 // wave's outstanding LDS operations and keeps the compiler from moving memory accesses across
 #define HPF_WAVE_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
+#ifndef HPF_Q100L_OCC
+#define HPF_Q100L_OCC 2    // ... and of its leaf-only instantiation
+#endif
 #ifndef HPF_Q100_OCC
 #define HPF_Q100_OCC 2     // the same for 52 < B <= 100 (7 waves per workgroup: 2 -> one workgroup per CU, 4 -> two)
 #endif
@@ -1259,7 +1262,41 @@ __device__ __forceinline__ void factor_q_body(
                 cv[tr * 4 + reg] = fma(gb, fma(both, hb, rowp * ha), ga * fma(colp, hb, own * ha));
             }
     };
-    if (par >= 0 && !cmp_c && (!lazy_leaf || wv == tcB)) {            // (lazy leaf: only the right-hand-side column G w is needed)
+    if (LEAF && B > 52) {
+        // leaf-only launches of the large blocks: the Schur complement goes out pair of row groups by pair of row groups (nothing of it is held:
+        // with the whole image of the push in registers next to the inverse's the kernel needs 216 registers = ONE workgroup per CU)
+        if (par >= 0) {
+            double* Ck = Call + ((size_t)s * n + k) * CT;
+            const int ti = lg & 1, tcn = jj & 1;
+            double ha = hl[p * 4 + 2 * tcn + tcn], hb = hl[p * 4 + 2 * (tcn ^ 1) + tcn];
+            if (col == B) {
+                ha = 1.0;
+                hb = 0.0;
+            }
+            if (col > B) {
+                ha = 0.0;
+                hb = 0.0;
+            }
+            const bool st_ok = TileIO<B>::ok(wv, jj);
+            auto one = [&](const int e) {
+                const int tr = e >> 2, reg = e & 3;
+                const int q = 8 * tr + 2 * reg + (lg >> 1);
+                const double ga = gl[q * 4 + 2 * ti + ti], gb = gl[q * 4 + 2 * ti + (ti ^ 1)];
+                const double own = ct[tr][reg];
+                const double rowp = xor16_f64(own);
+                const double colp = xor1_f64(own);
+                const double both = xor1_f64(rowp);
+                return fma(gb, fma(both, hb, rowp * ha), ga * fma(colp, hb, own * ha));
+            };
+#pragma unroll
+            for (int pp = 0; pp < TileIO<B>::NP; ++pp) {
+                const double a = one(2 * pp), b2 = one(2 * pp + 1);
+                if (st_ok) *reinterpret_cast<double2*>(Ck + TileIO<B>::off2(pp, wv, lg, jj)) = double2{a, b2};
+            }
+            const double z = one(TileIO<B>::NE - 1);
+            if (st_ok) Ck[TileIO<B>::off1(wv, lg, jj)] = z;
+        }
+    } else if (par >= 0 && !cmp_c && (!lazy_leaf || wv == tcB)) {            // (lazy leaf: only the right-hand-side column G w is needed)
         double* Ck = Call + ((size_t)s * n + k) * CT;
         double cv[NT * 4];
         schur_tiles(gl, hl, 1.0, true, cv);
@@ -1390,7 +1427,7 @@ __device__ __forceinline__ void factor_q_body(
 // LEAF: every bus of the launch is a constant-inverse leaf (elimination level 0 of the contracted tree): the general path
 // (assembly, child sums, Gauss-Jordan) is compiled out and with it most of the register budget -> more workgroups per CU.
 template <int B, bool LEAF>
-__global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 52 ? (LEAF ? 2 : HPF_Q100_OCC) : (B > 28 ? (LEAF ? 6 : HPF_Q_OCC) : 5))) void k_factor_q(
+__global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 52 ? (LEAF ? HPF_Q100L_OCC : HPF_Q100_OCC) : (B > 28 ? (LEAF ? 6 : HPF_Q_OCC) : 5))) void k_factor_q(
     Model M, TreeDev T, const int* __restrict__ nodes, int b, int N, int Nc, const int* __restrict__ active,
     const cplx* __restrict__ Uall, const cplx* __restrict__ Eall, const double* __restrict__ fall, double* __restrict__ Zall,
     double* __restrict__ wall, const double* __restrict__ linAall, double* __restrict__ Call, double* __restrict__ Hall,
