@@ -1262,10 +1262,10 @@ __device__ __forceinline__ void factor_q_body(
                 cv[tr * 4 + reg] = fma(gb, fma(both, hb, rowp * ha), ga * fma(colp, hb, own * ha));
             }
     };
-    if (LEAF && B > 52) {
-        // leaf-only launches of the large blocks: the Schur complement goes out pair of row groups by pair of row groups (nothing of it is held:
-        // with the whole image of the push in registers next to the inverse's the kernel needs 216 registers = ONE workgroup per CU)
-        if (par >= 0) {
+    if (B > 52) {
+        // large blocks: the Schur complement goes out pair of row groups by pair of row groups (nothing of it is held: with the whole image of
+        // the push in registers next to the inverse's the leaf-only kernel needs 216 registers = ONE workgroup per CU)
+        if (par >= 0 && !cmp_c) {
             double* Ck = Call + ((size_t)s * n + k) * CT;
             const int ti = lg & 1, tcn = jj & 1;
             double ha = hl[p * 4 + 2 * tcn + tcn], hb = hl[p * 4 + 2 * (tcn ^ 1) + tcn];
