@@ -57,6 +57,7 @@ def parse(argv=None):
     ap.add_argument("--cpu-iters", type=int, default=12, help="NR iterations of the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-workers", type=int, default=0, help="worker processes of the all-cores CPU leg (0 = host cores, at most 16)")
     ap.add_argument("--no-finish", action="store_true", help="skip the untimed solve-to-convergence + stats gather")
+    ap.add_argument("--no-probe", action="store_true", help="skip the untimed probe of the stream configuration (profiling runs: a fixed number of steps)")
     ap.add_argument("--sweep-1gpu", type=int, default=1024, help="(N = 1) scenarios of the single-GPU sweep leg (0 = skip)")
     ap.add_argument("--single", action="store_true", help="(default on rank 0 at N=1) also time a single-scenario solve: BASELINE config 3")
     ap.add_argument("--no-single", action="store_true", help="skip the single-scenario latency leg")
@@ -210,7 +211,7 @@ def main():
     # process keeps a queue busy (another library's stream) two groups share one and the step is ~30 % slower -- then three groups are the
     # better configuration for THIS process.  A few iterations of each, the default stays unless it is clearly on that cliff.
     groups_probe = None
-    if args.solver == "block_tree" and dm.scenario_groups(S) >= 4:
+    if args.solver == "block_tree" and dm.scenario_groups(S) >= 4 and not args.no_probe:
         def per_iter(k=4):
             dm.sync()
             t = time.perf_counter()

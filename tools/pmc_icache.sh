@@ -2,7 +2,7 @@
 # Instruction-cache counters of the bench kernels (one rocprofv3 --pmc pass per group, kernel-trace only):  bash tools/pmc_icache.sh <tag> [bench.py args...]
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 TAG=$1; shift
-ARGS="--steps 5 --warmup 2 --repeats 1 --cpu-iters 0 --no-finish --no-single --sweep-1gpu 0 $@"
+ARGS="--steps 5 --warmup 2 --repeats 1 --cpu-iters 0 --no-finish --no-probe --no-single --sweep-1gpu 0 $@"
 d=gpurun_out/${TAG}_ic; rm -rf $d; mkdir -p $d
 i=0
 for c in "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE" "SQ_IFETCH SQ_IFETCH_LEVEL SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQC_ICACHE_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVES SQ_INSTS_VALU"; do

@@ -3,7 +3,7 @@
 #   bash tools/pmc_tlb.sh <tag> [bench.py args...]  -> gpurun_out/<tag>_tlb.txt
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 TAG=$1; shift
-ARGS="--steps 5 --warmup 2 --repeats 1 --cpu-iters 0 --no-finish --no-single --sweep-1gpu 0 $@"
+ARGS="--steps 5 --warmup 2 --repeats 1 --cpu-iters 0 --no-finish --no-probe --no-single --sweep-1gpu 0 $@"
 d=gpurun_out/${TAG}_tlb; rm -rf $d; mkdir -p $d
 i=0
 for c in "TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_MISS_UNDER_MISS_sum" \
