@@ -827,6 +827,7 @@ int launch_back_w(hpf_handle* h, const TreeDev& T, const int* nodes, int count, 
 }
 
 #include "hpf_quad.hpp"
+#include "hpf_lin2x2.hpp"
 #include "hpf_leafbatch.hpp"
 
 // One launch per elimination level (b = 52 blocks, 256-thread workgroups): the scenario-batched workgroups of the level (lazy leaves
