@@ -265,6 +265,19 @@ def main():
     dm.sync()
     tim["gj_dev"] = dm.timing_get()["gj_dev"]
     dm.timing(False)
+    # ... and the same kernel with the chip to itself: the scenarios as ONE group (one launch per level, no other stream busy), K more steps
+    tim["gj_dev_one_group"] = None
+    if args.solver == "block_tree" and dm.scenario_groups(S) > 1:
+        g_now = dm.scenario_groups(S)
+        dm.set_option("scenario_groups", 1)
+        dm.iterate(2)
+        dm.timing(2)
+        dm.timing_reset()
+        dm.iterate(Kt)
+        dm.sync()
+        tim["gj_dev_one_group"] = dm.timing_get()["gj_dev"]
+        dm.timing(False)
+        dm.set_option("scenario_groups", g_now)
 
     # ---- untimed: finish the solves with the reference's stop rule, gather convergence statistics (RCCL) ----------
     sweep = None
@@ -311,6 +324,16 @@ def main():
     avg_ms = gj_ms / max(gj_n, 1)
     achieved_gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else None
     achieved_tf = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else None
+    one_group = None                              # the same kernel, all scenarios in one launch per level, nothing else on the chip
+    if bt and tim.get("gj_dev_one_group") and tim["gj_dev_one_group"][1]:
+        o_ms, o_n = tim["gj_dev_one_group"]
+        o_bpl = by_gj * S / max(o_n / max(Kt, 1), 1)
+        o_avg = o_ms / o_n
+        one_group = {"avg_ms": o_avg, "bytes_per_launch": o_bpl, "achieved": o_bpl / (o_avg * 1e-3) / 1e9,
+                     "frac": o_bpl / (o_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, "launches_per_step": o_n / max(Kt, 1),
+                     "mfma_frac": (fl_gj * S / max(o_n / max(Kt, 1), 1)) / (o_avg * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                     "note": "the same kernel with the scenarios as ONE group (one launch per elimination level, no other stream busy): the kernel's own "
+                             "figure, without the chip sharing of the %d concurrent groups the step is run with (which is faster as a whole)" % G}
     # the whole factor sweep (all factor kernels) and the whole step, algorithmic bytes over wall time
     sweep_bytes = dm.solve_bytes() * S
     nnz = len(inp["Y"].col)
@@ -368,6 +391,7 @@ def main():
                      "avg_ms": avg_ms, "avg_ms_hip_event_spans": ev_ms / max(ev_n, 1), "launches_timed": gj_n,
                      "launches_per_step": launches_per_step,
                      "concurrent_groups": G,
+                     "one_group": one_group,
                      "mfma": {"achieved": achieved_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": achieved_tf / FP64_PEAK_TFLOPS if achieved_tf else None},
                      "note": "achieved = algorithmic bytes of this kernel's buses (hpf_kernel_model: Schur complements in and out, "
