@@ -277,6 +277,12 @@ def main():
         dm.sync()
         tim["gj_dev_one_group"] = dm.timing_get()["gj_dev"]
         dm.timing(False)
+        dm.timing(True)                              # (HIP-event spans: the mismatch kernel of the one-group configuration)
+        dm.timing_reset()
+        dm.iterate(Kt)
+        dm.sync()
+        tim["mismatch_one_group"] = dm.timing_get()["mismatch"]
+        dm.timing(False)
         dm.set_option("scenario_groups", g_now)
 
     # ---- untimed: finish the solves with the reference's stop rule, gather convergence statistics (RCCL) ----------
@@ -332,6 +338,7 @@ def main():
         one_group = {"avg_ms": o_avg, "bytes_per_launch": o_bpl, "achieved": o_bpl / (o_avg * 1e-3) / 1e9,
                      "frac": o_bpl / (o_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, "launches_per_step": o_n / max(Kt, 1),
                      "mfma_frac": (fl_gj * S / max(o_n / max(Kt, 1), 1)) / (o_avg * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                     "assembly_frac": None,
                      "note": "the same kernel with the scenarios as ONE group (one launch per elimination level, no other stream busy): the kernel's own "
                              "figure, without the chip sharing of the %d concurrent groups the step is run with (which is faster as a whole)" % G}
     # the whole factor sweep (all factor kernels) and the whole step, algorithmic bytes over wall time
@@ -349,6 +356,10 @@ def main():
     # k_mismatch (harmonic_mismatch HG:360-390, the assembly kernel that reaches HBM): algorithmic bytes of a launch / its HIP-event span
     asm_gbs = (bytes_mismatch * S / max(tim["mismatch"][1] / max(Kt, 1), 1) / (tim["mismatch"][0] / max(tim["mismatch"][1], 1) * 1e-3) / 1e9
                if tim["mismatch"][1] else None)
+    if one_group and tim.get("mismatch_one_group") and tim["mismatch_one_group"][1]:
+        mm_ms, mm_n = tim["mismatch_one_group"]
+        one_group["assembly_frac"] = bytes_mismatch * S / max(mm_n / max(Kt, 1), 1) / (mm_ms / mm_n * 1e-3) / 1e9 / HBM_PEAK_GBS
+        one_group["assembly_ms_per_launch"] = mm_ms / mm_n
     kname = "k_factor_q<%d,false>" % (100 if b > 52 else (52 if b > 28 else (28 if b > 12 else 12))) if bt and b <= 100 else ("k_tree_factor (generic)" if bt else "rocsolver_dgetrf/dgetrs")
     kdesc = kname + (" alone (general multi-wave block-tree factor kernel: Gauss-Jordan buses and non-batched super-leaves; %d launches per "
                      "Newton step and scenario group, one per tree level)" % ln_gj)
