@@ -165,7 +165,7 @@ def main():
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (one rank per GPU: start it as `python bench.py --gpus N` or under "
                          "torch.distributed.run with --nproc-per-node N)" % (args.gpus, world))
-    cpu = cpu_baseline_start(args) if rank == 0 else None      # rank 0 of every world size; child processes, before any GPU initialisation
+    cpu = cpu_baseline_start(args) if (rank == 0 and world == 1) else None      # N = 1 only (the other ranks of a larger job would wait for it); child processes, before any GPU initialisation
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
