@@ -35,6 +35,8 @@ SYMBOLS = {
     "hpf_version": (C.c_int, []),
     "hpf_num_unknowns": (C.c_int, [_H]),
     "hpf_num_unknowns_fund": (C.c_int, [_H]),
+    "hpf_num_scenarios": (C.c_int, [_H]),
+    "hpf_max_scenarios": (C.c_int, [_H]),
     "hpf_tree_levels": (C.c_int, [_H]),
     "hpf_tree_depths": (C.c_int, [_H]),
     "hpf_set_loads": (C.c_int, [_H, C.c_int, c_dbl_p, c_dbl_p]),
@@ -63,6 +65,7 @@ SYMBOLS = {
     "hpf_timing_get": (C.c_int, [_H, C.c_int, c_dbl_p, C.POINTER(C.c_int64)]),
     "hpf_timing_reset": (C.c_int, [_H]),
     "hpf_dense_solve": (C.c_int, [C.c_int, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p]),
+    "hpf_sparse_solve": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, c_int_p, c_int_p, c_dbl_p, c_dbl_p, c_dbl_p]),
     "hpf_solve_flops": (C.c_double, [_H]),
     "hpf_solve_bytes": (C.c_double, [_H]),
     "hpf_back_bytes": (C.c_double, [_H]),

@@ -10,6 +10,12 @@ working unchanged.
 
 Everything numerical runs on the GPU through `DeviceModel`; nothing here falls back to the CPU.
 """
+import atexit
+import collections
+import contextlib
+import hashlib
+import os
+
 import numpy as np
 import pandas as pd
 import scipy.sparse as sp
@@ -94,21 +100,89 @@ def _device_model(buses, Y, NE, coupled, harmonics, solver="auto", max_scenarios
                        solver=solver, device=device, max_scenarios=max_scenarios, assembly_only=assembly_only)
 
 
+# ---- handle cache -------------------------------------------------------------------------------------------------------------------------
+# The reference's sweep is repeated hpf() calls (HG:511) with other buses.P / buses.Q; its functions are stateless, ours own a device handle whose
+# creation (tree planning on the host, uploads, allocation: 15 ms at 1 000 buses x 26 harmonics) costs more than the solve.  The reference call
+# shapes therefore BORROW a handle from a small LRU keyed on everything hpf_create consumes -- network constants, admittance pattern and values,
+# Norton arrays, harmonics, solver, and the HPF_* environment switches hpf_create reads -- and set loads / state / options themselves on every
+# call, so a borrowed handle and a fresh one give bit-identical results.  Not thread-safe (neither is the reference: module globals).
+_HANDLES = collections.OrderedDict()
+_HANDLE_CACHE = {"size": 4, "hits": 0, "misses": 0}
+
+
+def _digest(*arrays):
+    h = hashlib.blake2b(digest_size=16)
+    for a in arrays:
+        a = np.ascontiguousarray(a)
+        h.update(str((a.dtype.str, a.shape)).encode())
+        h.update(a.view(np.uint8).reshape(-1).data)
+    return h.digest()
+
+
+def handle_cache(size=None):
+    """Size of the LRU of device handles behind hpf / pf / harmonic_mismatch / build_harmonic_jacobian (default 4; 0 switches it off: every
+    call creates and destroys its own handle, as before round 5).  Returns the statistics dict (size, hits, misses)."""
+    if size is not None:
+        _HANDLE_CACHE["size"] = max(int(size), 0)
+        while len(_HANDLES) > _HANDLE_CACHE["size"]:
+            _HANDLES.popitem(last=False)[1].close()
+    return dict(_HANDLE_CACHE, held=len(_HANDLES))
+
+
+def close_all():
+    """Destroy every cached device handle (also run at interpreter exit)."""
+    while _HANDLES:
+        _HANDLES.popitem(last=False)[1].close()
+
+
+atexit.register(close_all)
+
+
+@contextlib.contextmanager
+def _borrow_model(buses, Y, NE, coupled, harmonics, solver="auto", assembly_only=False, device=0):
+    """A DeviceModel of one scenario for the duration of a reference-shaped call: from the cache, or created (and then kept)."""
+    if _HANDLE_CACHE["size"] <= 0:
+        dm = _device_model(buses, Y, NE, coupled, harmonics, solver=solver, device=device, assembly_only=assembly_only)
+        try:
+            yield dm
+        finally:
+            dm.close()
+        return
+    m, n, c = ingest.network_constants(buses)
+    if NE is None:
+        ne_key = b"none"
+    else:
+        dev, Y_N, I_N, n_dev = ingest.norton_arrays(buses, NE, coupled, len(harmonics))
+        ne_key = _digest(dev, Y_N, I_N)
+    env = tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("HPF_")))
+    key = (n, m, c, tuple(harmonics), bool(coupled), solver, bool(assembly_only), int(device), _digest(Y.rowptr, Y.col, Y.Yval), ne_key, env)
+    dm = _HANDLES.pop(key, None)
+    if dm is None:
+        _HANDLE_CACHE["misses"] += 1
+        dm = _device_model(buses, Y, NE, coupled, harmonics, solver=solver, device=device, assembly_only=assembly_only)
+    else:
+        _HANDLE_CACHE["hits"] += 1
+    try:
+        yield dm
+    except BaseException:
+        dm.close()                                     # (a failed call may leave the handle in any state: not kept)
+        raise
+    _HANDLES[key] = dm
+    while len(_HANDLES) > _HANDLE_CACHE["size"]:
+        _HANDLES.popitem(last=False)[1].close()
+
+
 def pf(Y, buses, thresh_f=1e-6, max_iter_f=30, plt_convergence=False, settings=None, verbose=True, _model=None):
     """HG:244-275 -> (V, err_t, n_iter_f): fundamental Newton-Raphson on the device from the reference's start
     (1 p.u. / 0.1 p.u., angle 0)."""
     st = settings or globals()["settings"]
     n = len(buses)
     Y = _as_admittance(Y, st.HARMONICS, n)
-    dm = _model or _device_model(buses, Y, None, False, Y.harmonics, solver="dense")
-    try:
+    with (contextlib.nullcontext(_model) if _model is not None else _borrow_model(buses, Y, None, False, Y.harmonics, solver="dense")) as dm:
         dm.set_loads(buses["P"].to_numpy(dtype=float), buses["Q"].to_numpy(dtype=float))
         dm.set_state(None, None, n_scen=1)
         n_iter, err, hist = dm.fund_pf(thresh_f, max_iter_f)
         Vm, Va = dm.get_state()
-    finally:
-        if _model is None:
-            dm.close()
     n_iter_f = int(n_iter[0])
     err_t = {i: float(hist[0, i]) for i in range(n_iter_f)}
     V = _frame(Vm[0], Va[0], Y.harmonics, n)
@@ -150,8 +224,7 @@ def hpf(buses, lines, coupled, thresh_h=1e-4, max_iter_h=50, plt_convergence=Fal
     n = len(buses)
     Y = build_admittance_matrices(buses, lines, harmonics)                       # HG:523
     NE = import_Norton_Equivalents(buses, coupled, st, ne_dir)                    # HG:528
-    dm = _device_model(buses, Y, NE, coupled, harmonics, solver=solver)
-    try:
+    with _borrow_model(buses, Y, NE, coupled, harmonics, solver=solver) as dm:
         dm.set_loads(buses["P"].to_numpy(dtype=float), buses["Q"].to_numpy(dtype=float))
         dm.set_state(None, None, n_scen=1)
         nf, ef, hf = dm.fund_pf(st.thresh_f, st.max_iter_f)                       # HG:525 (pf with its defaults)
@@ -165,8 +238,7 @@ def hpf(buses, lines, coupled, thresh_h=1e-4, max_iter_h=50, plt_convergence=Fal
                 print("Warning! Maximum of " + str(int(nf[0])) + " iterations reached.")
         # (block-tree: hpf_solve itself watches the static pivot order and repeats a flagged scenario with partial pivoting)
         want_J = bool(return_jacobian)
-        if want_J:
-            dm.set_option("keep_previous_state", 1)
+        dm.set_option("keep_previous_state", 1 if want_J else 0)      # (explicit both ways: the handle may be a borrowed one)
         n_iter, err, hist = dm.solve(thresh_h, max_iter_h)                        # HG:530-542
         stats = dm.stats()
         if details is not None:
@@ -189,8 +261,6 @@ def hpf(buses, lines, coupled, thresh_h=1e-4, max_iter_h=50, plt_convergence=Fal
                            n_iter_f=int(nf[0]), err_f=hf[0, :int(nf[0])].copy(), solver=dm.solver,
                            tree=(dm.tree_census() if dm.solver == "block_tree" else None),
                            stats=stats, Vm_raw=Vm_raw[0].copy(), Va_raw=Va_raw[0].copy(), N=dm.N)
-    finally:
-        dm.close()
     Vm, Va = _postprocess(Vm_raw[0], Va_raw[0])                                   # HG:545-549
     V = _frame(Vm, Va, harmonics, n)
     err_h = float(err[0])
@@ -217,13 +287,10 @@ def harmonic_mismatch(V, Y, buses, NE, settings=None):
     harmonics = list(dict.fromkeys(V.index.get_level_values(0)))
     Y = _as_admittance(Y, harmonics, n)
     coupled = np.asarray(next(iter(NE.values()))[1]).shape[0] > 1 if NE else False
-    dm = _device_model(buses, Y, NE, coupled, harmonics, solver="dense", assembly_only=True)
-    try:
+    with _borrow_model(buses, Y, NE, coupled, harmonics, solver="dense", assembly_only=True) as dm:
         dm.set_loads(buses["P"].to_numpy(dtype=float), buses["Q"].to_numpy(dtype=float))
         dm.set_state(*_state_arrays(V))
         f, err = dm.mismatch()
-    finally:
-        dm.close()
     return f[0], float(err[0])
 
 
@@ -235,13 +302,10 @@ def build_harmonic_jacobian(V, Y, NE, coupled, buses=None):
     n = len(buses)
     harmonics = list(dict.fromkeys(V.index.get_level_values(0)))
     Y = _as_admittance(Y, harmonics, n)
-    dm = _device_model(buses, Y, NE, coupled, harmonics, solver="dense", assembly_only=True)
-    try:
+    with _borrow_model(buses, Y, NE, coupled, harmonics, solver="dense", assembly_only=True) as dm:
         dm.set_loads(buses["P"].to_numpy(dtype=float), buses["Q"].to_numpy(dtype=float))
         dm.set_state(*_state_arrays(V))
         J = dm.jacobian_csr(0)
-    finally:
-        dm.close()
     return J
 
 
@@ -253,17 +317,57 @@ def harmonic_state_vector(V, c=None, buses=None):
     return np.append(V.V_a.to_numpy()[1:], V.V_m.to_numpy()[c:])
 
 
-def update_harmonic_state_vec(J, x, f, device=0):
-    """HG:476-479: x - spsolve(J, f).  The linear solve runs on the GPU (rocSOLVER LU with partial pivoting through
-    `hpf_dense_solve`); J may be a SciPy sparse matrix (as `build_harmonic_jacobian` returns it) or a dense array."""
+def _dims_from_context(N):
+    """(n, c, Hn) of the network the last init_network call loaded, if a Jacobian of N unknowns can belong to it (N = 2 n Hn - 1 - c)."""
+    b = _ctx["buses"]
+    if b is None:
+        return None
+    n = len(b)
+    c = ingest.network_constants(b)[2]
+    Hn, rem = divmod(N + 1 + c, 2 * n)
+    return (n, c, Hn) if rem == 0 and Hn >= 1 else None
+
+
+def update_harmonic_state_vec(J, x, f, device=0, dims=None):
+    """HG:476-479: x - spsolve(J, f), the linear solve on the GPU.
+
+    J sparse (what `build_harmonic_jacobian` / `hpf` return, and what the reference passes, HG:478): `hpf_sparse_solve` -- the CSR entries are
+    scattered on the device into bus-major 2Hn x 2Hn blocks and eliminated along the feeder tree; no N x N array exists on host or device, so the
+    1 000-bus x 26-harmonic Jacobian (N = 51 998, 1.2 M entries) is solved like the 46-unknown one.  The row / column numbering of the reference's
+    stacked matrix is a function of (n, c, Hn): taken from `dims=(n, c, Hn)`, else from the matrix itself (the Jacobians this package returns
+    carry it), else from the network of the last `init_network` call.  A meshed network's Jacobian (bus graph not a tree) and dense arrays go to
+    the dense rocSOLVER LU (`hpf_dense_solve`), which is bounded by 8 N^2 bytes of host and device memory."""
     lib = _lib.load()
-    Jd = np.asfortranarray(J.toarray() if hasattr(J, "toarray") else np.asarray(J), dtype=np.float64)
     fv = np.ascontiguousarray(f, dtype=np.float64)
     N = fv.size
+    dp = C.POINTER(C.c_double)
+    if sp.issparse(J):
+        if J.shape != (N, N):
+            raise ValueError("J must be %d x %d" % (N, N))
+        d = dims or getattr(J, "_hpf_dims", None) or _dims_from_context(N)
+        if d is not None and 2 * d[0] * d[2] - 1 - d[1] == N and 2 * d[2] <= 128:
+            Jc = J.tocsr()
+            if Jc.nnz >= 2 ** 31:
+                raise ValueError("hpf_sparse_solve takes 32-bit CSR indices (nnz < 2^31)")
+            indptr = np.ascontiguousarray(Jc.indptr, dtype=np.int32)
+            indices = np.ascontiguousarray(Jc.indices, dtype=np.int32)
+            data = np.ascontiguousarray(Jc.data, dtype=np.float64)
+            dx = np.empty(N)
+            ip = C.POINTER(C.c_int32)
+            rc = lib.hpf_sparse_solve(int(device), int(d[0]), int(d[1]), int(d[2]), indptr.ctypes.data_as(ip), indices.ctypes.data_as(ip),
+                                      data.ctypes.data_as(dp), fv.ctypes.data_as(dp), dx.ctypes.data_as(dp))
+            if rc == 0:
+                return np.asarray(x, dtype=np.float64) - dx
+            if rc != -3:                                   # (HPF_E_TOPOLOGY: meshed network -> the dense LU below)
+                raise RuntimeError("hpf_sparse_solve failed: %s (code %d)" % (lib.hpf_strerror(rc).decode(), rc))
+        if 8.0 * N * N > 16e9:
+            raise ValueError("update_harmonic_state_vec: a sparse Jacobian of %d unknowns %s; the dense fallback would need %.1f GB on the host -- "
+                             "solve such a network with hpf() (bordered block-tree step)"
+                             % (N, "on a meshed network" if d is not None else "whose (n, c, Hn) is unknown (pass dims=)", 8e-9 * N * N))
+    Jd = np.asfortranarray(J.toarray() if hasattr(J, "toarray") else np.asarray(J), dtype=np.float64)
     if Jd.shape != (N, N):
         raise ValueError("J must be %d x %d" % (N, N))
     dx = np.empty(N)
-    dp = C.POINTER(C.c_double)
     rc = lib.hpf_dense_solve(int(device), N, Jd.ctypes.data_as(dp), fv.ctypes.data_as(dp), dx.ctypes.data_as(dp))
     if rc != 0:
         raise RuntimeError("hpf_dense_solve failed: %s (code %d)" % (lib.hpf_strerror(rc).decode(), rc))

@@ -4,8 +4,8 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["hpf_lib.hip", "hpf_block.hip"]
-HEADERS = ["hpf_assembly.hpp", "hpf_internal.hpp", "hpf_gj.hpp", "hpf_gj_mfma.hpp", "hpf_quad.hpp", "hpf_lin2x2.hpp", "hpf_leafbatch.hpp", "hpf_tree_plan.hpp", os.path.join("..", "..", "include", "hpf.h")]
+SOURCES = ["hpf_lib.hip", "hpf_block.hip", "hpf_csr_solve.hip"]
+HEADERS = ["hpf_assembly.hpp", "hpf_internal.hpp", "hpf_gj.hpp", "hpf_gj_mfma.hpp", "hpf_gj_dense.hpp", "hpf_quad.hpp", "hpf_lin2x2.hpp", "hpf_leafbatch.hpp", "hpf_tree_plan.hpp", os.path.join("..", "..", "include", "hpf.h")]
 OUT = os.path.join(HERE, "libhpf.so")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 

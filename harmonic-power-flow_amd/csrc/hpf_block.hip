@@ -26,6 +26,7 @@
 
 #include "hpf_internal.hpp"
 #include "hpf_gj.hpp"
+#include "hpf_gj_dense.hpp"
 #include "hpf_gj_mfma.hpp"
 
 using namespace hpf;
@@ -101,15 +102,10 @@ __global__ __launch_bounds__(256) void k_tree_factor(Model M, TreeDev T, const i
     double* ws = wall + (size_t)s * n * b;
 
     extern __shared__ double lds[];
-    const int ldr = b | 1;
-    double* Rm = lds;                        // [b][ldr]
-    double* colbuf = Rm + (size_t)b * ldr;   // [b]
-    double* rowr = colbuf + b;               // [b]
-    double* rowj = rowr + b;                 // [b]
-    double* ybuf = rowj + b;                 // [b]
-    int* piv = (int*)(ybuf + b);             // [b]
-    int* pinv = piv + b;                     // [b]
-    int* pfwd = pinv + b;                    // [b]
+    const GjDenseLds L(lds, b);              // Rm [b][ldr] | colbuf, rowr, rowj, ybuf [b] | piv, pinv, pfwd [b]  (hpf_gj_dense.hpp)
+    const int ldr = L.ldr;
+    double *Rm = L.Rm, *ybuf = L.ybuf;
+    int *pinv = L.pinv, *pfwd = L.pfwd;
 
     // ---- A. assemble D_k in registers -------------------------------------------------------------------------
     double a[R][R];
@@ -182,112 +178,8 @@ __global__ __launch_bounds__(256) void k_tree_factor(Model M, TreeDev T, const i
         }
     }
 
-    // ---- C. in-place Gauss-Jordan inversion with partial pivoting ---------------------------------------------
-    for (int j = 0; j < b; ++j) {
-        const int jr = j >> 4, jc = j & 15;       // owner thread-row index (tr == jc... see below)
-        // column j -> LDS
-        if (tc == (j & 15)) {
-#pragma unroll
-            for (int ai = 0; ai < R; ++ai) {
-                const int i = tr + 16 * ai;
-                if (i < b) {
-#pragma unroll
-                    for (int ci = 0; ci < R; ++ci)
-                        if (ci == (j >> 4)) colbuf[i] = a[ai][ci];
-                }
-            }
-        }
-        __syncthreads();
-        // pivot row: largest |.| among rows >= j (lowest index wins ties), computed redundantly by every thread
-        int r = j;
-        double best = fabs(colbuf[j]);
-        for (int i = j + 1; i < b; ++i) {
-            const double v = fabs(colbuf[i]);
-            if (v > best) {
-                best = v;
-                r = i;
-            }
-        }
-        // rows r and j -> LDS
-        if (tr == (r & 15)) {
-#pragma unroll
-            for (int ai = 0; ai < R; ++ai)
-                if (ai == (r >> 4)) {
-#pragma unroll
-                    for (int ci = 0; ci < R; ++ci) {
-                        const int cc = tc + 16 * ci;
-                        if (cc < b) rowr[cc] = a[ai][ci];
-                    }
-                }
-        }
-        if (r != j && tr == (j & 15)) {
-#pragma unroll
-            for (int ai = 0; ai < R; ++ai)
-                if (ai == (j >> 4)) {
-#pragma unroll
-                    for (int ci = 0; ci < R; ++ci) {
-                        const int cc = tc + 16 * ci;
-                        if (cc < b) rowj[cc] = a[ai][ci];
-                    }
-                }
-        }
-        if (tid == 0) piv[j] = r;
-        __syncthreads();
-        const double inv = 1.0 / colbuf[r];
-        // scaled pivot row values of my columns (column j itself becomes 1/pivot)
-        double prow[R];
-#pragma unroll
-        for (int ci = 0; ci < R; ++ci) {
-            const int cc = tc + 16 * ci;
-            prow[ci] = cc < b ? (cc == j ? inv : rowr[cc] * inv) : 0.0;
-        }
-#pragma unroll
-        for (int ai = 0; ai < R; ++ai) {
-            const int i = tr + 16 * ai;
-            if (i >= b) continue;
-            if (i == j) {
-#pragma unroll
-                for (int ci = 0; ci < R; ++ci) a[ai][ci] = prow[ci];
-            } else {
-                // after the swap row r holds the old row j
-                const double fct = (i == r) ? colbuf[j] : colbuf[i];
-#pragma unroll
-                for (int ci = 0; ci < R; ++ci) {
-                    const int cc = tc + 16 * ci;
-                    if (cc >= b) continue;
-                    const double base = (i == r) ? rowj[cc] : a[ai][ci];
-                    a[ai][ci] = (cc == j) ? -fct * inv : fma(-fct, prow[ci], base);
-                }
-            }
-        }
-        (void)jr;
-        (void)jc;
-        // the LDS buffers are rewritten only after the next barrier pair, but colbuf is rewritten first:
-        __syncthreads();
-    }
-
-    // ---- D. R = (P D)^{-1} -> LDS; permutation pi with (P x)[k] = x[pi[k]] ------------------------------------
-#pragma unroll
-    for (int ai = 0; ai < R; ++ai) {
-        const int i = tr + 16 * ai;
-        if (i >= b) continue;
-#pragma unroll
-        for (int ci = 0; ci < R; ++ci) {
-            const int cc = tc + 16 * ci;
-            if (cc < b) Rm[(size_t)i * ldr + cc] = a[ai][ci];
-        }
-    }
-    if (tid == 0) {
-        for (int i = 0; i < b; ++i) pfwd[i] = i;
-        for (int j = 0; j < b; ++j) {
-            const int r = piv[j];
-            const int tmp = pfwd[j];
-            pfwd[j] = pfwd[r];
-            pfwd[r] = tmp;
-        }
-        for (int i = 0; i < b; ++i) pinv[pfwd[i]] = i;
-    }
-    __syncthreads();
+    // ---- C / D. in-place Gauss-Jordan inversion with partial pivoting: R = (P D)^{-1} -> LDS (Rm), permutation pfwd / pinv --------
+    gj_dense_invert<R>(a, b, L, nullptr);
 
     // ---- E. w_k = D^{-1} y,  Z_k = D^{-1} A(k, parent) ----------------------------------------------------------
     if (tid < b) {
@@ -926,21 +818,22 @@ int upload(hpf_handle* h, T** dst, const std::vector<T>& v) {
     return HPF_OK;
 }
 
-size_t factor_lds_bytes(int b) {
-    const int ldr = b | 1;
-    return sizeof(double) * ((size_t)b * ldr + 4 * (size_t)b) + sizeof(int) * 3 * (size_t)b;
-}
+size_t factor_lds_bytes(int b) { return gj_dense_lds_bytes(b); }
 
 template <int R>
 int launch_factor(hpf_handle* h, const TreeDev& T, const int* nodes, int count, const int* active) {
     ScopedTimer t(h, T_SOLVE);
     const int b = 2 * h->Hn;
     const size_t lds = factor_lds_bytes(b);
-    static bool attr_set = false;
-    if (!attr_set && lds > 64 * 1024) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_factor<R>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds);
-        attr_set = true;
+    if (lds > 64 * 1024) {
+        // (per launch, like launch_mismatch: the attribute belongs to the device the handle runs on -- a process-wide "already set" flag
+        //  would skip it for a second device -- and the call costs nothing next to the launch)
+        if (lds > 160 * 1024) return HPF_E_ARG;
+        const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tree_factor<R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (ea != hipSuccess) {
+            h->last_detail = (int)ea;
+            return HPF_E_HIP;
+        }
     }
     hipLaunchKernelGGL((k_tree_factor<R>), dim3((unsigned)count, (unsigned)h->cur_S), dim3(256), lds, h->cur_stream, h->M, T,
                        nodes, b, h->N, h->Nc, active, h->d_U, h->d_E, h->d_f, h->d_Z, h->d_w, h->cur_s0);
@@ -1316,8 +1209,7 @@ int tree_newton_step(hpf_handle* h, bool only_active) {
     // one launch per depth for all bus kinds (k_level_back) where the batched bodies exist and every body has four wavefronts
     // (groups of up to 32 scenarios only: larger launches are throughput-bound, and k_back_q alone runs at twice the
     //  occupancy of the fused kernel -- 5.2 vs 5.4 ms per step at 1 024 scenarios, 0.297 vs 0.288 ms at one)
-    static const int fuse_back_max = getenv("HPF_FUSEBACK_MAX") ? atoi(getenv("HPF_FUSEBACK_MAX")) : 32;
-    bool fused_back = h->fuse_back && h->cur_S <= fuse_back_max && h->leafbatch && h->has_ctree && h->gj_mode == 1 && BW == 52 &&
+    bool fused_back = h->fuse_back && h->cur_S <= h->fuse_back_max && h->leafbatch && h->has_ctree && h->gj_mode == 1 && BW == 52 &&
                       (int)T.bsl_dep_ptr.size() == T.n_depths + 1 && (int)T.bleaf_dep_ptr.size() == T.n_depths + 1 && (int)T.dep_nleaf.size() >= T.n_depths;
     for (int dl = 1; fused_back && dl < T.n_depths; ++dl)         // (a depth's batched records are exactly its leaves + bordered buses)
         fused_back = T.bsl_dep_ptr[dl + 1] - T.bsl_dep_ptr[dl] + T.bleaf_dep_ptr[dl + 1] - T.bleaf_dep_ptr[dl] == T.dep_nleaf[dl];
@@ -1532,8 +1424,7 @@ int ensure_blas(hpf_handle* h) {
 // virtual scenario slots of the bordered step: all 1 + m right-hand sides at once up to 256, above that chunks of up to 1 024 (a chunk
 // runs in the throughput regime of the tree kernels: 6.5 us per scenario-step at 256 live slots, 5.5 at 1 024; 72 MB of state per slot)
 int border_slots(const hpf_handle* h) {
-    static const int cap = getenv("HPF_BORDER_SLOTS") ? atoi(getenv("HPF_BORDER_SLOTS")) : 1024;
-    const int c = cap < 16 ? 16 : cap;
+    const int c = h->border_slot_cap < 16 ? 16 : h->border_slot_cap;   // (HPF_BORDER_SLOTS, read by hpf_create into the handle)
     return h->m_border + 1 < 256 ? h->m_border + 1 : (h->m_border + 1 < c ? ((h->m_border + 1 + 15) / 16) * 16 : c);
 }
 

@@ -156,6 +156,8 @@ struct hpf_handle {
     int gj_mode = 1;                  // BLOCK_TREE block inversion: 0 pivoted wave Gauss-Jordan (VALU, uncontracted tree), 1 MFMA static 4x4 blocks, NT waves per bus (hpf_quad.hpp)
     double piv_limit = 1e10;          // static pivot order: amplification of a 4x4 pivot block's inverse beyond which a scenario is repeated with partial pivoting
     int fuse_back = 1;                // HPF_FUSEBACK (read by hpf_create): 0 = the back sweep's batched launches after the last depth instead of inside the depths' launches
+    int fuse_back_max = 32;           // HPF_FUSEBACK_MAX (read by hpf_create): largest scenario group that takes the fused back sweep
+    int border_slot_cap = 1024;       // HPF_BORDER_SLOTS (read by hpf_create): cap of the virtual scenario slots of a meshed handle's bordered step
     int fuse_levels = 1;              // HPF_FUSELEVEL (read by hpf_create): 0 = separate launches for the batched and the per-scenario workgroups of a level
     int leafbatch = 1;                // HPF_LEAFBATCH (read by hpf_create): 0 = one workgroup per (leaf, scenario) instead of 16 scenarios per workgroup
     int debug_ablate = 0;             // HPF_DEBUG_ABLATE: timing-only ablation of factor-kernel phases (results invalid)

@@ -87,7 +87,9 @@ __host__ inline dim3 xcd_grid(int nbx, int S) {
     return S < 8 ? dim3((unsigned)nbx, (unsigned)S, 1) : dim3(8, (unsigned)nbx, (unsigned)((S + 7) / 8));
 }
 // unsigned division of t < 2^32 / d by a run-time d through its reciprocal m = floor(2^32 / d) + 1 (host: div_magic): exact there
-__device__ __forceinline__ int div_by(int t, unsigned magic) { return (int)__umulhi((unsigned)t, magic); }
+// (hpf_create refuses models with (n Hn + 256) Hn >= 2^32).  d = 1 has no 32-bit reciprocal: magic 0 stands for "t itself" (a model
+// with the fundamental alone, H_MAX = 1 or 2).
+__device__ __forceinline__ int div_by(int t, unsigned magic) { return magic ? (int)__umulhi((unsigned)t, magic) : t; }
 __host__ inline unsigned div_magic(int d) { return d <= 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)d + 1ull); }
 
 // ||.||_inf with NaN propagation: |x| as its IEEE bit pattern is monotone for non-negative doubles, and every NaN
@@ -1004,6 +1006,16 @@ int trace_record(hpf_handle* h, int it) {
     return HPF_OK;
 }
 
+// pinned double buffer + events through which the host reads the slot counters one chunk late (every object under its own check: a failed
+// creation is retried by the next call instead of leaving a null event behind)
+int ensure_poll_buffers(hpf_handle* h) {
+    for (int i = 0; i < 2; ++i) {
+        if (!h->h_act[i]) HIPCHK(hipHostMalloc((void**)&h->h_act[i], sizeof(int) * 4, hipHostMallocDefault));
+        if (!h->poll_ev[i]) HIPCHK(hipEventCreateWithFlags(&h->poll_ev[i], hipEventDisableTiming));
+    }
+    return HPF_OK;
+}
+
 // One pass of the NR loop (HG:530-542 / HG:257-265) from the current state over the scenarios selected by `mask` (nullptr: all).
 template <bool FUND>
 int nr_pass(hpf_handle* h, double thresh, int max_iter, const int* mask) {
@@ -1048,12 +1060,7 @@ int nr_pass(hpf_handle* h, double thresh, int max_iter, const int* mask) {
         return for_groups(h, slots, body);
     };
     if (pipelined) {
-        if (!h->h_act[0]) {
-            for (int i = 0; i < 2; ++i) {
-                HIPCHK(hipHostMalloc((void**)&h->h_act[i], sizeof(int) * 4, hipHostMallocDefault));
-                HIPCHK(hipEventCreateWithFlags(&h->poll_ev[i], hipEventDisableTiming));
-            }
-        }
+        if ((r = ensure_poll_buffers(h))) return r;
         // Between two chunks the slot list is compacted on the device (running scenarios first) and their count goes to the
         // host; the count the host knows is one chunk old, i.e. an upper bound (the count only falls): it sizes the grids and
         // the scenario groups of the next chunk.  Slots behind the true count hold -1 and their workgroups exit at once.
@@ -1123,7 +1130,7 @@ int nr_pass(hpf_handle* h, double thresh, int max_iter, const int* mask) {
 
 template <bool FUND>
 int nr_loop(hpf_handle* h, double thresh, int max_iter, int* n_iter, double* err, double* err_hist) {
-    if (!h->loads_set || !h->state_set) return HPF_E_STATE;
+    if (!h->loads_set || !h->state_set || h->S < 1) return HPF_E_STATE;
     if (max_iter < 0) return HPF_E_ARG;
     int r;
     const int S = h->S;
@@ -1259,12 +1266,7 @@ int solve_queue_fast(hpf_handle* h, int n_total, const double* P, const double* 
     if (hipMemsetAsync(h->d_nactive, 0, sizeof(int), h->stream) != hipSuccess) return cleanup(HPF_E_HIP);
     if (hipMemsetAsync(h->d_pivflag, 0, sizeof(int) * S_max, h->stream) != hipSuccess) return cleanup(HPF_E_HIP);
     hipLaunchKernelGGL(k_set_int, dim3((unsigned)((S_max + TPB - 1) / TPB)), dim3(TPB), 0, h->stream, h->d_active, S_max, -1);   // (empty slot list)
-    if (!h->h_act[0]) {
-        for (int i = 0; i < 2; ++i) {
-            if (hipHostMalloc((void**)&h->h_act[i], sizeof(int) * 4, hipHostMallocDefault) != hipSuccess) return cleanup(HPF_E_HIP);
-            if (hipEventCreateWithFlags(&h->poll_ev[i], hipEventDisableTiming) != hipSuccess) return cleanup(HPF_E_HIP);
-        }
-    }
+    if ((r = ensure_poll_buffers(h))) return cleanup(r);
     const size_t q_lds = sizeof(int) * 2 * (size_t)S_max;
     // one round between two chunks: compact -> harvest / refill -> initial mismatch of the new scenarios -> counters to the host
     auto round = [&](int buf) -> int {
@@ -1386,6 +1388,9 @@ int hpf_create(hpf_handle** out, const hpf_desc* d) {
         return HPF_E_ARG;
     if (d->m < d->n && (d->n_dev < 1 || !d->Y_N || !d->I_N)) return HPF_E_ARG;
     if (d->solver != HPF_SOLVER_DENSE && d->solver != HPF_SOLVER_BLOCK_TREE) return HPF_E_ARG;
+    // (the per-entry kernels split a thread id t <= n Hn + 255 into (bus, harmonic) through a 32-bit reciprocal of Hn: exact for t Hn < 2^32;
+    //  and the stacked index n Hn itself has to fit an int with room for the 2 N + 1 sizes derived from it)
+    if (((long long)d->n * d->Hn + 256) * d->Hn >= (1ll << 32) || (long long)d->n * d->Hn >= (1ll << 29)) return HPF_E_ARG;
     // host-side validation of the pattern: sorted columns, diagonal present, indices in range
     std::vector<int> diag(d->n, -1), erow(d->nnz);
     if (d->rowptr[0] != 0 || d->rowptr[d->n] != d->nnz) return HPF_E_ARG;
@@ -1423,6 +1428,8 @@ int hpf_create(hpf_handle** out, const hpf_desc* d) {
     if (const char* lb = getenv("HPF_LEAFBATCH")) h->leafbatch = atoi(lb) ? 1 : 0;
     if (const char* fl = getenv("HPF_FUSELEVEL")) h->fuse_levels = atoi(fl) ? 1 : 0;
     if (const char* fb = getenv("HPF_FUSEBACK")) h->fuse_back = atoi(fb) ? 1 : 0;
+    if (const char* fm = getenv("HPF_FUSEBACK_MAX")) h->fuse_back_max = atoi(fm);
+    if (const char* bs = getenv("HPF_BORDER_SLOTS")) h->border_slot_cap = atoi(bs);
     if (hipSetDevice(d->device) != hipSuccess) return fail(HPF_E_HIP);
     if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) return fail(HPF_E_HIP);
     h->stream = h->own_stream;
@@ -1512,6 +1519,8 @@ int hpf_destroy(hpf_handle* h) {
 
 int hpf_num_unknowns(const hpf_handle* h) { return h ? h->N : HPF_E_ARG; }
 int hpf_num_unknowns_fund(const hpf_handle* h) { return h ? h->Nf : HPF_E_ARG; }
+int hpf_num_scenarios(const hpf_handle* h) { return h ? ((h->loads_set || h->state_set) ? h->S : 0) : HPF_E_ARG; }
+int hpf_max_scenarios(const hpf_handle* h) { return h ? h->S_max : HPF_E_ARG; }
 int hpf_tree_levels(const hpf_handle* h) { return h ? active_tree(const_cast<hpf_handle*>(h)).n_levels : HPF_E_ARG; }
 int hpf_tree_depths(const hpf_handle* h) { return h ? active_tree(const_cast<hpf_handle*>(h)).n_depths : HPF_E_ARG; }
 
@@ -1559,7 +1568,7 @@ int hpf_set_state(hpf_handle* h, int n_scen, const double* Vm, const double* Va)
 
 int hpf_get_state(hpf_handle* h, double* Vm, double* Va) {
     if (!h || !Vm || !Va) return HPF_E_ARG;
-    if (!h->state_set) return HPF_E_STATE;
+    if (!h->state_set || h->S < 1) return HPF_E_STATE;
     const size_t count = (size_t)h->n * h->Hn, cnt = (size_t)h->S * count;
     std::vector<double> tm(cnt), ta(cnt);
     HIPCHK(hipMemcpyAsync(tm.data(), h->d_Vm, sizeof(double) * cnt, hipMemcpyDeviceToHost, h->stream));
@@ -1576,7 +1585,7 @@ int hpf_get_state(hpf_handle* h, double* Vm, double* Va) {
 
 static int mismatch_impl(hpf_handle* h, bool fund, double* f, double* err) {
     if (!h) return HPF_E_ARG;
-    if (!h->loads_set || !h->state_set) return HPF_E_STATE;
+    if (!h->loads_set || !h->state_set || h->S < 1) return HPF_E_STATE;
     int r;
     if ((r = fund ? launch_polar<true>(h) : launch_polar<false>(h))) return r;
     HIPCHK(hipMemsetAsync(h->d_errbits, 0, sizeof(unsigned long long) * h->S, h->stream));
@@ -1644,10 +1653,8 @@ static int jacobian_csr_impl(hpf_handle* h, int scen, int32_t* indptr, int32_t* 
     if (!h->loads_set || !h->state_set) return HPF_E_STATE;
     int r;
     if ((r = jcsr_pattern(h))) return r;
-    if (!h->d_jval) {
-        if ((r = dev_alloc(h, &h->d_jval, (size_t)h->jnnz))) return r;
-        if ((r = dev_alloc(h, &h->d_jcol, (size_t)h->jnnz))) return r;
-    }
+    if (!h->d_jval && (r = dev_alloc(h, &h->d_jval, (size_t)h->jnnz))) return r;      // (each buffer under its own check: a failed second
+    if (!h->d_jcol && (r = dev_alloc(h, &h->d_jcol, (size_t)h->jnnz))) return r;      //  allocation is retried by the next call)
     if ((r = launch_polar<false>(h))) return r;
     const size_t so = (size_t)scen * h->n * h->Hn;
     hipLaunchKernelGGL(k_jcsr_fill, dim3((unsigned)((h->N + TPB - 1) / TPB)), dim3(TPB), 0, h->stream, h->M, h->N, h->Nc, h->d_jptr,
@@ -1788,6 +1795,7 @@ int hpf_iterate(hpf_handle* h, int iters) {
 
 int hpf_get_stats(hpf_handle* h, hpf_stat* stats) {
     if (!h || !stats) return HPF_E_ARG;
+    if (!h->state_set || h->S < 1) return HPF_E_STATE;     // (no batch in the handle, e.g. after hpf_solve_queue)
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(stats, h->d_stats, sizeof(hpf_stat) * h->S, hipMemcpyDeviceToHost));
     return HPF_OK;
@@ -1795,6 +1803,7 @@ int hpf_get_stats(hpf_handle* h, hpf_stat* stats) {
 
 int hpf_get_stats_dev(hpf_handle* h, void* stats_dev) {
     if (!h || !stats_dev) return HPF_E_ARG;
+    if (!h->state_set || h->S < 1) return HPF_E_STATE;
     HIPCHK(hipMemcpyAsync(stats_dev, h->d_stats, sizeof(hpf_stat) * h->S, hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return HPF_OK;
@@ -1907,27 +1916,52 @@ int hpf_timing_reset(hpf_handle* h) {
 }
 
 // update_harmonic_state_vec (HG:476-479) as a standalone call: dx = J^-1 f for a caller-supplied dense column-major J
-// (rocSOLVER getrf / getrs, partial pivoting).  No handle: the reference function is stateless too.
+// (rocSOLVER getrf / getrs, partial pivoting).  No handle: the reference function is stateless too.  N * N >= 2^31 (N > 46 340): rocSOLVER's
+// 64-bit entry points, exactly as dense_solve does for a handle; a system whose 8 N^2 bytes do not fit the device's free memory is refused with
+// HPF_E_NOMEM before anything is allocated (the sparse form of the same call, hpf_sparse_solve, has no such bound).
 int hpf_dense_solve(int device, int N, const double* J_colmajor, const double* f, double* dx) {
     if (N < 1 || !J_colmajor || !f || !dx) return HPF_E_ARG;
     if (hipSetDevice(device) != hipSuccess) return HPF_E_HIP;
+    const size_t elems = (size_t)N * N;
+    const bool wide = elems >= ((size_t)1 << 31);
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return HPF_E_HIP;
+        // J + rocSOLVER's workspace (a few panels) + pivots: leave 5 % + 64 MiB of headroom
+        const double need = 8.0 * (double)elems * 1.05 + 64.0 * 1048576.0;
+        if (need > (double)free_b) return HPF_E_NOMEM;
+    }
     rocblas_handle blas = nullptr;
     double *dJ = nullptr, *df = nullptr;
-    int *dip = nullptr, *dinfo = nullptr, info = 0, rc = HPF_OK;
+    int64_t *dip = nullptr, *dinfo = nullptr;            // (sized for the 64-bit path; the 32-bit one uses the front half)
+    int64_t info64 = 0;
+    int info32 = 0, rc = HPF_OK;
     if (rocblas_create_handle(&blas) != rocblas_status_success) return HPF_E_ROCSOLVER;
-    if (hipMalloc((void**)&dJ, sizeof(double) * (size_t)N * N) != hipSuccess || hipMalloc((void**)&df, sizeof(double) * N) != hipSuccess ||
-        hipMalloc((void**)&dip, sizeof(int) * N) != hipSuccess || hipMalloc((void**)&dinfo, sizeof(int)) != hipSuccess)
+    if (hipMalloc((void**)&dJ, sizeof(double) * elems) != hipSuccess || hipMalloc((void**)&df, sizeof(double) * N) != hipSuccess ||
+        hipMalloc((void**)&dip, sizeof(int64_t) * N) != hipSuccess || hipMalloc((void**)&dinfo, sizeof(int64_t)) != hipSuccess)
         rc = HPF_E_NOMEM;
-    if (!rc && (hipMemcpy(dJ, J_colmajor, sizeof(double) * (size_t)N * N, hipMemcpyHostToDevice) != hipSuccess ||
+    if (!rc && (hipMemcpy(dJ, J_colmajor, sizeof(double) * elems, hipMemcpyHostToDevice) != hipSuccess ||
                 hipMemcpy(df, f, sizeof(double) * N, hipMemcpyHostToDevice) != hipSuccess))
         rc = HPF_E_HIP;
-    if (!rc && (rocsolver_dgetrf(blas, N, N, dJ, N, dip, dinfo) != rocblas_status_success ||
-                rocsolver_dgetrs(blas, rocblas_operation_none, N, 1, dJ, N, dip, df, N) != rocblas_status_success))
-        rc = HPF_E_ROCSOLVER;
-    if (!rc && (hipMemcpy(&info, dinfo, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
+    if (!rc) {
+        rocblas_status st;
+        if (wide) {
+            st = rocsolver_dgetrf_64(blas, N, N, dJ, N, dip, dinfo);
+            if (st == rocblas_status_success) st = rocsolver_dgetrs_64(blas, rocblas_operation_none, N, 1, dJ, N, dip, df, N);
+        } else {
+            st = rocsolver_dgetrf(blas, N, N, dJ, N, reinterpret_cast<int*>(dip), reinterpret_cast<int*>(dinfo));
+            if (st == rocblas_status_success)
+                st = rocsolver_dgetrs(blas, rocblas_operation_none, N, 1, dJ, N, reinterpret_cast<int*>(dip), df, N);
+        }
+        if (st == rocblas_status_memory_error)
+            rc = HPF_E_NOMEM;
+        else if (st != rocblas_status_success)
+            rc = HPF_E_ROCSOLVER;
+    }
+    if (!rc && (hipMemcpy(wide ? (void*)&info64 : (void*)&info32, dinfo, wide ? sizeof(int64_t) : sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
                 hipMemcpy(dx, df, sizeof(double) * N, hipMemcpyDeviceToHost) != hipSuccess))
         rc = HPF_E_HIP;
-    if (!rc && info != 0) rc = HPF_E_SINGULAR;
+    if (!rc && (wide ? info64 != 0 : info32 != 0)) rc = HPF_E_SINGULAR;
     hipFree(dJ);
     hipFree(df);
     hipFree(dip);

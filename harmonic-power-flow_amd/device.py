@@ -88,8 +88,7 @@ class DeviceModel:
             d.solver = _lib.SOLVER_DENSE
             rc = lib.hpf_create(C.byref(self._h), C.byref(d))
         _lib.check(rc, None, "hpf_create")
-        self.S_max = int(max_scenarios)
-        self.S = 0
+        self.S_max = int(lib.hpf_max_scenarios(self._h))
         self.N = lib.hpf_num_unknowns(self._h)
         self.Nf = lib.hpf_num_unknowns_fund(self._h)
         self.n_levels = lib.hpf_tree_levels(self._h)
@@ -116,28 +115,38 @@ class DeviceModel:
     def _chk(self, code, where):
         _lib.check(code, self._h, where)
 
+    @property
+    def S(self):
+        """Scenarios of the current batch -- asked from the library (hpf_num_scenarios), never mirrored here: the per-batch entry points of the
+        C ABI write exactly that many rows, so every output array below is sized from it (a host-side copy that disagreed with the library's
+        count was a heap overrun in round 4, DESIGN_LOG.md)."""
+        return int(self.lib.hpf_num_scenarios(self._h)) if getattr(self, "_h", None) else 0
+
+    def _batch(self, where):
+        S = self.S
+        if S < 1:
+            raise _lib.HpfError(-2, 0, where)          # HPF_E_STATE: no batch in the handle (fresh handle, or after solve_queue)
+        return S
+
     # -- state ---------------------------------------------------------------------------------------------
     def set_loads(self, P, Q):
         P = np.ascontiguousarray(np.atleast_2d(P), dtype=np.float64)
         Q = np.ascontiguousarray(np.atleast_2d(Q), dtype=np.float64)
         assert P.shape == Q.shape and P.shape[1] == self.n
-        self.S = P.shape[0]
-        self._chk(self.lib.hpf_set_loads(self._h, self.S, _dp(P), _dp(Q)), "hpf_set_loads")
+        self._chk(self.lib.hpf_set_loads(self._h, P.shape[0], _dp(P), _dp(Q)), "hpf_set_loads")
 
     def set_state(self, Vm=None, Va=None, n_scen=None):
         if Vm is None:
             S = n_scen or self.S or 1
             self._chk(self.lib.hpf_set_state(self._h, S, None, None), "hpf_set_state")
-            self.S = S
             return
         Vm = np.ascontiguousarray(np.atleast_2d(Vm), dtype=np.float64)
         Va = np.ascontiguousarray(np.atleast_2d(Va), dtype=np.float64)
         assert Vm.shape == Va.shape and Vm.shape[1] == self.n * self.Hn
         self._chk(self.lib.hpf_set_state(self._h, Vm.shape[0], _dp(Vm), _dp(Va)), "hpf_set_state")
-        self.S = Vm.shape[0]
 
     def get_state(self):
-        Vm = np.empty((self.S, self.n * self.Hn))
+        Vm = np.empty((self._batch("hpf_get_state"), self.n * self.Hn))
         Va = np.empty_like(Vm)
         self._chk(self.lib.hpf_get_state(self._h, _dp(Vm), _dp(Va)), "hpf_get_state")
         return Vm, Va
@@ -145,8 +154,9 @@ class DeviceModel:
     # -- kernels -------------------------------------------------------------------------------------------
     def mismatch(self, fund=False, want_f=True):
         N = self.Nf if fund else self.N
-        f = np.empty((self.S, N)) if want_f else None
-        err = np.empty(self.S)
+        S = self._batch("hpf_mismatch")
+        f = np.empty((S, N)) if want_f else None
+        err = np.empty(S)
         fn = self.lib.hpf_fund_mismatch if fund else self.lib.hpf_mismatch
         self._chk(fn(self._h, _dp(f) if want_f else None, _dp(err)), "hpf_mismatch")
         return f, err
@@ -180,12 +190,15 @@ class DeviceModel:
         data = np.empty(nnz, dtype=np.float64)
         fn = self.lib.hpf_jacobian_csr_last if last else self.lib.hpf_jacobian_csr
         self._chk(fn(self._h, int(scen), _ip(indptr), _ip(indices), _dp(data)), "hpf_jacobian_csr")
-        return sp.csr_matrix((data, indices, indptr), shape=(self.N, self.N))
+        J = sp.csr_matrix((data, indices, indptr), shape=(self.N, self.N))
+        J._hpf_dims = (self.n, self.c, self.Hn)        # the numbering of its rows / columns (api.update_harmonic_state_vec reads it)
+        return J
 
     def fund_pf(self, thresh=1e-6, max_iter=30):
-        n_iter = np.zeros(self.S, dtype=np.int32)
-        err = np.empty(self.S)
-        hist = np.empty((self.S, max(max_iter, 1)))
+        S = self._batch("hpf_fund_pf")
+        n_iter = np.zeros(S, dtype=np.int32)
+        err = np.empty(S)
+        hist = np.empty((S, max(max_iter, 1)))
         self._chk(self.lib.hpf_fund_pf(self._h, float(thresh), int(max_iter), _ip(n_iter), _dp(err), _dp(hist)),
                   "hpf_fund_pf")
         return n_iter, err, hist[:, :max_iter]
@@ -193,11 +206,12 @@ class DeviceModel:
     def solve(self, thresh=1e-4, max_iter=50, trace=False):
         """hpf_solve -> (n_iter [S], err [S], err_hist [S][max_iter+1]); with trace=True additionally the per-iteration states
         (Vm_traj, Va_traj) [S][max_iter+1][Hn*n] (entry k = state after iteration k; frozen scenarios repeat their last state)."""
-        n_iter = np.zeros(self.S, dtype=np.int32)
-        err = np.empty(self.S)
-        hist = np.empty((self.S, max_iter + 1))
+        S = self._batch("hpf_solve")
+        n_iter = np.zeros(S, dtype=np.int32)
+        err = np.empty(S)
+        hist = np.empty((S, max_iter + 1))
         if trace:
-            Vt = np.full((self.S, max_iter + 1, self.n * self.Hn), np.nan)
+            Vt = np.full((S, max_iter + 1, self.n * self.Hn), np.nan)
             At = np.full_like(Vt, np.nan)
             self._chk(self.lib.hpf_set_trace(self._h, _dp(Vt), _dp(At), max_iter + 1), "hpf_set_trace")
         try:
@@ -225,7 +239,6 @@ class DeviceModel:
             Va = np.empty_like(Vm)
         self._chk(self.lib.hpf_solve_queue(self._h, n_scen, _dp(P), _dp(Q), float(thresh_f), int(max_iter_f), float(thresh), int(max_iter),
                                            st, _dp(Vm) if want_voltages else None, _dp(Va) if want_voltages else None), "hpf_solve_queue")
-        self.S = 0
         rec = np.frombuffer(st, dtype=[("n_iter", "<i4"), ("flags", "<i4"), ("err", "<f8"), ("thd_max", "<f8")]).copy()
         return (rec, Vm, Va) if want_voltages else rec
 
@@ -236,7 +249,7 @@ class DeviceModel:
         self._chk(self.lib.hpf_sync(self._h), "hpf_sync")
 
     def stats(self):
-        st = (_lib.hpf_stat * self.S)()
+        st = (_lib.hpf_stat * self._batch("hpf_get_stats"))()
         self._chk(self.lib.hpf_get_stats(self._h, st), "hpf_get_stats")
         return np.array([(s.n_iter, s.flags, s.err, s.thd_max) for s in st],
                         dtype=[("n_iter", "i4"), ("flags", "i4"), ("err", "f8"), ("thd_max", "f8")])

@@ -64,12 +64,48 @@ def validate_bus_order(buses):
         raise ValueError("buses must be ordered slack, PV..., PQ..., nonlinear... (reference contract, HG:83)")
 
 
+# The network the reference's manual initialisers describe (HG:64-74, HG:97-110: a 4-bus ring like net2 with pi-model line shunts).  The
+# reference's own versions cannot run (the bus table is built as an ndarray of strings, so `buses.S/BASE_POWER` raises; HG:110 reads a V_nom column
+# that does not exist); what they INTEND is unambiguous -- the same tables through the same p.u. conversion as the CSV path -- and that is what
+# from_csv=False gives here.  SI units, columns as in the CSV dialect of net2.
+_MANUAL_BUSES = (("ID", "type", "component", "S", "P", "Q", "X_sh"),
+                 ((1, "slack", "generator", 0.0, 0.0, 0.0, 0.005), (2, "PQ", "lin_load_1", 0.0, 100.0, 100.0, 0.0),
+                  (3, "PQ", "lin_load_2", 0.0, 100.0, 100.0, 0.0), (4, "nonlinear", "smps", 0.0, 150.0, 100.0, 0.0)))
+_MANUAL_LINES = (("ID", "fromID", "toID", "R", "X", "G", "B"),
+                 ((1, 1, 2, 0.5, 0.5, 0.0, 0.05), (2, 2, 3, 1.0, 4.0, 0.0, 0.1), (3, 3, 4, 0.5, 1.0, 0.0, 0.05), (4, 4, 1, 0.5, 1.0, 0.0, 0.05)))
+
+
+def init_buses_manually(settings=None):
+    """HG:97-110 as intended (see _MANUAL_BUSES)."""
+    st = settings or Settings()
+    df = pd.DataFrame([dict(zip(_MANUAL_BUSES[0], r)) for r in _MANUAL_BUSES[1]])
+    df["S"] = df.S.astype(float) / st.BASE_POWER
+    df["P"] = df.P.astype(float) / st.BASE_POWER
+    df["Q"] = df.Q.astype(float) / st.BASE_POWER
+    df["X_sh"] = df.X_sh.astype(float) / st.base_impedance
+    return df
+
+
+def init_lines_manually(settings=None):
+    """HG:64-74."""
+    st = settings or Settings()
+    df = pd.DataFrame([dict(zip(_MANUAL_LINES[0], r)) for r in _MANUAL_LINES[1]])
+    df["R"] = df.R.astype(float) / st.base_impedance
+    df["X"] = df.X.astype(float) / st.base_impedance
+    df["G"] = df.G.astype(float) / st.base_admittance
+    df["B"] = df.B.astype(float) / st.base_admittance
+    return df
+
+
 def init_network(filename_buses, filename_lines, from_csv=True, settings=None):
-    """HG:113-128 -> (buses, lines, m, n, c)."""
-    if not from_csv:
-        raise NotImplementedError("the reference's manual initialisers are broken (HG:97-110); use CSV files")
-    buses = init_buses_from_csv(filename_buses, settings)
-    lines = init_lines_from_csv(filename_lines, settings)
+    """HG:113-128 -> (buses, lines, m, n, c).  from_csv=False: the built-in 4-bus network of the reference's manual initialisers (the file
+    names are ignored, as in the reference)."""
+    if from_csv:
+        buses = init_buses_from_csv(filename_buses, settings)
+        lines = init_lines_from_csv(filename_lines, settings)
+    else:
+        buses = init_buses_manually(settings)
+        lines = init_lines_manually(settings)
     validate_bus_order(buses)
     m, n, c = network_constants(buses)
     return buses, lines, m, n, c
@@ -144,10 +180,25 @@ def export_Norton_Equivalents(filename, freqs, Y_N_c, I_N_c, Y_N_uc, I_N_uc):
     return filename
 
 
+_NORTON_FILES = {}       # (real path, mtime_ns, size) -> parsed content: a sweep of hpf() calls parses a Norton file once (35 ms for smps_NE.csv)
+
+
 def read_Norton_file(filename):
     """Raw (SI) content of a `<component>_NE.csv`: (freqs, Y_N_c [K][K], I_N_c [K], Y_N_uc [K], I_N_uc [K]).
     Parsed value by value with `complex()` (the reference's parser, HG:296) — not through a pandas object->complex
-    conversion, which drops the sign of a zero real part."""
+    conversion, which drops the sign of a zero real part.  The parsed content is kept per (path, modification time, size); every call returns
+    fresh copies of the arrays."""
+    st_ = os.stat(filename)
+    key = (os.path.realpath(filename), st_.st_mtime_ns, st_.st_size)
+    hit = _NORTON_FILES.get(key)
+    if hit is None:
+        if len(_NORTON_FILES) >= 32:
+            _NORTON_FILES.clear()
+        hit = _NORTON_FILES[key] = _parse_Norton_file(filename)
+    return (list(hit[0]),) + tuple(a.copy() for a in hit[1:])
+
+
+def _parse_Norton_file(filename):
     df = pd.read_csv(filename, index_col=["Parameter", "Frequency"], dtype=str)
     df.columns = df.columns.astype(int)
     freqs = list(df.columns)

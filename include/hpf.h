@@ -95,6 +95,12 @@ int  hpf_version(void);
 /* Sizes: N = 2*n*Hn - 1 - c unknowns of the harmonic NR (HG:388,397); Nf = 2*n - 1 - c of the fundamental NR. */
 int  hpf_num_unknowns(const hpf_handle* h);
 int  hpf_num_unknowns_fund(const hpf_handle* h);
+/* Scenario counts, so that a host binding sizes the per-batch output arrays below from the LIBRARY and not from a mirror of its own: S = the
+ * current batch (set by hpf_set_loads / hpf_set_state; 0 when the handle holds no batch, e.g. right after hpf_create or hpf_solve_queue) and the
+ * capacity S_max of hpf_create.  Every per-batch output ([S][...] below) is written for exactly hpf_num_scenarios() scenarios; per-batch calls on a
+ * handle without a batch return HPF_E_STATE. */
+int  hpf_num_scenarios(const hpf_handle* h);
+int  hpf_max_scenarios(const hpf_handle* h);
 /* BLOCK_TREE: number of elimination levels of the dense tree (= factor-kernel launches per Newton step and scenario group;
  * pass-through buses are contracted first in the default mode) / of back-substitution levels; 0 for DENSE. */
 int  hpf_tree_levels(const hpf_handle* h);
@@ -171,8 +177,19 @@ int  hpf_set_trace(hpf_handle* h, double* Vm_traj, double* Va_traj, int cap);
 int  hpf_iterate(hpf_handle* h, int iters);
 
 /* update_harmonic_state_vec (HG:476-479) as a standalone, stateless call like the reference's: dx = J^-1 f for a dense
- * column-major N x N Jacobian supplied by the caller (rocSOLVER LU, partial pivoting); the caller forms x - dx. */
+ * column-major N x N Jacobian supplied by the caller (rocSOLVER LU, partial pivoting); the caller forms x - dx.  N * N >= 2^31 goes through
+ * rocSOLVER's 64-bit entry points; HPF_E_NOMEM (before anything is allocated) when 8 N^2 bytes do not fit the device's free memory. */
 int  hpf_dense_solve(int device, int N, const double* J_colmajor, const double* f, double* dx);
+/* The same call for the Jacobian in the form the reference passes it (HG:478: the scipy CSR matrix build_harmonic_jacobian returns, HG:469-472),
+ * at every size: indptr [N + 1], indices [nnz], data [nnz] of the N x N matrix in the reference's stacked row / column order, N = 2 n Hn - 1 - c
+ * (n buses, c = PV buses + 1, Hn harmonics: the numbering is a function of these three alone), f [N] -> dx [N] = J^-1 f.  The entries are
+ * scattered on the device into bus-major 2 Hn x 2 Hn blocks and eliminated along the feeder tree (partial pivoting inside a bus block; off-diagonal
+ * blocks may be dense); no N x N array exists on host or device (65 MB of blocks at 1 000 buses x 26 harmonics, where the dense matrix is
+ * 21.6 GB).  Duplicate (row, column) entries add up like scipy's.  HPF_E_TOPOLOGY when the bus graph of the pattern is not a tree connected from
+ * bus 0 (meshed network: use hpf_dense_solve where it fits), HPF_E_ARG for 2 Hn > 128 or an inconsistent CSR, HPF_E_SINGULAR when a bus block has
+ * no pivot.  Stateless like the reference's function: no handle. */
+int  hpf_sparse_solve(int device, int n, int c, int Hn, const int32_t* indptr, const int32_t* indices, const double* data, const double* f,
+                      double* dx);
 
 /* Per-scenario statistics after hpf_solve; `thd_max` from get_THD (HG:563-572) evaluated on device. */
 int  hpf_get_stats(hpf_handle* h, hpf_stat* stats /* [S] host */);

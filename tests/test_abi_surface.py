@@ -68,3 +68,45 @@ def test_every_environment_switch_of_the_library_is_documented_in_the_header():
     envs = set(re.findall(r'getenv\("(HPF_[A-Z_0-9]+)"\)', src))
     hdr = open(os.path.join(REPO, "include", "hpf.h")).read()
     assert envs and not [e for e in sorted(envs) if e not in hdr]
+
+
+def test_sparse_solve_validates_and_classifies_the_pattern_on_the_host():
+    """hpf_sparse_solve (update_harmonic_state_vec for the reference's CSR Jacobian): argument checks and the bus-graph analysis of the pattern run
+    on the host before any HIP call -- inconsistent CSR -> HPF_E_ARG, a bus graph that is not a tree from bus 0 -> HPF_E_TOPOLOGY."""
+    import ctypes as C
+    import numpy as np
+    import scipy.sparse as sp
+    from harmonic_power_flow_amd import _lib
+    lib = _lib.load()
+    ip, dp = C.POINTER(C.c_int32), C.POINTER(C.c_double)
+
+    def call(n, c, Hn, J, indptr=None):
+        J = J.tocsr()
+        ptr = np.ascontiguousarray(J.indptr if indptr is None else indptr, dtype=np.int32)
+        idx, data = np.ascontiguousarray(J.indices, dtype=np.int32), np.ascontiguousarray(J.data, dtype=float)
+        f, dx = np.ones(J.shape[0]), np.empty(J.shape[0])
+        return lib.hpf_sparse_solve(0, n, c, Hn, ptr.ctypes.data_as(ip), idx.ctypes.data_as(ip), data.ctypes.data_as(dp), f.ctypes.data_as(dp),
+                                    dx.ctypes.data_as(dp))
+    n, c, Hn = 4, 1, 3
+    Nc = n * Hn - 1
+    N = 2 * Nc - (c - 1)
+
+    def bus_of(r):
+        return ((r - Nc + c) if r >= Nc else (r + 1)) % n
+    ring = np.zeros((N, N))                                     # 0 - 1 - 2 - 3 - 0: one loop-closing line
+    for r in range(N):
+        for cc in range(N):
+            d = abs(bus_of(r) - bus_of(cc))
+            if d in (0, 1, n - 1):
+                ring[r, cc] = 1.0
+    assert call(n, c, Hn, sp.csr_matrix(ring)) == -3
+    assert call(n, c, Hn, sp.identity(N, format="csr")) == -3   # no coupling at all: not connected from bus 0
+    assert call(0, 1, 1, sp.identity(3, format="csr")) == -1
+    assert call(n, n + 1, Hn, sp.identity(N, format="csr")) == -1
+    assert call(3, 1, 70, sp.identity(2 * 3 * 70 - 2, format="csr")) == -1          # 2 Hn > 128
+    bad = sp.identity(N, format="csr").indptr.copy()
+    bad[3] = 1                                                  # decreasing row pointer
+    assert call(n, c, Hn, sp.identity(N, format="csr"), indptr=bad) == -1
+    assert lib.hpf_num_scenarios(None) == -1 and lib.hpf_max_scenarios(None) == -1
+    one = np.ones(1)
+    assert lib.hpf_dense_solve(0, 0, one.ctypes.data_as(dp), one.ctypes.data_as(dp), one.ctypes.data_as(dp)) == -1

@@ -219,9 +219,11 @@ def test_state_and_argument_errors():
     from harmonic_power_flow_amd._lib import HpfError
     st, buses, dm = _model(hp, "net2_H11_c")
     try:
-        with pytest.raises(HpfError):
-            dm.S = 1
-            dm.solve()                      # loads / state not set
+        assert dm.S == 0 and dm.S_max == 1   # (both asked from the library: hpf_num_scenarios / hpf_max_scenarios)
+        for call in (dm.solve, dm.get_state, dm.stats, dm.mismatch, dm.fund_pf):
+            with pytest.raises(HpfError) as e0:
+                call()                      # loads / state not set: no batch in the handle -> HPF_E_STATE, nothing is written
+            assert e0.value.code == -2
         dm.set_loads(buses["P"].to_numpy(float), buses["Q"].to_numpy(float))
         dm.set_state(None, None, n_scen=1)
         with pytest.raises(HpfError):

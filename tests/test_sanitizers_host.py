@@ -36,7 +36,7 @@ def test_host_side_of_libhpf_under_asan_ubsan():
     if not (os.path.exists(hipcc) and os.path.exists(clang)):
         pytest.skip("ROCm toolchain not present")
     lib = os.path.join(OUT, "libhpf_asan.so")
-    srcs = [os.path.join(CSRC, f) for f in ("hpf_lib.hip", "hpf_block.hip")]
+    srcs = [os.path.join(CSRC, f) for f in ("hpf_lib.hip", "hpf_block.hip", "hpf_csr_solve.hip")]
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(REPO, "include", "hpf.h")]
     if not _newer(lib, deps):
         subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value", "-w", "-fPIC",
