@@ -72,12 +72,10 @@ def launch_plan(args, env):
     this one imports torch or touches the GPU; nothing is re-executed in place."""
     if args.gpus <= 1 or "WORLD_SIZE" in env:
         return None
-    import socket
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    # --standalone: the launcher's own rendezvous store picks a free port itself (a port found by bind-and-close here could be taken by
+    # another process before the ranks connect); --local-addr 127.0.0.1: the container's hostname may not resolve
     return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+            "--standalone", "--local-addr", "127.0.0.1", os.path.abspath(__file__)] + sys.argv[1:]
 
 
 def run_launcher(cmd):
@@ -185,8 +183,8 @@ def main():
     inp = build_inputs(args, hp)
     n, S = inp["n"], args.scenarios
     from harmonic_power_flow_amd import synth
-    from harmonic_power_flow_amd.sweep import gather_stats, summarize
-    scen_ids = rank + world * np.arange(S)
+    from harmonic_power_flow_amd.sweep import gather_stats, scenario_ids, summarize
+    scen_ids = scenario_ids(rank, world, S)                  # rank r: r, r + world, r + 2 world, ... (tests/test_sweep_gloo.py)
     P0 = inp["buses"]["P"].to_numpy(float)
     Q0 = inp["buses"]["Q"].to_numpy(float)
     scale = np.stack([synth.scenario_scale(n, int(s)) for s in scen_ids])
@@ -229,7 +227,7 @@ def main():
         groups_probe = {"ms_per_step_4_groups": t4, "ms_per_step_3_groups": t3, "chosen": 4 if keep4 else 3}
     # R timed blocks of exactly K steps, each from the pf seed (W warm-up steps first), each bracketed by barrier + synchronize on both
     # sides and reduced with MAX over the ranks; the reported block is the median one
-    blocks = []
+    blocks, blocks_ranks = [], []
     for rep in range(max(args.repeats, 1)):
         if rep or groups_probe:
             dm.set_state(seed[0], seed[1])
@@ -243,11 +241,18 @@ def main():
         barrier()
         el = time.perf_counter() - t0
         if world > 1:
+            # every rank's own time of the block (a straggler shows in the line), then MAX over the ranks
             t = torch.tensor([el], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            parts = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(parts, t)
+            blocks_ranks.append([float(p.item()) for p in parts])
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
+        else:
+            blocks_ranks.append([el])
         blocks.append(el)
     elapsed = float(np.median(blocks))
+    median_block = int(np.argsort(blocks)[len(blocks) // 2])
     # per-kernel HIP-event timing (on the streams the kernels run on) over K more steps of the same configuration, continued
     # from the state the timed region left; kept out of the headline region because every span costs two event records
     Kt = min(args.steps, 20)                     # steps of each timing leg (bounded: every span is a pair of event records)
@@ -302,14 +307,13 @@ def main():
         sweep["solve_wall_s_rank0"] = t_sw        # hpf_solve of this rank's scenarios with the reference's stop rule (untimed leg)
         sweep["iters_per_s_rank0"] = float(n_iter.sum()) / t_sw
 
-    def leave():
-        # no rank tears its communicator down while another still works: rank 0 runs the single-GPU legs below before it gets here
-        if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
-
+    # The gather above was the last collective: the communicator is torn down HERE, by all ranks together, before rank 0 starts its
+    # single-GPU legs -- no rank waits inside a collective (an RCCL barrier spins on the GPU) while rank 0 works for a minute.
+    rccl_ranks = dist.get_world_size() if (world > 1 and backend == "nccl") else None
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
     if rank != 0:
-        leave()
         return
 
     K = args.steps
@@ -386,7 +390,9 @@ def main():
                        "barrier + synchronize and MAX-reduced over the ranks; ms_per_step / value are the MEDIAN block's",
         "scenario_groups_probe": groups_probe,      # untimed: four groups (default) against three in this process; the default stays unless > 10 % slower
         "backend": backend if world > 1 else None,
-        "rccl_ranks": (dist.get_world_size() if (world > 1 and backend == "nccl") else None),
+        "rccl_ranks": rccl_ranks,
+        "ms_per_step_ranks": [1e3 * t / K for t in blocks_ranks[median_block]],   # each rank's own time of the median block (value uses their MAX)
+        "scenario_ids_rank0": [int(scen_ids[0]), int(scen_ids[1]) if S > 1 else None, "... + %d" % world],
         "ms_per_iter_per_scenario": ms_step / S,
         "setup_ms": setup["model_setup_ms"], "setup": setup,
         "roofline": {"bound": "hbm",
@@ -440,7 +446,9 @@ def main():
         "phase_note": "HIP-event spans: gj = one per k_level / k_factor_q<B,false> launch; solve = one per launch of the other factor kernels "
                       "(k_leaf_batch, k_sleaf_batch, leaf-only k_factor_q: none with k_level); mismatch / update: per launch; back: per scenario "
                       "group and step (%d groups overlap on separate streams)" % G,
-        "vs_reference_measured": value / 0.0257,
+        "vs_reference_single_run_note": "not a like-for-like ratio and not reported as a number: the reference (one single-threaded pandas / SuperLU "
+                                        "process, ONE scenario) measured 38.9 s per NR iteration on this feeder in the build container; `value` is "
+                                        "the aggregate of %d scenarios in flight per GPU.  cpu_baseline is the comparator timed on this box." % S,
     }
     if sweep is not None:
         out["sweep"] = sweep
@@ -475,7 +483,6 @@ def main():
                                 out["setup"]["create_warm_ms"])
     out["cpu_baseline"] = cpu
     print(json.dumps(out), flush=True)
-    leave()
 
 
 def lib_sha16():

@@ -33,7 +33,8 @@ def solve_scenarios(dm, P, Q, thresh_f=1e-6, max_iter_f=30, thresh_h=1e-4, max_i
     harvested between chunks of Newton iterations and their slots take the next pending scenarios, so a sweep of many more scenarios
     than slots runs at the lock-step rate of a full handle instead of paying every wave's convergence tail (size the model for as
     many live scenarios as fit: 72 MB of solver state per scenario of the 1 000-bus x 25-harmonic feeder; larger batches amortise the
-    latency-bound upper tree levels).  A scenario the static-pivot monitor flags is solved again on its own with partial pivoting.
+    latency-bound upper tree levels).  A scenario the static-pivot monitor flags (flags bit 3), or whose mismatch turned non-finite in the
+    static-pivot kernels (bit 2), is solved again on its own through `hpf_solve`, which repeats exactly those with partial pivoting.
     refill=False: fixed waves of up to S_max scenarios (each through fund_pf + solve).
     -> structured array of per-scenario records (n_iter, flags, err, thd_max: the 24-byte record of the multi-GPU gather)
     [+ raw Vm, Va [n_scen][Hn*n]]; every record and voltage is bit-identical to the scenario solved alone."""
@@ -72,7 +73,9 @@ def solve_scenarios(dm, P, Q, thresh_f=1e-6, max_iter_f=30, thresh_h=1e-4, max_i
             rec = res
         for k in STAT_DTYPE.names:
             out[k][a:b] = rec[k]
-    for s in np.nonzero((out["flags"] & 8) != 0)[0]:        # static pivot order flagged: the scenario alone, hpf_solve repeats it pivoted
+    # static pivot order flagged (bit 3) or non-finite mismatch (bit 2) -- the two conditions hpf_solve's repeat pass looks at (k_mark_repeat):
+    # the scenario alone, hpf_solve repeats it pivoted
+    for s in np.nonzero((out["flags"] & (8 | 4)) != 0)[0]:
         wave(int(s), int(s) + 1)
     return (out, Vm, Va) if want_voltages else out
 

@@ -159,8 +159,8 @@ int  hpf_solve(hpf_handle* h, double thresh, int max_iter, int* n_iter, double* 
  * pending scenarios into the freed slots, so the handle stays full until the queue drains; every scenario's result is bit-identical to its
  * solve alone (the arithmetic of a scenario does not depend on its slot).  Other handles (DENSE, meshed networks, pivoted mode) run waves of
  * S_max scenarios.  Outputs (host, may be NULL; Vm and Va together): stats [n_total], raw voltages Vm, Va [n_total][Hn*n] (stacked order,
- * signed / un-wrapped like hpf_get_state).  In the queued mode a scenario flagged by the static-pivot monitor (flags bit 3) is reported,
- * not repeated: solve it again with hpf_solve.  Afterwards the handle holds no batch: set loads and state before per-batch calls. */
+ * signed / un-wrapped like hpf_get_state).  In the queued mode a scenario flagged by the static-pivot monitor (flags bit 3) or whose mismatch
+ * turned non-finite (flags bit 2) is reported, not repeated: solve it again with hpf_solve (which repeats exactly those with partial pivoting).  Afterwards the handle holds no batch: set loads and state before per-batch calls. */
 int  hpf_solve_queue(hpf_handle* h, int n_total, const double* P, const double* Q, double thresh_f, int max_iter_f, double thresh,
                      int max_iter, hpf_stat* stats, double* Vm, double* Va);
 

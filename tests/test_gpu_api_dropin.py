@@ -161,3 +161,99 @@ def test_fuchs_script_last_newton_step_through_hpf_dense_solve():
     assert J.shape == (14, 14)
     x = hp.update_harmonic_state_vec(J, U, dM)
     assert np.abs(np.asarray(x).ravel() - U_new).max() < 1e-10 * max(1.0, np.abs(U_new).max())
+
+
+def test_reference_call_shapes_reuse_a_cached_handle_bit_identically(tmp_path):
+    """the reference's sweep is repeated hpf() calls (HG:511).  The call shapes borrow a device handle from an LRU keyed on
+    the model (pattern, admittance values, Norton arrays, harmonics, solver, HPF_* environment): the second call on the same network creates
+    nothing, other loads on the same network reuse it too, a changed admittance or an environment switch does not; results are bit-identical
+    to a call without the cache; the reference-style loop build_harmonic_jacobian -> update_harmonic_state_vec -> harmonic_mismatch (HG:536-542)
+    runs on ONE assembly handle."""
+    import time
+    hp = _hp()
+    from harmonic_power_flow_amd import synth
+    fb, fl = synth.gen(1000, seed=0, outdir=str(tmp_path))
+    st = hp.Settings(H_MAX=51)
+    buses, lines, m, n, c = hp.init_network(fb, fl, settings=st)
+    hp.close_all()
+    hp.handle_cache(0)
+    V0, e0, it0, J0 = hp.hpf(buses, lines, True, settings=st, ne_dir=INPUTS, verbose=False)
+    hp.handle_cache(4)
+    base = hp.handle_cache()
+    t0 = time.perf_counter()
+    V1, e1, it1, J1 = hp.hpf(buses, lines, True, settings=st, ne_dir=INPUTS, verbose=False)
+    t1 = time.perf_counter()
+    V2, e2, it2, J2 = hp.hpf(buses, lines, True, settings=st, ne_dir=INPUTS, verbose=False)
+    t2 = time.perf_counter()
+    V3, e3, it3, _ = hp.hpf(buses, lines, True, settings=st, ne_dir=INPUTS, verbose=False, return_jacobian=False)
+    t3 = time.perf_counter()
+    s = hp.handle_cache()
+    assert s["misses"] - base["misses"] == 1 and s["hits"] - base["hits"] == 2 and s["held"] == 1
+    for V, e, it in ((V1, e1, it1), (V2, e2, it2), (V3, e3, it3)):
+        assert it == it0 and e == e0 and np.array_equal(V.to_numpy(), V0.to_numpy())
+    assert np.array_equal(J1.data, J0.data) and np.array_equal(J2.data, J0.data) and np.array_equal(J2.indices, J0.indices)
+    print(f"\nhpf() on syn1000 x 26 harmonics, end to end: first (creates the handle) {1e3 * (t1 - t0):.1f} ms, second {1e3 * (t2 - t1):.1f} ms, "
+          f"without the Jacobian export {1e3 * (t3 - t2):.1f} ms ({it0} iterations)")
+    # other loads: same handle; the result equals a fresh handle's
+    b2 = buses.copy()
+    b2["P"] = b2["P"] * 0.9
+    Va, ea, ita, _ = hp.hpf(b2, lines, True, settings=st, ne_dir=INPUTS, verbose=False, return_jacobian=False)
+    assert hp.handle_cache()["hits"] - s["hits"] == 1
+    hp.handle_cache(0)
+    Vb, eb, itb, _ = hp.hpf(b2, lines, True, settings=st, ne_dir=INPUTS, verbose=False, return_jacobian=False)
+    hp.handle_cache(4)
+    assert ita == itb and ea == eb and np.array_equal(Va.to_numpy(), Vb.to_numpy()) and not np.array_equal(Va.to_numpy(), V0.to_numpy())
+    # a changed line impedance is another model
+    l2 = lines.copy()
+    l2.loc[0, "R"] = l2.loc[0, "R"] * 1.5
+    s = hp.handle_cache()
+    hp.hpf(buses, l2, True, settings=st, ne_dir=INPUTS, verbose=False, return_jacobian=False)
+    assert hp.handle_cache()["misses"] - s["misses"] == 1
+    # the reference-style loop on one assembly handle
+    Y = hp.build_admittance_matrices(buses, lines, st.HARMONICS)
+    NE = hp.import_Norton_Equivalents(buses, True, st, INPUTS)
+    Vs, _, _ = hp.pf(Y, buses, settings=st, verbose=False)
+    s = hp.handle_cache()
+    V = Vs.copy()
+    f, err = hp.harmonic_mismatch(V, Y, buses, NE, settings=st)
+    for _ in range(2):
+        J = hp.build_harmonic_jacobian(V, Y, NE, True, buses=buses)
+        x = hp.update_harmonic_state_vec(J, hp.harmonic_state_vector(V, c=c), f)
+        V.iloc[1:, 1] = x[:n * 26 - 1]                          # update_harmonic_voltages, HG:484-485
+        V.iloc[c:, 0] = x[n * 26 - 1:]
+        f, err = hp.harmonic_mismatch(V, Y, buses, NE, settings=st)
+    s2 = hp.handle_cache()
+    assert s2["misses"] - s["misses"] == 1 and s2["hits"] - s["hits"] == 4
+    g = np.load(os.path.join(GOLD, "syn1000_H51_c.npz"), allow_pickle=True)
+    assert abs(err - g["err_hist"][2]) <= 1e-9 * g["err_hist"][2]      # two reference-style iterations land on the reference's err_h
+    hp.close_all()
+    assert hp.handle_cache()["held"] == 0
+
+
+def test_init_network_without_csv_is_the_manual_network_of_the_reference(tmp_path):
+    """init_network(from_csv=False) (HG:64-74, 97-110, 117-119): the built-in 4-bus ring with pi-model line shunts the reference's manual
+    initialisers describe (its own versions raise).  Pinned by the oracle on the same numbers written as CSV files: identical frames, identical
+    trajectories (the line shunts B != 0 exercise the off-by-one bus test of HG:163-168)."""
+    import hpf_oracle as o
+    hp = _hp()
+    st = hp.Settings(H_MAX=11)
+    buses, lines, m, n, c = hp.init_network(None, None, from_csv=False, settings=st)
+    assert (m, n, c) == (3, 4, 1)
+    fb, fl = str(tmp_path / "man_buses.csv"), str(tmp_path / "man_lines.csv")
+    open(fb, "w").write("ID;type;component;S;P;Q;X_sh\n1;slack;generator;0;0;0;0.005\n2;PQ;lin_load_1;0;100;100;0\n3;PQ;lin_load_2;0;100;100;0\n"
+                        "4;nonlinear;smps;0;150;100;0\n")
+    open(fl, "w").write("ID;fromID;toID;R;X;G;B\n1;1;2;0.5;0.5;0;0.05\n2;2;3;1;4;0;0.1\n3;3;4;0.5;1;0;0.05\n4;4;1;0.5;1;0;0.05\n")
+    b2, l2, m2, n2, c2 = hp.init_network(fb, fl, settings=st)
+    for col in ("P", "Q", "X_sh"):
+        assert np.array_equal(buses[col].to_numpy(), b2[col].to_numpy())
+    for col in ("fromID", "toID", "R", "X", "G", "B"):
+        assert np.array_equal(lines[col].to_numpy(float), l2[col].to_numpy(float))
+    det = {}
+    V, err_h, n_iter_h, J = hp.hpf(buses, lines, True, settings=st, ne_dir=INPUTS, verbose=False, details=det)
+    r = o.hpf(o.init_network(fb, fl), st.HARMONICS, True, INPUTS)
+    assert n_iter_h == r["n_iter_h"]
+    k = min(n_iter_h + 1, 4)
+    np.testing.assert_allclose(det["err_hist"][:k], r["err_hist"][:k], rtol=1e-9)
+    if err_h <= 1e-4:
+        Ud = V["V_m"].to_numpy() * np.exp(1j * V["V_a"].to_numpy())
+        assert np.abs(Ud - r["Vm"] * np.exp(1j * r["Va"])).max() < 1e-8

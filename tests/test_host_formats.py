@@ -110,7 +110,7 @@ def test_bench_gpus_flag_starts_one_rank_per_gpu(monkeypatch):
     args = bench.parse(["--gpus", "4", "--steps", "7", "--warmup", "2"])
     cmd = bench.launch_plan(args, {})
     assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
-    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and "--standalone" in cmd and cmd[cmd.index("--local-addr") + 1] == "127.0.0.1"
     assert cmd[-6:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"] and cmd[-7].endswith("bench.py")
     assert bench.launch_plan(args, {"WORLD_SIZE": "4", "RANK": "0"}) is None           # already a rank
     assert bench.launch_plan(bench.parse(["--gpus", "1"]), {}) is None

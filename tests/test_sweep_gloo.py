@@ -72,3 +72,17 @@ def test_scenario_scale_is_seeded_and_bounded():
     u = synth.scenario_scale(1000, 3)
     assert np.array_equal(u, synth.scenario_scale(1000, 3))
     assert u.min() >= 0.5 and u.max() <= 1.5 and not np.array_equal(u, synth.scenario_scale(1000, 4))
+
+
+def test_bench_deals_the_scenarios_with_the_tested_function():
+    """bench.py's rank r takes scenario ids r + world * i: it calls sweep.scenario_ids (no second formula of its own), and that function gives
+    exactly those ids."""
+    import re
+    from harmonic_power_flow_amd import sweep
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(repo, "bench.py")).read()
+    assert re.search(r"scen_ids\s*=\s*scenario_ids\(rank,\s*world,\s*S\)", src)
+    assert "rank + world * np.arange" not in src
+    for world in (1, 2, 8):
+        for r in range(world):
+            assert np.array_equal(sweep.scenario_ids(r, world, 5), r + world * np.arange(5))
