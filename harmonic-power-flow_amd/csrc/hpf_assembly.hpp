@@ -56,6 +56,8 @@ struct Model {
     const cplx* YNt = nullptr;   // device only, coupled: transposed copy [n_dev][p][q] -- the mismatch kernel's threads of one bus
                                  // (harmonic position q fastest) then read contiguous runs while they walk the columns p
     const cplx* IN;       // [n_dev][Hn]
+    const int* rowrec = nullptr; // device only: [n][8] per bus (rowptr[i], rowptr[i+1], col of its first three entries, 0, 0, 0): the mismatch
+                                 // kernel finds a row's bounds AND its first neighbours behind ONE 32-byte fetch instead of rowptr -> col
 };
 
 // U = Vm*exp(j*Va) (HG:403: real*complex, exact componentwise products) and the "normalised" voltage

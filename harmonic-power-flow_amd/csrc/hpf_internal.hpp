@@ -163,6 +163,7 @@ struct hpf_handle {
     int debug_ablate = 0;             // HPF_DEBUG_ABLATE: timing-only ablation of factor-kernel phases (results invalid)
 
     // model (device)
+    int* d_rowrec = nullptr;          // [n][8] row records of the mismatch kernel (Model::rowrec)
     int *d_rowptr = nullptr, *d_col = nullptr, *d_diag = nullptr, *d_erow = nullptr, *d_dev = nullptr;
     hpf::cplx *d_Y = nullptr, *d_YN = nullptr, *d_IN = nullptr, *d_YNt = nullptr;
     // per-scenario state (device)
@@ -170,7 +171,9 @@ struct hpf_handle {
     hpf::cplx *d_U = nullptr, *d_E = nullptr;
     double* d_f = nullptr;            // [S][N]  mismatch, overwritten by the Newton step during a solve
     hpf::cplx* d_I0 = nullptr;            // [S][n]  network current of the power rows, kept by the harmonic mismatch kernel
-    unsigned long long* d_errbits = nullptr;   // [S]
+    unsigned long long* d_errbits = nullptr;   // [S]   ||f||_inf as the bit pattern of the double (hpf_mismatch: k_err_reduce)
+    unsigned long long* d_errpart = nullptr;   // [S][errpart_stride] partial maxima of |f|, one per wavefront of the mismatch launch (k_mismatch)
+    int errpart_stride = 0;
     double* d_err = nullptr;          // [S]
     int* d_niter = nullptr;           // [S]
     int* d_active = nullptr;          // [S]

@@ -163,13 +163,13 @@ __device__ __forceinline__ cplx norton_injection_lds(const Model& M, int d, cons
 // the device type's Y_N^T (Hn x Hn complex: 10.8 KB at K = 25, shared by every bus of that type -- L2-resident) and the tile's bus
 // voltages; the Norton coupling rows of a nonlinear bus (HG:313-323: the only O(Hn^2) part of the mismatch) then run out of LDS.
 // The network part walks the CSR row (ascending columns, csr_matvec order) with 16-byte gathers of the neighbours' voltages, which
-// the XCD-aware placement (xcd_map) keeps in ONE L2 per scenario.  ||f||_inf: wave shuffle + one u64 atomicMax per workgroup.
+// the XCD-aware placement (xcd_map) keeps in ONE L2 per scenario.  ||f||_inf: wave shuffle + one partial maximum per wavefront.
 // f: the reference's stacked real layout (HG:388; dense solver, C ABI) or nullptr; fb: bus-major image [bus][2q + (Re|Im)] with
 // stride Bst and zeros where there is no equation (tree kernels) or nullptr.
 template <bool FUND>
 __global__ __launch_bounds__(TPB, 8) void k_mismatch(Model M, int count, int N, int Nc, const int* __restrict__ active, const cplx* __restrict__ U,
                            const double* __restrict__ P, const double* __restrict__ Q, double* __restrict__ f,
-                           unsigned long long* __restrict__ errbits, cplx* __restrict__ I0, double* __restrict__ fb, int Bst,
+                           unsigned long long* __restrict__ errpart, int pstride, cplx* __restrict__ I0, double* __restrict__ fb, int Bst,
                            int s0, int S_cnt, unsigned hn_magic) {
     extern __shared__ cplx mm_lds[];                    // [Hn*Hn] Y_N^T of the tile's first device type | [tile buses][Hn] voltages
     int bx, slot;
@@ -184,15 +184,18 @@ __global__ __launch_bounds__(TPB, 8) void k_mismatch(Model M, int count, int N, 
     const int i = live ? (FUND ? t : div_by(t, hn_magic)) : M.n - 1, q = (FUND || !live) ? 0 : t - i * Hn;
     // The kernel is bound by the chain of dependent fetches of a wavefront, so the harmonic variant issues them in BATCHES of independent,
     // branch-free loads (indices clamped into the row, values masked afterwards): A = the row bounds, Y_N^T and the tile's bus voltages
-    // (for LDS); B = col and Y of the row's first PF entries; C = the neighbours' voltages.  Longer rows finish in a loop.  Same
+    // (for LDS); B = Y of the row's first PF entries AND the neighbours' voltages (their columns come with the row bounds in the bus's row
+    // record: two dependent round trips, not three).  Longer rows finish in a loop.  Same
     // operations in the same order as mismatch_row / row_current: bit-identical results.
     constexpr int PF = 3;                               // (a feeder row holds 3 entries on average)
     int d0 = -1, i_first = 0;
     int e0 = 0, e1 = 0;
     cplx yv[PF], ug[PF];
     if (!FUND) {
-        e0 = M.rowptr[i];
-        e1 = M.rowptr[i + 1];
+        const int4 rr = reinterpret_cast<const int4*>(M.rowrec)[2 * i];          // (rowptr[i], rowptr[i+1], col[e0], col[e0+1])
+        const int rr2 = M.rowrec[8 * i + 4];                                      //  col[e0+2]
+        e0 = rr.x;
+        e1 = rr.y;
         const bool has_nl = M.coupled && M.YNt;
         i_first = div_by(bx * TPB, hn_magic);
         int i_last = div_by(bx * TPB + TPB - 1, hn_magic);
@@ -216,11 +219,11 @@ __global__ __launch_bounds__(TPB, 8) void k_mismatch(Model M, int count, int N, 
                 if (base + 3 * TPB < nyn) dst[base + 3 * TPB] = y3;
             }
         }
-        int jc[PF];
+        static_assert(PF == 3, "row records hold the first three neighbours");
+        const int jc[PF] = {rr.z, rr.w, rr2};               // (clamped into the row by the host: entries past the row's end repeat its last)
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
             const int e = e0 + u < e1 ? e0 + u : e1 - 1;
-            jc[u] = M.col[e];
             yv[u] = M.Y[(size_t)e * Hn + q];
         }
 #pragma unroll
@@ -274,18 +277,12 @@ __global__ __launch_bounds__(TPB, 8) void k_mismatch(Model M, int count, int N, 
             *reinterpret_cast<double2*>(o) = double2{k >= 1 ? v.re : 0.0, k >= M.c ? v.im : 0.0};
         }
     }
+    // ||f||_inf of the scenario: every WAVEFRONT leaves its partial maximum (no LDS, no workgroup barrier, no atomic -- 102 workgroups of a
+    // scenario used to meet on one L2 line); the consumer of the norm (k_finalize, k_queue_first, k_err_reduce) takes the maximum of the
+    // scenario's partials.  A maximum does not depend on the order: the result is the same word as before.
     b = wave_max_u64(b);
-    __shared__ unsigned long long red[TPB / 64];
-    if ((tid & 63) == 0) red[tid >> 6] = b;
-    __syncthreads();
-    if (tid == 0) {
-        unsigned long long r = red[0];
-#pragma unroll
-        for (int w = 1; w < TPB / 64; ++w) r = red[w] > r ? red[w] : r;
-        atomicMax(errbits + s, r);
-    }
+    if ((tid & 63) == 0) errpart[(size_t)s * pstride + (size_t)bx * (TPB / 64) + (tid >> 6)] = b;
 }
-
 // Dense Jacobian, network entries: one thread per (harmonic position, stored admittance entry) of one scenario.
 template <bool FUND>
 __global__ void k_jac_dense(Model M, int total, int N, int Nc, size_t J_stride, const int* __restrict__ active,
@@ -372,7 +369,7 @@ __global__ void k_jcsr_fill(Model M, int N, int Nc, const int* __restrict__ indp
 template <bool FUND>
 __global__ void k_update(int n, int Hn, int c, int count, int stride, int N, int Nc, const int* __restrict__ active,
                          const double* __restrict__ step, double* __restrict__ Vm, double* __restrict__ Va,
-                         cplx* __restrict__ U, cplx* __restrict__ E, unsigned long long* __restrict__ errbits,
+                         cplx* __restrict__ U, cplx* __restrict__ E,
                          const double* __restrict__ xbus, int Bst, int s0, unsigned hn_magic) {
     const int s = active ? active[blockIdx.y + s0] : (int)blockIdx.y + s0;   // slot -> scenario (active list; -1: frozen / empty slot)
     if (s < 0) return;
@@ -399,27 +396,38 @@ __global__ void k_update(int n, int Hn, int c, int count, int stride, int N, int
     polar<FUND>(vm, va, u, e);
     U[o] = u;
     E[o] = e;
-    if (k == 0) errbits[s] = 0ull;
 }
 
 // Per-scenario bookkeeping of the NR loop (HG:536-542 / HG:259-265).  The set of running scenarios is a SLOT LIST: active[i] =
 // scenario id that slot i runs, or -1 (frozen scenario / empty slot); every kernel of the loop maps its blockIdx.y through it.
 // first: slot i <- scenario i, record the initial mismatch, apply the stop rule (mask: a repeat pass starts masked scenarios only).
 // else: one thread per slot; a scenario that meets the stop rule freezes (its slot becomes -1).
-__global__ void k_finalize(int S, int first, double thresh, int max_iter, int hist_cap, int hist_off,
-                           const unsigned long long* __restrict__ errbits, double* __restrict__ err,
+// max over the np partial maxima a scenario's mismatch launch left (k_mismatch), taken by one wavefront; every lane receives it
+__device__ __forceinline__ unsigned long long slot_err_bits(const unsigned long long* __restrict__ part, int np) {
+    unsigned long long b = 0ull;
+    for (int i = threadIdx.x & 63; i < np; i += 64) {
+        const unsigned long long v = part[i];
+        b = v > b ? v : b;
+    }
+    return wave_max_u64(b);
+}
+
+// (one wavefront per slot: it first reduces the scenario's partial maxima)
+__global__ __launch_bounds__(64) void k_finalize(int S, int first, double thresh, int max_iter, int hist_cap, int hist_off,
+                           const unsigned long long* __restrict__ errpart, int pstride, int np, double* __restrict__ err,
                            int* __restrict__ niter, int* __restrict__ active, int* __restrict__ nactive,
                            double* __restrict__ hist, int s0, const int* __restrict__ mask) {
-    const int sl = blockIdx.x * blockDim.x + threadIdx.x;
+    const int sl = blockIdx.x;
     if (sl >= S) return;
     const int slot = sl + s0;
     if (first) {
         const int s = slot;
         if (mask && !mask[s]) {           // repeat pass: the other scenarios keep their result and stay frozen
-            active[slot] = -1;
+            if (threadIdx.x == 0) active[slot] = -1;
             return;
         }
-        const double e = __longlong_as_double((long long)errbits[s]);
+        const double e = __longlong_as_double((long long)slot_err_bits(errpart + (size_t)s * pstride, np));
+        if (threadIdx.x != 0) return;
         err[s] = e;
         niter[s] = 0;
         if (hist && hist_off == 0) hist[(size_t)s * hist_cap] = e;
@@ -430,13 +438,21 @@ __global__ void k_finalize(int S, int first, double thresh, int max_iter, int hi
     }
     const int s = active[slot];
     if (s < 0) return;
-    const double e = __longlong_as_double((long long)errbits[s]);
+    const double e = __longlong_as_double((long long)slot_err_bits(errpart + (size_t)s * pstride, np));
+    if (threadIdx.x != 0) return;
     const int it = niter[s] + 1;
     err[s] = e;
     niter[s] = it;
     if (hist) hist[(size_t)s * hist_cap + it - 1 + (hist_off == 0 ? 1 : 0)] = e;
     const int a = (e > thresh) && (it < max_iter);
     if (!a) active[slot] = -1;
+}
+
+// ||f||_inf of every scenario -> out[s] as the bit pattern of the double (hpf_mismatch: the host copies it)
+__global__ __launch_bounds__(64) void k_err_reduce(const unsigned long long* __restrict__ errpart, int pstride, int np,
+                                                   unsigned long long* __restrict__ out) {
+    const unsigned long long b = slot_err_bits(errpart + (size_t)blockIdx.x * pstride, np);
+    if (threadIdx.x == 0) out[blockIdx.x] = b;
 }
 
 // Stable compaction of the slot list (running scenarios to the front, -1 behind them) and their count -> *count.  One workgroup;
@@ -669,8 +685,7 @@ __global__ void k_queue_harvest(int n, int Hn, double thresh, int max_iter, cons
 __global__ void k_queue_init(int n, int Hn, const int* __restrict__ newlist, const int* __restrict__ slot_scen, const double* __restrict__ qP,
                              const double* __restrict__ qQ, const double* __restrict__ seedVm, const double* __restrict__ seedVa,
                              double* __restrict__ P, double* __restrict__ Q, double* __restrict__ Vm, double* __restrict__ Va,
-                             cplx* __restrict__ U, cplx* __restrict__ E, unsigned long long* __restrict__ errbits, int* __restrict__ niter,
-                             int* __restrict__ pivflag) {
+                             cplx* __restrict__ U, cplx* __restrict__ E, int* __restrict__ niter, int* __restrict__ pivflag) {
     const int s = newlist[blockIdx.y];
     if (s < 0) return;
     const int g = slot_scen[s];
@@ -690,20 +705,21 @@ __global__ void k_queue_init(int n, int Hn, const int* __restrict__ newlist, con
         Q[(size_t)s * n + i] = qQ[(size_t)g * n + i];
     }
     if (k == 0) {
-        errbits[s] = 0ull;
         niter[s] = 0;
         pivflag[s] = 0;
     }
 }
 
 // the initial mismatch of the new scenarios against the stop rule (HG:531,536): a scenario that meets it at once leaves the slot list
-__global__ void k_queue_first(int S_max, double thresh, int max_iter, const int* __restrict__ newlist, const int* __restrict__ base,
-                              const unsigned long long* __restrict__ errbits, double* __restrict__ err, int* __restrict__ active) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(64) void k_queue_first(int S_max, double thresh, int max_iter, const int* __restrict__ newlist, const int* __restrict__ base,
+                              const unsigned long long* __restrict__ errpart, int pstride, int np, double* __restrict__ err,
+                              int* __restrict__ active) {
+    const int idx = blockIdx.x;                          // one wavefront per entry of the new list
     if (idx >= S_max) return;
     const int s = newlist[idx];
     if (s < 0) return;
-    const double e = __longlong_as_double((long long)errbits[s]);
+    const double e = __longlong_as_double((long long)slot_err_bits(errpart + (size_t)s * pstride, np));
+    if (threadIdx.x != 0) return;
     err[s] = e;
     if (!((e > thresh) && (0 < max_iter))) active[*base + idx] = -1;
 }
@@ -862,6 +878,10 @@ int launch_polar(hpf_handle* h) {
 static bool bus_images(const hpf_handle* h) { return h->solver == HPF_SOLVER_BLOCK_TREE && h->has_ctree && h->gj_mode == 1; }
 static int tree_bst(const hpf_handle* h) { const int b = 2 * h->Hn; return b <= 12 ? 12 : (b <= 28 ? 28 : (b <= 52 ? 52 : (b <= 100 ? 100 : b))); }   // = wave_block_size, or b
 
+// partial maxima a mismatch launch leaves per scenario (one per wavefront of its workgroups): fundamental pf / harmonic mismatch
+template <bool FUND>
+static int err_parts(const hpf_handle* h) { return (TPB / 64) * (((FUND ? h->n : h->n * h->Hn) + TPB - 1) / TPB); }
+
 // stacked: also write the mismatch in the reference's stacked order (C ABI, dense solver, single-wave / generic tree kernels)
 template <bool FUND>
 int launch_mismatch(hpf_handle* h, const int* active, bool stacked = true) {
@@ -881,7 +901,7 @@ int launch_mismatch(hpf_handle* h, const int* active, bool stacked = true) {
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mismatch<FUND>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         }
         hipLaunchKernelGGL((k_mismatch<FUND>), xcd_grid(nbx, h->cur_S), dim3(TPB), lds, h->cur_stream, h->M, count, N, Nc,
-                           active, h->d_U, h->d_P, h->d_Q, (stacked || !img) ? h->d_f : nullptr, h->d_errbits, h->d_I0,
+                           active, h->d_U, h->d_P, h->d_Q, (stacked || !img) ? h->d_f : nullptr, h->d_errpart, h->errpart_stride, h->d_I0,
                            img ? h->d_fb : nullptr, tree_bst(h), h->cur_s0, h->cur_S, div_magic(h->Hn));
         HIPCHK(hipGetLastError());
     }
@@ -951,7 +971,7 @@ int launch_update(hpf_handle* h, const int* active) {
     const bool busx = !FUND && bus_images(h);
     const int bw = tree_bst(h);
     hipLaunchKernelGGL((k_update<FUND>), grid2(count, h->cur_S), dim3(TPB), 0, h->cur_stream, h->n, h->Hn, h->c, count,
-                       h->n * h->Hn, N, Nc, active, h->d_f, h->d_Vm, h->d_Va, h->d_U, h->d_E, h->d_errbits,
+                       h->n * h->Hn, N, Nc, active, h->d_f, h->d_Vm, h->d_Va, h->d_U, h->d_E,
                        busx ? h->d_x : nullptr, bw, h->cur_s0, div_magic(h->Hn));
     HIPCHK(hipGetLastError());
     return HPF_OK;
@@ -1023,12 +1043,11 @@ int nr_pass(hpf_handle* h, double thresh, int max_iter, const int* mask) {
     const int S = h->S;
     const int hist_off = FUND ? 1 : 0;                // pf records only post-update errors (HG:264)
     if ((r = launch_polar<FUND>(h))) return r;
-    HIPCHK(hipMemsetAsync(h->d_errbits, 0, sizeof(unsigned long long) * S, h->stream));
     if (mask) hipLaunchKernelGGL(k_mask_to_list, dim3((S + 63) / 64), dim3(64), 0, h->stream, S, mask, h->d_active);
     if ((r = launch_mismatch<FUND>(h, mask ? h->d_active : nullptr, false))) return r;
     HIPCHK(hipMemsetAsync(h->d_nactive, 0, sizeof(int), h->stream));
-    hipLaunchKernelGGL(k_finalize, dim3((S + 63) / 64), dim3(64), 0, h->stream, S, 1, thresh, max_iter, h->hist_cap,
-                       hist_off, h->d_errbits, h->d_err, h->d_niter, h->d_active, h->d_nactive, h->d_hist, 0, mask);
+    hipLaunchKernelGGL(k_finalize, dim3((unsigned)S), dim3(64), 0, h->stream, S, 1, thresh, max_iter, h->hist_cap,
+                       hist_off, h->d_errpart, h->errpart_stride, err_parts<FUND>(h), h->d_err, h->d_niter, h->d_active, h->d_nactive, h->d_hist, 0, mask);
     const bool trace = !FUND && h->trace_Vm != nullptr;
     if (trace && !mask && (r = trace_record(h, 0))) return r;
     // The per-scenario stop rule lives on the device (k_finalize after every iteration, in the scenario group's own pipeline):
@@ -1047,8 +1066,8 @@ int nr_pass(hpf_handle* h, double thresh, int max_iter, const int* mask) {
                 if ((rr = newton_step<FUND>(h, h->d_active))) return rr;
                 if ((rr = launch_update<FUND>(h, h->d_active))) return rr;
                 if ((rr = launch_mismatch<FUND>(h, h->d_active, false))) return rr;
-                hipLaunchKernelGGL(k_finalize, dim3((h->cur_S + 63) / 64), dim3(64), 0, h->cur_stream, h->cur_S, 0, thresh,
-                                   max_iter, h->hist_cap, hist_off, h->d_errbits, h->d_err, h->d_niter, h->d_active,
+                hipLaunchKernelGGL(k_finalize, dim3((unsigned)h->cur_S), dim3(64), 0, h->cur_stream, h->cur_S, 0, thresh,
+                                   max_iter, h->hist_cap, hist_off, h->d_errpart, h->errpart_stride, err_parts<FUND>(h), h->d_err, h->d_niter, h->d_active,
                                    h->d_nactive, h->d_hist, h->cur_s0, (const int*)nullptr);
             }
             return HPF_OK;
@@ -1277,13 +1296,13 @@ int solve_queue_fast(hpf_handle* h, int n_total, const double* P, const double* 
         hipLaunchKernelGGL(k_queue_harvest, dim3((unsigned)S_max), dim3(TPB), 0, h->stream, n, Hn, thresh, max_iter, hlist, hg, h->d_Vm,
                            h->d_Va, h->d_err, h->d_niter, h->d_pivflag, qst, qVm, qVa);
         hipLaunchKernelGGL(k_queue_init, grid2((int)count, S_max), dim3(TPB), 0, h->stream, n, Hn, newlist, slot_scen, qP, qQ, sVm, sVa,
-                           h->d_P, h->d_Q, h->d_Vm, h->d_Va, h->d_U, h->d_E, h->d_errbits, h->d_niter, h->d_pivflag);
+                           h->d_P, h->d_Q, h->d_Vm, h->d_Va, h->d_U, h->d_E, h->d_niter, h->d_pivflag);
         set_ctx(h, h->stream, 0, S_max);
         int rr = launch_mismatch<false>(h, newlist, false);
         full_ctx(h);
         if (rr) return rr;
-        hipLaunchKernelGGL(k_queue_first, dim3((unsigned)((S_max + 63) / 64)), dim3(64), 0, h->stream, S_max, thresh, max_iter, newlist, base,
-                           h->d_errbits, h->d_err, h->d_active);
+        hipLaunchKernelGGL(k_queue_first, dim3((unsigned)S_max), dim3(64), 0, h->stream, S_max, thresh, max_iter, newlist, base,
+                           h->d_errpart, h->errpart_stride, err_parts<false>(h), h->d_err, h->d_active);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(h->h_act[buf], h->d_nactive, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipMemcpyAsync(h->h_act[buf] + 1, next, sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -1297,8 +1316,8 @@ int solve_queue_fast(hpf_handle* h, int n_total, const double* P, const double* 
                 if ((rr = newton_step<false>(h, h->d_active))) return rr;
                 if ((rr = launch_update<false>(h, h->d_active))) return rr;
                 if ((rr = launch_mismatch<false>(h, h->d_active, false))) return rr;
-                hipLaunchKernelGGL(k_finalize, dim3((h->cur_S + 63) / 64), dim3(64), 0, h->cur_stream, h->cur_S, 0, thresh, max_iter, 1, 0,
-                                   h->d_errbits, h->d_err, h->d_niter, h->d_active, h->d_nactive, (double*)nullptr, h->cur_s0, (const int*)nullptr);
+                hipLaunchKernelGGL(k_finalize, dim3((unsigned)h->cur_S), dim3(64), 0, h->cur_stream, h->cur_S, 0, thresh, max_iter, 1, 0,
+                                   h->d_errpart, h->errpart_stride, err_parts<false>(h), h->d_err, h->d_niter, h->d_active, h->d_nactive, (double*)nullptr, h->cur_s0, (const int*)nullptr);
             }
             return HPF_OK;
         };
@@ -1332,8 +1351,8 @@ int solve_queue_fast(hpf_handle* h, int n_total, const double* P, const double* 
 }
 
 void free_all(hpf_handle* h) {
-    void* ptrs[] = {h->d_rowptr, h->d_col, h->d_diag, h->d_erow, h->d_dev, h->d_Y, h->d_YN, h->d_YNt, h->d_IN, h->d_P, h->d_Q,
-                    h->d_Vm, h->d_Va, h->d_U, h->d_E, h->d_I0, h->d_f, h->d_errbits, h->d_err, h->d_niter, h->d_active,
+    void* ptrs[] = {h->d_rowrec, h->d_rowptr, h->d_col, h->d_diag, h->d_erow, h->d_dev, h->d_Y, h->d_YN, h->d_YNt, h->d_IN, h->d_P, h->d_Q,
+                    h->d_Vm, h->d_Va, h->d_U, h->d_E, h->d_I0, h->d_f, h->d_errbits, h->d_errpart, h->d_err, h->d_niter, h->d_active,
                     h->d_nactive, h->d_pivflag, h->d_mask, h->d_Vm0, h->d_Va0, h->d_Vmp, h->d_Vap, h->d_tstamp, h->d_hist, h->d_stats, h->d_J, h->d_ipiv, h->d_info, h->d_Z, h->d_w, h->d_x, h->d_linA, h->d_C, h->d_dbg, h->d_H, h->d_chG, h->d_chH, h->d_chD, h->d_chy, h->d_chZ, h->d_lfK, h->d_lfS, h->d_fb, h->d_F, h->d_H2, h->d_jptr, h->d_jcol, h->d_jval};
     for (void* p : ptrs)
         if (p) hipFree(p);
@@ -1456,6 +1475,16 @@ int hpf_create(hpf_handle** out, const hpf_desc* d) {
     if ((r = dev_upload(h, &h->d_diag, diag.data(), (size_t)d->n))) return fail(r);
     if ((r = dev_upload(h, &h->d_erow, erow.data(), (size_t)d->nnz))) return fail(r);
     if ((r = dev_upload(h, &h->d_dev, d->dev_of_bus, (size_t)d->n))) return fail(r);
+    {   // row records of the mismatch kernel (Model::rowrec)
+        std::vector<int> rec((size_t)d->n * 8, 0);
+        for (int i = 0; i < d->n; ++i) {
+            const int e0 = d->rowptr[i], e1 = d->rowptr[i + 1];
+            rec[(size_t)i * 8] = e0;
+            rec[(size_t)i * 8 + 1] = e1;
+            for (int u = 0; u < 3; ++u) rec[(size_t)i * 8 + 2 + u] = d->col[e0 + u < e1 ? e0 + u : e1 - 1];
+        }
+        if ((r = dev_upload(h, &h->d_rowrec, rec.data(), rec.size()))) return fail(r);
+    }
     {   // device copy of the admittances: entry-major [nnz][Hn] (Model::yi)
         std::vector<cplx> yt((size_t)d->Hn * d->nnz);
         const cplx* src = (const cplx*)d->Yval;
@@ -1483,6 +1512,9 @@ int hpf_create(hpf_handle** out, const hpf_desc* d) {
     if ((r = dev_alloc(h, &h->d_I0, S * (size_t)h->n))) return fail(r);
     if ((r = dev_alloc(h, &h->d_f, S * (size_t)(h->N > h->Nf ? h->N : h->Nf)))) return fail(r);
     if ((r = dev_alloc(h, &h->d_errbits, S))) return fail(r);
+    h->errpart_stride = err_parts<false>(h) > err_parts<true>(h) ? err_parts<false>(h) : err_parts<true>(h);
+    if ((r = dev_alloc(h, &h->d_errpart, S * (size_t)h->errpart_stride))) return fail(r);
+    if (hipMemset(h->d_errpart, 0, sizeof(unsigned long long) * S * (size_t)h->errpart_stride) != hipSuccess) return fail(HPF_E_HIP);
     if ((r = dev_alloc(h, &h->d_err, S))) return fail(r);
     if ((r = dev_alloc(h, &h->d_niter, S))) return fail(r);
     if ((r = dev_alloc(h, &h->d_active, S))) return fail(r);
@@ -1493,7 +1525,7 @@ int hpf_create(hpf_handle** out, const hpf_desc* d) {
     Model& M = h->M;
     M.n = d->n; M.m = d->m; M.c = d->c; M.Hn = d->Hn; M.nnz = d->nnz; M.n_dev = d->n_dev; M.coupled = h->coupled; M.bus_major = 1;
     M.rowptr = h->d_rowptr; M.col = h->d_col; M.diag = h->d_diag; M.Y = h->d_Y; M.dev = h->d_dev;
-    M.YN = h->d_YN; M.IN = h->d_IN; M.YNt = h->d_YNt;
+    M.YN = h->d_YN; M.IN = h->d_IN; M.YNt = h->d_YNt; M.rowrec = h->d_rowrec;
     if (d->solver == HPF_SOLVER_BLOCK_TREE) {
         const auto t_tree = std::chrono::steady_clock::now();
         if ((r = tree_build(h, d))) return fail(r);
@@ -1588,8 +1620,9 @@ static int mismatch_impl(hpf_handle* h, bool fund, double* f, double* err) {
     if (!h->loads_set || !h->state_set || h->S < 1) return HPF_E_STATE;
     int r;
     if ((r = fund ? launch_polar<true>(h) : launch_polar<false>(h))) return r;
-    HIPCHK(hipMemsetAsync(h->d_errbits, 0, sizeof(unsigned long long) * h->S, h->stream));
     if ((r = fund ? launch_mismatch<true>(h, nullptr) : launch_mismatch<false>(h, nullptr))) return r;
+    hipLaunchKernelGGL(k_err_reduce, dim3((unsigned)h->S), dim3(64), 0, h->stream, h->d_errpart, h->errpart_stride,
+                       fund ? err_parts<true>(h) : err_parts<false>(h), h->d_errbits);
     HIPCHK(hipStreamSynchronize(h->stream));
     const int N = fund ? h->Nf : h->N;
     if (f) HIPCHK(hipMemcpy(f, h->d_f, sizeof(double) * (size_t)h->S * N, hipMemcpyDeviceToHost));
