@@ -389,6 +389,9 @@ def main():
         "repeat_note": "R timed blocks of exactly `steps` iterations, each from the pf seed after `warmup` iterations, each bracketed by "
                        "barrier + synchronize and MAX-reduced over the ranks; ms_per_step / value are the MEDIAN block's",
         "scenario_groups_probe": groups_probe,      # untimed: four groups (default) against three in this process; the default stays unless > 10 % slower
+        # build switches of the handle: none in a product run; under HPF_ENV_SWITCHES=1 (tools/) the HPF_* names found in the environment
+        "env_switches": (sorted(k for k in os.environ if k.startswith("HPF_") and k not in ("HPF_ENV_SWITCHES", "HPF_BENCH_BACKEND", "HPF_LIB_PATH"))
+                         if os.environ.get("HPF_ENV_SWITCHES", "0") not in ("", "0") else []),
         "backend": backend if world > 1 else None,
         "rccl_ranks": rccl_ranks,
         "ms_per_step_ranks": [1e3 * t / K for t in blocks_ranks[median_block]],   # each rank's own time of the median block (value uses their MAX)

@@ -29,6 +29,7 @@ class hpf_stat(C.Structure):
 _H = C.c_void_p
 SYMBOLS = {
     "hpf_create": (C.c_int, [C.POINTER(_H), C.POINTER(hpf_desc)]),
+    "hpf_create_opts": (C.c_int, [C.POINTER(_H), C.POINTER(hpf_desc), C.c_char_p]),
     "hpf_destroy": (C.c_int, [_H]),
     "hpf_strerror": (C.c_char_p, [C.c_int]),
     "hpf_last_error_detail": (C.c_int, [_H]),

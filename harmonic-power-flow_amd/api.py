@@ -154,6 +154,7 @@ def _borrow_model(buses, Y, NE, coupled, harmonics, solver="auto", assembly_only
     else:
         dev, Y_N, I_N, n_dev = ingest.norton_arrays(buses, NE, coupled, len(harmonics))
         ne_key = _digest(dev, Y_N, I_N)
+    # (the environment is part of a handle's build only under HPF_ENV_SWITCHES=1 -- hpf.h -- but keying on it always is harmless)
     env = tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("HPF_")))
     key = (n, m, c, tuple(harmonics), bool(coupled), solver, bool(assembly_only), int(device), _digest(Y.rowptr, Y.col, Y.Yval), ne_key, env)
     dm = _HANDLES.pop(key, None)

@@ -4,6 +4,10 @@
 #include <rocblas/rocblas.h>
 #include <stdint.h>
 
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
 #include <vector>
 
 #include "../../include/hpf.h"
@@ -132,6 +136,21 @@ struct Tree {
 }  // namespace hpf
 
 struct hpf_handle {
+    // Build switches (A/B runs, diagnostics: "HPF_LAZY=0 HPF_SLEAF=1 ..."): the option string of hpf_create_opts, and -- ONLY when the process
+    // opts in with HPF_ENV_SWITCHES=1 (the test-suite, tools/) -- the process environment.  Without that opt-in nothing a handle computes
+    // depends on environment variables.
+    std::string opts;
+    bool env_switches = false;
+    const char* sw(const char* name) const {
+        const size_t ln = strlen(name);
+        size_t pos = 0;
+        while ((pos = opts.find(name, pos)) != std::string::npos) {
+            const bool starts = pos == 0 || opts[pos - 1] == ' ' || opts[pos - 1] == ',' || opts[pos - 1] == ';';
+            if (starts && pos + ln < opts.size() && opts[pos + ln] == '=') return opts.c_str() + pos + ln + 1;   // (atoi / the readers stop at the separator)
+            pos += ln;
+        }
+        return env_switches ? getenv(name) : nullptr;
+    }
     hpf::Model M{};                   // device pointers
     int n = 0, m = 0, c = 0, Hn = 0, nnz = 0, n_dev = 0, coupled = 0, solver = 0, device = 0;
     int S_max = 0, S = 0;

@@ -1231,7 +1231,7 @@ int solve_queue_fast(hpf_handle* h, int n_total, const double* P, const double* 
     int r = HPF_OK;
     const int n = h->n, Hn = h->Hn, S_max = h->S_max;
     const size_t count = (size_t)n * Hn;
-    const bool info = getenv("HPF_QUEUE_INFO") != nullptr;
+    const bool info = h->sw("HPF_QUEUE_INFO") != nullptr;
     const auto t_0 = std::chrono::steady_clock::now();
     auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
     double *qP = nullptr, *qQ = nullptr, *sVm = nullptr, *sVa = nullptr, *qVm = nullptr, *qVa = nullptr;
@@ -1399,7 +1399,9 @@ const char* hpf_strerror(int code) {
 
 int hpf_last_error_detail(const hpf_handle* h) { return h ? h->last_detail : 0; }
 
-int hpf_create(hpf_handle** out, const hpf_desc* d) {
+int hpf_create(hpf_handle** out, const hpf_desc* d) { return hpf_create_opts(out, d, nullptr); }
+
+int hpf_create_opts(hpf_handle** out, const hpf_desc* d, const char* options) {
     if (!out || !d) return HPF_E_ARG;
     *out = nullptr;
     if (d->n < 1 || d->Hn < 1 || d->m < 1 || d->m > d->n || d->c < 1 || d->c > d->m || d->nnz < d->n ||
@@ -1440,19 +1442,21 @@ int hpf_create(hpf_handle** out, const hpf_desc* d) {
     h->Nc = d->n * d->Hn - 1;
     h->N = 2 * h->Nc - (d->c - 1);
     h->Nf = 2 * d->n - 1 - d->c;
+    if (options) h->opts = options;
+    if (const char* es = getenv("HPF_ENV_SWITCHES")) h->env_switches = atoi(es) != 0;
     // (dense systems beyond N * N = 2^31 -- 1 000 buses x 26 harmonics is already N = 51 998 -- go through rocSOLVER's 64-bit entry
     //  points, dense_solve; memory, 8 N^2 bytes per scenario, is what bounds them: HPF_E_NOMEM from the allocation)
-    if (const char* ab = getenv("HPF_DEBUG_ABLATE")) h->debug_ablate = atoi(ab);
-    if (const char* gm = getenv("HPF_GJ_MODE")) h->gj_mode = atoi(gm) ? 1 : 0;
-    if (const char* lb = getenv("HPF_LEAFBATCH")) h->leafbatch = atoi(lb) ? 1 : 0;
-    if (const char* fl = getenv("HPF_FUSELEVEL")) h->fuse_levels = atoi(fl) ? 1 : 0;
-    if (const char* fb = getenv("HPF_FUSEBACK")) h->fuse_back = atoi(fb) ? 1 : 0;
-    if (const char* fm = getenv("HPF_FUSEBACK_MAX")) h->fuse_back_max = atoi(fm);
-    if (const char* bs = getenv("HPF_BORDER_SLOTS")) h->border_slot_cap = atoi(bs);
+    if (const char* ab = h->sw("HPF_DEBUG_ABLATE")) h->debug_ablate = atoi(ab);
+    if (const char* gm = h->sw("HPF_GJ_MODE")) h->gj_mode = atoi(gm) ? 1 : 0;
+    if (const char* lb = h->sw("HPF_LEAFBATCH")) h->leafbatch = atoi(lb) ? 1 : 0;
+    if (const char* fl = h->sw("HPF_FUSELEVEL")) h->fuse_levels = atoi(fl) ? 1 : 0;
+    if (const char* fb = h->sw("HPF_FUSEBACK")) h->fuse_back = atoi(fb) ? 1 : 0;
+    if (const char* fm = h->sw("HPF_FUSEBACK_MAX")) h->fuse_back_max = atoi(fm);
+    if (const char* bs = h->sw("HPF_BORDER_SLOTS")) h->border_slot_cap = atoi(bs);
     if (hipSetDevice(d->device) != hipSuccess) return fail(HPF_E_HIP);
     if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) return fail(HPF_E_HIP);
     h->stream = h->own_stream;
-    if (const char* gs = getenv("HPF_GROUPS")) h->n_groups = atoi(gs) < 1 ? 1 : (atoi(gs) > 8 ? 8 : atoi(gs));
+    if (const char* gs = h->sw("HPF_GROUPS")) h->n_groups = atoi(gs) < 1 ? 1 : (atoi(gs) > 8 ? 8 : atoi(gs));
     for (int g = 0; g < 8; ++g) {
         if (g > 0 && hipStreamCreateWithFlags(&h->gstream[g], hipStreamNonBlocking) != hipSuccess) return fail(HPF_E_HIP);   // (group 0: group_stream)
         if (hipEventCreateWithFlags(&h->join_ev[g], hipEventDisableTiming) != hipSuccess) return fail(HPF_E_HIP);

@@ -241,7 +241,7 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
         // bundles of whole all-linear subtrees for the one-launch kernels: subtrees in bus order, a bundle is closed before a height
         // of it would need a second pass of the 256 threads (one thread per (bus, harmonic) of a height)
         T.n_lin_bundles = 0;
-        const char* lt_env = getenv("HPF_LINTREE");
+        const char* lt_env = h->sw("HPF_LINTREE");
         if (!(lt_env && atoi(lt_env) == 0) && T.n_lin_heights > 1) {
             const int NH = T.n_lin_heights, cap = std::max(1, 256 / d->Hn);
             std::vector<int> root_of(n, -1);
@@ -278,8 +278,8 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
             // buses is ONE unit (the chain walk follows its subtrees in the same workgroup) --, at most 256 * NP items (bus, harmonic)
             // and 256 / Hn chains per workgroup
             {
-                const char* lb_env2 = getenv("HPF_LINBUNDLE");
-                const char* cb_env = getenv("HPF_CHAINBUNDLE");
+                const char* lb_env2 = h->sw("HPF_LINBUNDLE");
+                const char* cb_env = h->sw("HPF_CHAINBUNDLE");
                 const bool chb = !(cb_env && atoi(cb_env) == 0) && T.n_chains > 0;
                 std::vector<int> node_chain(n, -1);
                 for (int r2 = 0; r2 < T.n_chains; ++r2)
@@ -423,13 +423,13 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
     std::vector<int> sl_slot(n, 0);                            // 1 + slot of the bus's Z0 image in Tree::d_Minv
     std::vector<long long> sl_off(n, -1);                      // offset of [Tc | Pb | Qb] in slimg
     std::vector<double> slimg, lbimg;
-    const char* sl_env = getenv("HPF_SLEAF");
+    const char* sl_env = h->sw("HPF_SLEAF");
     const bool sleaf_on = !(sl_env && atoi(sl_env) == 0) && wave_block_size(b) <= 52;   // HPF_SLEAF=0: every bus with dense children takes the Gauss-Jordan path
                                                                                        // (b > 52: plain constant-inverse leaves only, no lazy leaves / super-leaves yet)
     const int sleaf_mode = sl_env ? atoi(sl_env) : 2;          // 1: nonlinear buses only
     int n_sleaf = 0;
-    const char* sb_env = getenv("HPF_SLBACK");
-    const char* lb_env = getenv("HPF_LEAFBATCH");
+    const char* sb_env = h->sw("HPF_SLBACK");
+    const char* lb_env = h->sw("HPF_LEAFBATCH");
     const bool slback_on = !(sb_env && atoi(sb_env) == 0) && !(lb_env && atoi(lb_env) == 0);   // super-leaves keep T^-1 only; k_sleaf_back_batch
                                                                                              // rebuilds D^-1 t (needs the batched back sweep)
     std::vector<int> sb_ord(n, -1), sb_m(n, 0);
@@ -442,14 +442,14 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
     };
     std::vector<LazySuper> slzs;
     std::vector<std::vector<int>> slz_of(n);
-    const char* sz_env = getenv("HPF_SLLAZY");
+    const char* sz_env = h->sw("HPF_SLLAZY");
     const bool sllazy_on = !(sz_env && atoi(sz_env) == 0);     // HPF_SLLAZY=0: every super-leaf pushes its Schur complement itself
-    const char* sn_env = getenv("HPF_SLNEST");
+    const char* sn_env = h->sw("HPF_SLNEST");
     const bool slnest_on = !(sn_env && atoi(sn_env) == 0);     // HPF_SLNEST=0: bordered buses below a bordered bus stay on the Gauss-Jordan path
     std::vector<double> sbimg;
     std::vector<std::vector<int>> lazy_of(n);
     std::vector<int> is_lazy(n, 0);
-    const char* lz_env = getenv("HPF_LAZY");
+    const char* lz_env = h->sw("HPF_LAZY");
     const bool lazy_on = !(lz_env && atoi(lz_env) == 0) && wave_block_size(b) <= 52;
     const int lazy_mode = lz_env ? atoi(lz_env) : 2;          // 1: only leaves hanging directly under their dense parent
     constexpr int LZ_MAX = 4;
@@ -914,7 +914,7 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
     T.comp_v.clear();
     T.comp_c.clear();
     {
-        const char* cp_env = getenv("HPF_COMPRESS");
+        const char* cp_env = h->sw("HPF_COMPRESS");
         // default: handles of up to 256 scenarios -- a compress step trades a shorter chain of levels for more matrix-core work (the dense
         // push of the pending child), which pays while the levels do not fill the chip (measured crossover between 256 and 384 live
         // scenarios on the headline feeder, tools/groups_sweep.py); HPF_COMPRESS=1 / 0 force it on / off
@@ -1307,7 +1307,7 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
         T.bytes_back += nc2 * (TB + 8.0 * bd + 32.0 * d->Hn);
     }
     T.flops_per_solve = T.flops_factor + 2.0 * bd * bd * (n_dense_nonroot + T.n_comp);
-    if (getenv("HPF_TREE_INFO")) {
+    if (h->sw("HPF_TREE_INFO")) {
         int sl_nl = 0, sl_lin = 0, sl_lvl[4] = {0, 0, 0, 0};
         for (int i = 1; i < n; ++i)
             if (kept(i) && n_lazy[i] > 0 && dchild_ptr[i + 1] - dchild_ptr[i] == n_lazy[i]) {
@@ -1317,11 +1317,11 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
         fprintf(stderr, "hpf tree: buses whose dense children are all lazy leaves: %d nonlinear + %d linear (levels 1/2/3+: %d/%d/%d), %d built as super-leaves\n",
                 sl_nl, sl_lin, sl_lvl[1], sl_lvl[2], sl_lvl[3], n_sleaf);
     }
-    if (getenv("HPF_TREE_INFO"))
+    if (h->sw("HPF_TREE_INFO"))
         fprintf(stderr, "hpf tree (%s): %d buses, %d dense in %d levels, %d chains, %d constant-inverse leaves, %d lazy under %d parents\n",
                 contract ? "contracted" : "plain", n, T.n_dense, T.n_levels, T.n_chains, T.n_cleaf, T.n_lazy_leaves, T.n_lazy_parents);
     // host-side plan of the dense tree (tools/tree_plan.py): one line per dense bus -- to the file hpf_tree_plan names, or env HPF_TREE_DUMP
-    if (const char* dump_path = h->plan_path ? h->plan_path : getenv("HPF_TREE_DUMP")) {
+    if (const char* dump_path = h->plan_path ? h->plan_path : h->sw("HPF_TREE_DUMP")) {
         if (FILE* fp = fopen(dump_path, contract ? "w" : "a")) {
             h->plan_written = true;
             fprintf(fp, "# %s tree: k pard height depth kind(0 gauss-jordan, 1 constant-inverse leaf, 2 bordered) vector_only hbm_children via_chain compress_role\n",
@@ -1336,7 +1336,7 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
         }
     }
     T.plan_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
-    if (getenv("HPF_TREE_INFO")) fprintf(stderr, "hpf tree (%s): planned on the host in %.1f ms\n", contract ? "contracted" : "plain", T.plan_ms);
+    if (h->sw("HPF_TREE_INFO")) fprintf(stderr, "hpf tree (%s): planned on the host in %.1f ms\n", contract ? "contracted" : "plain", T.plan_ms);
     if (h->plan_only) return HPF_OK;            // hpf_tree_plan: host-only, nothing goes to a device
     int r;
     if ((r = upload(h, &T.d_parent, T.parent))) return r;
@@ -1429,6 +1429,7 @@ int tree_plan_dump(const hpf_desc* d, const char* path) {
     tmp.S_max = d->max_scenarios;
     tmp.plan_path = path;
     tmp.plan_only = true;
+    if (const char* es = getenv("HPF_ENV_SWITCHES")) tmp.env_switches = atoi(es) != 0;     // (the same opt-in as hpf_create)
     Tree T;
     const int r = tree_build_into(&tmp, d, T, true);
     tree_free_one_fwd(T);

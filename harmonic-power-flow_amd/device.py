@@ -41,7 +41,9 @@ class DeviceModel:
     `tree_census()["compress_steps"]` / `solve` details report which one a handle uses; env HPF_COMPRESS=0/1 forces it."""
 
     def __init__(self, n, m, c, harmonics, rowptr, col, Yval, dev_of_bus, Y_N, I_N, n_dev, coupled,
-                 solver="auto", device=0, max_scenarios=1, assembly_only=False):
+                 solver="auto", device=0, max_scenarios=1, assembly_only=False, options=None):
+        """options: build switches of THIS handle, "HPF_LAZY=0 HPF_SLEAF=1 ..." (hpf_create_opts; include/hpf.h lists them).  The process
+        environment is consulted for the same names only when HPF_ENV_SWITCHES=1 is set (A/B tooling, the test-suite)."""
         lib = _lib.load()
         self.lib = lib
         self.n, self.m, self.c = int(n), int(m), int(c)
@@ -81,12 +83,13 @@ class DeviceModel:
         d.Y_N = self.Y_N.view(np.float64).ctypes.data_as(_lib.c_dbl_p)
         d.I_N = self.I_N.view(np.float64).ctypes.data_as(_lib.c_dbl_p)
         self._h = C.c_void_p()
-        rc = lib.hpf_create(C.byref(self._h), C.byref(d))
+        opts = options.encode() if options else None
+        rc = lib.hpf_create_opts(C.byref(self._h), C.byref(d), opts)
         if rc == -3 and self._solver_request == "block_tree_or_dense" and 8 * N * N * int(max_scenarios) <= 240e9:
             # too many loop-closing lines for the bordered block-tree step: the dense GPU path (still no CPU path anywhere)
             self.solver = "dense"
             d.solver = _lib.SOLVER_DENSE
-            rc = lib.hpf_create(C.byref(self._h), C.byref(d))
+            rc = lib.hpf_create_opts(C.byref(self._h), C.byref(d), opts)
         _lib.check(rc, None, "hpf_create")
         self.S_max = int(lib.hpf_max_scenarios(self._h))
         self.N = lib.hpf_num_unknowns(self._h)

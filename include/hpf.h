@@ -87,6 +87,11 @@ typedef struct hpf_stat {
 } hpf_stat;
 
 int  hpf_create(hpf_handle** out, const hpf_desc* d);
+/* hpf_create with build switches for THIS handle: `options` = "NAME=value NAME=value ..." (separators: space, comma, semicolon; NULL or "" = none)
+ * with the HPF_* names listed at hpf_set_option below ("Switches read by hpf_create").  The process environment is consulted for the same names
+ * ONLY when the process opts in with HPF_ENV_SWITCHES=1 (A/B tooling, the test-suite): without it nothing a handle computes depends on
+ * environment variables.  hpf_create(out, d) = hpf_create_opts(out, d, NULL). */
+int  hpf_create_opts(hpf_handle** out, const hpf_desc* d, const char* options);
 int  hpf_destroy(hpf_handle* h);
 const char* hpf_strerror(int code);
 int  hpf_last_error_detail(const hpf_handle* h);      /* hipError_t / rocblas_status / pivot index of the last >0 code */
@@ -219,7 +224,10 @@ int  hpf_debug_stamps(hpf_handle* h, long long* out, int count);
  * on the handle's own stream (hpf_set_stream), the others on streams of the handle.  The runtime maps streams onto FOUR hardware queues: with a fifth
  * stream busy at the same time (the application's own work during a solve) two groups share a queue and serialise (1.25 instead of 0.90 ms per
  * step at the benchmark shape) -- such an application sets 3.
- * Environment read by hpf_create (diagnostics, A/B runs): HPF_LAZY=0 builds the elimination tree without lazy leaves (every
+ * Switches read by hpf_create (diagnostics, A/B runs; from the option string of hpf_create_opts, and from the environment only with
+ * HPF_ENV_SWITCHES=1; HPF_HOST_THREADS -- host threads of the tree planner, no effect on results -- is always read from the environment;
+ * HPF_TREE_DUMP takes a path: environment only): HPF_DEBUG_ABLATE (timing-only ablation of factor-kernel phases: results INVALID), HPF_GJ_MODE=0
+ * (the pivoted variant for every solve of the handle), HPF_LAZY=0 builds the elimination tree without lazy leaves (every
  * leaf writes its Schur complement; 1: only leaves directly under their dense parent), HPF_SLEAF=0 sends the nonlinear buses
  * whose dense children are all lazy leaves (super-leaves: bordered low-rank inverse) through Gauss-Jordan like every other bus,
  * HPF_LEAFBATCH=0 runs the lazy leaves one workgroup per (leaf, scenario) instead of 16 scenarios per workgroup on the matrix

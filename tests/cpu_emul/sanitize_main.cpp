@@ -123,6 +123,47 @@ int main() {
         bad = d;
         bad.rowptr = nullptr;
         if (hpf_create(&h, &bad) != HPF_E_ARG) return 2;
+        // hpf_sparse_solve: the host-side analysis of the pattern (bus adjacency from the CSR Jacobian just built, BFS tree, levels) under the
+        // sanitizers.  These feeders are radial: the analysis must accept them, so without a GPU the call ends at the first HIP call
+        // (HPF_E_HIP); a ring closed by one extra entry must be refused (HPF_E_TOPOLOGY) before any HIP call, a bad index with HPF_E_ARG.
+        {
+            std::vector<double> dx(N, 0.0);
+            const int rc = hpf_sparse_solve(0, n, F.c, Hn, indptr.data(), indices.data(), data.data(), f.data(), dx.data());
+            if (rc == HPF_E_ARG || rc == HPF_E_TOPOLOGY) {
+                printf("seed %u: hpf_sparse_solve refused a radial feeder: %d\n", seed, rc);
+                return 4;
+            }
+            if (Hn >= 2 && n >= 4) {
+                // one more entry: row of (bus n-1, harmonic position 1) gets a column of bus a, a not adjacent to it -> a cycle in the bus graph
+                const int rbus = n - 1;
+                int a = -1;
+                for (int cand = 1; cand < n - 1 && a < 0; ++cand) {
+                    bool adj = false;
+                    for (int e = F.rowptr[rbus]; e < F.rowptr[rbus + 1]; ++e) adj = adj || F.col[e] == cand;
+                    if (!adj) a = cand;
+                }
+                if (a >= 0) {
+                    const int r = 1 * n + rbus - 1, cnew = 1 * n + a - 1;          // Re row of stacked k = n + rbus, theta column of k = n + a
+                    std::vector<int> ip2(indptr), ix2;
+                    std::vector<double> dt2;
+                    for (int rr = 0; rr < N; ++rr) {
+                        ip2[rr] = (int)ix2.size();
+                        for (int e = indptr[rr]; e < indptr[rr + 1]; ++e) {
+                            ix2.push_back(indices[e]);
+                            dt2.push_back(data[e]);
+                        }
+                        if (rr == r) {
+                            ix2.push_back(cnew);
+                            dt2.push_back(1.0);
+                        }
+                    }
+                    ip2[N] = (int)ix2.size();
+                    if (hpf_sparse_solve(0, n, F.c, Hn, ip2.data(), ix2.data(), dt2.data(), f.data(), dx.data()) != HPF_E_TOPOLOGY) return 4;
+                    ix2[0] = N + 5;
+                    if (hpf_sparse_solve(0, n, F.c, Hn, ip2.data(), ix2.data(), dt2.data(), f.data(), dx.data()) != HPF_E_ARG) return 4;
+                }
+            }
+        }
 #endif
     }
 #ifdef WITH_LIBHPF

@@ -65,7 +65,7 @@ def test_every_environment_switch_of_the_library_is_documented_in_the_header():
     import glob
     import re
     src = "".join(open(f).read() for f in glob.glob(os.path.join(REPO, "harmonic-power-flow_amd", "csrc", "*")))
-    envs = set(re.findall(r'getenv\("(HPF_[A-Z_0-9]+)"\)', src))
+    envs = set(re.findall(r'(?:getenv|sw)\("(HPF_[A-Z_0-9]+)"\)', src))
     hdr = open(os.path.join(REPO, "include", "hpf.h")).read()
     assert envs and not [e for e in sorted(envs) if e not in hdr]
 

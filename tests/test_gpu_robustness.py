@@ -650,3 +650,36 @@ def test_caller_stream_carries_scenario_group_0(tmp_path):
         assert np.array_equal(ref[0].view(np.uint8), other[0].view(np.uint8))
         assert np.array_equal(ref[1], other[1]) and np.array_equal(ref[2], other[2])
     assert ((ref[0]["flags"] & 1) == 1).all()
+
+
+def test_build_switches_come_from_the_option_string_and_the_environment_only_on_opt_in(tmp_path, monkeypatch):
+    """a handle's numerics must not depend on the process environment.  hpf_create_opts takes the build switches of ONE
+    handle as a string; the HPF_* environment is consulted only under HPF_ENV_SWITCHES=1 (which the test-suite sets).  The census tells which
+    tree was built: the option string and the opted-in environment give the same handle, the environment without the opt-in gives the default."""
+    hp = _hp()
+    from harmonic_power_flow_amd import api
+    st, buses, Y, NE, _ = _feeder(hp, 300, 51, tmp_path, seed=2)
+
+    def census(options=None):
+        from harmonic_power_flow_amd import ingest
+        from harmonic_power_flow_amd.device import DeviceModel
+        m, n, c = ingest.network_constants(buses)
+        dev, Y_N, I_N, n_dev = ingest.norton_arrays(buses, NE, True, len(st.HARMONICS))
+        dm = DeviceModel(n, m, c, st.HARMONICS, Y.rowptr, Y.col, Y.Yval, dev, Y_N, I_N, n_dev, True, solver="block_tree", max_scenarios=4, options=options)
+        try:
+            return dm.tree_census()
+        finally:
+            dm.close()
+    for k in ("HPF_LAZY", "HPF_SLEAF", "HPF_COMPRESS"):
+        monkeypatch.delenv(k, raising=False)
+    default = census()
+    assert default["lazy_leaves"] > 0 and default["bordered"] > 0 and default["compress_steps"] > 0
+    by_string = census("HPF_LAZY=0 HPF_COMPRESS=0")
+    assert by_string["lazy_leaves"] == 0 and by_string["compress_steps"] == 0
+    assert census("HPF_SLEAF=0,HPF_LAZY=0")["bordered"] == 0                     # (comma separated; a second switch in the same string)
+    monkeypatch.setenv("HPF_LAZY", "0")
+    monkeypatch.setenv("HPF_COMPRESS", "0")
+    assert census() == by_string                                                  # environment, opted in (conftest: HPF_ENV_SWITCHES=1)
+    monkeypatch.setenv("HPF_ENV_SWITCHES", "0")
+    assert census() == default                                                    # ... and ignored without the opt-in
+    assert census("HPF_LAZY=0 HPF_COMPRESS=0") == by_string                       # (the option string always counts)

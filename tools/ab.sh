@@ -1,5 +1,6 @@
 #!/bin/bash
 # A/B of switches (or of tools/bin/libhpf_prev.so via HPF_LIB_PATH) in ONE gpurun call (same box): bash tools/ab.sh "<ENV=VAL> [<ENV=VAL> ...]" <S...>
+export HPF_ENV_SWITCHES=1
 cd "$GRAFT_REPO_ROOT"
 VS="$1"; shift
 for rep in 1 2; do

@@ -3,6 +3,7 @@
 scenarios, default build (k_level, bundle kernels, nested bordered buses) against the plain paths (HPF_FUSELEVEL=0 HPF_LINTREE=0
 HPF_SLNEST=0 in a child process): converged voltages one Newton iteration past the stop rule.   python tools/big_selfcheck.py [n=10000] [S=20]"""
 import os
+os.environ.setdefault("HPF_ENV_SWITCHES", "1")      # A/B tooling: HPF_* switches of the environment reach hpf_create (include/hpf.h)
 import subprocess
 import sys
 import tempfile

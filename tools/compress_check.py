@@ -2,6 +2,7 @@
 """First Newton step of the block-tree path with compress steps against the strictly leaf-first order (HPF_COMPRESS=0), bus by bus:
 where along p -> c -> v the two part.   python tools/compress_check.py [buses] [hmax] [seed]   (GPU)"""
 import os
+os.environ.setdefault("HPF_ENV_SWITCHES", "1")      # A/B tooling: HPF_* switches of the environment reach hpf_create (include/hpf.h)
 import sys
 import tempfile
 

@@ -2,6 +2,7 @@
 """BASELINE config 5 (10 000 buses, K = 49, coupled): run on the GPU (default) or with the CPU oracle (--oracle) and save the
 converged voltages for comparison.  The reference itself cannot run this size (dense Y_all = 80 GB, HG:141-143)."""
 import os
+os.environ.setdefault("HPF_ENV_SWITCHES", "1")      # A/B tooling: HPF_* switches of the environment reach hpf_create (include/hpf.h)
 import sys
 import tempfile
 import time

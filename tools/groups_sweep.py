@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Lock-step NR throughput of the headline feeder vs the number of scenario groups (streams): python tools/groups_sweep.py [S ...]"""
 import os
+os.environ.setdefault("HPF_ENV_SWITCHES", "1")      # A/B tooling: HPF_* switches of the environment reach hpf_create (include/hpf.h)
 import sys
 import time
 

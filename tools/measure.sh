@@ -6,6 +6,7 @@
 #   calib  : the same two counters on tools/pmc_calib.hip          -> gpurun_out/calib_*                          (tools/pmc_calib_report.py)
 #   mfma   : MFMA / LDS counters                                  -> gpurun_out/pmc_SQ_*
 # Counters are collected in their own runs with --kernel-trace only (pool rule); the program itself follows `--`.
+export HPF_ENV_SWITCHES=1
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 TAG=${1:-run}; shift
 WHAT=${@:-bench stats}

@@ -2,6 +2,7 @@
 """Time per Newton iteration of the bordered block-tree step on the headline feeder with k loop-closing lines:  python tools/mesh_time.py [k ...]  (GPU)"""
 import importlib.util
 import os
+os.environ.setdefault("HPF_ENV_SWITCHES", "1")      # A/B tooling: HPF_* switches of the environment reach hpf_create (include/hpf.h)
 import sys
 import tempfile
 import time

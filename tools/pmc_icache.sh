@@ -1,5 +1,6 @@
 #!/bin/bash
 # Instruction-cache counters of the bench kernels (one rocprofv3 --pmc pass per group, kernel-trace only):  bash tools/pmc_icache.sh <tag> [bench.py args...]
+export HPF_ENV_SWITCHES=1
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 TAG=$1; shift
 ARGS="--steps 5 --warmup 2 --repeats 1 --cpu-iters 0 --no-finish --no-probe --no-single --sweep-1gpu 0 $@"

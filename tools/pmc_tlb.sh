@@ -1,6 +1,7 @@
 #!/bin/bash
 # Address-translation counters of the bench kernels (one rocprofv3 --pmc pass, kernel-trace only): UTCL1 requests / hits / misses per kernel.
 #   bash tools/pmc_tlb.sh <tag> [bench.py args...]  -> gpurun_out/<tag>_tlb.txt
+export HPF_ENV_SWITCHES=1
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 TAG=$1; shift
 ARGS="--steps 5 --warmup 2 --repeats 1 --cpu-iters 0 --no-finish --no-probe --no-single --sweep-1gpu 0 $@"

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Wave-level instruction / wait counters of the bench kernels, one rocprofv3 --pmc pass per counter group (kernel-trace only, pool rule):
 #   bash tools/pmc_waves.sh <tag> [bench.py args...]   -> gpurun_out/<tag>_pmcw/<group>/ ; tools/pmc_waves.py sums them per kernel
+export HPF_ENV_SWITCHES=1
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 TAG=$1; shift
 ARGS="--steps 5 --warmup 2 --repeats 1 --cpu-iters 0 --no-finish --no-probe --no-single --sweep-1gpu 0 $@"

@@ -2,6 +2,7 @@
 """Lock-step NR throughput of the headline feeder as a function of the number of live scenarios on ONE GPU (how much of the
 step is workgroup latency of the narrow upper tree levels: it amortises with S).  python tools/scale_S.py [S ...]"""
 import os
+os.environ.setdefault("HPF_ENV_SWITCHES", "1")      # A/B tooling: HPF_* switches of the environment reach hpf_create (include/hpf.h)
 import sys
 import time
 

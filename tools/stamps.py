@@ -3,6 +3,7 @@
 Run on the GPU box: HPF_DEBUG_ABLATE=16 HPF_GROUPS=1 python tools/stamps.py [scenarios]"""
 import ctypes as C
 import os
+os.environ.setdefault("HPF_ENV_SWITCHES", "1")      # A/B tooling: HPF_* switches of the environment reach hpf_create (include/hpf.h)
 import sys
 import tempfile
 

@@ -1,5 +1,6 @@
 #!/bin/bash
 # per-launch timeline of one scenario group (rocprofv3 --kernel-trace, HPF_GROUPS=1):  bash tools/timeline_run.sh <tag> <scenarios> [ENV=VAL ...]
+export HPF_ENV_SWITCHES=1
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 TAG=$1; S=$2; shift; shift
 for kv in "$@"; do export "$kv"; done
