@@ -484,6 +484,8 @@ def main():
         out["setup"]["create_warm_ms"] = out["single_scenario"]["create_warm"]["create_ms"]
         out["setup_warm_ms"] = (out["setup"]["ingest_csv_ms"] + out["setup"]["admittance_ms"] + out["setup"]["norton_ms"] +
                                 out["setup"]["create_warm_ms"])
+    if world == 1 and bt and not args.no_single:
+        out["reference_call_shapes"] = reference_call_shapes(hp, inp, args)
     out["cpu_baseline"] = cpu
     print(json.dumps(out), flush=True)
 
@@ -540,9 +542,11 @@ def sweep_one_gpu(hp, inp, args, dev_index):
     P0 = inp["buses"]["P"].to_numpy(float)
     Q0 = inp["buses"]["Q"].to_numpy(float)
     scale = np.stack([synth.scenario_scale(n, s) for s in range(S)])
+    # the best single-GPU configuration for ~1 000 live scenarios: the leaf-first tree (HPF_COMPRESS=0: 5 - 8 % faster per step once the
+    # elimination levels fill the chip); rounding-level different Newton steps from the default build, same fixed points
     dm = hp.DeviceModel(n, inp["m"], inp["c"], inp["st"].HARMONICS, inp["Y"].rowptr, inp["Y"].col, inp["Y"].Yval,
                         inp["dev"], inp["Y_N"], inp["I_N"], inp["n_dev"], True, solver=args.solver,
-                        device=dev_index, max_scenarios=S)
+                        device=dev_index, max_scenarios=S, options="HPF_COMPRESS=0" if args.solver == "block_tree" else None)
     dm_Hn, N_unk, bytes_solve, bytes_back = dm.Hn, dm.N, dm.solve_bytes(), dm.back_bytes()
     try:
         dm.set_loads(P0 * scale, Q0 * scale)
@@ -582,9 +586,39 @@ def sweep_one_gpu(hp, inp, args, dev_index):
                                               "1 024 live scenarios the latency-bound tree levels amortise and the step runs against the HBM "
                                               "roof (counters of this configuration: profiles/r02/pmc_traffic_s1024.json, 26.2 GB per step)"},
                 "solve_wall_s": t_solve, "iters_per_s": float(n_iter.sum()) / t_solve, "pf_wall_s": t_pf,
-                "note": "one GPU, all scenarios live; solve = hpf_solve with the reference's stop rule (per-scenario freeze, "
+                "build_options": "HPF_COMPRESS=0",
+                "note": "one GPU, all scenarios live, leaf-first tree (options HPF_COMPRESS=0); solve = hpf_solve with the reference's stop rule (per-scenario freeze, "
                         "compaction of the running scenarios between chunks of 4 iterations, pipelined polling)"})
     return out
+
+
+def reference_call_shapes(hp, inp, args):
+    """The reference's own call shapes end to end on this feeder (untimed leg, N = 1): a repeated hp.hpf() call (HG:511: the handle comes from the
+    cache, the Norton CSV from the parse memo) and update_harmonic_state_vec on the CSR Jacobian (HG:476-479: hpf_sparse_solve)."""
+    st, buses = inp["st"], inp["buses"]
+    from harmonic_power_flow_amd import ingest
+    lines = ingest.init_lines_from_csv(inp["files"][1], st)
+    t0 = time.perf_counter()
+    V, err_h, n_it, J = hp.hpf(buses, lines, True, settings=st, ne_dir=INPUTS, verbose=False)
+    t1 = time.perf_counter()
+    V, err_h, n_it, J = hp.hpf(buses, lines, True, settings=st, ne_dir=INPUTS, verbose=False)
+    t2 = time.perf_counter()
+    V2, _, _, _ = hp.hpf(buses, lines, True, settings=st, ne_dir=INPUTS, verbose=False, return_jacobian=False)
+    t3 = time.perf_counter()
+    f = np.cos(0.37 * np.arange(J.shape[0]))
+    x0 = np.zeros(J.shape[0])
+    hp.update_harmonic_state_vec(J, x0, f)
+    t4 = time.perf_counter()
+    x1 = hp.update_harmonic_state_vec(J, x0, f)
+    t5 = time.perf_counter()
+    res = float(np.abs(J @ (x0 - x1) - f).max() / (np.abs(J).dot(np.abs(x0 - x1)).max() + np.abs(f).max()))
+    hp.close_all()
+    return {"hpf_first_call_ms": 1e3 * (t1 - t0), "hpf_second_call_ms": 1e3 * (t2 - t1), "hpf_second_call_without_jacobian_ms": 1e3 * (t3 - t2),
+            "n_iter_h": int(n_it), "jacobian_nnz": int(J.nnz), "unknowns": int(J.shape[0]),
+            "update_harmonic_state_vec_ms": 1e3 * (t5 - t4), "update_harmonic_state_vec_rel_residual": res,
+            "note": "hp.hpf() of ONE scenario of this feeder end to end (admittance build, Norton import, pf, harmonic NR, post-processing, the CSR "
+                    "Jacobian of the last iteration; second call: device handle from the cache) and x - J^-1 f for that CSR Jacobian through "
+                    "hpf_sparse_solve (no N x N array; the reference's spsolve takes ~1 s here, its hpf() 1 050 s)"}
 
 
 def single_scenario(hp, inp, args):

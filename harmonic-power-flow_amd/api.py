@@ -36,6 +36,12 @@ class AdmittanceSet:
 
     def __init__(self, rowptr, col, Yval, harmonics, n):
         self.rowptr, self.col, self.Yval, self.harmonics, self.n = rowptr, col, Yval, list(harmonics), n
+        self._key = None              # digest of the three arrays (handle cache), computed once per object
+
+    def key(self):
+        if self._key is None:
+            self._key = _digest(self.rowptr, self.col, self.Yval)
+        return self._key
 
     def to_frame(self):
         return admittance.to_dense_frame(self.rowptr, self.col, self.Yval, self.harmonics, self.n)
@@ -60,10 +66,25 @@ def init_network(filename_buses, filename_lines, from_csv=True, settings=None):
     return buses, lines, m, n, c
 
 
+_ADMITTANCES = collections.OrderedDict()      # digest of the inputs -> AdmittanceSet: repeated hpf() calls on one network (HG:511) build it once
+
+
 def build_admittance_matrices(buses, lines, harmonics):
-    """HG:132-171 -> AdmittanceSet (call `.to_frame()` for the reference's DataFrame)."""
-    rowptr, col, Yval = admittance.build_admittance_csr(buses, lines, list(harmonics))
-    return AdmittanceSet(rowptr, col, Yval, harmonics, len(buses))
+    """HG:132-171 -> AdmittanceSet (call `.to_frame()` for the reference's DataFrame).  The result is a function of the line table, the bus
+    shunts and the harmonics alone; the last four are kept (by a digest of exactly those inputs), so the reference's sweep -- hpf() per load
+    case -- builds the matrices of a network once.  Treat an AdmittanceSet as read-only."""
+    harmonics = list(harmonics)
+    key = _digest(lines.fromID.to_numpy(), lines.toID.to_numpy(), lines.R.to_numpy(dtype=float), lines.X.to_numpy(dtype=float),
+                  lines.G.to_numpy(dtype=float), lines.B.to_numpy(dtype=float), buses["X_sh"].to_numpy(dtype=float),
+                  np.asarray(harmonics, dtype=np.int64))
+    hit = _ADMITTANCES.pop(key, None)
+    if hit is None:
+        rowptr, col, Yval = admittance.build_admittance_csr(buses, lines, harmonics)
+        hit = AdmittanceSet(rowptr, col, Yval, harmonics, len(buses))
+    _ADMITTANCES[key] = hit
+    while len(_ADMITTANCES) > 4:
+        _ADMITTANCES.popitem(last=False)
+    return hit
 
 
 def import_Norton_Equivalents(buses, coupled, settings=None, ne_dir=None):
@@ -156,7 +177,7 @@ def _borrow_model(buses, Y, NE, coupled, harmonics, solver="auto", assembly_only
         ne_key = _digest(dev, Y_N, I_N)
     # (the environment is part of a handle's build only under HPF_ENV_SWITCHES=1 -- hpf.h -- but keying on it always is harmless)
     env = tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("HPF_")))
-    key = (n, m, c, tuple(harmonics), bool(coupled), solver, bool(assembly_only), int(device), _digest(Y.rowptr, Y.col, Y.Yval), ne_key, env)
+    key = (n, m, c, tuple(harmonics), bool(coupled), solver, bool(assembly_only), int(device), Y.key(), ne_key, env)
     dm = _HANDLES.pop(key, None)
     if dm is None:
         _HANDLE_CACHE["misses"] += 1

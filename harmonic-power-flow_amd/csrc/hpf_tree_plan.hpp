@@ -915,11 +915,12 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
     T.comp_c.clear();
     {
         const char* cp_env = h->sw("HPF_COMPRESS");
-        // default: handles of up to 256 scenarios -- a compress step trades a shorter chain of levels for more matrix-core work (the dense
-        // push of the pending child), which pays while the levels do not fill the chip (measured crossover between 256 and 384 live
-        // scenarios on the headline feeder, tools/groups_sweep.py); HPF_COMPRESS=1 / 0 force it on / off
-        const bool compress_on = contract && d->coupled && BWc != 0 && BWc <= 100 && T.n_dense > 2 &&
-                                 (cp_env ? atoi(cp_env) != 0 : h->S_max + (h->n_ties > 0 ? border_slots(h) : 0) <= 256);   // (live slots incl. the virtual ones of a meshed handle)
+        // A compress step trades a shorter chain of levels for more matrix-core work (the dense push of the pending child): it pays while the
+        // levels do not fill the chip (crossover between 256 and 384 live scenarios on the headline feeder: +5..8 % per step at 384..1 024,
+        // tools/groups_sweep.py).  The steps are nevertheless the default at EVERY capacity (round 5; rounds 3-4: up to 256 scenarios only), so
+        // that the Newton steps -- and with them the iteration count of a solver-sensitive case -- do not depend on the capacity a handle was
+        // created with; a sweep of several hundred live scenarios that wants the last 5 % passes HPF_COMPRESS=0 (hpf_create_opts).
+        const bool compress_on = contract && d->coupled && BWc != 0 && BWc <= 100 && T.n_dense > 2 && (cp_env ? atoi(cp_env) != 0 : true);
         auto is_gj = [&](int k2) { return kept(k2) && cleaf_of[k2] < 0 && sl_off[k2] < 0; };
         std::vector<int> cc(n, -1), isc(n, 0), keptl;
         for (int i = 0; i < n; ++i)

@@ -238,8 +238,8 @@ int  hpf_debug_stamps(hpf_handle* h, long long* out, int count);
  * and the per-scenario workgroups of an elimination level separately (k_leaf_batch / k_sleaf_batch + k_factor_q instead of k_level),
  * HPF_LINBUNDLE=0 / HPF_LINTREE=0 run the 2x2 algebra of the linear subtrees height by height in one launch / in one launch per
  * height, HPF_CHAINBUNDLE=0 gives the contracted chains their own launches, HPF_COMPRESS=0 eliminates the Gauss-Jordan buses strictly
- * leaves first (no compress steps: one elimination level per unit of tree height; the default for handles of more than 256 scenarios,
- * whose levels fill the chip -- HPF_COMPRESS=1 forces the compress steps there too), HPF_TREE_INFO=1 prints the tree statistics to stderr,
+ * leaves first (no compress steps: one elimination level per unit of tree height; 5 - 8 % faster per step from about 384 live scenarios on, whose
+ * levels fill the chip -- the steps are the default at every capacity so that a handle's Newton steps do not depend on its capacity), HPF_TREE_INFO=1 prints the tree statistics to stderr,
  * HPF_QUEUE_INFO=1 prints the phase times of hpf_solve_queue to stderr, HPF_BORDER_SLOTS=n caps the virtual scenario slots a meshed handle
  * allocates for its bordered step (default 1 024, at least 16: the m + 1 right-hand sides run in chunks of that many),
  * HPF_FUSEBACK=0 launches the back sweep's scenario-batched workgroups (bordered buses, leaves) after the last depth instead of inside the
@@ -302,7 +302,7 @@ int  hpf_setup_times(const hpf_handle* h, double* ms, int n_ms);
 int  hpf_scenario_groups(const hpf_handle* h, int live);
 /* Host-only planning run of the BLOCK_TREE elimination tree of a radial model (no device is touched, no handle, the process environment
  * is not modified): builds the contracted tree exactly as hpf_create would for a handle of d->max_scenarios scenarios (compress steps
- * are the default up to 256) and writes one line per dense bus (bus, dense parent, elimination level, back-sweep depth, kind, ...)
+ * are the default) and writes one line per dense bus (bus, dense parent, elimination level, back-sweep depth, kind, ...)
  * to `path` (replaced if it exists; tools/tree_plan.py reads it).  Returns the planning status: HPF_OK when the plan was written,
  * HPF_E_TOPOLOGY for a meshed model, HPF_E_ARG when the file cannot be written.  (env HPF_TREE_DUMP=<file> makes hpf_create itself
  * write the same dump.) */

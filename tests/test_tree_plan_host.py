@@ -63,9 +63,10 @@ def test_tree_plan_refuses_meshed_models_and_bad_arguments(tmp_path):
     assert lib.hpf_tree_plan(C.byref(d), None) == -1
 
 
-def test_tree_plan_follows_the_handle_capacity_and_leaves_the_environment_alone(monkeypatch, tmp_path):
-    """hpf_tree_plan plans for a handle of d->max_scenarios scenarios (compress steps are the default up to 256 only), does not touch the
-    process environment, and reports a path it cannot write instead of passing a stale file."""
+def test_tree_plan_does_not_depend_on_the_handle_capacity_and_leaves_the_environment_alone(monkeypatch, tmp_path):
+    """hpf_tree_plan plans exactly what hpf_create would: the same tree for every capacity d->max_scenarios (round 5: the compress steps are the
+    default everywhere; HPF_COMPRESS=0 builds the leaf-first tree), does not touch the process environment, and reports a path it cannot write
+    instead of passing a stale file."""
     import tree_plan
     from harmonic_power_flow_amd import _lib
     monkeypatch.delenv("HPF_COMPRESS", raising=False)
@@ -73,5 +74,7 @@ def test_tree_plan_follows_the_handle_capacity_and_leaves_the_environment_alone(
     small = tree_plan.plan(300, 51, max_scenarios=256)
     big = tree_plan.plan(300, 51, max_scenarios=257)
     assert os.environ["HPF_TREE_DUMP"] == "/nonexistent-dir/user-value"
-    assert any(r[8] for r in small) and not any(r[8] for r in big)
-    assert max(r[2] for r in small) < max(r[2] for r in big)
+    assert small == big and any(r[8] for r in small)
+    monkeypatch.setenv("HPF_COMPRESS", "0")
+    flat = tree_plan.plan(300, 51, max_scenarios=257)
+    assert not any(r[8] for r in flat) and max(r[2] for r in small) < max(r[2] for r in flat)
