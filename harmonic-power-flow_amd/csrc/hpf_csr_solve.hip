@@ -15,9 +15,11 @@
 // Nothing of size N x N exists anywhere: 3 b^2 + b doubles per bus (65 MB at 1 000 buses x 26 harmonics, where the dense matrix is 21.6 GB).
 // Off-diagonal blocks are treated as DENSE (the reference's are harmonic-diagonal, but this entry point takes any matrix on the pattern).
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <vector>
 
 #include "../../include/hpf.h"
@@ -150,23 +152,32 @@ __global__ __launch_bounds__(256) void k_csr_factor(int b, const int* __restrict
         for (int ai = 0; ai < R; ++ai)
 #pragma unroll
             for (int ci = 0; ci < R; ++ci) o[ai][ci] = 0.0;
-        for (int kk = 0; kk < b; ++kk) {
-            const double* Arow = Ak + (size_t)L.pfwd[kk] * b;
-            double av[R], rv[R];
+        // Z = (P D)^-1 (P Aup) = sum_r Rm[:, pinv[r]] Aup[r, :]: the rows of Aup are walked in storage order (independent, coalesced loads, four
+        // rows in flight), the permutation sits on the LDS column index of Rm
+        for (int r0 = 0; r0 < b; r0 += 4) {
+            double av[4][R], rv[R][4];
 #pragma unroll
-            for (int ci = 0; ci < R; ++ci) {
-                const int cc = tc + 16 * ci;
-                av[ci] = cc < b ? Arow[cc] : 0.0;
+            for (int u = 0; u < 4; ++u) {
+                const int r = r0 + u < b ? r0 + u : b - 1;
+                const bool on = r0 + u < b;
+                const int pc = L.pinv[r];
+#pragma unroll
+                for (int ci = 0; ci < R; ++ci) {
+                    const int cc = tc + 16 * ci;
+                    av[u][ci] = (on && cc < b) ? Ak[(size_t)r * b + cc] : 0.0;
+                }
+#pragma unroll
+                for (int ai = 0; ai < R; ++ai) {
+                    const int i = tr + 16 * ai;
+                    rv[ai][u] = i < b ? L.Rm[(size_t)i * L.ldr + pc] : 0.0;
+                }
             }
 #pragma unroll
-            for (int ai = 0; ai < R; ++ai) {
-                const int i = tr + 16 * ai;
-                rv[ai] = i < b ? L.Rm[(size_t)i * L.ldr + kk] : 0.0;
-            }
+            for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int ai = 0; ai < R; ++ai)
+                for (int ai = 0; ai < R; ++ai)
 #pragma unroll
-                for (int ci = 0; ci < R; ++ci) o[ai][ci] = fma(rv[ai], av[ci], o[ai][ci]);
+                    for (int ci = 0; ci < R; ++ci) o[ai][ci] = fma(rv[ai][u], av[u][ci], o[ai][ci]);
         }
         double* Zk = Z + (size_t)k * bb;
 #pragma unroll
@@ -240,6 +251,9 @@ extern "C" int hpf_sparse_solve(int device, int n, int c, int Hn, const int32_t*
                                 const double* f, double* dx) {
     if (n < 1 || c < 1 || c > n || Hn < 1 || !indptr || !indices || !data || !f || !dx) return HPF_E_ARG;
     if ((long long)n * Hn >= (1ll << 29)) return HPF_E_ARG;
+    const bool info = getenv("HPF_SPARSE_INFO") != nullptr;              // phase times to stderr (diagnostic; no effect on the result)
+    const auto t_0 = std::chrono::steady_clock::now();
+    auto ms_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
     const int b = 2 * Hn;
     if (b > 128) return HPF_E_ARG;                       // (the block inversion keeps a b x b block in the LDS of one workgroup: 132 KB at b = 128)
     const int Nc = n * Hn - 1;
@@ -327,6 +341,8 @@ extern "C" int hpf_sparse_solve(int device, int n, int c, int Hn, const int32_t*
         }
     }
     // ---- device -------------------------------------------------------------------------------------------------------------------------
+    const double ms_host = ms_since(t_0);
+    const auto t_1 = std::chrono::steady_clock::now();
     if (hipSetDevice(device) != hipSuccess) return HPF_E_HIP;
     const size_t nnz = (size_t)indptr[N], bb = (size_t)b * b;
     {
@@ -359,6 +375,13 @@ extern "C" int hpf_sparse_solve(int device, int n, int c, int Hn, const int32_t*
               hipMemsetAsync(d_Adn, 0, sizeof(double) * (size_t)n * bb, st) == hipSuccess &&
               hipMemsetAsync(d_y, 0, sizeof(double) * (size_t)n * b, st) == hipSuccess && hipMemsetAsync(d_sing, 0, sizeof(int), st) == hipSuccess;
     if (!ok) return HPF_E_HIP;
+    double ms_up = 0.0;
+    std::chrono::steady_clock::time_point t_2 = std::chrono::steady_clock::now();
+    if (info) {
+        hipDeviceSynchronize();
+        ms_up = ms_since(t_1);
+        t_2 = std::chrono::steady_clock::now();
+    }
     hipLaunchKernelGGL(k_csr_pad, dim3((unsigned)(((size_t)n * b + 255) / 256)), dim3(256), 0, st, n, c, b, d_D);
     hipLaunchKernelGGL(k_csr_scatter, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, N, n, c, Nc, b, d_indptr, d_indices, d_data, d_f, d_parent,
                        d_D, d_Aup, d_Adn, d_y);
@@ -389,6 +412,11 @@ extern "C" int hpf_sparse_solve(int device, int n, int c, int Hn, const int32_t*
         hipLaunchKernelGGL(k_csr_back, dim3((unsigned)cnt), dim3(256), 0, st, n, c, Nc, b, d_dep + dep_ptr[dl], d_parent, d_Z, d_w, d_xb, d_dx);
     }
     if (hipGetLastError() != hipSuccess) return HPF_E_HIP;
+    if (info) {
+        hipDeviceSynchronize();
+        fprintf(stderr, "hpf_sparse_solve: N %d, %zu entries, %d buses in %d levels / %d depths: host analysis %.2f ms, allocation + upload %.2f ms, "
+                        "scatter + factor + back sweep %.2f ms\n", N, nnz, n, n_levels, n_depths, ms_host, ms_up, ms_since(t_2));
+    }
     int sing = 0;
     if (hipMemcpy(&sing, d_sing, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
         hipMemcpy(dx, d_dx, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost) != hipSuccess)

@@ -192,7 +192,7 @@ int  hpf_dense_solve(int device, int N, const double* J_colmajor, const double* 
  * blocks may be dense); no N x N array exists on host or device (65 MB of blocks at 1 000 buses x 26 harmonics, where the dense matrix is
  * 21.6 GB).  Duplicate (row, column) entries add up like scipy's.  HPF_E_TOPOLOGY when the bus graph of the pattern is not a tree connected from
  * bus 0 (meshed network: use hpf_dense_solve where it fits), HPF_E_ARG for 2 Hn > 128 or an inconsistent CSR, HPF_E_SINGULAR when a bus block has
- * no pivot.  Stateless like the reference's function: no handle. */
+ * no pivot.  Stateless like the reference's function: no handle.  (env HPF_SPARSE_INFO=1 prints its phase times to stderr.) */
 int  hpf_sparse_solve(int device, int n, int c, int Hn, const int32_t* indptr, const int32_t* indices, const double* data, const double* f,
                       double* dx);
 
