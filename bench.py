@@ -57,6 +57,7 @@ def parse(argv=None):
     ap.add_argument("--cpu-iters", type=int, default=12, help="NR iterations of the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-workers", type=int, default=0, help="worker processes of the all-cores CPU leg (0 = host cores, at most 16)")
     ap.add_argument("--no-finish", action="store_true", help="skip the untimed solve-to-convergence + stats gather")
+    ap.add_argument("--no-one-group", action="store_true", help="skip the one-group timing legs (profiling runs: every k_level launch then has the step's own shape)")
     ap.add_argument("--no-probe", action="store_true", help="skip the untimed probe of the stream configuration (profiling runs: a fixed number of steps)")
     ap.add_argument("--sweep-1gpu", type=int, default=1024, help="(N = 1) scenarios of the single-GPU sweep leg (0 = skip)")
     ap.add_argument("--single", action="store_true", help="(default on rank 0 at N=1) also time a single-scenario solve: BASELINE config 3")
@@ -272,7 +273,7 @@ def main():
     dm.timing(False)
     # ... and the same kernel with the chip to itself: the scenarios as ONE group (one launch per level, no other stream busy), K more steps
     tim["gj_dev_one_group"] = None
-    if args.solver == "block_tree" and dm.scenario_groups(S) > 1:
+    if args.solver == "block_tree" and dm.scenario_groups(S) > 1 and not args.no_one_group:
         g_now = dm.scenario_groups(S)
         dm.set_option("scenario_groups", 1)
         dm.iterate(2)

@@ -27,8 +27,8 @@ for path in sorted(glob.glob(os.path.join(GOLD, "*_H*.npz"))):
     if name.endswith("mesh5") or name.startswith("syn10000"):
         continue
     g = np.load(path, allow_pickle=True)
-    if "V_final" not in g.files or len(name.split("_")) != 3:
-        continue
+    if "V_final" not in g.files or len(name.split("_")) != 3 or name.split("_")[2] not in ("c", "uc"):
+        continue                                       # (scenario / mesh / config fixtures have their own tests: test_gpu_bench_config.py)
     net_name, hs, cs = name.split("_")[:3]
     hmax, coupled = int(hs[1:]), cs == "c"
     st = hp.Settings(H_MAX=hmax)

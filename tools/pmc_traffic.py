@@ -28,7 +28,7 @@ def short(name):
 
 def main():
     out_path = sys.argv[1]
-    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 7
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 17
     calib = sys.argv[3] if len(sys.argv) > 3 and sys.argv[3] != "-" else os.path.join(REPO, "profiles", "r02", "pmc_calib.json")
     prefix = sys.argv[4] if len(sys.argv) > 4 else "pmc_"           # gpurun_out/<prefix>FETCH_SIZE, <prefix>WRITE_SIZE
     command = sys.argv[5] if len(sys.argv) > 5 else None
@@ -49,7 +49,7 @@ def main():
         res[c] = agg
     out = {"format": 2,
            "command": "rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-trace --output-format csv -- python3 bench.py --steps 5 --warmup 2 --repeats 1 "
-                      "--cpu-iters 0 --no-finish --no-single --sweep-1gpu 0 (two separate passes; tools/measure.sh <tag> pmc)",
+                      "--cpu-iters 0 --no-finish --no-probe --no-one-group --no-single --sweep-1gpu 0 (two separate passes; tools/measure.sh <tag> pmc; 17 steps of four scenario groups: 2 warm-up + 5 timed + 2 x 5 timing legs)",
            "steps_profiled": steps, "fetch_factor": ff, "write_factor": wf, "calibration": os.path.relpath(calib, REPO),
            "per_step_bytes": {}, "per_launch_bytes": {}}
     for k, (nd, kb) in sorted(res["FETCH_SIZE"].items()):
