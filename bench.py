@@ -445,8 +445,8 @@ def main():
                               "avg_ms_hip_event_span": tim["mismatch"][0] / max(tim["mismatch"][1], 1),
                               "note": "algorithmic bytes (voltages in, mismatch image out) of one launch (one scenario group) / its HIP-event span; "
                                       "rocprofv3 of the same command: profiles/*kernel_stats.csv, counters: profiles/pmc_traffic_latest.json"},
-        "phase_ms_per_launch": {k: (v[0] / max(v[1], 1)) for k, v in tim.items() if v[1]},
-        "phase_launches_per_step": {k: v[1] / max(Kt, 1) for k, v in tim.items() if v[1]},
+        "phase_ms_per_launch": {k: (v[0] / max(v[1], 1)) for k, v in tim.items() if v and v[1]},
+        "phase_launches_per_step": {k: v[1] / max(Kt, 1) for k, v in tim.items() if v and v[1]},
         "phase_note": "HIP-event spans: gj = one per k_level / k_factor_q<B,false> launch; solve = one per launch of the other factor kernels "
                       "(k_leaf_batch, k_sleaf_batch, leaf-only k_factor_q: none with k_level); mismatch / update: per launch; back: per scenario "
                       "group and step (%d groups overlap on separate streams)" % G,

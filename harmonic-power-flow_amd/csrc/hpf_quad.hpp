@@ -142,6 +142,9 @@ __device__ __forceinline__ void lz_aop(const double* p, double (&a)[NT]) {
 // wave's outstanding LDS operations and keeps the compiler from moving memory accesses across
 #define HPF_WAVE_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
+#ifndef HPF_LEAF_XCD
+#define HPF_LEAF_XCD 1     // leaf-only launches: all scenarios of a leaf on one XCD (0: the plain (leaf, scenario) grid; A/B)
+#endif
 #ifndef HPF_Q100L_OCC
 #define HPF_Q100L_OCC 2    // ... and of its leaf-only instantiation
 #endif
@@ -1434,7 +1437,7 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 52 ? (LEAF ? HPF_Q100L_O
     const cplx* __restrict__ I0all, const double* __restrict__ chG, const double* __restrict__ chH,
     const double* __restrict__ chD, const double* __restrict__ chy, const double* __restrict__ Minv,
     double* __restrict__ lfK, double* __restrict__ lfS, long long* __restrict__ dbg, int ablate, int s0,
-    int* __restrict__ pivflag, double piv_limit, unsigned long long* __restrict__ tstamp) {
+    int* __restrict__ pivflag, double piv_limit, unsigned long long* __restrict__ tstamp, int leaf_count, unsigned leaf_S) {
     constexpr int NT = (B + 16) / 16, RP = 16 * NT > 64 ? 16 * NT : 64;
     FqLds<B> lds;
     if constexpr (LEAF) {                    // (the arrays a leaf-only launch never touches cost nothing as separate objects)
@@ -1447,7 +1450,20 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16), (B > 52 ? (LEAF ? HPF_Q100L_O
         __shared__ __attribute__((aligned(16))) double smem[factor_q_lds<B>()];
         lds = FqLds<B>::carve(smem);
     }
-    factor_q_body<B, LEAF>(lds, blockIdx.x, blockIdx.y, M, T, nodes, b, N, Nc, active, Uall, Eall, fall, Zall, wall, linAall, Call, Hall, I0all, chG,
+    int bx = blockIdx.x, by = blockIdx.y;
+#if HPF_LEAF_XCD
+    if constexpr (LEAF) {
+        // Leaf-only launches (every workgroup does the same work: no imbalance) as a 1-D grid of 8 ceil(count / 8) S workgroups: id -> (leaf, scenario)
+        // with the leaf's low three bits fastest, then the scenario, then the leaf's high bits.  The hardware deals consecutive ids round-robin over
+        // the 8 XCDs, so ALL scenarios of leaf L run on XCD L mod 8, one after the other: the leaf's per-model image (23 KB at b = 52, 80 KB at
+        // b = 100 -- as much as the Schur complement the workgroup writes) is fetched into that L2 once and hit by the other scenarios.
+        const unsigned id = blockIdx.x, t = id >> 3, S_ = gridDim.y == 1 ? leaf_S : 1u;
+        by = (int)(t % S_);
+        bx = (int)((t / S_) * 8u + (id & 7u));
+        if (bx >= leaf_count) return;
+    }
+#endif
+    factor_q_body<B, LEAF>(lds, bx, by, M, T, nodes, b, N, Nc, active, Uall, Eall, fall, Zall, wall, linAall, Call, Hall, I0all, chG,
                            chH, chD, chy, Minv, lfK, lfS, dbg, ablate, s0, pivflag, piv_limit, tstamp);
 }
 
@@ -1590,11 +1606,14 @@ int launch_factor_q2(hpf_handle* h, const TreeDev& T, const int* nodes, int coun
     unsigned long long* ts = nullptr;                   // device-clock stamps of this launch (timing leg, general kernel only)
     if (!LEAF && h->timing && h->d_tstamp && h->ts_next < hpf_handle::TS_CAP) ts = h->d_tstamp + 2 * (size_t)(h->ts_next++);
     constexpr int NT = (B + 16) / 16;
-    const dim3 grid((unsigned)count, (unsigned)h->cur_S);
+    dim3 grid((unsigned)count, (unsigned)h->cur_S);
+#if HPF_LEAF_XCD
+    if (LEAF) grid = dim3((unsigned)(((count + 7) / 8) * 8) * (unsigned)h->cur_S, 1, 1);        // (leaf-major id decode in the kernel)
+#endif
     hipLaunchKernelGGL((k_factor_q<B, LEAF>), grid, dim3(64 * NT), 0, h->cur_stream, h->M, T, nodes,
                        2 * h->Hn, h->N, h->Nc, active, h->d_U, h->d_E, h->d_fb, h->d_Z, h->d_w, h->d_linA, h->d_C, h->d_H,
                        h->d_I0, h->d_chG, h->d_chH, h->d_chD, h->d_chy, active_tree(h).d_Minv, h->d_lfK, h->d_lfS, h->d_dbg, h->debug_ablate, h->cur_s0,
-                       h->d_pivflag, h->piv_limit, ts);
+                       h->d_pivflag, h->piv_limit, ts, count, (unsigned)h->cur_S);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         h->last_detail = (int)e;
