@@ -727,6 +727,9 @@ int launch_back_w(hpf_handle* h, const TreeDev& T, const int* nodes, int count, 
 // are independent of each other, so they share ONE grid -- batched workgroups first (they live longest) -- instead of two
 // dependent launches in the stream: the level costs the longer of the two lives, not their sum.  The three bodies carve their LDS
 // from one buffer (the largest of the three).  kind: 0 no batched workgroups, 1 k_leaf_batch's, 2 k_sleaf_batch's.
+#ifndef HPF_BATCH_XCD
+#define HPF_BATCH_XCD 1    // k_level: the scenario-batched workgroups of a bus on one XCD (0: bus-fastest ids; A/B)
+#endif
 template <int B>
 constexpr int level_lds() {
     constexpr int a = factor_q_lds<B>(), b2 = SLEAF_BATCH_LDS, c2 = LEAF_BATCH_LDS;
@@ -748,9 +751,20 @@ __global__ __launch_bounds__(256, HPF_Q_OCC) void k_level(
     // surviving wavefronts only).
     static_assert(64 * ((B + 16) / 16) <= 256, "k_level: blocks of up to 52 rows");
     __shared__ __attribute__((aligned(16))) double smem[level_lds<B>()];
-    const int ytiles = (S_cnt + LB_SB - 1) / LB_SB, nbb = kind ? nbatch * ytiles : 0;
+    const int ytiles = (S_cnt + LB_SB - 1) / LB_SB;
+#if HPF_BATCH_XCD
+    // scenario-batched workgroups (homogeneous within a level): id -> (bus mod 8, scenario tile, bus / 8) -- every scenario tile of bus k on XCD
+    // k mod 8, one after the other, in every scenario group alike: the bus's per-model operand images (27 - 33 KB) are fetched into ONE L2
+    const int nbb = kind ? ((nbatch + 7) / 8) * 8 * ytiles : 0;
+    if ((int)blockIdx.x < nbb) {
+        const int t_ = (int)blockIdx.x >> 3;
+        const int by = t_ % ytiles, bx = (t_ / ytiles) * 8 + ((int)blockIdx.x & 7);
+        if (bx >= nbatch) return;
+#else
+    const int nbb = kind ? nbatch * ytiles : 0;
     if ((int)blockIdx.x < nbb) {
         const int bx = (int)blockIdx.x % nbatch, by = (int)blockIdx.x / nbatch;
+#endif
         if (tstamp && threadIdx.x == 0) atomicMin(tstamp, (unsigned long long)wall_clock64());
         if (kind == 1)
             leaf_batch_body<B>(smem, bx, by, M, T, nodes, b, active, S_cnt, Uall, Eall, fall, wall, linAall, Call, Hall, chG, chH, chD, chy,
@@ -782,7 +796,11 @@ int launch_level(hpf_handle* h, const TreeDev& T, const int* nodes, int kind, in
     if (h->timing && h->d_tstamp && h->ts_next < hpf_handle::TS_CAP) ts = h->d_tstamp + 2 * (size_t)(h->ts_next++);
     const Tree& tr = active_tree(h);
     const unsigned ytiles = (unsigned)((h->cur_S + LB_SB - 1) / LB_SB);
+#if HPF_BATCH_XCD
+    const unsigned grid = (kind ? (unsigned)(((nbatch + 7) / 8) * 8) * ytiles : 0u) + (unsigned)ngen * (unsigned)h->cur_S;
+#else
     const unsigned grid = (kind ? (unsigned)nbatch * ytiles : 0u) + (unsigned)ngen * (unsigned)h->cur_S;
+#endif
     if (grid == 0) return HPF_OK;
     hipLaunchKernelGGL((k_level<B>), dim3(grid), dim3(256), 0, h->cur_stream, h->M, T, nodes, kind, nbatch, ngen, 2 * h->Hn,
                        h->N, h->Nc, active, h->cur_S, h->d_U, h->d_E, h->d_fb, h->d_Z, h->d_w, h->d_linA, h->d_C, h->d_H, h->d_I0, h->d_chG,
@@ -857,14 +875,29 @@ __global__ __launch_bounds__(256) void k_level_back(
     double* __restrict__ xall, const double* __restrict__ Hall, const double* __restrict__ Minv, const double* __restrict__ lbimg,
     const double* __restrict__ sbimg, const double* __restrict__ lzimg, const double* __restrict__ lfK, const double* __restrict__ lfS, int s0) {
     static_assert(64 * ((B + 16) / 16) == 256, "k_level_back: blocks of 52 rows (four wavefronts in every body)");
-    const int ytiles = (S_cnt + LB_SB - 1) / LB_SB, nb_sl = n_sl * ytiles, nb_lf = n_lf * ytiles;
+    const int ytiles = (S_cnt + LB_SB - 1) / LB_SB;
     const int bid = (int)blockIdx.x;
+#if HPF_BATCH_XCD
+    // (the scenario-batched workgroups as in k_level: every scenario tile of a bus on XCD (bus mod 8), one after the other)
+    const int nb_sl = ((n_sl + 7) / 8) * 8 * ytiles, nb_lf = ((n_lf + 7) / 8) * 8 * ytiles;
+    if (bid < nb_sl) {
+        const int t_ = bid >> 3, bx = (t_ / ytiles) * 8 + (bid & 7);
+        if (bx >= n_sl) return;
+        sleaf_back_batch_body<B>(bx, t_ % ytiles, M, sl_nodes, b, active, S_cnt, wall, xall, Hall, sbimg, lzimg, Zall, lfS, s0);
+    } else if (bid < nb_sl + nb_lf) {
+        const int i = bid - nb_sl, t_ = i >> 3, bx = (t_ / ytiles) * 8 + (i & 7);
+        if (bx >= n_lf) return;
+        leaf_back_batch_body<B>(bx, t_ % ytiles, M, lf_nodes, b, active, S_cnt, wall, xall, Hall, lbimg, lfK, lfS, s0);
+    } else {
+#else
+    const int nb_sl = n_sl * ytiles, nb_lf = n_lf * ytiles;
     if (bid < nb_sl) {
         sleaf_back_batch_body<B>(bid % n_sl, bid / n_sl, M, sl_nodes, b, active, S_cnt, wall, xall, Hall, sbimg, lzimg, Zall, lfS, s0);
     } else if (bid < nb_sl + nb_lf) {
         const int i = bid - nb_sl;
         leaf_back_batch_body<B>(i % n_lf, i / n_lf, M, lf_nodes, b, active, S_cnt, wall, xall, Hall, lbimg, lfK, lfS, s0);
     } else {
+#endif
         const int i = bid - nb_sl - nb_lf;
         back_q_body<B>(i % n_gj, i / n_gj, M, T, gj_nodes, b, N, Nc, active, Zall, wall, xall, (double*)nullptr, Hall, Minv, lfK, lfS, s0);
     }
@@ -875,8 +908,12 @@ int launch_level_back(hpf_handle* h, const TreeDev& T, const int* sl_nodes, int 
                       const int* active) {
     const Tree& tr = active_tree(h);
     const unsigned ytiles = (unsigned)((h->cur_S + LB_SB - 1) / LB_SB);
+#if HPF_BATCH_XCD
+    const unsigned grid = (unsigned)(((n_sl + 7) / 8) * 8 + ((n_lf + 7) / 8) * 8) * ytiles + (unsigned)n_gj * (unsigned)h->cur_S;
+#else
     const unsigned grid = (unsigned)(n_sl + n_lf) * ytiles + (unsigned)n_gj * (unsigned)h->cur_S;
-    if (grid == 0) return HPF_OK;
+#endif
+    if ((unsigned)(n_sl + n_lf) * ytiles + (unsigned)n_gj * (unsigned)h->cur_S == 0) return HPF_OK;
     hipLaunchKernelGGL((k_level_back<B>), dim3(grid), dim3(256), 0, h->cur_stream, h->M, T, sl_nodes, n_sl, lf_nodes, n_lf, gj_nodes, n_gj, 2 * h->Hn,
                        h->N, h->Nc, active, h->cur_S, h->d_Z, h->d_w, h->d_x, h->d_H, tr.d_Minv, tr.d_lbimg, tr.d_sbimg, tr.d_lzimg, h->d_lfK, h->d_lfS,
                        h->cur_s0);

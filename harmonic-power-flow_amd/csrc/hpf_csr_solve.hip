@@ -219,17 +219,19 @@ __global__ __launch_bounds__(256) void k_csr_back(int n, int c, int Nc, int b, c
     }
 }
 
-struct DevBuf {
-    std::vector<void*> ptrs;
+// one device allocation for everything a call needs, carved with 256-byte alignment (one hipMalloc + one hipFree per call: allocation calls are
+// the part of a call whose duration the driver does not bound)
+struct DevPool {
+    char* base = nullptr;
+    size_t used = 0, cap = 0;
+    static size_t pad(size_t b) { return (b + 255) & ~(size_t)255; }
     template <class T>
-    bool alloc(T** p, size_t count) {
-        *p = nullptr;
-        if (hipMalloc((void**)p, sizeof(T) * (count ? count : 1)) != hipSuccess) return false;
-        ptrs.push_back(*p);
-        return true;
+    void carve(T** p, size_t count) {
+        *p = reinterpret_cast<T*>(base + used);
+        used += pad(sizeof(T) * (count ? count : 1));
     }
-    ~DevBuf() {
-        for (void* p : ptrs) hipFree(p);
+    ~DevPool() {
+        if (base) hipFree(base);
     }
 };
 
@@ -351,15 +353,40 @@ extern "C" int hpf_sparse_solve(int device, int n, int c, int Hn, const int32_t*
         const double need = 8.0 * (4.0 * (double)n * (double)bb + 3.0 * (double)n * b + 2.0 * N) + 12.0 * (double)nnz + 64.0 * 1048576.0;
         if (need > (double)free_b) return HPF_E_NOMEM;
     }
-    DevBuf B;
     int *d_indptr, *d_indices, *d_parent, *d_child_ptr, *d_child, *d_lvl, *d_dep, *d_sing;
     double *d_data, *d_f, *d_D, *d_Aup, *d_Adn, *d_y, *d_Z, *d_w, *d_xb, *d_dx;
-    if (!B.alloc(&d_indptr, (size_t)N + 1) || !B.alloc(&d_indices, nnz) || !B.alloc(&d_data, nnz) || !B.alloc(&d_f, (size_t)N) ||
-        !B.alloc(&d_parent, (size_t)n) || !B.alloc(&d_child_ptr, (size_t)n + 1) || !B.alloc(&d_child, child.size()) ||
-        !B.alloc(&d_lvl, (size_t)n) || !B.alloc(&d_dep, (size_t)n) || !B.alloc(&d_sing, (size_t)1) || !B.alloc(&d_D, (size_t)n * bb) ||
-        !B.alloc(&d_Aup, (size_t)n * bb) || !B.alloc(&d_Adn, (size_t)n * bb) || !B.alloc(&d_y, (size_t)n * b) || !B.alloc(&d_Z, (size_t)n * bb) ||
-        !B.alloc(&d_w, (size_t)n * b) || !B.alloc(&d_xb, (size_t)n * b) || !B.alloc(&d_dx, (size_t)N))
-        return HPF_E_NOMEM;
+    DevPool B;
+    for (int pass = 0; pass < 2; ++pass) {               // pass 0 sizes the pool, pass 1 carves it
+        B.used = 0;
+        B.carve(&d_D, (size_t)n * bb);                   // (the three zero-initialised block arrays and y first: one memset)
+        B.carve(&d_Aup, (size_t)n * bb);
+        B.carve(&d_Adn, (size_t)n * bb);
+        B.carve(&d_y, (size_t)n * b);
+        B.carve(&d_sing, (size_t)1);
+        const size_t zeroed = B.used;
+        B.carve(&d_Z, (size_t)n * bb);
+        B.carve(&d_w, (size_t)n * b);
+        B.carve(&d_xb, (size_t)n * b);
+        B.carve(&d_dx, (size_t)N);
+        B.carve(&d_data, nnz);
+        B.carve(&d_f, (size_t)N);
+        B.carve(&d_indptr, (size_t)N + 1);
+        B.carve(&d_indices, nnz);
+        B.carve(&d_parent, (size_t)n);
+        B.carve(&d_child_ptr, (size_t)n + 1);
+        B.carve(&d_child, child.size());
+        B.carve(&d_lvl, (size_t)n);
+        B.carve(&d_dep, (size_t)n);
+        if (pass == 0) {
+            B.cap = B.used;
+            if (hipMalloc((void**)&B.base, B.cap) != hipSuccess) {
+                B.base = nullptr;
+                return HPF_E_NOMEM;
+            }
+        } else if (hipMemsetAsync(B.base, 0, zeroed, nullptr) != hipSuccess) {
+            return HPF_E_HIP;
+        }
+    }
     hipStream_t st = nullptr;                            // (the legacy default stream: every call below is ordered, the copies are synchronous)
     bool ok = hipMemcpy(d_indptr, indptr, sizeof(int) * ((size_t)N + 1), hipMemcpyHostToDevice) == hipSuccess &&
               hipMemcpy(d_indices, indices, sizeof(int) * nnz, hipMemcpyHostToDevice) == hipSuccess &&
@@ -369,11 +396,7 @@ extern "C" int hpf_sparse_solve(int device, int n, int c, int Hn, const int32_t*
               hipMemcpy(d_child_ptr, child_ptr.data(), sizeof(int) * ((size_t)n + 1), hipMemcpyHostToDevice) == hipSuccess &&
               hipMemcpy(d_child, child.data(), sizeof(int) * child.size(), hipMemcpyHostToDevice) == hipSuccess &&
               hipMemcpy(d_lvl, lvl_nodes.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice) == hipSuccess &&
-              hipMemcpy(d_dep, dep_nodes.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice) == hipSuccess &&
-              hipMemsetAsync(d_D, 0, sizeof(double) * (size_t)n * bb, st) == hipSuccess &&
-              hipMemsetAsync(d_Aup, 0, sizeof(double) * (size_t)n * bb, st) == hipSuccess &&
-              hipMemsetAsync(d_Adn, 0, sizeof(double) * (size_t)n * bb, st) == hipSuccess &&
-              hipMemsetAsync(d_y, 0, sizeof(double) * (size_t)n * b, st) == hipSuccess && hipMemsetAsync(d_sing, 0, sizeof(int), st) == hipSuccess;
+              hipMemcpy(d_dep, dep_nodes.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice) == hipSuccess;
     if (!ok) return HPF_E_HIP;
     double ms_up = 0.0;
     std::chrono::steady_clock::time_point t_2 = std::chrono::steady_clock::now();

@@ -202,6 +202,7 @@ struct hpf_handle {
     int* d_mask = nullptr;            // [S] scenarios of a repeat pass
     double *d_Vm0 = nullptr, *d_Va0 = nullptr;   // [S][Hn*n] state at the entry of hpf_solve (repeat with partial pivoting starts from it)
     double *d_Vmp = nullptr, *d_Vap = nullptr;   // [S][Hn*n] option "keep_previous_state": the state each scenario's LAST Newton step started from
+    double *d_swapVm = nullptr, *d_swapVa = nullptr;   // [S][Hn*n] hpf_jacobian(_csr)_last: the current state while the kept one stands in its place
     int queue_chunk = 4;              // option "queue_chunk": iterations between two harvest / refill rounds of hpf_solve_queue
     int keep_prev = 0;
     bool prev_valid = false;          // d_Vmp / d_Vap belong to the last hpf_solve (set_state / set_loads invalidate them)

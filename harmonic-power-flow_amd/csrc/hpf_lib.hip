@@ -1353,7 +1353,7 @@ int solve_queue_fast(hpf_handle* h, int n_total, const double* P, const double* 
 void free_all(hpf_handle* h) {
     void* ptrs[] = {h->d_rowrec, h->d_rowptr, h->d_col, h->d_diag, h->d_erow, h->d_dev, h->d_Y, h->d_YN, h->d_YNt, h->d_IN, h->d_P, h->d_Q,
                     h->d_Vm, h->d_Va, h->d_U, h->d_E, h->d_I0, h->d_f, h->d_errbits, h->d_errpart, h->d_err, h->d_niter, h->d_active,
-                    h->d_nactive, h->d_pivflag, h->d_mask, h->d_Vm0, h->d_Va0, h->d_Vmp, h->d_Vap, h->d_tstamp, h->d_hist, h->d_stats, h->d_J, h->d_ipiv, h->d_info, h->d_Z, h->d_w, h->d_x, h->d_linA, h->d_C, h->d_dbg, h->d_H, h->d_chG, h->d_chH, h->d_chD, h->d_chy, h->d_chZ, h->d_lfK, h->d_lfS, h->d_fb, h->d_F, h->d_H2, h->d_jptr, h->d_jcol, h->d_jval};
+                    h->d_nactive, h->d_pivflag, h->d_mask, h->d_Vm0, h->d_Va0, h->d_Vmp, h->d_Vap, h->d_swapVm, h->d_swapVa, h->d_tstamp, h->d_hist, h->d_stats, h->d_J, h->d_ipiv, h->d_info, h->d_Z, h->d_w, h->d_x, h->d_linA, h->d_C, h->d_dbg, h->d_H, h->d_chG, h->d_chH, h->d_chD, h->d_chy, h->d_chZ, h->d_lfK, h->d_lfS, h->d_fb, h->d_F, h->d_H2, h->d_jptr, h->d_jcol, h->d_jval};
     for (void* p : ptrs)
         if (p) hipFree(p);
     tree_free(h);
@@ -1726,13 +1726,12 @@ static int with_previous_state(hpf_handle* h, int scen, const std::function<int(
         if (ni <= 0 || !h->prev_valid) return HPF_E_STATE;
     }
     const size_t cnt = (size_t)h->S * h->n * h->Hn;
-    double *tm = nullptr, *ta = nullptr;
+    // (the swap buffers belong to the handle: no allocation / release per call -- a hipFree right after another handle returned tens of GB to
+    //  the driver was seen to take 60 ms)
     int r;
-    if ((r = dev_alloc(h, &tm, cnt))) return r;
-    if ((r = dev_alloc(h, &ta, cnt))) {
-        hipFree(tm);
-        return r;
-    }
+    if (!h->d_swapVm && (r = dev_alloc(h, &h->d_swapVm, (size_t)h->S_alloc * h->n * h->Hn))) return r;
+    if (!h->d_swapVa && (r = dev_alloc(h, &h->d_swapVa, (size_t)h->S_alloc * h->n * h->Hn))) return r;
+    double *tm = h->d_swapVm, *ta = h->d_swapVa;
     hipMemcpyAsync(tm, h->d_Vm, sizeof(double) * cnt, hipMemcpyDeviceToDevice, h->stream);
     hipMemcpyAsync(ta, h->d_Va, sizeof(double) * cnt, hipMemcpyDeviceToDevice, h->stream);
     hipMemcpyAsync(h->d_Vm, h->d_Vmp, sizeof(double) * cnt, hipMemcpyDeviceToDevice, h->stream);
@@ -1742,8 +1741,6 @@ static int with_previous_state(hpf_handle* h, int scen, const std::function<int(
     hipMemcpyAsync(h->d_Va, ta, sizeof(double) * cnt, hipMemcpyDeviceToDevice, h->stream);
     if (!r) r = launch_polar<false>(h);
     hipStreamSynchronize(h->stream);
-    hipFree(tm);
-    hipFree(ta);
     return r;
 }
 
