@@ -264,18 +264,20 @@ extern "C" int hpf_sparse_solve(int device, int n, int c, int Hn, const int32_t*
     // ---- host: bus adjacency of the pattern, tree from bus 0 ---------------------------------------------------------------------------
     std::vector<std::vector<int>> adj(n);
     {
-        std::vector<int> stamp(n, -1);
+        std::vector<int> stamp(n, -1), bus_of(N);      // bus of every real index: one division per index instead of one per entry
+        for (int r = 0; r < N; ++r) {
+            int l;
+            rc_to_bus(r, n, c, Nc, bus_of[r], l);
+        }
         // rows of one bus are not contiguous in the stacked order: stamp[j] = i marks "edge (i, j) already listed" only while the walk stays
         // on bus i, so an edge can be listed several times (once per row group); the lists are made unique afterwards
         for (int r = 0; r < N; ++r) {
             if (indptr[r + 1] < indptr[r]) return HPF_E_ARG;
-            int i, l;
-            rc_to_bus(r, n, c, Nc, i, l);
+            const int i = bus_of[r];
             for (int e = indptr[r]; e < indptr[r + 1]; ++e) {
                 const int col = indices[e];
                 if (col < 0 || col >= N) return HPF_E_ARG;
-                int j, lc;
-                rc_to_bus(col, n, c, Nc, j, lc);
+                const int j = bus_of[col];
                 if (j != i && stamp[j] != r) {
                     if (adj[i].empty() || adj[i].back() != j) adj[i].push_back(j);
                     stamp[j] = r;

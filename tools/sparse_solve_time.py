@@ -5,7 +5,7 @@ import harmonic_power_flow_amd as hp
 from harmonic_power_flow_amd import synth
 REPO = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 INPUTS = os.path.join(REPO, "tests", "golden", "inputs")
-for nb, hm in ((1000, 51), (2000, 99)):
+for nb, hm in ((1000, 51), (2000, 99), (10000, 99)):
     fb, fl = synth.gen(nb, seed=0, outdir=tempfile.mkdtemp())
     st = hp.Settings(H_MAX=hm)
     buses, lines, m, n, c = hp.init_network(fb, fl, settings=st)
