@@ -227,7 +227,7 @@ struct DevPool {
     static size_t pad(size_t b) { return (b + 255) & ~(size_t)255; }
     template <class T>
     void carve(T** p, size_t count) {
-        *p = reinterpret_cast<T*>(base + used);
+        *p = base ? reinterpret_cast<T*>(base + used) : nullptr;      // (sizing pass: no pointer arithmetic on a null base)
         used += pad(sizeof(T) * (count ? count : 1));
     }
     ~DevPool() {
