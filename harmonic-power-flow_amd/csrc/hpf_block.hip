@@ -26,6 +26,7 @@
 
 #include "hpf_internal.hpp"
 #include "hpf_gj.hpp"
+#include "hpf_blk_jobs.hpp"
 #include "hpf_gj_dense.hpp"
 #include "hpf_gj_mfma.hpp"
 
@@ -1056,7 +1057,8 @@ static void tree_free_one(Tree& T) {
 void tree_free(hpf_handle* h) {
     tree_free_one(h->tree);
     tree_free_one(h->ctree);
-    void* bp[] = {h->d_tb_bus, h->d_tb_ptr, h->d_tb_adj, h->d_bM, h->d_brhs, h->d_bipiv, h->d_binfo, h->d_bM0, h->d_brhs0};
+    void* bp[] = {h->d_tb_bus, h->d_tb_ptr, h->d_tb_adj, h->d_bM, h->d_brhs, h->d_bipiv, h->d_binfo, h->d_bM0, h->d_brhs0,
+                  h->d_sel_P, h->d_sel_pidx, h->d_sel_toff, h->d_sel_S, h->d_sel_Z, h->d_sel_Up, h->d_sel_W, h->d_sel_X, h->d_sel_tie, h->d_sel_jobs};
     for (void* q2 : bp)
         if (q2) hipFree(q2);
 }
@@ -1435,6 +1437,29 @@ int tree_find_ties(hpf_handle* h, const hpf_desc* d) {
     h->m_border = h->n_tb * 2 * d->Hn;
     if (h->m_border > 16384 || wave_block_size(2 * d->Hn) == 0) return HPF_E_TOPOLOGY;  // stated bound of the bordered step (hpf.h): the
                                                                                         // m x m border system is dense (2 GiB at 16 384)
+    // Factor-once form (default; HPF_MESH_SEL=0: the m virtual sweeps of rounds 2-4): the buses on the endpoints' root paths are marked for the
+    // planner.  Coupled models only (an uncoupled model has no dense block on the 2x2 path), and while the blocks of J_t^-1 E_T on those
+    // paths fit comfortably (|P| n_tb b^2 doubles).
+    h->tb_bus_host = tb_bus;
+    h->mesh_sel = false;
+    h->sel_forced.clear();
+    {
+        const char* ms = h->sw("HPF_MESH_SEL");
+        if (!(ms && atoi(ms) == 0) && d->coupled) {
+            std::vector<char> fp(n, 0);
+            size_t nP = 0;
+            for (int i : tb_bus)
+                for (int k = i; k >= 0 && !fp[k]; k = parent[k]) {
+                    fp[k] = 1;
+                    ++nP;
+                }
+            const double bytes = 8.0 * (double)nP * (double)h->n_tb * 4.0 * d->Hn * d->Hn;
+            if (bytes <= 16.0 * 1073741824.0) {
+                h->mesh_sel = true;
+                h->sel_forced = std::move(fp);
+            }
+        }
+    }
     int r;
     if ((r = upload(h, &h->d_tb_bus, tb_bus))) return r;
     if ((r = upload(h, &h->d_tb_ptr, tb_ptr))) return r;
@@ -1461,6 +1486,7 @@ int ensure_blas(hpf_handle* h) {
 // virtual scenario slots of the bordered step: all 1 + m right-hand sides at once up to 256, above that chunks of up to 1 024 (a chunk
 // runs in the throughput regime of the tree kernels: 6.5 us per scenario-step at 256 live slots, 5.5 at 1 024; 72 MB of state per slot)
 int border_slots(const hpf_handle* h) {
+    if (h->mesh_sel) return 1;                           // factor-once form: one virtual slot (the sweeps of y and of the second pass)
     const int c = h->border_slot_cap < 16 ? 16 : h->border_slot_cap;   // (HPF_BORDER_SLOTS, read by hpf_create into the handle)
     return h->m_border + 1 < 256 ? h->m_border + 1 : (h->m_border + 1 < c ? ((h->m_border + 1 + 15) / 16) * 16 : c);
 }
@@ -1485,6 +1511,224 @@ __global__ __launch_bounds__(1024) void k_border_absmax(int m, const double* __r
         __syncthreads();
     }
     if (threadIdx.x == 0) *out = red[0];
+}
+
+// ---- factor-once bordered step: selected inversion over the endpoints' root paths ----------------------------------------------------------
+// (the algebra of hpf_csr_solve.hip's meshed branch, with the blocks read from the sweep of virtual slot v: S_k^-1 from the inverse slot of the
+//  plain Gauss-Jordan bus k (tile image -> dense, row-major), A(k, parent) / A(parent, k) harmonic-diagonal 2x2 blocks of the slot's state)
+// one workgroup per bus q of P:  S[q] = S_k^-1,  Z[q] = S_k^-1 A(k, p),  Up[q] = S_p^-1 A(p, k)
+__global__ __launch_bounds__(256) void k_sel_prepare(Model M, int b, size_t CT, int v, const int* __restrict__ P, const int* __restrict__ toff,
+                                                     const cplx* __restrict__ Uall, const cplx* __restrict__ Eall, const double* __restrict__ Zall,
+                                                     double* __restrict__ Sd, double* __restrict__ Zd, double* __restrict__ Up) {
+    __shared__ double hg[2][64 * 4];                     // [0]: A(k, p), [1]: A(p, k), per harmonic 2x2 row-major (Hn <= 64)
+    const int q = blockIdx.x, k = P[4 * q], par = P[4 * q + 1];
+    const int Hn = M.Hn, n = M.n;
+    const size_t so = (size_t)v * n * Hn, bb = (size_t)b * b;
+    const int pbus = par >= 0 ? P[4 * par] : -1;
+    if ((int)threadIdx.x < 2 * Hn && pbus >= 0) {
+        const int w = threadIdx.x / Hn, hq = threadIdx.x - w * Hn;
+        double g4[4];
+        if (w == 0)
+            coupling_block(M, Uall + so, Eall + so, hq, k, pbus, P[4 * q + 2], g4);
+        else
+            coupling_block(M, Uall + so, Eall + so, hq, pbus, k, P[4 * q + 3], g4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hg[w][hq * 4 + e] = g4[e];
+    }
+    __syncthreads();
+    const double* Zk = Zall + ((size_t)v * n + k) * CT;
+    const double* Zp = pbus >= 0 ? Zall + ((size_t)v * n + pbus) * CT : nullptr;
+    for (int idx = threadIdx.x; idx < b * b; idx += 256) {
+        const int i = idx / b, cc = idx - i * b, hq = cc >> 1, t2 = cc & 1;
+        Sd[q * bb + idx] = Zk[toff[idx]];
+        double z = 0.0, u = 0.0;
+        if (pbus >= 0) {
+            const int o0 = toff[i * b + 2 * hq], o1 = toff[i * b + 2 * hq + 1];
+            z = fma(Zk[o1], hg[0][hq * 4 + 2 + t2], Zk[o0] * hg[0][hq * 4 + t2]);
+            u = fma(Zp[o1], hg[1][hq * 4 + 2 + t2], Zp[o0] * hg[1][hq * 4 + t2]);
+        }
+        Zd[q * bb + idx] = z;
+        Up[q * bb + idx] = u;
+    }
+}
+
+// coupling blocks of the ties at the state of slot v: tie[(e * Hn + q) * 4 + .] = A(i, j) at harmonic position q, e the directed tie (tb_adj order)
+__global__ void k_sel_ties(Model M, int v, int n_dir, const int* __restrict__ tb_bus, const int* __restrict__ tb_ptr, const int* __restrict__ tb_adj,
+                           int n_tb, const cplx* __restrict__ Uall, const cplx* __restrict__ Eall, double* __restrict__ tie) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_dir * M.Hn) return;
+    const int e = t / M.Hn, q = t - e * M.Hn;
+    int a = 0;
+    while (a + 1 < n_tb && tb_ptr[a + 1] <= e) ++a;
+    const size_t so = (size_t)v * M.n * M.Hn;
+    double g4[4];
+    coupling_block(M, Uall + so, Eall + so, q, tb_bus[a], tb_adj[3 * e], tb_adj[3 * e + 1], g4);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) tie[(size_t)t * 4 + u] = g4[u];
+}
+
+// border matrix I + Q^T Z (column-major m x m) from the blocks X[j, t] of the selected inversion: thread = (row (a, l), column (t, cc))
+__global__ __launch_bounds__(256) void k_border_build_sel(int b, int Hn, int m, int n_tb, const int* __restrict__ tb_ptr, const int* __restrict__ tb_adj,
+                                                          const int* __restrict__ pidx, const double* __restrict__ tie, const double* __restrict__ X,
+                                                          double* __restrict__ bM) {
+    const int row = blockIdx.x * 256 + threadIdx.x, col = blockIdx.y;
+    if (row >= m) return;
+    const int a = row / b, l = row - a * b, q = l >> 1, t = l & 1;
+    const int tcol = col / b, cc = col - tcol * b;
+    const size_t bb = (size_t)b * b;
+    double acc = row == col ? 1.0 : 0.0;
+    for (int e = tb_ptr[a]; e < tb_ptr[a + 1]; ++e) {
+        const double* g4 = tie + ((size_t)e * Hn + q) * 4;
+        const double* Xj = X + ((size_t)pidx[tb_adj[3 * e]] * n_tb + tcol) * bb;
+        acc = fma(g4[t * 2], Xj[(size_t)(2 * q) * b + cc], acc);
+        acc = fma(g4[t * 2 + 1], Xj[(size_t)(2 * q + 1) * b + cc], acc);
+    }
+    bM[(size_t)col * m + row] = acc;
+}
+
+// Host side, once per handle (after tree_build): P ordered by depth, the forward pairs ordered by height, the block-product jobs with their
+// final device addresses, the buffers.
+int tree_sel_build(hpf_handle* h, const hpf_desc* d) {
+    if (!h->mesh_sel) return HPF_OK;
+    const Tree& T = active_tree(h);
+    const int n = h->n, b = 2 * h->Hn, mT = h->n_tb;
+    const size_t bb = (size_t)b * b;
+    if ((int)T.plain_gj.size() != n || (int)T.toff_tab.size() != b * b || h->Hn > 64) return HPF_E_STATE;
+    std::vector<int> order, depth(n, 0), height(n, 0);
+    {
+        std::vector<std::vector<int>> ch(n);
+        for (int i = 1; i < n; ++i) ch[T.parent[i]].push_back(i);
+        order.push_back(0);
+        for (size_t oi = 0; oi < order.size(); ++oi)
+            for (int j : ch[order[oi]]) {
+                depth[j] = depth[order[oi]] + 1;
+                order.push_back(j);
+            }
+        for (int oi = n - 1; oi > 0; --oi) {
+            const int i = order[oi];
+            if (height[i] + 1 > height[T.parent[i]]) height[T.parent[i]] = height[i] + 1;
+        }
+    }
+    std::vector<int> e_up(n, -1), e_dn(n, -1);
+    for (int i = 1; i < n; ++i) {
+        const int p = T.parent[i];
+        for (int e = d->rowptr[i]; e < d->rowptr[i + 1]; ++e)
+            if (d->col[e] == p) e_up[i] = e;
+        for (int e = d->rowptr[p]; e < d->rowptr[p + 1]; ++e)
+            if (d->col[e] == i) e_dn[i] = e;
+    }
+    std::vector<int> pidx(n, -1), Pbus, Prec;
+    for (int oi = 0; oi < n; ++oi) {
+        const int k = order[oi];
+        if (!h->sel_forced[k]) continue;
+        if (!T.plain_gj[k]) return HPF_E_STATE;              // (the planner keeps marked buses on the plain Gauss-Jordan path)
+        pidx[k] = (int)Pbus.size();
+        Pbus.push_back(k);
+    }
+    const size_t nP = Pbus.size();
+    int max_depth = 0, max_height = 0;
+    for (int k : Pbus) {
+        Prec.push_back(k);
+        Prec.push_back(k > 0 ? pidx[T.parent[k]] : -1);
+        Prec.push_back(k > 0 ? e_up[k] : 0);
+        Prec.push_back(k > 0 ? e_dn[k] : 0);
+        max_depth = std::max(max_depth, depth[k]);
+        max_height = std::max(max_height, height[k]);
+    }
+    struct Pair {
+        int bus, t, pred, child;
+    };
+    std::vector<Pair> raw;
+    for (int t = 0; t < mT; ++t) {
+        int pred = -1, chb = -1;
+        for (int k = h->tb_bus_host[t]; k >= 0; k = T.parent[k]) {
+            raw.push_back({k, t, pred, chb});
+            pred = (int)raw.size() - 1;
+            chb = k;
+        }
+    }
+    const size_t npairs = raw.size();
+    std::vector<int> perm(npairs), newidx(npairs), pair_of(nP * (size_t)mT, -1);
+    for (size_t q = 0; q < npairs; ++q) perm[q] = (int)q;
+    std::stable_sort(perm.begin(), perm.end(), [&](int a, int c2) { return height[raw[a].bus] < height[raw[c2].bus]; });
+    for (size_t q = 0; q < npairs; ++q) newidx[perm[q]] = (int)q;
+    std::vector<Pair> pairs(npairs);
+    std::vector<size_t> lvl_cnt(max_height + 2, 0);
+    for (size_t q = 0; q < npairs; ++q) {
+        pairs[q] = raw[perm[q]];
+        if (pairs[q].pred >= 0) pairs[q].pred = newidx[pairs[q].pred];
+        lvl_cnt[height[pairs[q].bus] + 1]++;
+        pair_of[(size_t)pidx[pairs[q].bus] * mT + pairs[q].t] = (int)q;
+    }
+    h->sel_nP = (int)nP;
+    h->sel_npairs = (int)npairs;
+    h->sel_R = (b + 15) / 16;
+    auto dalloc = [&](double** p2, size_t cnt) { return hipMalloc((void**)p2, sizeof(double) * (cnt ? cnt : 1)) == hipSuccess; };
+    if (!dalloc(&h->d_sel_S, nP * bb) || !dalloc(&h->d_sel_Z, nP * bb) || !dalloc(&h->d_sel_Up, nP * bb) || !dalloc(&h->d_sel_W, npairs * bb) ||
+        !dalloc(&h->d_sel_X, nP * (size_t)mT * bb) || !dalloc(&h->d_sel_tie, (size_t)2 * h->n_ties * h->Hn * 4))
+        return HPF_E_NOMEM;
+    int r;
+    if ((r = upload(h, &h->d_sel_P, Prec))) return r;
+    if ((r = upload(h, &h->d_sel_pidx, pidx))) return r;
+    if ((r = upload(h, &h->d_sel_toff, T.toff_tab))) return r;
+    std::vector<BlkJob> jobs;
+    jobs.reserve(npairs + nP * (size_t)mT);
+    h->sel_fwd_beg.assign(1, 0);
+    {
+        size_t q = 0;
+        for (int l = 0; l <= max_height; ++l) {
+            for (size_t e = 0; e < lvl_cnt[l + 1]; ++e, ++q) {
+                const Pair& pr = pairs[q];
+                if (pr.pred < 0)
+                    jobs.push_back({nullptr, h->d_sel_S + (size_t)pidx[pr.bus] * bb, nullptr, h->d_sel_W + q * bb, 1.0});
+                else
+                    jobs.push_back({h->d_sel_Up + (size_t)pidx[pr.child] * bb, h->d_sel_W + (size_t)pr.pred * bb, nullptr, h->d_sel_W + q * bb, -1.0});
+            }
+            h->sel_fwd_beg.push_back(jobs.size());
+        }
+    }
+    h->sel_back_beg.assign(1, jobs.size());
+    {
+        size_t q = 0;                                        // (Pbus is ordered by depth)
+        for (int dl = 0; dl <= max_depth; ++dl) {
+            for (; q < nP && depth[Pbus[q]] == dl; ++q) {
+                const int k = Pbus[q];
+                for (int t = 0; t < mT; ++t) {
+                    const int pq = pair_of[q * mT + t];
+                    const double* wq = pq >= 0 ? h->d_sel_W + (size_t)pq * bb : nullptr;
+                    double* xo = h->d_sel_X + (q * mT + t) * bb;
+                    if (k == 0)
+                        jobs.push_back({nullptr, wq, nullptr, xo, 1.0});
+                    else
+                        jobs.push_back({h->d_sel_Z + q * bb, h->d_sel_X + ((size_t)pidx[T.parent[k]] * mT + t) * bb, wq, xo, -1.0});
+                }
+            }
+            h->sel_back_beg.push_back(jobs.size());
+        }
+    }
+    if (hipMalloc(&h->d_sel_jobs, sizeof(BlkJob) * (jobs.size() ? jobs.size() : 1)) != hipSuccess) return HPF_E_NOMEM;
+    if (hipMemcpy(h->d_sel_jobs, jobs.data(), sizeof(BlkJob) * jobs.size(), hipMemcpyHostToDevice) != hipSuccess) return HPF_E_HIP;
+    if (h->sw("HPF_TREE_INFO"))
+        fprintf(stderr, "hpf tree: factor-once bordered step: %d ties, %d endpoint buses (border %d), %zu buses on their root paths, %zu forward pairs, "
+                        "%zu block products per Newton step and scenario\n", h->n_ties, mT, h->m_border, nP, npairs, jobs.size());
+    return HPF_OK;
+}
+
+// the selected inversion of slot v -> the border matrix (h->d_bM)
+static void tree_sel_run(hpf_handle* h, int v, hipStream_t st) {
+    const int b = 2 * h->Hn, BW = wave_block_size(b), NT = (BW + 16) / 16, m = h->m_border;
+    const size_t CT = (size_t)NT * NT * 256;
+    const BlkJob* jobs = static_cast<const BlkJob*>(h->d_sel_jobs);
+    hipLaunchKernelGGL(k_sel_prepare, dim3((unsigned)h->sel_nP), dim3(256), 0, st, h->M, b, CT, v, h->d_sel_P, h->d_sel_toff, h->d_U, h->d_E, h->d_Z,
+                       h->d_sel_S, h->d_sel_Z, h->d_sel_Up);
+    hipLaunchKernelGGL(k_sel_ties, dim3((unsigned)((2 * h->n_ties * h->Hn + 255) / 256)), dim3(256), 0, st, h->M, v, 2 * h->n_ties, h->d_tb_bus, h->d_tb_ptr,
+                       h->d_tb_adj, h->n_tb, h->d_U, h->d_E, h->d_sel_tie);
+    for (size_t l = 0; l + 1 < h->sel_fwd_beg.size(); ++l)
+        launch_jobs(h->sel_R, b, (int)(h->sel_fwd_beg[l + 1] - h->sel_fwd_beg[l]), jobs + h->sel_fwd_beg[l], st);
+    for (size_t l = 0; l + 1 < h->sel_back_beg.size(); ++l)
+        launch_jobs(h->sel_R, b, (int)(h->sel_back_beg[l + 1] - h->sel_back_beg[l]), jobs + h->sel_back_beg[l], st);
+    hipLaunchKernelGGL(k_border_build_sel, dim3((unsigned)((m + 255) / 256), (unsigned)m), dim3(256), 0, st, b, h->Hn, m, h->n_tb, h->d_tb_ptr, h->d_tb_adj,
+                       h->d_sel_pidx, h->d_sel_tie, h->d_sel_X, h->d_bM);
 }
 
 int tree_newton_step_bordered(hpf_handle* h, bool only_active) {
@@ -1522,7 +1766,18 @@ int tree_newton_step_bordered(hpf_handle* h, bool only_active) {
         return rc;
     };
     for (int r : todo) {
-        for (int c0 = 0; c0 < 1 + m; c0 += VC) {
+        if (h->mesh_sel) {
+            // factor-once form: ONE sweep of the scenario's own right-hand side in the virtual slot (y and Q^T y), then the selected inversion
+            // of that slot's factors -> border matrix
+            hipLaunchKernelGGL(k_border_prepare, dim3((unsigned)((cmax + 255) / 256), 1u), dim3(256), 0, st, n, h->Hn, BW, b, r, v0, 0,
+                               h->d_tb_bus, h->n_tb, (const double*)nullptr, h->d_U, h->d_E, h->d_I0, h->d_fb);
+            int rc = sweep(1);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_border_build, dim3((unsigned)((m + 255) / 256), 1u), dim3(256), 0, st, h->M, BW, b, r, v0, 0, m,
+                               h->d_tb_bus, h->d_tb_ptr, h->d_tb_adj, h->d_U, h->d_E, h->d_x, h->d_bM, h->d_brhs);
+            tree_sel_run(h, v0, st);
+        }
+        for (int c0 = 0; !h->mesh_sel && c0 < 1 + m; c0 += VC) {
             const int V = 1 + m - c0 < VC ? 1 + m - c0 : VC;
             hipLaunchKernelGGL(k_border_prepare, dim3((unsigned)((cmax + 255) / 256), (unsigned)V), dim3(256), 0, st, n, h->Hn, BW, b, r, v0, c0,
                                h->d_tb_bus, h->n_tb, (const double*)nullptr, h->d_U, h->d_E, h->d_I0, h->d_fb);

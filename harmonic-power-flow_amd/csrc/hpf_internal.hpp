@@ -96,6 +96,8 @@ struct Tree {
     std::vector<int> ah_ptr;
     int* d_arec = nullptr;
     std::vector<int> lvl_all_leaf;    // [n_levels] 1: every bus of the elimination level is a constant-inverse leaf
+    std::vector<int> toff_tab;        // [b][b] offset of (row, col) of a block in a tile image (TileIO<B>::off), -1: not stored
+    std::vector<char> plain_gj;       // [n] 1: dense bus on the plain Gauss-Jordan path (its inverse S_k^-1 is in its inverse slot after a sweep)
     int n_cleaf = 0;
     double* d_Minv = nullptr;         // [n_cleaf][NT*NT*256]
     // lazy leaves: constant-inverse leaves directly under their dense parent never write their Schur complement; the parent
@@ -163,6 +165,22 @@ struct hpf_handle {
     double *d_bM = nullptr, *d_brhs = nullptr;   // border system (m x m column-major, m)
     int *d_bipiv = nullptr, *d_binfo = nullptr;
     double *d_bM0 = nullptr, *d_brhs0 = nullptr;   // kept copy of the border system (residual check of the unpivoted LU) | copy of its right-hand side + 2 check words
+    // factor-once form of the bordered step (tree_sel_build / tree_sel_run, hpf_block.hip): the tree is swept ONCE per Newton step and scenario
+    // for y = J_t^-1 f; the border matrix comes from a selected inversion over P = the union of the endpoints' root paths, whose buses the planner
+    // keeps as plain Gauss-Jordan buses (sel_forced) so that S_k^-1 sits in their inverse slot
+    bool mesh_sel = false;
+    std::vector<char> sel_forced;     // [n] 1: bus on a root path of a tie endpoint (empty: not used)
+    std::vector<int> tb_bus_host;     // [n_tb] endpoint buses (host copy of d_tb_bus)
+    int sel_nP = 0, sel_npairs = 0, sel_R = 0;
+    int *d_sel_P = nullptr;           // [nP][4]: bus, index of its parent in P (-1: root), CSR entries (bus, parent), (parent, bus)
+    int *d_sel_pidx = nullptr;        // [n] index in P or -1
+    int *d_sel_toff = nullptr;        // [b][b] offset of (row, col) in a tile image of the inverse slot
+    double *d_sel_S = nullptr, *d_sel_Z = nullptr, *d_sel_Up = nullptr;   // [nP][b][b] S^-1, S^-1 A(k, parent), S_parent^-1 A(parent, k): dense, row-major
+    double *d_sel_W = nullptr;        // [npairs][b][b] forward blocks W[k, t]
+    double *d_sel_X = nullptr;        // [nP][n_tb][b][b] (J_t^-1 E_T) restricted to P
+    double *d_sel_tie = nullptr;      // [2 n_ties][Hn][4] the ties' coupling blocks of the current state
+    void *d_sel_jobs = nullptr;       // BlkJob list: forward by height, back by depth
+    std::vector<size_t> sel_fwd_beg, sel_back_beg;
     int border_pivoting = 0;          // option "border_pivoting": 1 = every border system through the pivoted LU (A/B, tests)
     int border_repivots = 0;          // border systems that went through the pivoted LU after the residual check
     std::vector<int> host_act;        // the slot list as the host last saw it (the bordered step walks the running scenarios)
@@ -305,5 +323,6 @@ int tree_newton_step(hpf_handle* h, bool only_active);   // assembles, eliminate
 int tree_newton_step_bordered(hpf_handle* h, bool only_active);   // the same for a network with loop-closing lines (h->n_ties > 0)
 int ensure_blas(hpf_handle* h);                                   // rocBLAS handle on first use (dense LU, border system)
 int border_slots(const hpf_handle* h);                            // virtual scenario slots of the bordered step (behind the S_max real ones)
+int tree_sel_build(hpf_handle* h, const hpf_desc* d);             // factor-once bordered step: P, forward pairs, block-product jobs, buffers (after tree_build)
 
 }  // namespace hpf

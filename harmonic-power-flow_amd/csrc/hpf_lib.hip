@@ -1533,6 +1533,7 @@ int hpf_create_opts(hpf_handle** out, const hpf_desc* d, const char* options) {
     if (d->solver == HPF_SOLVER_BLOCK_TREE) {
         const auto t_tree = std::chrono::steady_clock::now();
         if ((r = tree_build(h, d))) return fail(r);
+        if ((r = tree_sel_build(h, d))) return fail(r);
         h->setup_ms[1] = h->tree.plan_ms + h->ctree.plan_ms;
         h->setup_ms[2] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_tree).count() - h->setup_ms[1];
         const auto t_al = std::chrono::steady_clock::now();

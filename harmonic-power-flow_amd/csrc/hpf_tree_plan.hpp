@@ -79,13 +79,21 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
             if (!T.lin[i]) T.lin[T.parent[i]] = 0;
         }
     }
+    // factor-once bordered step of a meshed network (h->sel_forced, set by tree_find_ties): the buses on the root paths of the ties' endpoints
+    // stay PLAIN Gauss-Jordan buses -- no 2x2 algebra, no contracted chain, no constant-inverse / lazy / bordered form, no compress role --, so
+    // that their inverse S_k^-1 is in the inverse slot after a sweep: the selected inversion of tree_sel_run reads it from there
+    const std::vector<char>& fp = h->sel_forced;
+    const bool use_fp = contract && (int)fp.size() == n;
+    if (use_fp)
+        for (int i = 0; i < n; ++i)
+            if (fp[i]) T.lin[i] = 0;                           // (closed under "parent of": the rule above stays true)
     // pass-through buses (contract): linear bus, not the root, exactly one child with nonlinear buses below it -> its block is
     // harmonic-diagonal and eliminating it FIRST only re-links that child to the grandparent (2x2-per-harmonic fill)
     std::vector<int> pass(n, 0), ndc(n, 0);
     for (int i = 1; i < n; ++i)
         if (!T.lin[i]) ndc[T.parent[i]]++;
     if (contract)
-        for (int i = 1; i < n; ++i) pass[i] = (!T.lin[i] && i < d->m && ndc[i] == 1) ? 1 : 0;
+        for (int i = 1; i < n; ++i) pass[i] = (!T.lin[i] && i < d->m && ndc[i] == 1 && !(use_fp && fp[i])) ? 1 : 0;
     auto kept = [&](int i) { return !T.lin[i] && !pass[i]; };
     std::vector<int> pard(n, -1);                              // parent in the dense tree (through chains)
     for (size_t oi = 1; oi < order.size(); ++oi) {
@@ -468,6 +476,7 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
     if (BWc)
         for (int row = 0; row < b; ++row)
             for (int col = 0; col < b; ++col) toff_tab[(size_t)row * b + col] = (int)tile_off(row, col);
+    T.toff_tab = toff_tab;
     if (contract && d->coupled && BWc) {
         typedef std::complex<double> cd;
         const int Hn = d->Hn, nnz = d->nnz;
@@ -663,6 +672,7 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
             for (int pos = 0; pos < T.n_dense; ++pos) {
                 const int k = T.lvl_nodes[pos];
                 if (k < d->m || dchild_ptr[k + 1] != dchild_ptr[k] || d->dev_of_bus[k] < 0) continue;
+                if (use_fp && fp[k]) continue;
                 leaf_pos[k] = (int)cand.size();
                 cand.push_back(k);
             }
@@ -770,6 +780,7 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
             const int L = (int)lazy_of[k].size();
             const int LS = (int)slz_of[k].size();                      // vector-only bordered children (registered when THEY were built)
             if (k < (d->c > 1 ? d->c : 1) || L + LS == 0 || dchild_ptr[k + 1] - dchild_ptr[k] != L + LS) continue;
+            if (use_fp && fp[k]) continue;
             if (k < d->m && sleaf_mode < 2) continue;                  // linear (PQ) buses: power-row map W_k on the fundamental
             // border columns: per lazy leaf one complex column (G, H), per bordered child its m1_c columns (g Pb_c[:, i], Qb_c[i, :] h)
             std::vector<std::vector<cd>> colG, colH;
@@ -948,10 +959,10 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
                 }
                 nrm[k2] = std::max(gjb[k2], m1 + 1);
                 int best = nrm[k2], bc = -1;
-                if (gjb[k2] && pard[k2] >= 0 && gjb[pard[k2]])
+                if (gjb[k2] && pard[k2] >= 0 && gjb[pard[k2]] && !(use_fp && fp[k2]))
                     for (int i = dchild_ptr[k2]; i < dchild_ptr[k2 + 1]; ++i) {
                         const int c1 = dchild[i];
-                        if (!gjb[c1]) continue;
+                        if (!gjb[c1] || (use_fp && fp[c1])) continue;
                         const int levk = std::max(1, (c1 == a1 ? m2 : m1) + 1), levc = std::max(nrm[c1], levk + 1);
                         if (levc < best) {
                             best = levc;
@@ -1156,6 +1167,7 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
     const long long sl_base = (long long)lzimg.size();          // super-leaf constants ride behind the lazy images
     lzimg.insert(lzimg.end(), slimg.begin(), slimg.end());
     T.lvl_all_leaf.assign(T.n_levels > 0 ? T.n_levels : 1, 1);
+    T.plain_gj.assign(n, 0);
     for (int pos = 0; pos < T.n_dense; ++pos) {
         const int k = T.lvl_nodes[pos];
         int* r = &fdesc[(size_t)pos * FDESC];
@@ -1177,6 +1189,7 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
         r[14] = ((k > 0 && pass[T.parent[k]]) ? 1 : 0) | (is_lazy[k] ? 2 : 0);   // bit 0: linked to its dense parent through a contracted chain; bit 1: lazy leaf
         r[15] = lz_idx[k] >= 0 ? -(lz_idx[k] + 1) : cleaf_of[k] + 1;     // > 0: constant-inverse leaf, 1 + slot in Tree::d_Minv; < 0: -(1 + lazy record)
         if (cleaf_of[k] < 0) T.lvl_all_leaf[height[k]] = 0;
+        T.plain_gj[k] = (cleaf_of[k] < 0 && !is_lazy[k] && !(sl_off[k] >= 0 && lz_idx[k] >= 0) && !comp_role[k] && !(k > 0 && pass[T.parent[k]])) ? 1 : 0;
         for (int i = 0; i < 4; ++i) {                              // first four 2x2-algebra children: (child, e_dn, e_up), no child3 hop
             const int cp = T.child_ptr[k] + i;
             const bool has = cp < T.child_mid[k];

@@ -241,7 +241,10 @@ int  hpf_debug_stamps(hpf_handle* h, long long* out, int count);
  * leaves first (no compress steps: one elimination level per unit of tree height; 5 - 8 % faster per step from about 384 live scenarios on, whose
  * levels fill the chip -- the steps are the default at every capacity so that a handle's Newton steps do not depend on its capacity), HPF_TREE_INFO=1 prints the tree statistics to stderr,
  * HPF_QUEUE_INFO=1 prints the phase times of hpf_solve_queue to stderr, HPF_BORDER_SLOTS=n caps the virtual scenario slots a meshed handle
- * allocates for its bordered step (default 1 024, at least 16: the m + 1 right-hand sides run in chunks of that many),
+ * allocates for its bordered step (default 1 024, at least 16: the m + 1 right-hand sides run in chunks of that many; only with HPF_MESH_SEL=0),
+ * HPF_MESH_SEL=0 runs the bordered step of a meshed handle in its form of rounds 2 - 4 (the m unit right-hand sides as virtual scenarios through
+ * the tree kernels, the tree re-factorised for each) instead of the factor-once form (one sweep + a selected inversion over the tie endpoints'
+ * root paths, whose buses the planner then keeps as plain Gauss-Jordan buses; coupled models),
  * HPF_FUSEBACK=0 launches the back sweep's scenario-batched workgroups (bordered buses, leaves) after the last depth instead of inside the
  * depths' launches (k_level_back: groups of up to HPF_FUSEBACK_MAX = 32 scenarios, blocks of 52),
  * HPF_GROUPS=n presets "scenario_groups".  Every switch selects a path with the same Newton steps (tests/test_gpu_robustness.py). */

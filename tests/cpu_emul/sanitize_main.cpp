@@ -125,7 +125,8 @@ int main() {
         if (hpf_create(&h, &bad) != HPF_E_ARG) return 2;
         // hpf_sparse_solve: the host-side analysis of the pattern (bus adjacency from the CSR Jacobian just built, BFS tree, levels) under the
         // sanitizers.  These feeders are radial: the analysis must accept them, so without a GPU the call ends at the first HIP call
-        // (HPF_E_HIP); a ring closed by one extra entry must be refused (HPF_E_TOPOLOGY) before any HIP call, a bad index with HPF_E_ARG.
+        // (HPF_E_HIP); a ring closed by one extra entry on ONE side only (a block pattern that is not symmetric) must be refused (HPF_E_TOPOLOGY) before
+        // any HIP call, a bad index with HPF_E_ARG; the ring closed from both ends is a meshed pattern and is accepted.
         {
             std::vector<double> dx(N, 0.0);
             const int rc = hpf_sparse_solve(0, n, F.c, Hn, indptr.data(), indices.data(), data.data(), f.data(), dx.data());
@@ -159,6 +160,30 @@ int main() {
                     }
                     ip2[N] = (int)ix2.size();
                     if (hpf_sparse_solve(0, n, F.c, Hn, ip2.data(), ix2.data(), dt2.data(), f.data(), dx.data()) != HPF_E_TOPOLOGY) return 4;
+                    {
+                        // the same edge listed from BOTH ends: a meshed pattern (spanning tree + one tie) -- the analysis (ties, root paths, forward pairs,
+                        // block-product jobs are built after the first HIP call, which fails here) must accept it
+                        const int r2 = 1 * n + a - 1, c2 = 1 * n + rbus - 1;
+                        std::vector<int> ip3(ip2), ix3;
+                        std::vector<double> dt3;
+                        for (int rr = 0; rr < N; ++rr) {
+                            ip3[rr] = (int)ix3.size();
+                            for (int e = ip2[rr]; e < ip2[rr + 1]; ++e) {
+                                ix3.push_back(ix2[e]);
+                                dt3.push_back(dt2[e]);
+                            }
+                            if (rr == r2) {
+                                ix3.push_back(c2);
+                                dt3.push_back(1.0);
+                            }
+                        }
+                        ip3[N] = (int)ix3.size();
+                        const int rc3 = hpf_sparse_solve(0, n, F.c, Hn, ip3.data(), ix3.data(), dt3.data(), f.data(), dx.data());
+                        if (rc3 == HPF_E_ARG || rc3 == HPF_E_TOPOLOGY) {
+                            printf("seed %u: hpf_sparse_solve refused a feeder with one tie: %d\n", seed, rc3);
+                            return 4;
+                        }
+                    }
                     ix2[0] = N + 5;
                     if (hpf_sparse_solve(0, n, F.c, Hn, ip2.data(), ix2.data(), dt2.data(), f.data(), dx.data()) != HPF_E_ARG) return 4;
                 }

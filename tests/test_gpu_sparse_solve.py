@@ -106,6 +106,163 @@ def test_sparse_solve_vs_superlu_on_the_same_matrix(n, hmax, n_pv, tmp_path):
     assert np.abs(x1 - fused).max() <= 1e-9 * scale
 
 
+def _add_ties(fl, n, k, seed=42):
+    """k loop-closing lines on a synthetic feeder (the generator of the meshed oracle fixtures, oracle/make_golden_bench.py: test infrastructure)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mgb", os.path.join(os.path.dirname(GOLD), "..", "oracle", "make_golden_bench.py"))
+    mgb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mgb)
+    return mgb.add_ties(fl, n, k, seed)
+
+
+def _meshed(hp, n, hmax, k, tmp_path, solver="auto"):
+    from harmonic_power_flow_amd import api, synth
+    fb, fl = synth.gen(n, seed=0, outdir=str(tmp_path))
+    ties = _add_ties(fl, n, k)
+    st = hp.Settings(H_MAX=hmax)
+    buses, lines, m, nn, c = hp.init_network(fb, fl, settings=st)
+    Y = hp.build_admittance_matrices(buses, lines, st.HARMONICS)
+    NE = hp.import_Norton_Equivalents(buses, True, st, INPUTS)
+    dm = api._device_model(buses, Y, NE, True, st.HARMONICS, solver=solver)
+    dm.set_loads(buses["P"].to_numpy(float), buses["Q"].to_numpy(float))
+    dm.set_state(None, None, n_scen=1)
+    dm.fund_pf(1e-6, 30)
+    return st, dm, c, ties
+
+
+@pytest.mark.parametrize("n,hmax,k", [(60, 11, 1), (150, 27, 3), (260, 51, 6), (120, 99, 2)])
+def test_sparse_solve_of_meshed_networks_vs_superlu(n, hmax, k, tmp_path):
+    """Loop-closing lines (round 5): the CSR Jacobian of a feeder with k ties goes through hpf_sparse_solve's bordered elimination (spanning tree
+    factorised once, selected inversion over the endpoints' root paths, dense border system) -- against SuperLU on the same matrix at 1e-9 of the
+    step, every block-size class, and against the step of the library's own bordered Newton iteration."""
+    import scipy.sparse.linalg as spl
+    from harmonic_power_flow_amd import _lib
+    hp = _hp()
+    st, dm, c, ties = _meshed(hp, n, hmax, k, tmp_path, solver="block_tree")
+    try:
+        assert dm.tree_census()["ties"] == k
+        Vm0, Va0 = dm.get_state()
+        f, _ = dm.mismatch()
+        J = dm.jacobian_csr(0)
+        dm.solve(1e-4, 1)
+        Vm1, Va1 = dm.get_state()
+    finally:
+        dm.close()
+    x0 = np.append(Va0[0][1:], Vm0[0][c:])
+    # the C entry point itself accepts the pattern (no dense fallback of the api involved)
+    lib = _lib.load()
+    ip, dp = C.POINTER(C.c_int32), C.POINTER(C.c_double)
+    Jc = J.tocsr()
+    indptr, indices, data = Jc.indptr.astype(np.int32), Jc.indices.astype(np.int32), np.ascontiguousarray(Jc.data, dtype=float)
+    f0 = np.ascontiguousarray(f[0], dtype=float)
+    dx = np.full(f0.size, np.nan)
+    rc = lib.hpf_sparse_solve(0, n, c, len(st.HARMONICS), indptr.ctypes.data_as(ip), indices.ctypes.data_as(ip), data.ctypes.data_as(dp),
+                              f0.ctypes.data_as(dp), dx.ctypes.data_as(dp))
+    assert rc == 0
+    ref = spl.spsolve(J.tocsc(), f0)
+    scale = np.abs(ref).max()
+    assert np.abs(dx - ref).max() <= 1e-9 * scale, (np.abs(dx - ref).max(), scale)
+    x1 = hp.update_harmonic_state_vec(J, x0, f0)
+    assert np.array_equal(x1, x0 - dx)
+    fused = np.append(Va1[0][1:], Vm1[0][c:])
+    assert np.abs(x1 - fused).max() <= 1e-8 * scale
+
+
+def test_sparse_solve_of_the_headline_feeder_with_20_ties(tmp_path):
+    """1 000 buses x 25 harmonics + 20 loop-closing lines (40 endpoint buses, border 2 080; the meshed oracle fixture's network): the dense LU of
+    this matrix would be 21.6 GB.  Relative residual, SuperLU on the same matrix, wall time."""
+    import scipy.sparse.linalg as spl
+    hp = _hp()
+    st, dm, c, ties = _meshed(hp, 1000, 51, 20, tmp_path, solver="block_tree")
+    try:
+        Vm0, Va0 = dm.get_state()
+        f, _ = dm.mismatch()
+        J = dm.jacobian_csr(0)
+    finally:
+        dm.close()
+    x0 = np.append(Va0[0][1:], Vm0[0][c:])
+    hp.update_harmonic_state_vec(J, x0, f[0])
+    t0 = time.perf_counter()
+    x1 = hp.update_harmonic_state_vec(J, x0, f[0])
+    t1 = time.perf_counter()
+    dx = x0 - x1
+    res = np.abs(J @ dx - f[0]).max() / (np.abs(J).dot(np.abs(dx)).max() + np.abs(f[0]).max())
+    t2 = time.perf_counter()
+    ref = spl.spsolve(J.tocsc(), f[0])
+    t3 = time.perf_counter()
+    dev = np.abs(dx - ref).max() / np.abs(ref).max()
+    print(f"\nsyn1000 + 20 ties, N = {J.shape[0]}: {1e3 * (t1 - t0):.1f} ms (SuperLU on the host: {1e3 * (t3 - t2):.0f} ms); relative residual {res:.1e}, "
+          f"{dev:.1e} of the step from SuperLU")
+    assert res < 1e-12 and dev < 1e-9
+
+
+def test_sparse_solve_ring_of_dense_blocks_through_the_c_abi():
+    """The smallest meshed pattern, dense random blocks (nothing of the reference's structure): buses 0 - 1 - 2 - 0 (tree 0 -> 1, 0 -> 2, tie 1 - 2) and a
+    5-bus graph with two ties sharing an endpoint, against numpy.linalg.solve; a singular border system is reported (HPF_E_SINGULAR)."""
+    from harmonic_power_flow_amd import _lib
+    import scipy.sparse as sp
+    lib = _lib.load()
+    ip, dp = C.POINTER(C.c_int32), C.POINTER(C.c_double)
+
+    def call(n, c, Hn, A, f):
+        J = sp.csr_matrix(A)
+        indptr, indices = J.indptr.astype(np.int32), J.indices.astype(np.int32)
+        data, f = np.ascontiguousarray(J.data, dtype=float), np.ascontiguousarray(f, dtype=float)
+        dx = np.full(f.size, np.nan)
+        rc = lib.hpf_sparse_solve(0, n, c, Hn, indptr.ctypes.data_as(ip), indices.ctypes.data_as(ip), data.ctypes.data_as(dp), f.ctypes.data_as(dp),
+                                  dx.ctypes.data_as(dp))
+        return rc, dx
+    rng = np.random.default_rng(11)
+    for n, c, Hn, edges in ((3, 1, 2, [(0, 1), (0, 2), (1, 2)]), (5, 2, 3, [(0, 1), (1, 2), (2, 3), (3, 4), (4, 1), (4, 2)]), (4, 1, 9, [(0, 1), (1, 2), (2, 3), (3, 0)])):
+        Nc = n * Hn - 1
+        N = 2 * Nc - (c - 1)
+
+        def bus_of(r):
+            k = r - Nc + c if r >= Nc else r + 1
+            return k % n
+        adj = {(a, b2) for a, b2 in edges} | {(b2, a) for a, b2 in edges} | {(a, a) for a in range(n)}
+        A = np.zeros((N, N))
+        for r in range(N):
+            for cc in range(N):
+                if (bus_of(r), bus_of(cc)) in adj:
+                    A[r, cc] = rng.normal() + (3.0 * Hn if r == cc else 0.0)
+        f = rng.normal(size=N)
+        rc, dx = call(n, c, Hn, A, f)
+        assert rc == 0, (n, rc)
+        ref = np.linalg.solve(A, f)
+        assert np.abs(dx - ref).max() <= 1e-11 * np.abs(ref).max(), (n, np.abs(dx - ref).max())
+    # an exactly singular BORDER system on a regular tree part: identity diagonal blocks, tree couplings present in the pattern with value 0, and the
+    # tie blocks A(1, 2) = A(2, 1) = -I  ->  I + Q^T Z = [I -I; -I I]: rocSOLVER's zero pivot is reported (HPF_E_SINGULAR), nothing is returned as solved
+    n, c, Hn = 3, 1, 2
+    Nc = n * Hn - 1
+    N = 2 * Nc - (c - 1)
+
+    def bl(r):
+        t = 1 if r >= Nc else 0
+        k = r - Nc + c if t else r + 1
+        return k % n, 2 * (k // n) + t
+    rows, cols, vals = [], [], []
+    for r in range(N):
+        for cc in range(N):
+            (i, l), (j, lc) = bl(r), bl(cc)
+            if i == j:
+                v = 1.0 if l == lc else None
+            elif {i, j} == {1, 2}:
+                v = -1.0 if l == lc else None
+            else:
+                v = 0.0
+            if v is not None:
+                rows.append(r), cols.append(cc), vals.append(v)
+    Js = sp.csr_matrix((np.array(vals), (np.array(rows), np.array(cols))), shape=(N, N))
+    assert (Js.data == 0.0).any()                             # (explicit zeros keep the tree edges 0 - 1, 0 - 2 in the pattern)
+    indptr, indices = Js.indptr.astype(np.int32), Js.indices.astype(np.int32)
+    data, f = np.ascontiguousarray(Js.data, dtype=float), np.ones(N)
+    dx = np.full(N, np.nan)
+    rc = lib.hpf_sparse_solve(0, n, c, Hn, indptr.ctypes.data_as(ip), indices.ctypes.data_as(ip), data.ctypes.data_as(dp), f.ctypes.data_as(dp),
+                              dx.ctypes.data_as(dp))
+    assert rc == 3
+
+
 def test_sparse_solve_block_size_100_residual(tmp_path):
     """b = 2 Hn = 100 (H_MAX = 99, the block size of BASELINE config 5; R = 7 register tiles, 81 KB of LDS per workgroup): 600 buses, 2.3 M entries;
     relative residual of the solution and agreement with the fused block-tree step."""
@@ -171,7 +328,7 @@ def test_sparse_solve_error_paths_and_meshed_fallback():
     A2[np.ix_(rows2, rows2)] = 0.0
     rc, _ = call(n, c, Hn, sp.csr_matrix(A2), f)
     assert rc == 3
-    # the reference's meshed nets (net2: a ring) keep working through the api: sparse route refused (-3), dense LU
+    # the reference's meshed nets (net2: a ring of 4 buses): the sparse route's bordered elimination (round 5; dense LU before)
     g = np.load(os.path.join(GOLD, "net2_H11_c.npz"), allow_pickle=True)
     J = sp.csr_matrix((g["J0_data"], (g["J0_row"], g["J0_col"])), shape=tuple(g["J0_shape"]))
     x0 = np.append(g["V_traj"][0][1:, 1], g["V_traj"][0][1:, 0])

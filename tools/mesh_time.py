@@ -48,5 +48,7 @@ for k in [int(a) for a in sys.argv[1:]] or [5, 20]:
     t0 = time.perf_counter()
     it, err, _ = dm.solve(1e-4, 50)
     t = time.perf_counter() - t0
-    print("syn1000 + %d ties: census %s; %d iterations in %.3f s = %.2f ms per iteration (err %.1e)" % (k, dm.tree_census()["ties"], it[0], t, 1e3 * t / it[0], err[0]))
+    cs = dm.tree_census()
+    print("syn1000 + %d ties: census %s; %d iterations in %.3f s = %.2f ms per iteration (err %.1e); levels %d, border systems through the pivoted LU %d"
+          % (k, cs["ties"], it[0], t, 1e3 * t / it[0], err[0], cs["levels"], cs["border_repivots"]))
     dm.close()
