@@ -106,7 +106,7 @@ def _frame(Vm, Va, harmonics, n):
     return pd.DataFrame({"V_m": np.asarray(Vm), "V_a": np.asarray(Va)}, index=idx)
 
 
-def _device_model(buses, Y, NE, coupled, harmonics, solver="auto", max_scenarios=1, device=0, assembly_only=False):
+def _device_model(buses, Y, NE, coupled, harmonics, solver="auto", max_scenarios=1, device=0, assembly_only=False, options=None):
     m, n, c = ingest.network_constants(buses)
     Hn = len(harmonics)
     if NE is None:
@@ -118,7 +118,7 @@ def _device_model(buses, Y, NE, coupled, harmonics, solver="auto", max_scenarios
     else:
         dev, Y_N, I_N, n_dev = ingest.norton_arrays(buses, NE, coupled, Hn)
     return DeviceModel(n, m, c, harmonics, Y.rowptr, Y.col, Y.Yval, dev, Y_N, I_N, n_dev, coupled,
-                       solver=solver, device=device, max_scenarios=max_scenarios, assembly_only=assembly_only)
+                       solver=solver, device=device, max_scenarios=max_scenarios, assembly_only=assembly_only, options=options)
 
 
 # ---- handle cache -------------------------------------------------------------------------------------------------------------------------
@@ -357,8 +357,10 @@ def update_harmonic_state_vec(J, x, f, device=0, dims=None):
     scattered on the device into bus-major 2Hn x 2Hn blocks and eliminated along the feeder tree; no N x N array exists on host or device, so the
     1 000-bus x 26-harmonic Jacobian (N = 51 998, 1.2 M entries) is solved like the 46-unknown one.  The row / column numbering of the reference's
     stacked matrix is a function of (n, c, Hn): taken from `dims=(n, c, Hn)`, else from the matrix itself (the Jacobians this package returns
-    carry it), else from the network of the last `init_network` call.  A meshed network's Jacobian (bus graph not a tree) and dense arrays go to
-    the dense rocSOLVER LU (`hpf_dense_solve`), which is bounded by 8 N^2 bytes of host and device memory."""
+    carry it), else from the network of the last `init_network` call.  A meshed network's Jacobian (spanning tree + loop-closing lines) takes the
+    same route -- tree part factorised once, dense border system of the lines' endpoint buses.  Dense arrays, and sparse matrices the sparse route
+    refuses (bus graph not connected from bus 0, block pattern not symmetric, border beyond 16 384 unknowns), go to the dense rocSOLVER LU
+    (`hpf_dense_solve`), which is bounded by 8 N^2 bytes of host and device memory."""
     lib = _lib.load()
     fv = np.ascontiguousarray(f, dtype=np.float64)
     N = fv.size
@@ -380,12 +382,12 @@ def update_harmonic_state_vec(J, x, f, device=0, dims=None):
                                       data.ctypes.data_as(dp), fv.ctypes.data_as(dp), dx.ctypes.data_as(dp))
             if rc == 0:
                 return np.asarray(x, dtype=np.float64) - dx
-            if rc != -3:                                   # (HPF_E_TOPOLOGY: meshed network -> the dense LU below)
+            if rc != -3:                                   # (HPF_E_TOPOLOGY: a pattern the sparse route does not take -> the dense LU below)
                 raise RuntimeError("hpf_sparse_solve failed: %s (code %d)" % (lib.hpf_strerror(rc).decode(), rc))
         if 8.0 * N * N > 16e9:
             raise ValueError("update_harmonic_state_vec: a sparse Jacobian of %d unknowns %s; the dense fallback would need %.1f GB on the host -- "
                              "solve such a network with hpf() (bordered block-tree step)"
-                             % (N, "on a meshed network" if d is not None else "whose (n, c, Hn) is unknown (pass dims=)", 8e-9 * N * N))
+                             % (N, "that hpf_sparse_solve refuses (HPF_E_TOPOLOGY)" if d is not None else "whose (n, c, Hn) is unknown (pass dims=)", 8e-9 * N * N))
     Jd = np.asfortranarray(J.toarray() if hasattr(J, "toarray") else np.asarray(J), dtype=np.float64)
     if Jd.shape != (N, N):
         raise ValueError("J must be %d x %d" % (N, N))

@@ -35,9 +35,10 @@ enum {
                                   rocSOLVER's 64-bit entry points one scenario after the other; HPF_E_NOMEM when they do not fit */
     HPF_SOLVER_BLOCK_TREE = 1  /* bus-major 2Hn x 2Hn block elimination along the feeder tree.  Radial networks directly; meshed
                                   networks as BFS spanning tree + k loop-closing lines, solved as a bordered system on top of the
-                                  same tree factorisation (m + 2 right-hand sides per scenario and Newton step, m = 2Hn x number
-                                  of distinct endpoint buses of the loop-closing lines, in chunks of up to 1 024 virtual scenarios;
-                                  m x m border system on rocSOLVER); m <= 16 384 and 2Hn <= 100, else HPF_E_TOPOLOGY */
+                                  same tree factorisation (m = 2Hn x number of distinct endpoint buses of the loop-closing lines;
+                                  two sweeps of the tree per scenario and Newton step + a selected inversion over the endpoints' root
+                                  paths; uncoupled models and HPF_MESH_SEL=0: m + 2 right-hand sides as virtual scenarios in chunks
+                                  of up to 1 024; m x m border system on rocSOLVER); m <= 16 384 and 2Hn <= 100, else HPF_E_TOPOLOGY */
 };
 
 enum {
@@ -190,9 +191,13 @@ int  hpf_dense_solve(int device, int N, const double* J_colmajor, const double* 
  * (n buses, c = PV buses + 1, Hn harmonics: the numbering is a function of these three alone), f [N] -> dx [N] = J^-1 f.  The entries are
  * scattered on the device into bus-major 2 Hn x 2 Hn blocks and eliminated along the feeder tree (partial pivoting inside a bus block; off-diagonal
  * blocks may be dense); no N x N array exists on host or device (65 MB of blocks at 1 000 buses x 26 harmonics, where the dense matrix is
- * 21.6 GB).  Duplicate (row, column) entries add up like scipy's.  HPF_E_TOPOLOGY when the bus graph of the pattern is not a tree connected from
- * bus 0 (meshed network: use hpf_dense_solve where it fits), HPF_E_ARG for 2 Hn > 128 or an inconsistent CSR, HPF_E_SINGULAR when a bus block has
- * no pivot.  Stateless like the reference's function: no handle.  (env HPF_SPARSE_INFO=1 prints its phase times to stderr.) */
+ * 21.6 GB).  Duplicate (row, column) entries add up like scipy's.  A MESHED bus graph (spanning tree + loop-closing lines) is solved as a bordered
+ * system: the tree part is factorised once, a selected inversion over the root paths of the lines' endpoint buses gives the m x m border matrix
+ * (m = 2 Hn x number of distinct endpoint buses <= 16 384; rocSOLVER LU), one more right-hand-side sweep the solution (1 000 buses x 26 harmonics
+ * + 20 lines: 27 ms, 1e-12 of the step from SuperLU).  HPF_E_TOPOLOGY when the bus graph is not connected from bus 0, the block pattern is not
+ * symmetric (a block (i, j) without (j, i)) or the border exceeds that bound -- use hpf_dense_solve where it fits --, HPF_E_ARG for 2 Hn > 128 or an
+ * inconsistent CSR, HPF_E_SINGULAR when a bus block or the border system has no pivot.  Stateless like the reference's function: no handle.
+ * (env HPF_SPARSE_INFO=1 prints its phase times to stderr.) */
 int  hpf_sparse_solve(int device, int n, int c, int Hn, const int32_t* indptr, const int32_t* indices, const double* data, const double* f,
                       double* dx);
 

@@ -362,12 +362,13 @@ def _add_ties(fl, n, k, seed=42):
     return mgb.add_ties(fl, n, k, seed)
 
 
-@pytest.mark.parametrize("n,hmax,k", [(300, 51, 3), (120, 11, 1), (200, 27, 4), (260, 51, 12)])
+@pytest.mark.parametrize("n,hmax,k", [(300, 51, 3), (120, 11, 1), (200, 27, 4), (260, 51, 12), (100, 99, 2)])
 def test_meshed_feeder_bordered_block_tree_vs_dense(n, hmax, k, tmp_path):
-    """A radial feeder plus k loop-closing lines: BFS spanning tree + bordered system on the block-tree path (m + 2 right-hand sides
-    per Newton step in chunks of up to 256 virtual scenarios, m x m border system on rocSOLVER; fundamental pf through the dense LU)
-    against the dense rocSOLVER path on the full meshed Jacobian: pf seed, first Newton step, converged voltages (fixed point)
-    within 1e-8.  The last case (12 tie lines at K = 25: m = 1 196 border unknowns, five chunks) is beyond round 2's bound of 1 024."""
+    """A radial feeder plus k loop-closing lines: BFS spanning tree + bordered system on the block-tree path, in BOTH forms -- factor-once (round 5,
+    default: one sweep + selected inversion over the endpoints' root paths) and the m virtual sweeps of rounds 2 - 4 (HPF_MESH_SEL=0: m + 2
+    right-hand sides per Newton step in chunks of virtual scenarios) --, m x m border system on rocSOLVER, fundamental pf through the dense LU,
+    against the dense rocSOLVER path on the full meshed Jacobian: pf seed, first Newton step, converged voltages (fixed point) within 1e-8.
+    (260, 51, 12): m = 1 196 border unknowns; (100, 99, 2): blocks of 100 (the kernels of BASELINE config 5)."""
     hp = _hp()
     from harmonic_power_flow_amd import api, synth
     fb, fl = synth.gen(n, seed=4, outdir=str(tmp_path))
@@ -378,8 +379,9 @@ def test_meshed_feeder_bordered_block_tree_vs_dense(n, hmax, k, tmp_path):
     assert len(Y.col) == n + 2 * (n - 1) + 2 * k
     NE = hp.import_Norton_Equivalents(buses, True, st, INPUTS)
     out = {}
-    for solver in ("dense", "block_tree"):
-        dm = api._device_model(buses, Y, NE, True, st.HARMONICS, solver=solver)
+    for solver in ("dense", "block_tree", "virtual"):
+        dm = api._device_model(buses, Y, NE, True, st.HARMONICS, solver="dense" if solver == "dense" else "block_tree",
+                               options="HPF_MESH_SEL=0" if solver == "virtual" else None)
         try:
             dm.set_loads(buses["P"].to_numpy(float), buses["Q"].to_numpy(float))
             dm.set_state(None, None, n_scen=1)
@@ -402,16 +404,18 @@ def test_meshed_feeder_bordered_block_tree_vs_dense(n, hmax, k, tmp_path):
             out[solver] = (v0, v1, dm.get_state(), int(n_iter[0]), float(err[0]), stt)
         finally:
             dm.close()
-    (v0d, v1d, vfd, itd, ed, _), (v0b, v1b, vfb, itb, eb, stb) = out["dense"], out["block_tree"]
+    v0d, v1d, vfd, itd, ed, _ = out["dense"]
     step = max(np.abs(v1d[0] - v0d[0]).max(), np.abs(v1d[1] - v0d[1]).max())
-    d1 = max(np.abs(v1d[0] - v1b[0]).max(), np.abs(v1d[1] - v1b[1]).max())
     Ud = vfd[0][0] * np.exp(1j * vfd[1][0])
-    Ub = vfb[0][0] * np.exp(1j * vfb[1][0])
-    print("\nn=%d H_MAX=%d ties %s: first step %.1e (deviation %.1e); dense %d it (err %.1e), bordered block-tree %d it (err %.1e); fixed points differ by %.2e"
-          % (n, hmax, ties, step, d1, itd, ed, itb, eb, np.abs(Ud - Ub).max()))
-    assert d1 <= 1e-8 * max(1.0, step)
-    assert ed <= 1e-4 and eb <= 1e-4 and (stb["flags"][0] & 1)
-    assert np.abs(Ud - Ub).max() < TOL_V
+    for form in ("block_tree", "virtual"):
+        v0b, v1b, vfb, itb, eb, stb = out[form]
+        d1 = max(np.abs(v1d[0] - v1b[0]).max(), np.abs(v1d[1] - v1b[1]).max())
+        Ub = vfb[0][0] * np.exp(1j * vfb[1][0])
+        print("\nn=%d H_MAX=%d ties %s, %s: first step %.1e (deviation %.1e); dense %d it (err %.1e), bordered block-tree %d it (err %.1e); fixed points differ by %.2e"
+              % (n, hmax, ties, "factor-once" if form == "block_tree" else "virtual sweeps", step, d1, itd, ed, itb, eb, np.abs(Ud - Ub).max()))
+        assert d1 <= 1e-8 * max(1.0, step)
+        assert ed <= 1e-4 and eb <= 1e-4 and (stb["flags"][0] & 1)
+        assert np.abs(Ud - Ub).max() < TOL_V
 
 
 def test_border_system_unpivoted_lu_with_residual_check_vs_pivoted(tmp_path):
