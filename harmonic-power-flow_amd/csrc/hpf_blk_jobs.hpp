@@ -4,6 +4,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "hpf_gj_dense.hpp"
+
 namespace hpf {
 namespace {                  // (kernels with internal linkage: every translation unit that includes this launches its own copy)
 
@@ -16,7 +18,7 @@ struct BlkJob {
 };
 // K-chunk of the LDS staging: 2 b kc doubles within 64 KB (no launch attribute), a multiple of 4
 inline int blk_jobs_kc(int b) {
-    int kc = ((8192 - b) / (2 * b)) & ~3;                 // b (kc + 1) + kc b <= 8 192 doubles
+    int kc = ((8192 - b) / (2 * b)) & ~3;                 // b (kc + 1) + kc b <= 8 192 doubles (kc a multiple of 4: a chunk's zero padding stays inside)
     const int bpad = (b + 3) & ~3;
     return kc > bpad ? bpad : (kc < 4 ? 4 : kc);
 }
@@ -33,36 +35,73 @@ __global__ __launch_bounds__(256) void k_blk_jobs(int b, int kc, const BlkJob* _
 #pragma unroll
         for (int ci = 0; ci < R; ++ci) o[ai][ci] = 0.0;
     if (jb.A) {
-        // A[:, k0 : k0 + kc] and B[k0 : k0 + kc, :] go through LDS (coalesced loads issued at once: one memory round trip per chunk; the products
-        // then read As by row -- one address per 16 lanes -- and Bs by column)
+        // A[:, k0 : k0 + kc] and B[k0 : k0 + kc, :] go through LDS (16-byte coalesced loads, all issued before the first store: one memory round
+        // trip per chunk; b is even, so every row starts 16-byte aligned); the products then read As by row -- one address per 16 lanes -- and Bs
+        // by column, four k at a time (a chunk is padded with zeros to a multiple of four)
         const int lda = kc + 1;
         double* As = blk_lds;
         double* Bs = blk_lds + (size_t)b * lda;
+        const double2* A2 = reinterpret_cast<const double2*>(jb.A);
+        const double2* B2 = reinterpret_cast<const double2*>(jb.B);
+        const int bh = b >> 1;
         for (int k0 = 0; k0 < b; k0 += kc) {
-            const int kn = b - k0 < kc ? b - k0 : kc;
+            const int kn = b - k0 < kc ? b - k0 : kc, kn4 = (kn + 3) & ~3, knh = kn >> 1;      // (k0, kn even)
             if (k0) __syncthreads();
-            for (int idx = tid; idx < b * kn; idx += 256) {
-                const int i = idx / kn, kk = idx - i * kn;
-                As[i * lda + kk] = jb.A[(size_t)i * b + k0 + kk];
+            constexpr int LQ = 6;                            // loads in flight per thread and operand
+            for (int base = 0; base < b * knh; base += 256 * LQ) {
+                double2 va[LQ], vb[LQ];
+#pragma unroll
+                for (int u = 0; u < LQ; ++u) {
+                    const int idx = base + u * 256 + tid;
+                    va[u] = double2{0.0, 0.0};
+                    vb[u] = double2{0.0, 0.0};
+                    if (idx < b * knh) {
+                        const int i = idx / knh, kh = idx - i * knh;
+                        va[u] = A2[(size_t)i * bh + (k0 >> 1) + kh];
+                        vb[u] = B2[(size_t)(k0 >> 1) * b + idx];           // rows k0 .. k0 + kn - 1 of B are contiguous: kn * b / 2 pairs
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < LQ; ++u) {
+                    const int idx = base + u * 256 + tid;
+                    if (idx < b * knh) {
+                        const int i = idx / knh, kh = idx - i * knh;
+                        As[i * lda + 2 * kh] = va[u].x;
+                        As[i * lda + 2 * kh + 1] = va[u].y;
+                        Bs[2 * idx] = vb[u].x;
+                        Bs[2 * idx + 1] = vb[u].y;
+                    }
+                }
             }
-            for (int idx = tid; idx < kn * b; idx += 256) Bs[idx] = jb.B[(size_t)k0 * b + idx];
+            if (kn4 > kn) {                                  // zero padding of the chunk's last k group
+                for (int idx = tid; idx < b * (kn4 - kn); idx += 256) {
+                    const int i = idx / (kn4 - kn), kk = kn + idx - i * (kn4 - kn);
+                    As[i * lda + kk] = 0.0;
+                    Bs[kk * b + i] = 0.0;
+                }
+            }
             __syncthreads();
-            for (int kk = 0; kk < kn; ++kk) {
-                double g[R], z[R];
+            for (int kk = 0; kk < kn4; kk += 4) {
+                double g[R][4], z[4][R];
 #pragma unroll
                 for (int ai = 0; ai < R; ++ai) {
                     const int i = tr + 16 * ai;
-                    g[ai] = i < b ? As[i * lda + kk] : 0.0;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) g[ai][u] = i < b ? As[i * lda + kk + u] : 0.0;
                 }
 #pragma unroll
-                for (int ci = 0; ci < R; ++ci) {
-                    const int cc = tc + 16 * ci;
-                    z[ci] = cc < b ? Bs[kk * b + cc] : 0.0;
-                }
+                for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int ai = 0; ai < R; ++ai)
+                    for (int ci = 0; ci < R; ++ci) {
+                        const int cc = tc + 16 * ci;
+                        z[u][ci] = cc < b ? Bs[(kk + u) * b + cc] : 0.0;
+                    }
 #pragma unroll
-                    for (int ci = 0; ci < R; ++ci) o[ai][ci] = fma(g[ai], z[ci], o[ai][ci]);
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int ai = 0; ai < R; ++ai)
+#pragma unroll
+                        for (int ci = 0; ci < R; ++ci) o[ai][ci] = fma(g[ai][u], z[u][ci], o[ai][ci]);
             }
         }
     } else {
@@ -84,6 +123,49 @@ __global__ __launch_bounds__(256) void k_blk_jobs(int b, int kc, const BlkJob* _
                 jb.C[(size_t)i * b + cc] = fma(jb.alpha, o[ai][ci], base);
             }
         }
+}
+
+// one block inverted in place, no pivoting (gj_dense_invert_npvt); *flag <- nonzero when a pivot is zero
+template <int R>
+__global__ __launch_bounds__(256) void k_blk_invert(int b, double* __restrict__ blk, int* __restrict__ flag) {
+    __shared__ double cb[128], rr[128];
+    __shared__ int zp;
+    const int tid = threadIdx.x, tr = tid >> 4, tc = tid & 15;
+    if (tid == 0) zp = 0;
+    double a[R][R];
+#pragma unroll
+    for (int ai = 0; ai < R; ++ai)
+#pragma unroll
+        for (int ci = 0; ci < R; ++ci) {
+            const int i = tr + 16 * ai, cc = tc + 16 * ci;
+            a[ai][ci] = (i < b && cc < b) ? blk[(size_t)i * b + cc] : 0.0;
+        }
+    __syncthreads();
+    gj_dense_invert_npvt<R>(a, b, cb, rr, &zp);
+#pragma unroll
+    for (int ai = 0; ai < R; ++ai)
+#pragma unroll
+        for (int ci = 0; ci < R; ++ci) {
+            const int i = tr + 16 * ai, cc = tc + 16 * ci;
+            if (i < b && cc < b) blk[(size_t)i * b + cc] = a[ai][ci];
+        }
+    if (tid == 0 && zp) atomicMax(flag, zp);
+}
+template <int R>
+inline void launch_invert_R(int b, double* blk, int* flag, hipStream_t st) {
+    hipLaunchKernelGGL((k_blk_invert<R>), dim3(1), dim3(256), 0, st, b, blk, flag);
+}
+inline void launch_invert(int R, int b, double* blk, int* flag, hipStream_t st) {
+    switch (R) {
+        case 1: launch_invert_R<1>(b, blk, flag, st); break;
+        case 2: launch_invert_R<2>(b, blk, flag, st); break;
+        case 3: launch_invert_R<3>(b, blk, flag, st); break;
+        case 4: launch_invert_R<4>(b, blk, flag, st); break;
+        case 5: launch_invert_R<5>(b, blk, flag, st); break;
+        case 6: launch_invert_R<6>(b, blk, flag, st); break;
+        case 7: launch_invert_R<7>(b, blk, flag, st); break;
+        default: launch_invert_R<8>(b, blk, flag, st); break;
+    }
 }
 
 template <int R>

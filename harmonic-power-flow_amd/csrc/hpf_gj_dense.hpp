@@ -143,4 +143,63 @@ __device__ __forceinline__ void gj_dense_invert(double (&a)[R][R], int b, const 
     __syncthreads();
 }
 
+// The same inversion WITHOUT pivoting (static pivot order 0, 1, ..., b - 1): on return a = D^-1 in the threads' registers, no permutation.
+// Two barriers per step, no pivot search.  cb / rr: two LDS arrays of b doubles.  A zero (or NaN) pivot sets *zero_pivot = step + 1.
+template <int R>
+__device__ __forceinline__ void gj_dense_invert_npvt(double (&a)[R][R], int b, double* cb, double* rr, int* zero_pivot) {
+    const int tid = threadIdx.x, tr = tid >> 4, tc = tid & 15;
+    for (int j = 0; j < b; ++j) {
+        if (tc == (j & 15)) {
+#pragma unroll
+            for (int ai = 0; ai < R; ++ai) {
+                const int i = tr + 16 * ai;
+                if (i < b) {
+#pragma unroll
+                    for (int ci = 0; ci < R; ++ci)
+                        if (ci == (j >> 4)) cb[i] = a[ai][ci];
+                }
+            }
+        }
+        if (tr == (j & 15)) {
+#pragma unroll
+            for (int ai = 0; ai < R; ++ai)
+                if (ai == (j >> 4)) {
+#pragma unroll
+                    for (int ci = 0; ci < R; ++ci) {
+                        const int cc = tc + 16 * ci;
+                        if (cc < b) rr[cc] = a[ai][ci];
+                    }
+                }
+        }
+        __syncthreads();
+        const double piv = cb[j];
+        if (tid == 0 && zero_pivot && !(fabs(piv) > 0.0)) *zero_pivot = j + 1;
+        const double inv = 1.0 / piv;
+        double prow[R];
+#pragma unroll
+        for (int ci = 0; ci < R; ++ci) {
+            const int cc = tc + 16 * ci;
+            prow[ci] = cc < b ? (cc == j ? inv : rr[cc] * inv) : 0.0;
+        }
+#pragma unroll
+        for (int ai = 0; ai < R; ++ai) {
+            const int i = tr + 16 * ai;
+            if (i >= b) continue;
+            if (i == j) {
+#pragma unroll
+                for (int ci = 0; ci < R; ++ci) a[ai][ci] = prow[ci];
+            } else {
+                const double fct = cb[i];
+#pragma unroll
+                for (int ci = 0; ci < R; ++ci) {
+                    const int cc = tc + 16 * ci;
+                    if (cc >= b) continue;
+                    a[ai][ci] = (cc == j) ? -fct * inv : fma(-fct, prow[ci], a[ai][ci]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace hpf

@@ -180,7 +180,17 @@ struct hpf_handle {
     double *d_sel_X = nullptr;        // [nP][n_tb][b][b] (J_t^-1 E_T) restricted to P
     double *d_sel_tie = nullptr;      // [2 n_ties][Hn][4] the ties' coupling blocks of the current state
     void *d_sel_jobs = nullptr;       // BlkJob list: forward by height, back by depth
-    std::vector<size_t> sel_fwd_beg, sel_back_beg;
+    std::vector<size_t> sel_fwd_beg, sel_back_beg, sel_hl_ptr;
+    bool sel_back_only = true;        // second pass = corrected forward vectors on P + the back sweep alone (HPF_MESH_BACK2=0: a whole sweep)
+    bool tree_back_only = false;      // tree_newton_step skips its factor part (set around that second pass only)
+    int *d_sel_hl = nullptr, *d_sel_slot = nullptr, *d_sel_cptr = nullptr, *d_sel_clist = nullptr;   // P by height | endpoint number | children in P
+    double *d_sel_dw = nullptr;       // [nP][b] corrections of the forward vectors
+    double border_piv_limit = 1e3;    // ... amplification of a 4 x 4 pivot block's inverse beyond which that border system goes to the pivoted LU
+    bool border_gj_mfma = true;       // ... its diagonal blocks inverted on the matrix cores (k_blk_invert_mfma; HPF_BORDER_GJ_MFMA=0: VALU)
+    bool border_gj = false;           // border system by block Gauss-Jordan on the b x b grid (n_tb <= HPF_BORDER_GJ, default 96) instead of rocSOLVER's LU
+    double *d_bB = nullptr;           // [n_tb][n_tb + 1][b][b] the border system in block layout, right-hand side in block column n_tb
+    void *d_bgj_jobs = nullptr;       // its block-product jobs: per step the row scaling, then the elimination
+    std::vector<size_t> bgj_beg;
     int border_pivoting = 0;          // option "border_pivoting": 1 = every border system through the pivoted LU (A/B, tests)
     int border_repivots = 0;          // border systems that went through the pivoted LU after the residual check
     std::vector<int> host_act;        // the slot list as the host last saw it (the bordered step walks the running scenarios)

@@ -72,7 +72,9 @@ def test_every_environment_switch_of_the_library_is_documented_in_the_header():
 
 def test_sparse_solve_validates_and_classifies_the_pattern_on_the_host():
     """hpf_sparse_solve (update_harmonic_state_vec for the reference's CSR Jacobian): argument checks and the bus-graph analysis of the pattern run
-    on the host before any HIP call -- inconsistent CSR -> HPF_E_ARG, a bus graph that is not a tree from bus 0 -> HPF_E_TOPOLOGY."""
+    on the host before any HIP call -- inconsistent CSR -> HPF_E_ARG; a bus graph that is not connected from bus 0, or a block pattern that is not
+    symmetric -> HPF_E_TOPOLOGY; a ring (spanning tree + one loop-closing line) passes the analysis (round 5: bordered elimination) and ends at the first
+    HIP call where there is no GPU."""
     import ctypes as C
     import numpy as np
     import scipy.sparse as sp
@@ -99,7 +101,13 @@ def test_sparse_solve_validates_and_classifies_the_pattern_on_the_host():
             d = abs(bus_of(r) - bus_of(cc))
             if d in (0, 1, n - 1):
                 ring[r, cc] = 1.0
-    assert call(n, c, Hn, sp.csr_matrix(ring)) == -3
+    assert call(n, c, Hn, sp.csr_matrix(ring)) not in (-1, -3)
+    one_way = ring.copy()                                       # the blocks (3, 0) without the blocks (0, 3): not a symmetric block pattern
+    for r in range(N):
+        for cc in range(N):
+            if bus_of(r) == 3 and bus_of(cc) == 0:
+                one_way[r, cc] = 0.0
+    assert call(n, c, Hn, sp.csr_matrix(one_way)) == -3
     assert call(n, c, Hn, sp.identity(N, format="csr")) == -3   # no coupling at all: not connected from bus 0
     assert call(0, 1, 1, sp.identity(3, format="csr")) == -1
     assert call(n, n + 1, Hn, sp.identity(N, format="csr")) == -1
