@@ -487,6 +487,7 @@ def main():
                                 out["setup"]["create_warm_ms"])
     if world == 1 and bt and not args.no_single:
         out["reference_call_shapes"] = reference_call_shapes(hp, inp, args)
+        out["meshed"] = meshed_feeder(hp, args)
     out["cpu_baseline"] = cpu
     print(json.dumps(out), flush=True)
 
@@ -620,6 +621,41 @@ def reference_call_shapes(hp, inp, args):
             "note": "hp.hpf() of ONE scenario of this feeder end to end (admittance build, Norton import, pf, harmonic NR, post-processing, the CSR "
                     "Jacobian of the last iteration; second call: device handle from the cache) and x - J^-1 f for that CSR Jacobian through "
                     "hpf_sparse_solve (no N x N array; the reference's spsolve takes ~1 s here, its hpf() 1 050 s)"}
+
+
+def meshed_feeder(hp, args):
+    """The feeder with loop-closing lines (untimed leg, N = 1): ms per Newton iteration of ONE scenario through the bordered block-tree step
+    (factor-once form: one sweep + selected inversion over the tie endpoints' root paths + block Gauss-Jordan of the border system)."""
+    from harmonic_power_flow_amd import api, synth
+    out = {}
+    for k in (5, 20):
+        tmp = tempfile.mkdtemp(prefix="hpf_bench_mesh_")
+        fb, fl = synth.gen(args.buses, seed=0, outdir=tmp)
+        synth.add_ties(fl, args.buses, k)
+        st = hp.Settings(H_MAX=args.hmax)
+        buses, lines, m, n, c = hp.init_network(fb, fl, settings=st)
+        Y = hp.build_admittance_matrices(buses, lines, st.HARMONICS)
+        NE = hp.import_Norton_Equivalents(buses, True, st, INPUTS)
+        dm = api._device_model(buses, Y, NE, True, st.HARMONICS, solver="block_tree")
+        try:
+            dm.set_loads(buses["P"].to_numpy(float), buses["Q"].to_numpy(float))
+            dm.set_state(None, None, n_scen=1)
+            dm.fund_pf(1e-6, 30)
+            seed = dm.get_state()
+            dm.solve(1e-4, 3)                              # warm
+            dm.set_state(*seed)
+            t0 = time.perf_counter()
+            it, err, _ = dm.solve(1e-4, 50)
+            t = time.perf_counter() - t0
+            cs = dm.tree_census()
+            out["ties_%d" % k] = {"ms_per_iter": 1e3 * t / max(int(it[0]), 1), "n_iter_h": int(it[0]), "err_h": float(err[0]),
+                                  "border_unknowns": int(cs["border_unknowns"]), "root_path_buses": int(cs["root_path_buses"]),
+                                  "levels": int(cs["levels"]), "pivoted_border_systems": int(cs["border_repivots"])}
+        finally:
+            dm.close()
+    out["note"] = ("one scenario, reference stop rule; the virtual-sweep form of rounds 2 - 4 (HPF_MESH_SEL=0) takes 4.6 / 16.2 ms per iteration at 5 / 20 ties, "
+                   "DESIGN.md 3.5")
+    return out
 
 
 def single_scenario(hp, inp, args):

@@ -2052,7 +2052,7 @@ int hpf_tree_census(const hpf_handle* h, int* counts, int n_counts) {
     if (h->solver != HPF_SOLVER_BLOCK_TREE) return HPF_E_STATE;
     const Tree& T = active_tree(const_cast<hpf_handle*>(h));
     const int fused = tree_levels_fused(const_cast<hpf_handle*>(h)) ? 1 : 0;
-    for (int i = 0; i < n_counts; ++i) counts[i] = i < 8 ? T.census[i] : (i == 8 ? h->n_ties : (i == 9 ? fused : (i == 10 ? T.n_comp : (i == 11 ? h->border_repivots : 0))));
+    for (int i = 0; i < n_counts; ++i) counts[i] = i < 8 ? T.census[i] : (i == 8 ? h->n_ties : (i == 9 ? fused : (i == 10 ? T.n_comp : (i == 11 ? h->border_repivots : (i == 12 ? h->m_border : (i == 13 ? (h->mesh_sel ? h->sel_nP : 0) : (i == 14 ? (h->mesh_sel ? (h->border_gj ? 2 : 1) : 0) : 0)))))));
     return HPF_OK;
 }
 

@@ -297,10 +297,10 @@ class DeviceModel:
 
     def tree_census(self):
         """Which kernel takes which bus of the block tree (hpf_tree_census)."""
-        out = (C.c_int32 * 12)()
-        self._chk(self.lib.hpf_tree_census(self._h, out, 12), "hpf_tree_census")
+        out = (C.c_int32 * 15)()
+        self._chk(self.lib.hpf_tree_census(self._h, out, 15), "hpf_tree_census")
         names = ("dense_buses", "gauss_jordan", "const_leaves", "lazy_leaves", "bordered", "nested_bordered", "levels", "depths", "ties",
-                 "fused_levels", "compress_steps", "border_repivots")
+                 "fused_levels", "compress_steps", "border_repivots", "border_unknowns", "root_path_buses", "bordered_form")
         return dict(zip(names, (int(v) for v in out)))
 
     def solve_bytes(self):

@@ -50,3 +50,28 @@ def scenario_scale(n, s):
     """Per-bus load multiplier of Monte-Carlo scenario `s`:
     u ~ U[0.5, 1.5] i.i.d. per bus from `default_rng(1000 + s)`; P_i,Q_i <- P_i,Q_i * u_i."""
     return np.random.default_rng(1000 + s).uniform(0.5, 1.5, size=n)
+
+
+def add_ties(fl, n, k, seed=42):
+    """Append k loop-closing lines to a lines CSV written by `gen` (random bus pairs that are not yet connected, impedances from the feeder's palette):
+    the meshed variants of the synthetic feeders (the networks of the meshed oracle fixtures: same generator, same seed) -> list of (from, to)."""
+    rows = open(fl).read().splitlines()
+    have = set()
+    for r in rows[1:]:
+        c = r.split(";")
+        have.add((min(int(c[1]), int(c[2])), max(int(c[1]), int(c[2]))))
+    rng = np.random.default_rng(seed)
+    pal = [(0.5, 0.5), (1, 4), (0.5, 1)]
+    out = []
+    lid = len(rows)
+    while len(out) < k:
+        a, b = int(rng.integers(2, n + 1)), int(rng.integers(2, n + 1))
+        if a == b or (min(a, b), max(a, b)) in have:
+            continue
+        have.add((min(a, b), max(a, b)))
+        r, x = pal[int(rng.integers(0, len(pal)))]
+        rows.append("%d;%d;%d;%.10g;%.10g;0;0" % (lid, a, b, r * 20.0 / n, x * 20.0 / n))
+        lid += 1
+        out.append((a, b))
+    open(fl, "w").write("\n".join(rows) + "\n")
+    return out

@@ -302,7 +302,10 @@ int  hpf_kernel_model(const hpf_handle* h, int which, double* bytes, double* flo
  * level is ONE launch (k_level: scenario-batched and per-scenario workgroups in one grid; timing class 5 then covers it) -- blocks of 52
  * in the default mode; smaller blocks only when every level has scenario-batched workgroups (levels without them run k_factor_q's own grid),
  * [10] compress steps (Gauss-Jordan buses eliminated before their tallest dense child: levels counts the shortened chain),
- * [11] border systems of a meshed network that were repeated with the pivoted LU since hpf_create (option "border_pivoting").
+ * [11] border systems of a meshed network that were repeated with the pivoted LU since hpf_create (option "border_pivoting"),
+ * [12] border unknowns of a meshed network (2 Hn x distinct endpoint buses of the loop-closing lines), [13] buses on the endpoints' root paths
+ * (kept as plain Gauss-Jordan buses by the factor-once bordered step; 0: virtual-sweep form), [14] form of the bordered step: 0 virtual sweeps,
+ * 1 factor-once with rocSOLVER's LU of the border system, 2 factor-once with the block Gauss-Jordan solve.
  * HPF_E_STATE for DENSE. */
 int  hpf_tree_census(const hpf_handle* h, int* counts, int n_counts);
 /* Wall-clock milliseconds hpf_create spent: ms[0] total, [1] planning the elimination trees on the host (classification of the buses,

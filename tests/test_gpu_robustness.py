@@ -387,6 +387,10 @@ def test_meshed_feeder_bordered_block_tree_vs_dense(n, hmax, k, tmp_path):
             dm.set_state(None, None, n_scen=1)
             nf, _, _ = dm.fund_pf(1e-6, 30)
             v0 = dm.get_state()
+            if solver != "dense":
+                cs = dm.tree_census()                       # factor-once with the block Gauss-Jordan border solve | virtual sweeps
+                assert cs["ties"] == k and cs["bordered_form"] == (2 if solver == "block_tree" else 0) and cs["border_unknowns"] % (2 * len(st.HARMONICS)) == 0
+                assert (cs["root_path_buses"] > 0) == (solver == "block_tree")
             if "dense" in out:
                 np.testing.assert_allclose(v0[0], out["dense"][0][0], rtol=0, atol=1e-12)
                 np.testing.assert_allclose(v0[1], out["dense"][0][1], rtol=0, atol=1e-12)

@@ -1,13 +1,13 @@
+#!/usr/bin/env python3
+"""Mismatch histories of the two forms of the bordered step on the headline feeder + k ties:  python tools/mesh_hist.py k   (GPU)"""
 import os, sys, tempfile
 os.environ.setdefault("HPF_ENV_SWITCHES", "1")
 sys.path.insert(0, os.getcwd())
-import importlib.util
 import numpy as np
 import harmonic_power_flow_amd as hp
 from harmonic_power_flow_amd import api, synth
-spec = importlib.util.spec_from_file_location("mgb", "oracle/make_golden_bench.py"); mgb = importlib.util.module_from_spec(spec); spec.loader.exec_module(mgb)
 k = int(sys.argv[1])
-tmp = tempfile.mkdtemp(); fb, fl = synth.gen(1000, seed=0, outdir=tmp); mgb.add_ties(fl, 1000, k)
+tmp = tempfile.mkdtemp(); fb, fl = synth.gen(1000, seed=0, outdir=tmp); synth.add_ties(fl, 1000, k)
 st = hp.Settings(H_MAX=51); buses, lines, m, n, c = hp.init_network(fb, fl, settings=st)
 Y = hp.build_admittance_matrices(buses, lines, st.HARMONICS); NE = hp.import_Norton_Equivalents(buses, True, st, "tests/golden/inputs")
 res = {}

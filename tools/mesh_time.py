@@ -1,6 +1,5 @@
 #!/usr/bin/env python3
 """Time per Newton iteration of the bordered block-tree step on the headline feeder with k loop-closing lines:  python tools/mesh_time.py [k ...]  (GPU)"""
-import importlib.util
 import os
 os.environ.setdefault("HPF_ENV_SWITCHES", "1")      # A/B tooling: HPF_* switches of the environment reach hpf_create (include/hpf.h)
 import sys
@@ -13,27 +12,10 @@ import harmonic_power_flow_amd as hp              # noqa: E402
 from harmonic_power_flow_amd import api, synth    # noqa: E402
 
 INPUTS = os.path.join(REPO, "tests", "golden", "inputs")
-spec = importlib.util.spec_from_file_location("mgb", os.path.join(REPO, "oracle", "make_golden_bench.py"))
 for k in [int(a) for a in sys.argv[1:]] or [5, 20]:
     tmp = tempfile.mkdtemp()
     fb, fl = synth.gen(1000, seed=0, outdir=tmp)
-    rows = open(fl).read().splitlines()
-    # (the tie generator of the fixtures, restated here so that the tool does not import test infrastructure)
-    import numpy as np
-    have = {(min(int(c.split(";")[1]), int(c.split(";")[2])), max(int(c.split(";")[1]), int(c.split(";")[2]))) for c in rows[1:]}
-    rng = np.random.default_rng(42)
-    pal = [(0.5, 0.5), (1, 4), (0.5, 1)]
-    lid, out = len(rows), []
-    while len(out) < k:
-        a, b = int(rng.integers(2, 1001)), int(rng.integers(2, 1001))
-        if a == b or (min(a, b), max(a, b)) in have:
-            continue
-        have.add((min(a, b), max(a, b)))
-        r, x = pal[int(rng.integers(0, len(pal)))]
-        rows.append("%d;%d;%d;%.10g;%.10g;0;0" % (lid, a, b, r * 20.0 / 1000, x * 20.0 / 1000))
-        lid += 1
-        out.append((a, b))
-    open(fl, "w").write("\n".join(rows) + "\n")
+    synth.add_ties(fl, 1000, k)
     st = hp.Settings(H_MAX=51)
     buses, lines, m, n, c = hp.init_network(fb, fl, settings=st)
     Y = hp.build_admittance_matrices(buses, lines, st.HARMONICS)
