@@ -14,7 +14,7 @@ namespace {
 #define HPF_BI_WAVE_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
 template <int B>
-__global__ __launch_bounds__(64 * ((B + 16) / 16)) void k_blk_invert_mfma(int b, double* __restrict__ blk, double limit, int* __restrict__ flag) {
+__global__ __launch_bounds__(64 * ((B + 16) / 16)) void k_blk_invert_mfma(int b, double* __restrict__ blk, long long stride, double limit, int* __restrict__ flag) {
     constexpr int NT = (B + 16) / 16;
     constexpr int NB16 = B / 16, WS = 17, NBUF = NB16 > 1 ? 2 : 1;
     __shared__ double img_s[(NB16 > 0 ? NBUF : 1) * NT * 16 * WS];
@@ -24,6 +24,8 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16)) void k_blk_invert_mfma(int b,
     const int tid = threadIdx.x, lane = tid & 63, lg = lane >> 4, jj = lane & 15;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = 16 * wv + jj;
+    blk += (long long)blockIdx.x * stride;               // one block per workgroup: a batch of systems (scenarios) per launch
+    flag += blockIdx.x;
     d4_t ct[NT];
 #pragma unroll
     for (int tr = 0; tr < NT; ++tr)
@@ -145,12 +147,12 @@ __global__ __launch_bounds__(64 * ((B + 16) / 16)) void k_blk_invert_mfma(int b,
         }
 }
 
-inline bool launch_invert_mfma(int BW, int b, double* blk, double limit, int* flag, hipStream_t st) {
+inline bool launch_invert_mfma(int BW, int b, double* blk, long long stride, int ny, double limit, int* flag, hipStream_t st) {
     switch (BW) {
-        case 12: hipLaunchKernelGGL((k_blk_invert_mfma<12>), dim3(1), dim3(64), 0, st, b, blk, limit, flag); return true;
-        case 28: hipLaunchKernelGGL((k_blk_invert_mfma<28>), dim3(1), dim3(128), 0, st, b, blk, limit, flag); return true;
-        case 52: hipLaunchKernelGGL((k_blk_invert_mfma<52>), dim3(1), dim3(256), 0, st, b, blk, limit, flag); return true;
-        case 100: hipLaunchKernelGGL((k_blk_invert_mfma<100>), dim3(1), dim3(448), 0, st, b, blk, limit, flag); return true;
+        case 12: hipLaunchKernelGGL((k_blk_invert_mfma<12>), dim3((unsigned)ny), dim3(64), 0, st, b, blk, stride, limit, flag); return true;
+        case 28: hipLaunchKernelGGL((k_blk_invert_mfma<28>), dim3((unsigned)ny), dim3(128), 0, st, b, blk, stride, limit, flag); return true;
+        case 52: hipLaunchKernelGGL((k_blk_invert_mfma<52>), dim3((unsigned)ny), dim3(256), 0, st, b, blk, stride, limit, flag); return true;
+        case 100: hipLaunchKernelGGL((k_blk_invert_mfma<100>), dim3((unsigned)ny), dim3(448), 0, st, b, blk, stride, limit, flag); return true;
         default: return false;
     }
 }

@@ -11,10 +11,12 @@ namespace {                  // (kernels with internal linkage: every translatio
 
 // One b x b block product per workgroup:  C = add + alpha A B  (A == nullptr: C = add + alpha B; add == nullptr: zero).  Thread (tr, tc) owns the
 // R x R sub-grid {tr + 16 a} x {tc + 16 c} like the factor kernel; the operands come from L2 (every block is read by many jobs of a launch).
+// A launch may carry a second grid dimension y (scenarios of a batch): every operand then moves by its own stride (in doubles) per y.
 struct BlkJob {
     const double *A, *B, *add;
     double* C;
     double alpha;
+    long long sA, sB, sAdd, sC;
 };
 // K-chunk of the LDS staging: 2 b kc doubles within 64 KB (no launch attribute), a multiple of 4
 inline int blk_jobs_kc(int b) {
@@ -27,7 +29,14 @@ inline size_t blk_jobs_lds(int b) { return sizeof(double) * ((size_t)b * (blk_jo
 template <int R>
 __global__ __launch_bounds__(256) void k_blk_jobs(int b, int kc, const BlkJob* __restrict__ jobs) {
     extern __shared__ double blk_lds[];
-    const BlkJob jb = jobs[blockIdx.x];
+    BlkJob jb = jobs[blockIdx.x];
+    {
+        const long long y = blockIdx.y;
+        if (jb.A) jb.A += y * jb.sA;
+        jb.B += y * jb.sB;
+        if (jb.add) jb.add += y * jb.sAdd;
+        jb.C += y * jb.sC;
+    }
     const int tid = threadIdx.x, tr = tid >> 4, tc = tid & 15;
     double o[R][R];
 #pragma unroll
@@ -127,9 +136,11 @@ __global__ __launch_bounds__(256) void k_blk_jobs(int b, int kc, const BlkJob* _
 
 // one block inverted in place, no pivoting (gj_dense_invert_npvt); *flag <- nonzero when a pivot is zero
 template <int R>
-__global__ __launch_bounds__(256) void k_blk_invert(int b, double* __restrict__ blk, int* __restrict__ flag) {
+__global__ __launch_bounds__(256) void k_blk_invert(int b, double* __restrict__ blk, long long stride, int* __restrict__ flag) {
     __shared__ double cb[128], rr[128];
     __shared__ int zp;
+    blk += (long long)blockIdx.x * stride;
+    flag += blockIdx.x;
     const int tid = threadIdx.x, tr = tid >> 4, tc = tid & 15;
     if (tid == 0) zp = 0;
     double a[R][R];
@@ -152,36 +163,36 @@ __global__ __launch_bounds__(256) void k_blk_invert(int b, double* __restrict__ 
     if (tid == 0 && zp) atomicMax(flag, zp);
 }
 template <int R>
-inline void launch_invert_R(int b, double* blk, int* flag, hipStream_t st) {
-    hipLaunchKernelGGL((k_blk_invert<R>), dim3(1), dim3(256), 0, st, b, blk, flag);
+inline void launch_invert_R(int b, double* blk, long long stride, int ny, int* flag, hipStream_t st) {
+    hipLaunchKernelGGL((k_blk_invert<R>), dim3((unsigned)ny), dim3(256), 0, st, b, blk, stride, flag);
 }
-inline void launch_invert(int R, int b, double* blk, int* flag, hipStream_t st) {
+inline void launch_invert(int R, int b, double* blk, long long stride, int ny, int* flag, hipStream_t st) {
     switch (R) {
-        case 1: launch_invert_R<1>(b, blk, flag, st); break;
-        case 2: launch_invert_R<2>(b, blk, flag, st); break;
-        case 3: launch_invert_R<3>(b, blk, flag, st); break;
-        case 4: launch_invert_R<4>(b, blk, flag, st); break;
-        case 5: launch_invert_R<5>(b, blk, flag, st); break;
-        case 6: launch_invert_R<6>(b, blk, flag, st); break;
-        case 7: launch_invert_R<7>(b, blk, flag, st); break;
-        default: launch_invert_R<8>(b, blk, flag, st); break;
+        case 1: launch_invert_R<1>(b, blk, stride, ny, flag, st); break;
+        case 2: launch_invert_R<2>(b, blk, stride, ny, flag, st); break;
+        case 3: launch_invert_R<3>(b, blk, stride, ny, flag, st); break;
+        case 4: launch_invert_R<4>(b, blk, stride, ny, flag, st); break;
+        case 5: launch_invert_R<5>(b, blk, stride, ny, flag, st); break;
+        case 6: launch_invert_R<6>(b, blk, stride, ny, flag, st); break;
+        case 7: launch_invert_R<7>(b, blk, stride, ny, flag, st); break;
+        default: launch_invert_R<8>(b, blk, stride, ny, flag, st); break;
     }
 }
 
 template <int R>
-inline void launch_jobs_R(int b, int count, const BlkJob* jobs, hipStream_t st) {
-    if (count > 0) hipLaunchKernelGGL((k_blk_jobs<R>), dim3((unsigned)count), dim3(256), blk_jobs_lds(b), st, b, blk_jobs_kc(b), jobs);
+inline void launch_jobs_R(int b, int count, const BlkJob* jobs, hipStream_t st, int ny) {
+    if (count > 0 && ny > 0) hipLaunchKernelGGL((k_blk_jobs<R>), dim3((unsigned)count, (unsigned)ny), dim3(256), blk_jobs_lds(b), st, b, blk_jobs_kc(b), jobs);
 }
-inline void launch_jobs(int R, int b, int count, const BlkJob* jobs, hipStream_t st) {
+inline void launch_jobs(int R, int b, int count, const BlkJob* jobs, hipStream_t st, int ny = 1) {
     switch (R) {
-        case 1: launch_jobs_R<1>(b, count, jobs, st); break;
-        case 2: launch_jobs_R<2>(b, count, jobs, st); break;
-        case 3: launch_jobs_R<3>(b, count, jobs, st); break;
-        case 4: launch_jobs_R<4>(b, count, jobs, st); break;
-        case 5: launch_jobs_R<5>(b, count, jobs, st); break;
-        case 6: launch_jobs_R<6>(b, count, jobs, st); break;
-        case 7: launch_jobs_R<7>(b, count, jobs, st); break;
-        default: launch_jobs_R<8>(b, count, jobs, st); break;
+        case 1: launch_jobs_R<1>(b, count, jobs, st, ny); break;
+        case 2: launch_jobs_R<2>(b, count, jobs, st, ny); break;
+        case 3: launch_jobs_R<3>(b, count, jobs, st, ny); break;
+        case 4: launch_jobs_R<4>(b, count, jobs, st, ny); break;
+        case 5: launch_jobs_R<5>(b, count, jobs, st, ny); break;
+        case 6: launch_jobs_R<6>(b, count, jobs, st, ny); break;
+        case 7: launch_jobs_R<7>(b, count, jobs, st, ny); break;
+        default: launch_jobs_R<8>(b, count, jobs, st, ny); break;
     }
 }
 

@@ -1060,7 +1060,8 @@ void tree_free(hpf_handle* h) {
     tree_free_one(h->ctree);
     void* bp[] = {h->d_tb_bus, h->d_tb_ptr, h->d_tb_adj, h->d_bM, h->d_brhs, h->d_bipiv, h->d_binfo, h->d_bM0, h->d_brhs0,
                   h->d_sel_P, h->d_sel_pidx, h->d_sel_toff, h->d_sel_S, h->d_sel_Z, h->d_sel_Up, h->d_sel_W, h->d_sel_X, h->d_sel_tie, h->d_sel_jobs,
-                  h->d_sel_hl, h->d_sel_slot, h->d_sel_cptr, h->d_sel_clist, h->d_sel_dw, h->d_bB, h->d_bgj_jobs};
+                  h->d_sel_hl, h->d_sel_slot, h->d_sel_cptr, h->d_sel_clist, h->d_sel_dw, h->d_bB, h->d_bgj_jobs,
+                  h->d_sel_bM, h->d_sel_rhs, h->d_sel_g, h->d_sel_res, h->d_sel_info};
     for (void* q2 : bp)
         if (q2) hipFree(q2);
 }
@@ -1457,8 +1458,6 @@ int tree_find_ties(hpf_handle* h, const hpf_desc* d) {
                 }
             const double bytes = 8.0 * (double)nP * (double)h->n_tb * 4.0 * d->Hn * d->Hn;
             if (bytes <= 16.0 * 1073741824.0) {
-                const char* bo = h->sw("HPF_MESH_BACK2");
-                h->sel_back_only = !(bo && atoi(bo) == 0);     // HPF_MESH_BACK2=0: the second pass re-runs the whole sweep (A/B)
                 h->mesh_sel = true;
                 h->sel_forced = std::move(fp);
             }
@@ -1490,7 +1489,7 @@ int ensure_blas(hpf_handle* h) {
 // virtual scenario slots of the bordered step: all 1 + m right-hand sides at once up to 256, above that chunks of up to 1 024 (a chunk
 // runs in the throughput regime of the tree kernels: 6.5 us per scenario-step at 256 live slots, 5.5 at 1 024; 72 MB of state per slot)
 int border_slots(const hpf_handle* h) {
-    if (h->mesh_sel) return 1;                           // factor-once form: one virtual slot (the sweeps of y and of the second pass)
+    if (h->mesh_sel) return 0;                           // factor-once form: the scenarios are swept in their own slots
     const int c = h->border_slot_cap < 16 ? 16 : h->border_slot_cap;   // (HPF_BORDER_SLOTS, read by hpf_create into the handle)
     return h->m_border + 1 < 256 ? h->m_border + 1 : (h->m_border + 1 < c ? ((h->m_border + 1 + 15) / 16) * 16 : c);
 }
@@ -1518,16 +1517,23 @@ __global__ __launch_bounds__(1024) void k_border_absmax(int m, const double* __r
 }
 
 // ---- factor-once bordered step: selected inversion over the endpoints' root paths ----------------------------------------------------------
-// (the algebra of hpf_csr_solve.hip's meshed branch, with the blocks read from the sweep of virtual slot v: S_k^-1 from the inverse slot of the
-//  plain Gauss-Jordan bus k (tile image -> dense, row-major), A(k, parent) / A(parent, k) harmonic-diagonal 2x2 blocks of the slot's state)
-// one workgroup per bus q of P:  S[q] = S_k^-1,  Z[q] = S_k^-1 A(k, p),  Up[q] = S_p^-1 A(p, k)
-__global__ __launch_bounds__(256) void k_sel_prepare(Model M, int b, size_t CT, int v, const int* __restrict__ P, const int* __restrict__ toff,
-                                                     const cplx* __restrict__ Uall, const cplx* __restrict__ Eall, const double* __restrict__ Zall,
-                                                     double* __restrict__ Sd, double* __restrict__ Zd, double* __restrict__ Up) {
+// (the algebra of hpf_csr_solve.hip's meshed branch, with the blocks read from the sweep of the scenarios' own slots: S_k^-1 from the inverse slot of
+//  the plain Gauss-Jordan bus k (tile image -> dense, row-major), A(k, parent) / A(parent, k) harmonic-diagonal 2x2 blocks of the scenario's state)
+// Every kernel below works on a BATCH of scenarios: grid dimension y (z) = position in the batch = index of the scenario's buffers; the scenario
+// itself is the one in slot s0 + y of the (active) slot list, -1 = frozen / empty: nothing to do.
+__device__ __forceinline__ int sel_scenario(const int* __restrict__ active, int s0, int y) { return active ? active[s0 + y] : s0 + y; }
+
+// one workgroup per bus q of P and scenario:  S[q] = S_k^-1,  Z[q] = S_k^-1 A(k, p),  Up[q] = S_p^-1 A(p, k)
+__global__ __launch_bounds__(256) void k_sel_prepare(Model M, int b, size_t CT, const int* __restrict__ active, int s0, int nP, const int* __restrict__ P,
+                                                     const int* __restrict__ toff, const cplx* __restrict__ Uall, const cplx* __restrict__ Eall,
+                                                     const double* __restrict__ Zall, double* __restrict__ Sd, double* __restrict__ Zd,
+                                                     double* __restrict__ Up) {
     __shared__ double hg[2][64 * 4];                     // [0]: A(k, p), [1]: A(p, k), per harmonic 2x2 row-major (Hn <= 64)
+    const int v = sel_scenario(active, s0, blockIdx.y);
+    if (v < 0) return;
     const int q = blockIdx.x, k = P[4 * q], par = P[4 * q + 1];
     const int Hn = M.Hn, n = M.n;
-    const size_t so = (size_t)v * n * Hn, bb = (size_t)b * b;
+    const size_t so = (size_t)v * n * Hn, bb = (size_t)b * b, yo = (size_t)blockIdx.y * nP * bb;
     const int pbus = par >= 0 ? P[4 * par] : -1;
     if ((int)threadIdx.x < 2 * Hn && pbus >= 0) {
         const int w = threadIdx.x / Hn, hq = threadIdx.x - w * Hn;
@@ -1544,23 +1550,24 @@ __global__ __launch_bounds__(256) void k_sel_prepare(Model M, int b, size_t CT, 
     const double* Zp = pbus >= 0 ? Zall + ((size_t)v * n + pbus) * CT : nullptr;
     for (int idx = threadIdx.x; idx < b * b; idx += 256) {
         const int i = idx / b, cc = idx - i * b, hq = cc >> 1, t2 = cc & 1;
-        Sd[q * bb + idx] = Zk[toff[idx]];
+        Sd[yo + q * bb + idx] = Zk[toff[idx]];
         double z = 0.0, u = 0.0;
         if (pbus >= 0) {
             const int o0 = toff[i * b + 2 * hq], o1 = toff[i * b + 2 * hq + 1];
             z = fma(Zk[o1], hg[0][hq * 4 + 2 + t2], Zk[o0] * hg[0][hq * 4 + t2]);
             u = fma(Zp[o1], hg[1][hq * 4 + 2 + t2], Zp[o0] * hg[1][hq * 4 + t2]);
         }
-        Zd[q * bb + idx] = z;
-        Up[q * bb + idx] = u;
+        Zd[yo + q * bb + idx] = z;
+        Up[yo + q * bb + idx] = u;
     }
 }
 
-// coupling blocks of the ties at the state of slot v: tie[(e * Hn + q) * 4 + .] = A(i, j) at harmonic position q, e the directed tie (tb_adj order)
-__global__ void k_sel_ties(Model M, int v, int n_dir, const int* __restrict__ tb_bus, const int* __restrict__ tb_ptr, const int* __restrict__ tb_adj,
-                           int n_tb, const cplx* __restrict__ Uall, const cplx* __restrict__ Eall, double* __restrict__ tie) {
+// coupling blocks of the ties at the scenario's state: tie[(e * Hn + q) * 4 + .] = A(i, j) at harmonic position q, e the directed tie (tb_adj order)
+__global__ void k_sel_ties(Model M, const int* __restrict__ active, int s0, int n_dir, const int* __restrict__ tb_bus, const int* __restrict__ tb_ptr,
+                           const int* __restrict__ tb_adj, int n_tb, const cplx* __restrict__ Uall, const cplx* __restrict__ Eall, double* __restrict__ tie) {
+    const int v = sel_scenario(active, s0, blockIdx.y);
     const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= n_dir * M.Hn) return;
+    if (v < 0 || t >= n_dir * M.Hn) return;
     const int e = t / M.Hn, q = t - e * M.Hn;
     int a = 0;
     while (a + 1 < n_tb && tb_ptr[a + 1] <= e) ++a;
@@ -1568,73 +1575,138 @@ __global__ void k_sel_ties(Model M, int v, int n_dir, const int* __restrict__ tb
     double g4[4];
     coupling_block(M, Uall + so, Eall + so, q, tb_bus[a], tb_adj[3 * e], tb_adj[3 * e + 1], g4);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) tie[(size_t)t * 4 + u] = g4[u];
+    for (int u = 0; u < 4; ++u) tie[((size_t)blockIdx.y * n_dir * M.Hn + t) * 4 + u] = g4[u];
 }
 
-// border matrix I + Q^T Z (column-major m x m) from the blocks X[j, t] of the selected inversion: thread = (row (a, l), column (t, cc))
-__global__ __launch_bounds__(256) void k_border_build_sel(int b, int Hn, int m, int n_tb, const int* __restrict__ tb_ptr, const int* __restrict__ tb_adj,
-                                                          const int* __restrict__ pidx, const double* __restrict__ tie, const double* __restrict__ X,
-                                                          double* __restrict__ bM, double* __restrict__ bB) {
+// right-hand side Q^T y of the border system from the scenario's first sweep (x = y in the bus-image layout, stride Bst)
+__global__ void k_border_rhs_sel(int b, int Hn, int m, int n, int Bst, int n_dir, const int* __restrict__ active, int s0, const int* __restrict__ tb_ptr,
+                                 const int* __restrict__ tb_adj, const double* __restrict__ tie, const double* __restrict__ xall, double* __restrict__ brhs) {
+    const int v = sel_scenario(active, s0, blockIdx.y);
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (v < 0 || row >= m) return;
+    const int a = row / b, l = row - a * b, q = l >> 1, t = l & 1;
+    const double* x = xall + (size_t)v * n * Bst;
+    double acc = 0.0;
+    for (int e = tb_ptr[a]; e < tb_ptr[a + 1]; ++e) {
+        const double* g4 = tie + (((size_t)blockIdx.y * n_dir + e) * Hn + q) * 4;
+        const int j = tb_adj[3 * e];
+        acc = fma(g4[t * 2], x[(size_t)j * Bst + 2 * q], acc);
+        acc = fma(g4[t * 2 + 1], x[(size_t)j * Bst + 2 * q + 1], acc);
+    }
+    brhs[(size_t)blockIdx.y * m + row] = acc;
+}
+
+// border matrix I + Q^T Z (column-major m x m) from the blocks X[j, t] of the selected inversion: thread = (row (a, l), column (t, cc)), z = batch
+__global__ __launch_bounds__(256) void k_border_build_sel(int b, int Hn, int m, int n_tb, int nP, int n_dir, const int* __restrict__ active, int s0,
+                                                          const int* __restrict__ tb_ptr, const int* __restrict__ tb_adj, const int* __restrict__ pidx,
+                                                          const double* __restrict__ tie, const double* __restrict__ X, double* __restrict__ bM,
+                                                          double* __restrict__ bB) {
+    const int y = blockIdx.z;
+    if (sel_scenario(active, s0, y) < 0) return;
     const int row = blockIdx.x * 256 + threadIdx.x, col = blockIdx.y;
     if (row >= m) return;
     const int a = row / b, l = row - a * b, q = l >> 1, t = l & 1;
     const int tcol = col / b, cc = col - tcol * b;
     const size_t bb = (size_t)b * b;
+    const double* Xy = X + (size_t)y * nP * n_tb * bb;
     double acc = row == col ? 1.0 : 0.0;
     for (int e = tb_ptr[a]; e < tb_ptr[a + 1]; ++e) {
-        const double* g4 = tie + ((size_t)e * Hn + q) * 4;
-        const double* Xj = X + ((size_t)pidx[tb_adj[3 * e]] * n_tb + tcol) * bb;
+        const double* g4 = tie + (((size_t)y * n_dir + e) * Hn + q) * 4;
+        const double* Xj = Xy + ((size_t)pidx[tb_adj[3 * e]] * n_tb + tcol) * bb;
         acc = fma(g4[t * 2], Xj[(size_t)(2 * q) * b + cc], acc);
         acc = fma(g4[t * 2 + 1], Xj[(size_t)(2 * q + 1) * b + cc], acc);
     }
-    bM[(size_t)col * m + row] = acc;
-    if (bB) bB[((size_t)a * (n_tb + 1) + tcol) * bb + (size_t)l * b + cc] = acc;      // block layout of the block Gauss-Jordan solve (border_block_gj)
+    bM[(size_t)y * m * m + (size_t)col * m + row] = acc;
+    if (bB) bB[(size_t)y * n_tb * (n_tb + 1) * bb + ((size_t)a * (n_tb + 1) + tcol) * bb + (size_t)l * b + cc] = acc;      // block layout (border_block_gj)
 }
 
-// right-hand side -> block column n_tb of the block layout (first column of each block, the rest zero) | solution back into the vector
+// right-hand side -> block column n_tb of the block layout (first column of each block, the rest zero) | solution back into a vector
 __global__ void k_border_rhs_blocks(int b, int n_tb, const double* __restrict__ rhs, double* __restrict__ bB) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= n_tb * b * b) return;
     const int s = t / (b * b), e = t - s * b * b, l = e / b, cc = e - l * b;
-    bB[((size_t)s * (n_tb + 1) + n_tb) * b * b + e] = cc == 0 ? rhs[(size_t)s * b + l] : 0.0;
+    bB[(size_t)blockIdx.y * n_tb * (n_tb + 1) * b * b + ((size_t)s * (n_tb + 1) + n_tb) * b * b + e] =
+        cc == 0 ? rhs[(size_t)blockIdx.y * n_tb * b + (size_t)s * b + l] : 0.0;
 }
 __global__ void k_border_g_blocks(int b, int n_tb, const double* __restrict__ bB, double* __restrict__ g) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= n_tb * b) return;
     const int s = t / b, l = t - s * b;
-    g[t] = bB[((size_t)s * (n_tb + 1) + n_tb) * b * b + (size_t)l * b];
+    g[(size_t)blockIdx.y * n_tb * b + t] = bB[(size_t)blockIdx.y * n_tb * (n_tb + 1) * b * b + ((size_t)s * (n_tb + 1) + n_tb) * b * b + (size_t)l * b];
+}
+
+// residual check of a border solve against the untouched column-major copy: res[2 y] = max |rhs - M g|, res[2 y + 1] = max |rhs| (as bit patterns of
+// non-negative doubles: atomicMax on 64-bit integers orders them; a NaN anywhere raises the first word to +inf)
+__global__ __launch_bounds__(256) void k_border_check(int m, const double* __restrict__ bM, const double* __restrict__ rhs, const double* __restrict__ g,
+                                                      unsigned long long* __restrict__ res) {
+    // 16 rows x 16 column parts per workgroup: thread (r, part) sums every 16th column of its row
+    __shared__ double part_s[16][17];
+    const int y = blockIdx.y, r = threadIdx.x & 15, part = threadIdx.x >> 4, row = blockIdx.x * 16 + r;
+    double acc = 0.0;
+    if (row < m) {
+        const double* Mr = bM + (size_t)y * m * m + row;
+        const double* gy = g + (size_t)y * m;
+        for (int c2 = part; c2 < m; c2 += 16) acc = fma(Mr[(size_t)c2 * m], gy[c2], acc);
+    }
+    part_s[part][r] = acc;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        double rr = 0.0, a = 0.0;
+        if (row < m) {
+            double sum = 0.0;
+#pragma unroll
+            for (int p2 = 0; p2 < 16; ++p2) sum += part_s[p2][r];
+            const double f0 = rhs[(size_t)y * m + row];
+            rr = fabs(f0 - sum);
+            a = fabs(f0);
+            if (!(rr == rr) || !(a == a)) rr = INFINITY;
+        }
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {
+            rr = fmax(rr, __shfl_xor(rr, off, 64));
+            a = fmax(a, __shfl_xor(a, off, 64));
+        }
+        if (threadIdx.x == 0) {
+            atomicMax(res + 2 * y, (unsigned long long)__double_as_longlong(rr));
+            atomicMax(res + 2 * y + 1, (unsigned long long)__double_as_longlong(a));
+        }
+    }
 }
 
 // Second pass of the factor-once form.  x = J_t^-1 (f - E_T g) differs from y = J_t^-1 f only through the forward vectors of the buses of P (the
 // subtrees off P hold no endpoint bus: their forward vectors stay): dw_k = S_k^-1 dy_k - sum over the children c of k in P of Up_c dw_c,
-// dy = -g at the endpoint buses.  One workgroup per bus of P and height level; the forward vector of the bus in slot v (stride Bst) is corrected
-// in place -- the back sweep alone then gives x.
-__global__ __launch_bounds__(256) void k_sel_dw(int b, int Bst, int n, int v, const int* __restrict__ nodes, const int* __restrict__ P,
-                                                const int* __restrict__ slot, const int* __restrict__ cptr, const int* __restrict__ clist,
-                                                const double* __restrict__ Sd, const double* __restrict__ Up, const double* __restrict__ g,
-                                                double* __restrict__ dw, double* __restrict__ wall) {
+// dy = -g at the endpoint buses.  One workgroup per bus of P, height level and scenario; the forward vector of the bus in the scenario's slot
+// (stride Bst) is corrected in place -- the back sweep alone then gives x.
+__global__ __launch_bounds__(256) void k_sel_dw(int b, int Bst, int n, int nP, int m, const int* __restrict__ active, int s0, const int* __restrict__ nodes,
+                                                const int* __restrict__ P, const int* __restrict__ slot, const int* __restrict__ cptr,
+                                                const int* __restrict__ clist, const double* __restrict__ Sd, const double* __restrict__ Up,
+                                                const double* __restrict__ g, double* __restrict__ dw, double* __restrict__ wall) {
+    const int v = sel_scenario(active, s0, blockIdx.y);
+    if (v < 0) return;
     const int q = nodes[blockIdx.x], k = P[4 * q];
     const int part = threadIdx.x & 3;                    // four threads per row, every fourth column each
-    const size_t bb = (size_t)b * b;
+    const size_t bb = (size_t)b * b, yo = (size_t)blockIdx.y * nP * bb;
+    const double* gy = g + (size_t)blockIdx.y * m;
+    double* dwy = dw + (size_t)blockIdx.y * nP * b;
     const int sl = slot[q];
     for (int i = threadIdx.x >> 2; i < ((b + 63) & ~63); i += 64) {
         double acc = 0.0;
         if (i < b) {
             if (sl >= 0) {
-                const double* Sr = Sd + (size_t)q * bb + (size_t)i * b;
-                for (int j = part; j < b; j += 4) acc = fma(-Sr[j], g[(size_t)sl * b + j], acc);
+                const double* Sr = Sd + yo + (size_t)q * bb + (size_t)i * b;
+                for (int j = part; j < b; j += 4) acc = fma(-Sr[j], gy[(size_t)sl * b + j], acc);
             }
             for (int cp = cptr[q]; cp < cptr[q + 1]; ++cp) {
                 const int c = clist[cp];
-                const double* Ur = Up + (size_t)c * bb + (size_t)i * b;
-                const double* dc = dw + (size_t)c * b;
+                const double* Ur = Up + yo + (size_t)c * bb + (size_t)i * b;
+                const double* dc = dwy + (size_t)c * b;
                 for (int j = part; j < b; j += 4) acc = fma(-Ur[j], dc[j], acc);
             }
         }
         acc += __shfl_xor(acc, 1, 64);
         acc += __shfl_xor(acc, 2, 64);
         if (part == 0 && i < b) {
-            dw[(size_t)q * b + i] = acc;
+            dwy[(size_t)q * b + i] = acc;
             wall[((size_t)v * n + k) * Bst + i] += acc;
         }
     }
@@ -1733,15 +1805,37 @@ int tree_sel_build(hpf_handle* h, const hpf_desc* d) {
         if ((r2 = upload(h, &h->d_sel_slot, slot))) return r2;
         if ((r2 = upload(h, &h->d_sel_cptr, cptr))) return r2;
         if ((r2 = upload(h, &h->d_sel_clist, clist))) return r2;
-        if (hipMalloc((void**)&h->d_sel_dw, sizeof(double) * nP * b) != hipSuccess) return HPF_E_NOMEM;
     }
     h->sel_nP = (int)nP;
     h->sel_npairs = (int)npairs;
     h->sel_R = (b + 15) / 16;
+    // Buffers for `sel_cap` scenarios at a time (a batch of the group's running scenarios goes through the selected inversion and the border solve
+    // together): as many as fit HPF_MESH_BATCH_GB (default 48) of the handle's capacity, at least one.
+    const size_t mb = (size_t)h->m_border;
+    {
+        const char* bg = h->sw("HPF_BORDER_GJ");
+        const int lim = bg ? atoi(bg) : 96;
+        h->border_gj = mT <= lim && mT >= 1;
+        const double per = 8.0 * ((double)bb * (3.0 * nP + npairs + (double)nP * mT + (h->border_gj ? (double)mT * (mT + 1) : 0.0)) + (double)mb * mb + (double)nP * b +
+                                  3.0 * mb + 8.0 * h->n_ties * h->Hn);
+        const char* gb = h->sw("HPF_MESH_BATCH_GB");
+        const double budget = (gb ? atof(gb) : 48.0) * 1073741824.0;
+        long long cap = (long long)(budget / per);
+        cap = cap < 1 ? 1 : (cap > h->S_max ? h->S_max : cap);
+        h->sel_cap = (int)cap;
+    }
+    const size_t cap = (size_t)h->sel_cap;
+    h->sel_res_host.assign(2 * cap, 0ull);
+    h->sel_info_host.assign(cap, 0);
+    if (hipMalloc((void**)&h->d_sel_dw, sizeof(double) * cap * nP * b) != hipSuccess) return HPF_E_NOMEM;
     auto dalloc = [&](double** p2, size_t cnt) { return hipMalloc((void**)p2, sizeof(double) * (cnt ? cnt : 1)) == hipSuccess; };
-    if (!dalloc(&h->d_sel_S, nP * bb) || !dalloc(&h->d_sel_Z, nP * bb) || !dalloc(&h->d_sel_Up, nP * bb) || !dalloc(&h->d_sel_W, npairs * bb) ||
-        !dalloc(&h->d_sel_X, nP * (size_t)mT * bb) || !dalloc(&h->d_sel_tie, (size_t)2 * h->n_ties * h->Hn * 4))
+    if (!dalloc(&h->d_sel_S, cap * nP * bb) || !dalloc(&h->d_sel_Z, cap * nP * bb) || !dalloc(&h->d_sel_Up, cap * nP * bb) ||
+        !dalloc(&h->d_sel_W, cap * npairs * bb) || !dalloc(&h->d_sel_X, cap * nP * (size_t)mT * bb) ||
+        !dalloc(&h->d_sel_tie, cap * 2 * h->n_ties * h->Hn * 4) || !dalloc(&h->d_sel_bM, cap * mb * mb) || !dalloc(&h->d_sel_rhs, cap * mb) ||
+        !dalloc(&h->d_sel_g, cap * mb) || hipMalloc((void**)&h->d_sel_res, sizeof(unsigned long long) * 2 * cap) != hipSuccess ||
+        hipMalloc((void**)&h->d_sel_info, sizeof(int) * cap) != hipSuccess)
         return HPF_E_NOMEM;
+    const long long sS = (long long)(nP * bb), sW = (long long)(npairs * bb), sX = (long long)(nP * (size_t)mT * bb);
     int r;
     if ((r = upload(h, &h->d_sel_P, Prec))) return r;
     if ((r = upload(h, &h->d_sel_pidx, pidx))) return r;
@@ -1755,9 +1849,9 @@ int tree_sel_build(hpf_handle* h, const hpf_desc* d) {
             for (size_t e = 0; e < lvl_cnt[l + 1]; ++e, ++q) {
                 const Pair& pr = pairs[q];
                 if (pr.pred < 0)
-                    jobs.push_back({nullptr, h->d_sel_S + (size_t)pidx[pr.bus] * bb, nullptr, h->d_sel_W + q * bb, 1.0});
+                    jobs.push_back({nullptr, h->d_sel_S + (size_t)pidx[pr.bus] * bb, nullptr, h->d_sel_W + q * bb, 1.0, 0, sS, 0, sW});
                 else
-                    jobs.push_back({h->d_sel_Up + (size_t)pidx[pr.child] * bb, h->d_sel_W + (size_t)pr.pred * bb, nullptr, h->d_sel_W + q * bb, -1.0});
+                    jobs.push_back({h->d_sel_Up + (size_t)pidx[pr.child] * bb, h->d_sel_W + (size_t)pr.pred * bb, nullptr, h->d_sel_W + q * bb, -1.0, sS, sW, 0, sW});
             }
             h->sel_fwd_beg.push_back(jobs.size());
         }
@@ -1773,9 +1867,9 @@ int tree_sel_build(hpf_handle* h, const hpf_desc* d) {
                     const double* wq = pq >= 0 ? h->d_sel_W + (size_t)pq * bb : nullptr;
                     double* xo = h->d_sel_X + (q * mT + t) * bb;
                     if (k == 0)
-                        jobs.push_back({nullptr, wq, nullptr, xo, 1.0});
+                        jobs.push_back({nullptr, wq, nullptr, xo, 1.0, 0, sW, 0, sX});
                     else
-                        jobs.push_back({h->d_sel_Z + q * bb, h->d_sel_X + ((size_t)pidx[T.parent[k]] * mT + t) * bb, wq, xo, -1.0});
+                        jobs.push_back({h->d_sel_Z + q * bb, h->d_sel_X + ((size_t)pidx[T.parent[k]] * mT + t) * bb, wq, xo, -1.0, sS, sX, sW, sX});
                 }
             }
             h->sel_back_beg.push_back(jobs.size());
@@ -1790,25 +1884,23 @@ int tree_sel_build(hpf_handle* h, const hpf_desc* d) {
     // the right-hand side rides as block column n_tb.  Measured on syn1000 + 5 / 20 / 40 / 80 ties (n_tb = 10 / 39 / 78 / 150): 1.40 / 3.2 / 9.0 / 47 ms
     // per Newton step against 2.2 / 5.7 / 11.7 / 31 ms with rocSOLVER (1.5 x the flops of an LU, block products at ~2 TFLOP/s).
     {
-        const char* bg = h->sw("HPF_BORDER_GJ");
-        const int lim = bg ? atoi(bg) : 96;
-        h->border_gj = mT <= lim && mT >= 1;
         const char* bl = h->sw("HPF_BORDER_PIVLIM");
         if (bl && atof(bl) > 0.0) h->border_piv_limit = atof(bl);
         const char* bm = h->sw("HPF_BORDER_GJ_MFMA");
         h->border_gj_mfma = !(bm && atoi(bm) == 0);     // 0: the diagonal blocks through the VALU Gauss-Jordan (gj_dense_invert_npvt; A/B)
         if (h->border_gj) {
             const size_t W = (size_t)mT + 1;
-            if (!dalloc(&h->d_bB, (size_t)mT * W * bb)) return HPF_E_NOMEM;
+            if (!dalloc(&h->d_bB, cap * (size_t)mT * W * bb)) return HPF_E_NOMEM;
+            const long long sB = (long long)((size_t)mT * W * bb);
             std::vector<BlkJob> gj;
             h->bgj_beg.assign(1, 0);
             auto blk = [&](size_t s2, size_t t2) { return h->d_bB + (s2 * W + t2) * bb; };
             for (size_t k = 0; k < (size_t)mT; ++k) {
-                for (size_t t2 = k + 1; t2 < W; ++t2) gj.push_back({blk(k, k), blk(k, t2), nullptr, blk(k, t2), 1.0});
+                for (size_t t2 = k + 1; t2 < W; ++t2) gj.push_back({blk(k, k), blk(k, t2), nullptr, blk(k, t2), 1.0, sB, sB, 0, sB});
                 h->bgj_beg.push_back(gj.size());
                 for (size_t i = 0; i < (size_t)mT; ++i)
                     if (i != k)
-                        for (size_t t2 = k + 1; t2 < W; ++t2) gj.push_back({blk(i, k), blk(k, t2), blk(i, t2), blk(i, t2), -1.0});
+                        for (size_t t2 = k + 1; t2 < W; ++t2) gj.push_back({blk(i, k), blk(k, t2), blk(i, t2), blk(i, t2), -1.0, sB, sB, sB, sB});
                 h->bgj_beg.push_back(gj.size());
             }
             if (hipMalloc(&h->d_bgj_jobs, sizeof(BlkJob) * (gj.size() ? gj.size() : 1)) != hipSuccess) return HPF_E_NOMEM;
@@ -1821,40 +1913,130 @@ int tree_sel_build(hpf_handle* h, const hpf_desc* d) {
     return HPF_OK;
 }
 
-// the selected inversion of slot v -> the border matrix (h->d_bM)
-static void tree_sel_run(hpf_handle* h, int v, hipStream_t st) {
-    const int b = 2 * h->Hn, BW = wave_block_size(b), NT = (BW + 16) / 16, m = h->m_border;
+// the selected inversion of the scenarios in slots s0 .. s0 + cn - 1 (their factors are in their slots) -> border matrices, right-hand sides
+static void tree_sel_run(hpf_handle* h, const int* active, int s0, int cn, hipStream_t st) {
+    const int b = 2 * h->Hn, BW = wave_block_size(b), NT = (BW + 16) / 16, m = h->m_border, n_dir = 2 * h->n_ties;
     const size_t CT = (size_t)NT * NT * 256;
     const BlkJob* jobs = static_cast<const BlkJob*>(h->d_sel_jobs);
-    hipLaunchKernelGGL(k_sel_prepare, dim3((unsigned)h->sel_nP), dim3(256), 0, st, h->M, b, CT, v, h->d_sel_P, h->d_sel_toff, h->d_U, h->d_E, h->d_Z,
-                       h->d_sel_S, h->d_sel_Z, h->d_sel_Up);
-    hipLaunchKernelGGL(k_sel_ties, dim3((unsigned)((2 * h->n_ties * h->Hn + 255) / 256)), dim3(256), 0, st, h->M, v, 2 * h->n_ties, h->d_tb_bus, h->d_tb_ptr,
+    hipLaunchKernelGGL(k_sel_ties, dim3((unsigned)((n_dir * h->Hn + 255) / 256), (unsigned)cn), dim3(256), 0, st, h->M, active, s0, n_dir, h->d_tb_bus, h->d_tb_ptr,
                        h->d_tb_adj, h->n_tb, h->d_U, h->d_E, h->d_sel_tie);
+    hipLaunchKernelGGL(k_border_rhs_sel, dim3((unsigned)((m + 255) / 256), (unsigned)cn), dim3(256), 0, st, b, h->Hn, m, h->n, BW, n_dir, active, s0, h->d_tb_ptr,
+                       h->d_tb_adj, (const double*)h->d_sel_tie, (const double*)h->d_x, h->d_sel_rhs);
+    hipLaunchKernelGGL(k_sel_prepare, dim3((unsigned)h->sel_nP, (unsigned)cn), dim3(256), 0, st, h->M, b, CT, active, s0, h->sel_nP, h->d_sel_P, h->d_sel_toff,
+                       h->d_U, h->d_E, h->d_Z, h->d_sel_S, h->d_sel_Z, h->d_sel_Up);
     for (size_t l = 0; l + 1 < h->sel_fwd_beg.size(); ++l)
-        launch_jobs(h->sel_R, b, (int)(h->sel_fwd_beg[l + 1] - h->sel_fwd_beg[l]), jobs + h->sel_fwd_beg[l], st);
+        launch_jobs(h->sel_R, b, (int)(h->sel_fwd_beg[l + 1] - h->sel_fwd_beg[l]), jobs + h->sel_fwd_beg[l], st, cn);
     for (size_t l = 0; l + 1 < h->sel_back_beg.size(); ++l)
-        launch_jobs(h->sel_R, b, (int)(h->sel_back_beg[l + 1] - h->sel_back_beg[l]), jobs + h->sel_back_beg[l], st);
-    hipLaunchKernelGGL(k_border_build_sel, dim3((unsigned)((m + 255) / 256), (unsigned)m), dim3(256), 0, st, b, h->Hn, m, h->n_tb, h->d_tb_ptr, h->d_tb_adj,
-                       h->d_sel_pidx, h->d_sel_tie, h->d_sel_X, h->d_bM, h->border_gj ? h->d_bB : (double*)nullptr);
+        launch_jobs(h->sel_R, b, (int)(h->sel_back_beg[l + 1] - h->sel_back_beg[l]), jobs + h->sel_back_beg[l], st, cn);
+    hipLaunchKernelGGL(k_border_build_sel, dim3((unsigned)((m + 255) / 256), (unsigned)m, (unsigned)cn), dim3(256), 0, st, b, h->Hn, m, h->n_tb, h->sel_nP, n_dir,
+                       active, s0, h->d_tb_ptr, h->d_tb_adj, h->d_sel_pidx, (const double*)h->d_sel_tie, (const double*)h->d_sel_X, h->d_sel_bM,
+                       h->border_gj ? h->d_bB : (double*)nullptr);
 }
 
-// the block Gauss-Jordan solve of the border system in h->d_bB (block layout, right-hand side from h->d_brhs) -> h->d_brhs, zero pivots -> h->d_binfo
-static void border_block_gj(hpf_handle* h, hipStream_t st) {
+// the block Gauss-Jordan solve of the cn border systems in h->d_bB (block layout, right-hand sides h->d_sel_rhs) -> h->d_sel_g, weak / zero pivots -> h->d_sel_info
+static void border_block_gj(hpf_handle* h, int cn, hipStream_t st) {
     const int b = 2 * h->Hn, mT = h->n_tb, R = h->sel_R;
     const size_t bb = (size_t)b * b, W = (size_t)mT + 1;
+    const long long sB = (long long)((size_t)mT * W * bb);
     const BlkJob* jobs = static_cast<const BlkJob*>(h->d_bgj_jobs);
-    hipMemsetAsync(h->d_binfo, 0, sizeof(int), st);
-    hipLaunchKernelGGL(k_border_rhs_blocks, dim3((unsigned)((mT * bb + 255) / 256)), dim3(256), 0, st, b, mT, (const double*)h->d_brhs, h->d_bB);
+    hipLaunchKernelGGL(k_border_rhs_blocks, dim3((unsigned)((mT * bb + 255) / 256), (unsigned)cn), dim3(256), 0, st, b, mT, (const double*)h->d_sel_rhs, h->d_bB);
     for (int k = 0; k < mT; ++k) {
-        if (!h->border_gj_mfma || !launch_invert_mfma(wave_block_size(b), b, h->d_bB + ((size_t)k * W + k) * bb, h->border_piv_limit, h->d_binfo, st))
-            launch_invert(R, b, h->d_bB + ((size_t)k * W + k) * bb, h->d_binfo, st);
-        launch_jobs(R, b, (int)(h->bgj_beg[2 * k + 1] - h->bgj_beg[2 * k]), jobs + h->bgj_beg[2 * k], st);
-        launch_jobs(R, b, (int)(h->bgj_beg[2 * k + 2] - h->bgj_beg[2 * k + 1]), jobs + h->bgj_beg[2 * k + 1], st);
+        double* dk = h->d_bB + ((size_t)k * W + k) * bb;
+        if (!h->border_gj_mfma || !launch_invert_mfma(wave_block_size(b), b, dk, sB, cn, h->border_piv_limit, h->d_sel_info, st)) launch_invert(R, b, dk, sB, cn, h->d_sel_info, st);
+        launch_jobs(R, b, (int)(h->bgj_beg[2 * k + 1] - h->bgj_beg[2 * k]), jobs + h->bgj_beg[2 * k], st, cn);
+        launch_jobs(R, b, (int)(h->bgj_beg[2 * k + 2] - h->bgj_beg[2 * k + 1]), jobs + h->bgj_beg[2 * k + 1], st, cn);
     }
-    hipLaunchKernelGGL(k_border_g_blocks, dim3((unsigned)((mT * b + 255) / 256)), dim3(256), 0, st, b, mT, (const double*)h->d_bB, h->d_brhs);
+    hipLaunchKernelGGL(k_border_g_blocks, dim3((unsigned)((mT * b + 255) / 256), (unsigned)cn), dim3(256), 0, st, b, mT, (const double*)h->d_bB, h->d_sel_g);
+}
+
+// Newton step of a meshed handle in the factor-once form, for the running scenarios of slots h->cur_s0 .. + h->cur_S (see tree_newton_step_bordered):
+//   1. ONE sweep of the tree for all of them (their own right-hand sides, their own slots: y = J_t^-1 f and the factors);
+//   2. in batches of sel_cap scenarios: selected inversion -> border matrices, border solve (block Gauss-Jordan, or rocSOLVER's unpivoted LU one
+//      system after the other), residual check of every solution against the untouched column-major copy -- ONE host synchronisation per batch --,
+//      pivoted rocSOLVER LU for the systems that fail it, correction of the forward vectors on P;
+//   3. the back sweep alone for all of them.
+static int tree_newton_step_sel(hpf_handle* h, bool only_active) {
+    const int m = h->m_border, b = 2 * h->Hn, BW = wave_block_size(b), n = h->n;
+    const int s0 = h->cur_s0, cnt = h->cur_S;
+    hipStream_t st = h->cur_stream;
+    const int* active = only_active ? h->d_active : nullptr;
+    int rc = tree_newton_step(h, only_active);
+    if (rc) return rc;
+    for (int c0 = 0; c0 < cnt; c0 += h->sel_cap) {
+        const int cn = cnt - c0 < h->sel_cap ? cnt - c0 : h->sel_cap;
+        const int sb = s0 + c0;
+        tree_sel_run(h, active, sb, cn, st);
+        hipMemsetAsync(h->d_sel_info, 0, sizeof(int) * cn, st);
+        hipMemsetAsync(h->d_sel_res, 0, sizeof(unsigned long long) * 2 * cn, st);
+        if (h->border_gj) {
+            border_block_gj(h, cn, st);
+        } else {
+            if (ensure_blas(h) || rocblas_set_stream(h->blas, st) != rocblas_status_success) return HPF_E_ROCSOLVER;
+            for (int y = 0; y < cn; ++y) {                     // (large borders: one system after the other through the handle's scratch matrix)
+                hipMemcpyAsync(h->d_bM, h->d_sel_bM + (size_t)y * m * m, sizeof(double) * (size_t)m * m, hipMemcpyDeviceToDevice, st);
+                hipMemcpyAsync(h->d_sel_g + (size_t)y * m, h->d_sel_rhs + (size_t)y * m, sizeof(double) * m, hipMemcpyDeviceToDevice, st);
+                if (rocsolver_dgetrf_npvt(h->blas, m, m, h->d_bM, m, h->d_sel_info + y) != rocblas_status_success ||
+                    rocblas_dtrsv(h->blas, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_unit, m, h->d_bM, m, h->d_sel_g + (size_t)y * m, 1) != rocblas_status_success ||
+                    rocblas_dtrsv(h->blas, rocblas_fill_upper, rocblas_operation_none, rocblas_diagonal_non_unit, m, h->d_bM, m, h->d_sel_g + (size_t)y * m, 1) != rocblas_status_success)
+                    return HPF_E_ROCSOLVER;
+            }
+        }
+        hipLaunchKernelGGL(k_border_check, dim3((unsigned)((m + 15) / 16), (unsigned)cn), dim3(256), 0, st, m, (const double*)h->d_sel_bM, (const double*)h->d_sel_rhs,
+                           (const double*)h->d_sel_g, h->d_sel_res);
+        if (hipMemcpyAsync(h->sel_res_host.data(), h->d_sel_res, sizeof(unsigned long long) * 2 * cn, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipMemcpyAsync(h->sel_info_host.data(), h->d_sel_info, sizeof(int) * cn, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) {
+            h->last_detail = (int)hipGetLastError();
+            return HPF_E_HIP;
+        }
+        const bool info_on = h->sw("HPF_BORDER_INFO") != nullptr;
+        for (int y = 0; y < cn; ++y) {
+            const int sc = only_active ? ((size_t)(sb + y) < h->host_act.size() ? h->host_act[sb + y] : -1) : sb + y;
+            if (sc < 0) continue;
+            double r0, r1;
+            memcpy(&r0, &h->sel_res_host[2 * y], sizeof(double));
+            memcpy(&r1, &h->sel_res_host[2 * y + 1], sizeof(double));
+            const int info = h->sel_info_host[y];
+            if (info_on)
+                fprintf(stderr, "hpf border system (m = %d, scenario %d): |rhs - M g| / |rhs| = %.2e, info %d\n", m, sc, r1 > 0.0 ? r0 / r1 : 0.0, info);
+            if (!(h->border_pivoting || info != 0 || !(r0 <= 1e-10 * r1) || !(r1 < INFINITY))) continue;
+            // this system again, with partial pivoting, from the untouched copy
+            ++h->border_repivots;
+            if (ensure_blas(h) || rocblas_set_stream(h->blas, st) != rocblas_status_success) return HPF_E_ROCSOLVER;
+            int pinfo = 0;
+            hipMemcpyAsync(h->d_bM, h->d_sel_bM + (size_t)y * m * m, sizeof(double) * (size_t)m * m, hipMemcpyDeviceToDevice, st);
+            hipMemcpyAsync(h->d_sel_g + (size_t)y * m, h->d_sel_rhs + (size_t)y * m, sizeof(double) * m, hipMemcpyDeviceToDevice, st);
+            if (rocsolver_dgetrf(h->blas, m, m, h->d_bM, m, h->d_bipiv, h->d_binfo) != rocblas_status_success ||
+                rocsolver_dgetrs(h->blas, rocblas_operation_none, m, 1, h->d_bM, m, h->d_bipiv, h->d_sel_g + (size_t)y * m, m) != rocblas_status_success)
+                return HPF_E_ROCSOLVER;
+            if (hipMemcpyAsync(&pinfo, h->d_binfo, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+                h->last_detail = (int)hipGetLastError();
+                return HPF_E_HIP;
+            }
+            if (pinfo != 0) {                             // exactly singular border system
+                h->last_detail = sc;
+                return HPF_E_SINGULAR;
+            }
+        }
+        for (size_t l = 0; l + 1 < h->sel_hl_ptr.size(); ++l)
+            hipLaunchKernelGGL(k_sel_dw, dim3((unsigned)(h->sel_hl_ptr[l + 1] - h->sel_hl_ptr[l]), (unsigned)cn), dim3(256), 0, st, b, BW, n, h->sel_nP, m, active, sb,
+                               h->d_sel_hl + h->sel_hl_ptr[l], h->d_sel_P, h->d_sel_slot, h->d_sel_cptr, h->d_sel_clist, (const double*)h->d_sel_S,
+                               (const double*)h->d_sel_Up, (const double*)h->d_sel_g, h->d_sel_dw, h->d_w);
+    }
+    h->tree_back_only = true;
+    rc = tree_newton_step(h, only_active);
+    h->tree_back_only = false;
+    if (rc) return rc;
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        h->last_detail = (int)e;
+        return HPF_E_HIP;
+    }
+    return HPF_OK;
 }
 
 int tree_newton_step_bordered(hpf_handle* h, bool only_active) {
+    if (h->mesh_sel) return tree_newton_step_sel(h, only_active);
     const int m = h->m_border, VC = border_slots(h), v0 = h->S_max;
     const int b = 2 * h->Hn, BW = wave_block_size(b), n = h->n;
     const int s0 = h->cur_s0, cnt = h->cur_S;
@@ -1889,18 +2071,7 @@ int tree_newton_step_bordered(hpf_handle* h, bool only_active) {
         return rc;
     };
     for (int r : todo) {
-        if (h->mesh_sel) {
-            // factor-once form: ONE sweep of the scenario's own right-hand side in the virtual slot (y and Q^T y), then the selected inversion
-            // of that slot's factors -> border matrix
-            hipLaunchKernelGGL(k_border_prepare, dim3((unsigned)((cmax + 255) / 256), 1u), dim3(256), 0, st, n, h->Hn, BW, b, r, v0, 0,
-                               h->d_tb_bus, h->n_tb, (const double*)nullptr, h->d_U, h->d_E, h->d_I0, h->d_fb);
-            int rc = sweep(1);
-            if (rc) return rc;
-            hipLaunchKernelGGL(k_border_build, dim3((unsigned)((m + 255) / 256), 1u), dim3(256), 0, st, h->M, BW, b, r, v0, 0, m,
-                               h->d_tb_bus, h->d_tb_ptr, h->d_tb_adj, h->d_U, h->d_E, h->d_x, h->d_bM, h->d_brhs);
-            tree_sel_run(h, v0, st);
-        }
-        for (int c0 = 0; !h->mesh_sel && c0 < 1 + m; c0 += VC) {
+        for (int c0 = 0; c0 < 1 + m; c0 += VC) {
             const int V = 1 + m - c0 < VC ? 1 + m - c0 : VC;
             hipLaunchKernelGGL(k_border_prepare, dim3((unsigned)((cmax + 255) / 256), (unsigned)V), dim3(256), 0, st, n, h->Hn, BW, b, r, v0, c0,
                                h->d_tb_bus, h->n_tb, (const double*)nullptr, h->d_U, h->d_E, h->d_I0, h->d_fb);
@@ -1922,9 +2093,7 @@ int tree_newton_step_bordered(hpf_handle* h, bool only_active) {
         hipMemcpyAsync(h->d_brhs0, h->d_brhs, sizeof(double) * m, hipMemcpyDeviceToDevice, st);
         hipMemcpyAsync(rwork, h->d_brhs, sizeof(double) * m, hipMemcpyDeviceToDevice, st);
         const double one = 1.0, neg = -1.0;
-        if (h->mesh_sel && h->border_gj) {
-            border_block_gj(h, st);
-        } else if (rocsolver_dgetrf_npvt(h->blas, m, m, h->d_bM, m, h->d_binfo) != rocblas_status_success ||
+        if (rocsolver_dgetrf_npvt(h->blas, m, m, h->d_bM, m, h->d_binfo) != rocblas_status_success ||
             rocblas_dtrsv(h->blas, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_unit, m, h->d_bM, m, h->d_brhs, 1) != rocblas_status_success ||
             rocblas_dtrsv(h->blas, rocblas_fill_upper, rocblas_operation_none, rocblas_diagonal_non_unit, m, h->d_bM, m, h->d_brhs, 1) != rocblas_status_success)
             return HPF_E_ROCSOLVER;
@@ -1955,21 +2124,9 @@ int tree_newton_step_bordered(hpf_handle* h, bool only_active) {
             h->last_detail = r;
             return HPF_E_SINGULAR;
         }
-        int rc;
-        if (h->mesh_sel && h->sel_back_only) {
-            // second pass = the forward vectors of P corrected in the slot of the first sweep + the back sweep alone
-            for (size_t l = 0; l + 1 < h->sel_hl_ptr.size(); ++l)
-                hipLaunchKernelGGL(k_sel_dw, dim3((unsigned)(h->sel_hl_ptr[l + 1] - h->sel_hl_ptr[l])), dim3(256), 0, st, b, BW, n, v0,
-                                   h->d_sel_hl + h->sel_hl_ptr[l], h->d_sel_P, h->d_sel_slot, h->d_sel_cptr, h->d_sel_clist, h->d_sel_S, h->d_sel_Up,
-                                   (const double*)h->d_brhs, h->d_sel_dw, h->d_w);
-            h->tree_back_only = true;
-            rc = sweep(1);
-            h->tree_back_only = false;
-        } else {
-            hipLaunchKernelGGL(k_border_prepare, dim3((unsigned)((cmax + 255) / 256), 1u), dim3(256), 0, st, n, h->Hn, BW, b, r, v0, 0,
-                               h->d_tb_bus, h->n_tb, (const double*)h->d_brhs, h->d_U, h->d_E, h->d_I0, h->d_fb);
-            rc = sweep(1);
-        }
+        hipLaunchKernelGGL(k_border_prepare, dim3((unsigned)((cmax + 255) / 256), 1u), dim3(256), 0, st, n, h->Hn, BW, b, r, v0, 0,
+                           h->d_tb_bus, h->n_tb, (const double*)h->d_brhs, h->d_U, h->d_E, h->d_I0, h->d_fb);
+        int rc = sweep(1);
         if (rc) return rc;
         hipLaunchKernelGGL(k_border_finish, dim3((unsigned)((std::max(cmax, VC) + 255) / 256)), dim3(256), 0, st, cmax, r, v0, VC, h->d_x,
                            h->d_pivflag);

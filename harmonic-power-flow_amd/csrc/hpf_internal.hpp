@@ -181,10 +181,15 @@ struct hpf_handle {
     double *d_sel_tie = nullptr;      // [2 n_ties][Hn][4] the ties' coupling blocks of the current state
     void *d_sel_jobs = nullptr;       // BlkJob list: forward by height, back by depth
     std::vector<size_t> sel_fwd_beg, sel_back_beg, sel_hl_ptr;
-    bool sel_back_only = true;        // second pass = corrected forward vectors on P + the back sweep alone (HPF_MESH_BACK2=0: a whole sweep)
     bool tree_back_only = false;      // tree_newton_step skips its factor part (set around that second pass only)
     int *d_sel_hl = nullptr, *d_sel_slot = nullptr, *d_sel_cptr = nullptr, *d_sel_clist = nullptr;   // P by height | endpoint number | children in P
     double *d_sel_dw = nullptr;       // [nP][b] corrections of the forward vectors
+    int sel_cap = 1;                  // scenarios whose selected inversion / border solve run as one batch (every d_sel_* / d_bB buffer holds that many)
+    double *d_sel_bM = nullptr, *d_sel_rhs = nullptr, *d_sel_g = nullptr;   // per batch position: border matrix (column-major, untouched by the solve), Q^T y, solution g
+    unsigned long long* d_sel_res = nullptr;   // [sel_cap][2] residual check words (k_border_check)
+    int* d_sel_info = nullptr;        // [sel_cap] weak / zero pivot of the block Gauss-Jordan solve, info of the unpivoted LU
+    std::vector<unsigned long long> sel_res_host;
+    std::vector<int> sel_info_host;
     double border_piv_limit = 1e3;    // ... amplification of a 4 x 4 pivot block's inverse beyond which that border system goes to the pivoted LU
     bool border_gj_mfma = true;       // ... its diagonal blocks inverted on the matrix cores (k_blk_invert_mfma; HPF_BORDER_GJ_MFMA=0: VALU)
     bool border_gj = false;           // border system by block Gauss-Jordan on the b x b grid (n_tb <= HPF_BORDER_GJ, default 96) instead of rocSOLVER's LU

@@ -249,8 +249,8 @@ int  hpf_debug_stamps(hpf_handle* h, long long* out, int count);
  * allocates for its bordered step (default 1 024, at least 16: the m + 1 right-hand sides run in chunks of that many; only with HPF_MESH_SEL=0),
  * HPF_MESH_SEL=0 runs the bordered step of a meshed handle in its form of rounds 2 - 4 (the m unit right-hand sides as virtual scenarios through
  * the tree kernels, the tree re-factorised for each) instead of the factor-once form (one sweep + a selected inversion over the tie endpoints'
- * root paths, whose buses the planner then keeps as plain Gauss-Jordan buses; coupled models), HPF_MESH_BACK2=0 lets the second pass of that
- * form re-run the whole sweep instead of the back sweep alone, HPF_BORDER_GJ=n solves border systems of up to n endpoint buses (default 96) by a
+ * root paths, whose buses the planner then keeps as plain Gauss-Jordan buses; coupled models), HPF_MESH_BATCH_GB=x bounds the memory of
+ * the per-scenario buffers of that form (default 48: as many scenarios per batch as fit, at least one), HPF_BORDER_GJ=n solves border systems of up to n endpoint buses (default 96) by a
  * block Gauss-Jordan elimination with the library's own block-product kernel and larger ones by rocSOLVER's LU (0: always rocSOLVER;
  * HPF_BORDER_GJ_MFMA=0 inverts its diagonal blocks on the vector units instead of the matrix cores, HPF_BORDER_PIVLIM=x sets the amplification of
  * a 4 x 4 pivot block beyond which such a system goes to the pivoted LU, default 1e3; HPF_BORDER_INFO=1 prints every border solve's residual),

@@ -612,6 +612,56 @@ def test_meshed_feeder_several_scenarios_and_sweep_api(tmp_path):
         assert it1[0] == itb[s] and np.abs(U1 - Ub[s]).max() < 1e-10
 
 
+def test_meshed_batches_of_scenarios_equal_one_scenario_at_a_time(tmp_path):
+    """Factor-once bordered step (round 5): the selected inversion and the border solve of a group's running scenarios go through the block-product
+    kernels as ONE batch (second grid dimension); with HPF_MESH_BATCH_GB too small for more than one scenario's buffers the same scenarios go one
+    after the other, and with HPF_BORDER_GJ=0 the border systems take rocSOLVER's unpivoted LU one by one.  Same seed -> the batched and the serial
+    run must agree bit for bit (the same arithmetic per scenario, whatever the batch), scenarios converging at different iterations included;
+    the rocSOLVER form agrees at the fixed point."""
+    hp = _hp()
+    from harmonic_power_flow_amd import api, synth
+    n, hmax, k, S = 220, 27, 3, 7
+    fb, fl = synth.gen(n, seed=5, outdir=str(tmp_path))
+    _add_ties(fl, n, k)
+    st = hp.Settings(H_MAX=hmax)
+    buses, lines, m, nn, c = hp.init_network(fb, fl, settings=st)
+    Y = hp.build_admittance_matrices(buses, lines, st.HARMONICS)
+    NE = hp.import_Norton_Equivalents(buses, True, st, INPUTS)
+    P0, Q0 = buses["P"].to_numpy(float), buses["Q"].to_numpy(float)
+    scale = np.stack([synth.scenario_scale(n, s) for s in range(S)])
+    scale[3] *= 0.2                                           # (a light scenario: converges earlier than the others)
+    seed = None
+    out = {}
+    for name, opt in (("batched", None), ("serial", "HPF_MESH_BATCH_GB=0.000001"), ("rocsolver", "HPF_BORDER_GJ=0")):
+        dm = api._device_model(buses, Y, NE, True, st.HARMONICS, solver="block_tree", max_scenarios=S, options=opt)
+        try:
+            dm.set_loads(P0 * scale, Q0 * scale)
+            dm.set_state(None, None, n_scen=S)
+            dm.fund_pf(1e-6, 30)
+            if seed is None:
+                seed = dm.get_state()
+            dm.set_state(*seed)                               # (the same fundamental seed for every run)
+            it, err, hist = dm.solve(1e-4, 50)
+            stop = dm.get_state()
+            dm.mismatch(want_f=False)
+            dm.iterate(2)
+            dm.sync()
+            out[name] = (it.copy(), err.copy(), stop, dm.get_state(), dm.tree_census())
+        finally:
+            dm.close()
+    itb, errb, stopb, fixb, csb = out["batched"]
+    its, errs, stops, fixs, css = out["serial"]
+    itr, errr, stopr, fixr, csr = out["rocsolver"]
+    print("\nmeshed batch of %d: iterations %s (serial %s, rocSOLVER border %s), forms %d / %d / %d" % (S, itb, its, itr, csb["bordered_form"], css["bordered_form"],
+                                                                                                    csr["bordered_form"]))
+    assert csb["bordered_form"] == 2 and css["bordered_form"] == 2 and csr["bordered_form"] == 1
+    assert (errb <= 1e-4).all() and len(set(itb.tolist())) > 1
+    assert np.array_equal(itb, its) and np.array_equal(stopb[0], stops[0]) and np.array_equal(stopb[1], stops[1])
+    assert np.array_equal(fixb[0], fixs[0]) and np.array_equal(fixb[1], fixs[1])
+    Ub, Ur = fixb[0] * np.exp(1j * fixb[1]), fixr[0] * np.exp(1j * fixr[1])
+    assert (errr <= 1e-4).all() and np.abs(Ub - Ur).max() < TOL_V
+
+
 def test_many_scenarios_compaction_over_several_tiles(tmp_path):
     """1 500 scenarios of a small feeder in one handle: the slot-list compaction works in tiles of 1 024 slots, the scenario
     groups split the compacted list -- every record equals the single-scenario solve of that scenario."""

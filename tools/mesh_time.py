@@ -20,9 +20,16 @@ for k in [int(a) for a in sys.argv[1:]] or [5, 20]:
     buses, lines, m, n, c = hp.init_network(fb, fl, settings=st)
     Y = hp.build_admittance_matrices(buses, lines, st.HARMONICS)
     NE = hp.import_Norton_Equivalents(buses, True, st, INPUTS)
-    dm = api._device_model(buses, Y, NE, True, st.HARMONICS, solver="block_tree")
-    dm.set_loads(buses["P"].to_numpy(float), buses["Q"].to_numpy(float))
-    dm.set_state(None, None, n_scen=1)
+    S = int(os.environ.get("MESH_S", "1"))                 # scenarios (load scalings of the sweep generator)
+    dm = api._device_model(buses, Y, NE, True, st.HARMONICS, solver="block_tree", max_scenarios=S)
+    P0, Q0 = buses["P"].to_numpy(float), buses["Q"].to_numpy(float)
+    if S > 1:
+        import numpy as np
+        scale = np.stack([synth.scenario_scale(n, s) for s in range(S)])
+        dm.set_loads(P0 * scale, Q0 * scale)
+    else:
+        dm.set_loads(P0, Q0)
+    dm.set_state(None, None, n_scen=S)
     dm.fund_pf(1e-6, 30)
     seed = dm.get_state()
     dm.solve(1e-4, 3)
@@ -32,5 +39,6 @@ for k in [int(a) for a in sys.argv[1:]] or [5, 20]:
     t = time.perf_counter() - t0
     cs = dm.tree_census()
     print("syn1000 + %d ties: census %s; %d iterations in %.3f s = %.2f ms per iteration (err %.1e); levels %d, border systems through the pivoted LU %d"
-          % (k, cs["ties"], it[0], t, 1e3 * t / it[0], err[0], cs["levels"], cs["border_repivots"]))
+          % (k, cs["ties"], it.max(), t, 1e3 * t / it.max(), err.max(), cs["levels"], cs["border_repivots"])
+          + ("" if S == 1 else "; %d scenarios, %d scenario-iterations: %.1f us each" % (S, it.sum(), 1e6 * t / it.sum())))
     dm.close()

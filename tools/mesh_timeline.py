@@ -15,6 +15,8 @@ def nm(r):
 
 
 idx = [i for i, r in enumerate(rows) if nm(r) == "k_border_prepare"]
+if not idx:                                             # factor-once form: an iteration from one k_mismatch to the next (sweep, selected inversion, ...)
+    idx = [i for i, r in enumerate(rows) if nm(r) == "k_mismatch"]
 a, b = idx[len(idx) // 2], idx[len(idx) // 2 + 1]
 if len(sys.argv) > 2 and sys.argv[2] == "two":          # (virtual form: two prepare launches per iteration)
     b = idx[len(idx) // 2 + 2]
