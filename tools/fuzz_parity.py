@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Randomised parity sweep on the GPU: the first Newton step (pf seed -> one iteration) of the block-tree path against the dense
-rocSOLVER path over random radial feeders (size, share of nonlinear buses, PV buses, harmonic count -> block sizes 12 / 28 / 52 and
-the generic kernels).  One step is compared (not converged states) because later iterates of the solver-sensitive cases amplify
+"""Randomised parity sweep on the GPU: the first Newton step (pf seed -> one iteration) of the block-tree path, and hpf_sparse_solve on the
+CSR Jacobian of the same state, against the dense rocSOLVER path over random feeders (size, share of nonlinear buses, PV buses, loop-closing lines,
+harmonic count -> block sizes 12 / 28 / 52 / 100).  One step is compared (not converged states) because later iterates of the solver-sensitive cases amplify
 rounding differences; the deviation is judged relative to the size of the step (first steps of 10-100 rad occur).  python tools/fuzz_parity.py [cases=24] [seed=0]"""
 import os
 import sys
@@ -24,16 +24,12 @@ for case in range(cases):
         n = min(n, 160)                     # (the dense comparator: N = 2 n Hn)
     frac = float(rng.choice([0.05, 0.15, 0.35, 0.6, 0.85]))
     n_pv = int(rng.choice([0, 0, 1, 2]))
-    n_ties = int(rng.choice([0, 0, 0, 1, 3]))
+    n_ties = int(rng.choice([0, 0, 0, 1, 3, 6]))
     seed = int(rng.integers(0, 10 ** 6))
     tmp = tempfile.mkdtemp()
     fb, fl = synth.gen(n, seed=seed, frac_nl=frac, outdir=tmp)
-    if n_ties:                              # loop-closing lines: the block-tree path's bordered step
-        import importlib.util
-        spec = importlib.util.spec_from_file_location("mgb", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "make_golden_bench.py"))
-        mgb = importlib.util.module_from_spec(spec)
-        spec.loader.exec_module(mgb)
-        mgb.add_ties(fl, n, n_ties, seed=seed)
+    if n_ties:                              # loop-closing lines: the block-tree path's bordered step, hpf_sparse_solve's bordered elimination
+        synth.add_ties(fl, n, n_ties, seed=seed)
     if n_pv:
         rows = open(fb).read().splitlines()
         for bid in range(2, 2 + n_pv):
@@ -59,7 +55,7 @@ for case in range(cases):
             dm.set_state(None, None, n_scen=S)
             dm.fund_pf(1e-6, 30)
             seed_state = dm.get_state()
-            if solver == "dense" and n_ties == 0:
+            if solver == "dense":
                 # the reference's own call shape on the same state: CSR Jacobian -> update_harmonic_state_vec (hpf_sparse_solve), scenario 0
                 f0, _ = dm.mismatch()
                 J0 = dm.jacobian_csr(0)
@@ -75,7 +71,7 @@ for case in range(cases):
     step = max(np.abs(res["dense"][0] - seed_state[0]).max(), np.abs(res["dense"][1] - seed_state[1]).max(), 1.0)
     worst = max(worst, dVm / step, dVa / step)
     d_sp = float("nan")
-    if n_ties == 0:
+    if True:
         x_dense = np.append(res["dense"][1][0][1:], res["dense"][0][0][c:])
         d_sp = np.abs(x_sp - x_dense).max()
         worst = max(worst, d_sp / step)
