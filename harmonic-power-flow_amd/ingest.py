@@ -124,6 +124,9 @@ def _find_ne_file(ne_dir, device):
     raise FileNotFoundError("no Norton-equivalent file for component %r in %s" % (device, ne_dir))
 
 
+_NORTON_FRAMES = {}
+
+
 def import_Norton_Equivalents(buses, coupled, settings=None, ne_dir=None):
     """HG:278-310 -> {device: [I_N, Y_N]} as DataFrames in p.u., exactly the reference's objects."""
     st = settings or Settings()
@@ -133,7 +136,14 @@ def import_Norton_Equivalents(buses, coupled, settings=None, ne_dir=None):
     comps = buses["component"].to_numpy()
     NE = {}
     for device in dict.fromkeys(comps[types == "nonlinear"]):            # unique device names, first-seen order (HG:285)
-        have, Ycc, Ic, Yuc, Iuc = read_Norton_file(_find_ne_file(ne_dir, device))
+        path = _find_ne_file(ne_dir, device)
+        # (repeated hpf() calls, HG:511: the two frames of a device are built once per file version / harmonic set / base and handed out as copies)
+        fkey = (path, os.stat(path).st_mtime_ns, bool(coupled), tuple(want), float(st.base_current), float(st.base_admittance))
+        hit = _NORTON_FRAMES.get(fkey)
+        if hit is not None:
+            NE[device] = [hit[0].copy(), hit[1].copy()]
+            continue
+        have, Ycc, Ic, Yuc, Iuc = read_Norton_file(path)
         pos = {f: j for j, f in enumerate(have)}
         missing = [f for f in want if f not in pos]
         if missing:
@@ -151,6 +161,9 @@ def import_Norton_Equivalents(buses, coupled, settings=None, ne_dir=None):
                                index=pd.Index([0], name="Frequency"))
             y_n = pd.DataFrame((Yuc[sel] / st.base_admittance)[None, :], columns=want,
                                index=pd.Index([0], name="Frequency"))
+        if len(_NORTON_FRAMES) > 16:
+            _NORTON_FRAMES.clear()
+        _NORTON_FRAMES[fkey] = (i_n.copy(), y_n.copy())
         NE[device] = [i_n, y_n]
     return NE
 
