@@ -271,6 +271,10 @@ def hpf(buses, lines, coupled, thresh_h=1e-4, max_iter_h=50, plt_convergence=Fal
         dm.set_option("keep_previous_state", 1 if want_J else 0)      # (explicit both ways: the handle may be a borrowed one)
         n_iter, err, hist = dm.solve(thresh_h, max_iter_h)                        # HG:530-542
         stats = dm.stats()
+        # a meshed network on the block-tree path has no pivoted repeat of its own (hpf.h): with solver="auto" a scenario the static-pivot monitor
+        # flagged, or whose mismatch turned non-finite, is solved again on the dense rocSOLVER path where that fits
+        retry_dense = (solver == "auto" and dm.solver == "block_tree" and dm.tree_census()["ties"] > 0 and
+                       bool(stats["flags"][0] & (4 | 8)) and not (stats["flags"][0] & 16) and 8.0 * dm.N * dm.N <= 64e9)
         if details is not None:
             details["repeated_with_pivoting"] = bool(stats["flags"][0] & 16)
         if verbose and (stats["flags"][0] & 16):
@@ -291,6 +295,11 @@ def hpf(buses, lines, coupled, thresh_h=1e-4, max_iter_h=50, plt_convergence=Fal
                            n_iter_f=int(nf[0]), err_f=hf[0, :int(nf[0])].copy(), solver=dm.solver,
                            tree=(dm.tree_census() if dm.solver == "block_tree" else None),
                            stats=stats, Vm_raw=Vm_raw[0].copy(), Va_raw=Va_raw[0].copy(), N=dm.N)
+    if retry_dense:
+        if verbose:
+            print("Warning! The bordered block-tree step was flagged (static pivot order / non-finite mismatch); solving again with the dense LU.")
+        return hpf(buses, lines, coupled, thresh_h=thresh_h, max_iter_h=max_iter_h, plt_convergence=plt_convergence, settings=settings, ne_dir=ne_dir,
+                   solver="dense", verbose=verbose, return_jacobian=return_jacobian, details=details, extra_iters=extra_iters)
     Vm, Va = _postprocess(Vm_raw[0], Va_raw[0])                                   # HG:545-549
     V = _frame(Vm, Va, harmonics, n)
     err_h = float(err[0])

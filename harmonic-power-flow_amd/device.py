@@ -58,12 +58,14 @@ class DeviceModel:
         self.I_N = np.ascontiguousarray(I_N, dtype=np.complex128)
         N = 2 * self.n * self.Hn - 1 - self.c
         if solver == "auto":
-            # radial feeders: block-tree elimination; small meshed networks: dense rocSOLVER LU; large meshed networks with a few
-            # loop-closing lines: the block-tree path's bordered step (tried first, dense if the library refuses the topology)
+            # radial feeders: block-tree elimination; meshed networks (spanning tree + loop-closing lines) of 32 buses and more: the block-tree
+            # path's bordered step (tried first, dense if the library refuses the topology: border beyond 16 384 unknowns) -- 0.3 - 1.1 ms per
+            # iteration where the dense LU takes 2 - 250 (tools/mesh_vs_dense.py: N = 478 ... 15 598; rounds 2 - 4 drew the line at N > 8 192);
+            # smaller networks (the reference's net1 - net3): dense rocSOLVER LU
             if is_radial(self.n, self.rowptr, self.col):
                 solver = "block_tree" if self.n >= 32 else "dense"
             else:
-                solver = "block_tree_or_dense" if (self.n >= 32 and N > 8192) else "dense"
+                solver = "block_tree_or_dense" if self.n >= 32 else "dense"
         self._solver_request = solver
         if solver == "block_tree_or_dense":
             solver = "block_tree"

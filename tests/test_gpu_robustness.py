@@ -612,6 +612,31 @@ def test_meshed_feeder_several_scenarios_and_sweep_api(tmp_path):
         assert it1[0] == itb[s] and np.abs(U1 - Ub[s]).max() < 1e-10
 
 
+def test_auto_takes_the_bordered_block_tree_path_for_meshed_feeders_of_32_buses_and_more(tmp_path):
+    """solver="auto" (round 5): a meshed feeder of 100 buses (N = 2 798, far below the N > 8 192 of rounds 2 - 4) runs the bordered block-tree step and lands
+    on the dense path's voltages; a 20-bus ring stays on the dense LU."""
+    hp = _hp()
+    from harmonic_power_flow_amd import synth
+    fb, fl = synth.gen(100, seed=3, outdir=str(tmp_path))
+    synth.add_ties(fl, 100, 3)
+    st = hp.Settings(H_MAX=27)
+    buses, lines, m, n, c = hp.init_network(fb, fl, settings=st)
+    da, dd = {}, {}
+    Va_, ea, ia, _ = hp.hpf(buses, lines, True, settings=st, ne_dir=INPUTS, verbose=False, details=da, extra_iters=2)
+    Vd_, ed, idn, _ = hp.hpf(buses, lines, True, settings=st, ne_dir=INPUTS, verbose=False, details=dd, solver="dense", extra_iters=2)
+    assert da["solver"] == "block_tree" and da["tree"]["ties"] == 3 and da["tree"]["bordered_form"] == 2 and dd["solver"] == "dense"
+    Ua = Va_["V_m"].to_numpy() * np.exp(1j * Va_["V_a"].to_numpy())
+    Ud = Vd_["V_m"].to_numpy() * np.exp(1j * Vd_["V_a"].to_numpy())
+    print("\nauto on a meshed feeder of 100 buses: %s, %d it (dense %d), fixed points differ by %.2e" % (da["solver"], ia, idn, np.abs(Ua - Ud).max()))
+    assert ea <= 1e-4 and ed <= 1e-4 and np.abs(Ua - Ud).max() < TOL_V
+    fb2, fl2 = synth.gen(20, seed=3, outdir=str(tmp_path), prefix="small")
+    synth.add_ties(fl2, 20, 1)
+    buses2, lines2, _, _, _ = hp.init_network(fb2, fl2, settings=st)
+    d2 = {}
+    hp.hpf(buses2, lines2, True, settings=st, ne_dir=INPUTS, verbose=False, details=d2)
+    assert d2["solver"] == "dense"
+
+
 def test_meshed_batches_of_scenarios_equal_one_scenario_at_a_time(tmp_path):
     """Factor-once bordered step (round 5): the selected inversion and the border solve of a group's running scenarios go through the block-product
     kernels as ONE batch (second grid dimension); with HPF_MESH_BATCH_GB too small for more than one scenario's buffers the same scenarios go one
