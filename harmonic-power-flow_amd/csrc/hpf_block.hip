@@ -1463,6 +1463,7 @@ int tree_find_ties(hpf_handle* h, const hpf_desc* d) {
             }
         }
     }
+    if (h->plan_only) return HPF_OK;                     // (hpf_tree_plan: the host side alone -- ties, endpoint buses, the planner's mask)
     int r;
     if ((r = upload(h, &h->d_tb_bus, tb_bus))) return r;
     if ((r = upload(h, &h->d_tb_ptr, tb_ptr))) return r;
@@ -1819,7 +1820,9 @@ int tree_sel_build(hpf_handle* h, const hpf_desc* d) {
         const double per = 8.0 * ((double)bb * (3.0 * nP + npairs + (double)nP * mT + (h->border_gj ? (double)mT * (mT + 1) : 0.0)) + (double)mb * mb + (double)nP * b +
                                   3.0 * mb + 8.0 * h->n_ties * h->Hn);
         const char* gb = h->sw("HPF_MESH_BATCH_GB");
-        const double budget = (gb ? atof(gb) : 48.0) * 1073741824.0;
+        double budget = (gb ? atof(gb) : 48.0) * 1073741824.0;
+        size_t free_b = 0, total_b = 0;                  // (never more than half of what the device has free at this point: the scenario state follows)
+        if (!gb && hipMemGetInfo(&free_b, &total_b) == hipSuccess && budget > 0.5 * (double)free_b) budget = 0.5 * (double)free_b;
         long long cap = (long long)(budget / per);
         cap = cap < 1 ? 1 : (cap > h->S_max ? h->S_max : cap);
         h->sel_cap = (int)cap;

@@ -2069,7 +2069,7 @@ int hpf_scenario_groups(const hpf_handle* h, int live) {
 
 int hpf_tree_plan(const hpf_desc* d, const char* path) {
     if (!d || !path || d->n < 1 || !d->rowptr || !d->col || !d->Yval || !d->dev_of_bus) return HPF_E_ARG;
-    if (d->nnz != d->n + 2 * (d->n - 1)) return HPF_E_TOPOLOGY;           // radial models only
+    if (d->nnz < d->n + 2 * (d->n - 1) || ((d->nnz - d->n) & 1)) return HPF_E_TOPOLOGY;           // (a connected symmetric pattern has at least the tree's entries)
     if (d->max_scenarios < 1) return HPF_E_ARG;
     remove(path);                                                           // (a stale file of an earlier run must not pass for this one)
     return tree_plan_dump(d, path);

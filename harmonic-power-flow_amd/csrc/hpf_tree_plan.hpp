@@ -82,18 +82,18 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
     // factor-once bordered step of a meshed network (h->sel_forced, set by tree_find_ties): the buses on the root paths of the ties' endpoints
     // stay PLAIN Gauss-Jordan buses -- no 2x2 algebra, no contracted chain, no constant-inverse / lazy / bordered form, no compress role --, so
     // that their inverse S_k^-1 is in the inverse slot after a sweep: the selected inversion of tree_sel_run reads it from there
-    const std::vector<char>& fp = h->sel_forced;
-    const bool use_fp = contract && (int)fp.size() == n;
+    const std::vector<char>& fmask = h->sel_forced;
+    const bool use_fp = contract && (int)fmask.size() == n;
     if (use_fp)
         for (int i = 0; i < n; ++i)
-            if (fp[i]) T.lin[i] = 0;                           // (closed under "parent of": the rule above stays true)
+            if (fmask[i]) T.lin[i] = 0;                           // (closed under "parent of": the rule above stays true)
     // pass-through buses (contract): linear bus, not the root, exactly one child with nonlinear buses below it -> its block is
     // harmonic-diagonal and eliminating it FIRST only re-links that child to the grandparent (2x2-per-harmonic fill)
     std::vector<int> pass(n, 0), ndc(n, 0);
     for (int i = 1; i < n; ++i)
         if (!T.lin[i]) ndc[T.parent[i]]++;
     if (contract)
-        for (int i = 1; i < n; ++i) pass[i] = (!T.lin[i] && i < d->m && ndc[i] == 1 && !(use_fp && fp[i])) ? 1 : 0;
+        for (int i = 1; i < n; ++i) pass[i] = (!T.lin[i] && i < d->m && ndc[i] == 1 && !(use_fp && fmask[i])) ? 1 : 0;
     auto kept = [&](int i) { return !T.lin[i] && !pass[i]; };
     std::vector<int> pard(n, -1);                              // parent in the dense tree (through chains)
     for (size_t oi = 1; oi < order.size(); ++oi) {
@@ -672,7 +672,7 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
             for (int pos = 0; pos < T.n_dense; ++pos) {
                 const int k = T.lvl_nodes[pos];
                 if (k < d->m || dchild_ptr[k + 1] != dchild_ptr[k] || d->dev_of_bus[k] < 0) continue;
-                if (use_fp && fp[k]) continue;
+                if (use_fp && fmask[k]) continue;
                 leaf_pos[k] = (int)cand.size();
                 cand.push_back(k);
             }
@@ -780,7 +780,7 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
             const int L = (int)lazy_of[k].size();
             const int LS = (int)slz_of[k].size();                      // vector-only bordered children (registered when THEY were built)
             if (k < (d->c > 1 ? d->c : 1) || L + LS == 0 || dchild_ptr[k + 1] - dchild_ptr[k] != L + LS) continue;
-            if (use_fp && fp[k]) continue;
+            if (use_fp && fmask[k]) continue;
             if (k < d->m && sleaf_mode < 2) continue;                  // linear (PQ) buses: power-row map W_k on the fundamental
             // border columns: per lazy leaf one complex column (G, H), per bordered child its m1_c columns (g Pb_c[:, i], Qb_c[i, :] h)
             std::vector<std::vector<cd>> colG, colH;
@@ -959,10 +959,10 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
                 }
                 nrm[k2] = std::max(gjb[k2], m1 + 1);
                 int best = nrm[k2], bc = -1;
-                if (gjb[k2] && pard[k2] >= 0 && gjb[pard[k2]] && !(use_fp && fp[k2]))
+                if (gjb[k2] && pard[k2] >= 0 && gjb[pard[k2]] && !(use_fp && fmask[k2]))
                     for (int i = dchild_ptr[k2]; i < dchild_ptr[k2 + 1]; ++i) {
                         const int c1 = dchild[i];
-                        if (!gjb[c1] || (use_fp && fp[c1])) continue;
+                        if (!gjb[c1] || (use_fp && fmask[c1])) continue;
                         const int levk = std::max(1, (c1 == a1 ? m2 : m1) + 1), levc = std::max(nrm[c1], levk + 1);
                         if (levc < best) {
                             best = levc;
@@ -1338,13 +1338,17 @@ static int tree_build_into(hpf_handle* h, const hpf_desc* d, Tree& T, bool contr
     if (const char* dump_path = h->plan_path ? h->plan_path : h->sw("HPF_TREE_DUMP")) {
         if (FILE* fp = fopen(dump_path, contract ? "w" : "a")) {
             h->plan_written = true;
-            fprintf(fp, "# %s tree: k pard height depth kind(0 gauss-jordan, 1 constant-inverse leaf, 2 bordered) vector_only hbm_children via_chain compress_role\n",
-                    contract ? "contracted" : "plain");
+            fprintf(fp, "# %s tree: k pard height depth kind(0 gauss-jordan, 1 constant-inverse leaf, 2 bordered) vector_only hbm_children via_chain compress_role "
+                        "plain_gauss_jordan_on_a_root_path_of_a_tie_endpoint\n", contract ? "contracted" : "plain");
+            if (h->n_ties > 0)
+                fprintf(fp, "# meshed: %d loop-closing lines, %d endpoint buses, border %d unknowns, bordered step %s\n", h->n_ties, h->n_tb, h->m_border,
+                        h->mesh_sel ? "factor-once" : "virtual sweeps");
             for (int pos = 0; pos < T.n_dense; ++pos) {
                 const int k = T.lvl_nodes[pos];
                 const int kind = cleaf_of[k] >= 0 ? 1 : ((sl_off[k] >= 0 && lz_idx[k] >= 0) ? 2 : 0);
-                fprintf(fp, "%d %d %d %d %d %d %d %d %d\n", k, pard[k], height[k], depth[k], kind, is_lazy[k],
-                        dchild_ptr[k + 1] - dchild_ptr[k] - n_lazy[k] - n_slz[k], (k > 0 && pass[T.parent[k]]) ? 1 : 0, comp_role[k]);
+                fprintf(fp, "%d %d %d %d %d %d %d %d %d %d\n", k, pard[k], height[k], depth[k], kind, is_lazy[k],
+                        dchild_ptr[k + 1] - dchild_ptr[k] - n_lazy[k] - n_slz[k], (k > 0 && pass[T.parent[k]]) ? 1 : 0, comp_role[k],
+                        (use_fp && fmask[k]) ? (T.plain_gj[k] ? 1 : -1) : 0);
             }
             fclose(fp);
         }
@@ -1445,7 +1449,9 @@ int tree_plan_dump(const hpf_desc* d, const char* path) {
     tmp.plan_only = true;
     if (const char* es = getenv("HPF_ENV_SWITCHES")) tmp.env_switches = atoi(es) != 0;     // (the same opt-in as hpf_create)
     Tree T;
-    const int r = tree_build_into(&tmp, d, T, true);
+    int r = tree_find_ties(&tmp, d);                     // (meshed models: the loop-closing lines and the buses the factor-once bordered step keeps plain)
+    if (r) return r;
+    r = tree_build_into(&tmp, d, T, true);
     tree_free_one_fwd(T);
     if (r) return r;
     return tmp.plan_written ? HPF_OK : HPF_E_ARG;       // (the file could not be opened)

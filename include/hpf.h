@@ -250,7 +250,7 @@ int  hpf_debug_stamps(hpf_handle* h, long long* out, int count);
  * HPF_MESH_SEL=0 runs the bordered step of a meshed handle in its form of rounds 2 - 4 (the m unit right-hand sides as virtual scenarios through
  * the tree kernels, the tree re-factorised for each) instead of the factor-once form (one sweep + a selected inversion over the tie endpoints'
  * root paths, whose buses the planner then keeps as plain Gauss-Jordan buses; coupled models), HPF_MESH_BATCH_GB=x bounds the memory of
- * the per-scenario buffers of that form (default 48: as many scenarios per batch as fit, at least one), HPF_BORDER_GJ=n solves border systems of up to n endpoint buses (default 96) by a
+ * the per-scenario buffers of that form (default 48, and not more than half of the device's free memory: as many scenarios per batch as fit, at least one), HPF_BORDER_GJ=n solves border systems of up to n endpoint buses (default 96) by a
  * block Gauss-Jordan elimination with the library's own block-product kernel and larger ones by rocSOLVER's LU (0: always rocSOLVER;
  * HPF_BORDER_GJ_MFMA=0 inverts its diagonal blocks on the vector units instead of the matrix cores, HPF_BORDER_PIVLIM=x sets the amplification of
  * a 4 x 4 pivot block beyond which such a system goes to the pivoted LU, default 1e3; HPF_BORDER_INFO=1 prints every border solve's residual),
@@ -315,11 +315,13 @@ int  hpf_setup_times(const hpf_handle* h, double* ms, int n_ms);
 /* Number of scenario groups (independent pipelines on separate HIP streams) a Newton step of `live` running scenarios is split into:
  * option "scenario_groups" bounded by a minimum group size; 1 for DENSE and for meshed networks. */
 int  hpf_scenario_groups(const hpf_handle* h, int live);
-/* Host-only planning run of the BLOCK_TREE elimination tree of a radial model (no device is touched, no handle, the process environment
+/* Host-only planning run of the BLOCK_TREE elimination tree of a model (no device is touched, no handle, the process environment
  * is not modified): builds the contracted tree exactly as hpf_create would for a handle of d->max_scenarios scenarios (compress steps
  * are the default) and writes one line per dense bus (bus, dense parent, elimination level, back-sweep depth, kind, ...)
  * to `path` (replaced if it exists; tools/tree_plan.py reads it).  Returns the planning status: HPF_OK when the plan was written,
- * HPF_E_TOPOLOGY for a meshed model, HPF_E_ARG when the file cannot be written.  (env HPF_TREE_DUMP=<file> makes hpf_create itself
+ * HPF_E_TOPOLOGY as hpf_create would return it, HPF_E_ARG when the file cannot be written.  A meshed model (spanning tree + loop-closing lines):
+ * a comment line with the lines / endpoint buses / border size, and a last column that marks the buses on the endpoints' root paths, which the
+ * factor-once bordered step keeps as plain Gauss-Jordan buses (1; -1 would be a planner fault).  (env HPF_TREE_DUMP=<file> makes hpf_create itself
  * write the same dump.) */
 int  hpf_tree_plan(const hpf_desc* d, const char* path);
 

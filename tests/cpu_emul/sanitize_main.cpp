@@ -25,7 +25,7 @@ struct Feeder {
     std::vector<cplx> Y, YN, IN;
 };
 
-static Feeder make(int n, int Hn, int n_pv, double frac_nl, int coupled, unsigned seed) {
+static Feeder make(int n, int Hn, int n_pv, double frac_nl, int coupled, unsigned seed, int n_ties = 0) {
     std::mt19937 rng(seed);
     std::uniform_real_distribution<double> u(0.2, 1.5);
     Feeder F;
@@ -37,6 +37,13 @@ static Feeder make(int n, int Hn, int n_pv, double frac_nl, int coupled, unsigne
         const int p = (int)(rng() % i);
         adj[i].push_back(p);
         adj[p].push_back(i);
+    }
+    for (int t = 0, tries = 0; t < n_ties && tries < 1000; ++tries) {     // loop-closing lines: pairs of buses that are not adjacent yet
+        const int a = 1 + (int)(rng() % (n - 1)), b2 = 1 + (int)(rng() % (n - 1));
+        if (a == b2 || std::find(adj[a].begin(), adj[a].end(), b2) != adj[a].end()) continue;
+        adj[a].push_back(b2);
+        adj[b2].push_back(a);
+        ++t;
     }
     F.rowptr.assign(1, 0);
     for (int i = 0; i < n; ++i) {
@@ -196,7 +203,8 @@ int main() {
     const int hn_list[4] = {5, 13, 26, 40};
     for (int t = 0; t < 8; ++t) {
         const int Hn = hn_list[t % 4], n = 120 + 60 * t;
-        Feeder F = make(n, Hn, t % 3, 0.35, 1, 100 + t);
+        const int ties = (t & 1) ? 1 + t / 2 : 0;              // every other feeder is meshed: tree_find_ties + the planner's plain-Gauss-Jordan mask
+        Feeder F = make(n, Hn, t % 3, 0.35, 1, 100 + t, ties);
         hpf_desc d;
         memset(&d, 0, sizeof d);
         d.n = F.n; d.m = F.m; d.c = F.c; d.Hn = Hn; d.nnz = (int)F.col.size(); d.n_dev = 2; d.coupled = 1; d.solver = HPF_SOLVER_BLOCK_TREE;
@@ -205,8 +213,28 @@ int main() {
         d.Y_N = (const double*)F.YN.data(); d.I_N = (const double*)F.IN.data();
         const int rc = hpf_tree_plan(&d, "/tmp/hpf_sanitize_plan.txt");
         if (rc != HPF_OK) {
-            printf("hpf_tree_plan failed: %d (n %d Hn %d)\n", rc, n, Hn);
+            printf("hpf_tree_plan failed: %d (n %d Hn %d, %d ties)\n", rc, n, Hn, ties);
             return 3;
+        }
+        if (ties) {                                            // every marked bus must have come out as a plain Gauss-Jordan bus (last column 1, never -1)
+            FILE* fp = fopen("/tmp/hpf_sanitize_plan.txt", "r");
+            char line[512];
+            int marked = 0, bad = 0, meshed_line = 0;
+            while (fp && fgets(line, sizeof line, fp)) {
+                if (line[0] == '#') {
+                    meshed_line += strstr(line, "# meshed:") != nullptr;
+                    continue;
+                }
+                int v[10];
+                if (sscanf(line, "%d %d %d %d %d %d %d %d %d %d", v, v + 1, v + 2, v + 3, v + 4, v + 5, v + 6, v + 7, v + 8, v + 9) != 10) continue;
+                marked += v[9] == 1;
+                bad += v[9] == -1 || (v[9] == 1 && (v[4] != 0 || v[5] != 0 || v[7] != 0 || v[8] != 0));
+            }
+            if (fp) fclose(fp);
+            if (!meshed_line || marked < 2 || bad) {
+                printf("meshed plan: %d marked buses, %d faults, meshed line %d (n %d Hn %d, %d ties)\n", marked, bad, meshed_line, n, Hn, ties);
+                return 3;
+            }
         }
         ++checked;
     }

@@ -55,7 +55,25 @@ def test_compress_plan_dependencies(n, hmax, monkeypatch):
     assert all(flat[k]["kind"] == comp[k]["kind"] and flat[k]["vector_only"] == comp[k]["vector_only"] for k in flat)
 
 
-def test_tree_plan_refuses_meshed_models_and_bad_arguments(tmp_path):
+def test_tree_plan_of_a_meshed_model_keeps_the_tie_endpoints_root_paths_plain(tmp_path):
+    """Round 5 (factor-once bordered step): the planner keeps every bus on a root path of a tie endpoint as a PLAIN Gauss-Jordan bus -- dense, not a
+    constant-inverse / lazy leaf, not a bordered bus, not linked through a contracted chain, no compress role -- so that its inverse sits in its
+    inverse slot after a sweep.  hpf_tree_plan (host only) marks them in its last column."""
+    import tree_plan
+    radial = tree_plan.plan(300, 51)
+    meshed = tree_plan.plan(300, 51, ties=4)
+    assert all(r[9] == 0 for r in radial)
+    marked = {r[0]: r for r in meshed if r[9] != 0}
+    assert len(marked) >= 8 and all(r[9] == 1 for r in marked.values())
+    for k, r in marked.items():
+        assert r[4] == 0 and r[5] == 0 and r[7] == 0 and r[8] == 0           # kind, vector_only, via_chain, compress_role
+        assert r[1] == -1 or r[1] in marked                               # closed under "dense parent of"
+    assert 0 in marked                                                     # the root is on every root path
+    # the marked buses cost levels: more Gauss-Jordan buses, a chain at least as long
+    assert sum(1 for r in meshed if r[4] == 0) > sum(1 for r in radial if r[4] == 0)
+
+
+def test_tree_plan_bad_arguments(tmp_path):
     from harmonic_power_flow_amd import _lib
     lib = _lib.load()
     assert lib.hpf_tree_plan(None, b"/tmp/x") == -1

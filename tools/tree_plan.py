@@ -18,9 +18,11 @@ from harmonic_power_flow_amd import _lib, ingest, synth   # noqa: E402
 INPUTS = os.path.join(REPO, "tests", "golden", "inputs")
 
 
-def plan(nb, hmax, seed=0, max_scenarios=1):
+def plan(nb, hmax, seed=0, max_scenarios=1, ties=0):
     tmp = tempfile.mkdtemp(prefix="hpf_plan_")
     fb, fl = synth.gen(nb, seed=seed, outdir=tmp)
+    if ties:
+        synth.add_ties(fl, nb, ties)
     st = hp.Settings(H_MAX=hmax)
     buses, lines, m, n, c = hp.init_network(fb, fl, settings=st)
     Y = hp.build_admittance_matrices(buses, lines, st.HARMONICS)
