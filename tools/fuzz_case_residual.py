@@ -50,3 +50,41 @@ print("step size %.2e, cond estimate (1-norm, via splu) n/a" % sc)
 for k, dx in steps.items():
     res = np.abs(J @ dx - f[0]).max() / (np.abs(J).dot(np.abs(dx)).max() + np.abs(f[0]).max())
     print("%-18s rel. residual %.2e   max |dx - refined| / step %.2e" % (k, res, np.abs(dx - ref).max() / sc))
+# where the fused step's residual sits: per bus max |J dx - f| of its rows (stacked order: theta rows k - 1, V rows Nc + k - c, k = q n + i), the
+# worst buses with their parent and kind (hpf_tree_plan dump of the same model)
+if os.environ.get("FUZZ_CASE_BUSES"):
+    import ctypes as C
+    from harmonic_power_flow_amd import _lib, ingest
+    Hn = len(st.HARMONICS)
+    Nc = nn * Hn - 1
+    r = np.abs(J @ steps["block_tree"] - f[0])
+    e = np.abs(steps["block_tree"] - ref)
+    per_bus_r, per_bus_e = np.zeros(nn), np.zeros(nn)
+    for idx in range(J.shape[0]):
+        k = idx - Nc + c if idx >= Nc else idx + 1
+        per_bus_r[k % nn] = max(per_bus_r[k % nn], r[idx])
+        per_bus_e[k % nn] = max(per_bus_e[k % nn], e[idx])
+    dev, Y_N, I_N, n_dev = ingest.norton_arrays(buses, NE, True, Hn)
+    d = _lib.hpf_desc()
+    rowptr = np.ascontiguousarray(Y.rowptr, dtype=np.int32); col = np.ascontiguousarray(Y.col, dtype=np.int32)
+    Yv = np.ascontiguousarray(Y.Yval, dtype=np.complex128); dev = np.ascontiguousarray(dev, dtype=np.int32)
+    Y_N = np.ascontiguousarray(Y_N, dtype=np.complex128); I_N = np.ascontiguousarray(I_N, dtype=np.complex128)
+    d.n, d.m, d.c, d.Hn, d.nnz = nn, m, c, Hn, len(col)
+    d.n_dev, d.coupled, d.solver, d.device, d.max_scenarios = int(n_dev), 1, 1, 0, 1
+    d.rowptr, d.col = rowptr.ctypes.data_as(_lib.c_int_p), col.ctypes.data_as(_lib.c_int_p)
+    d.Yval = Yv.view(np.float64).ctypes.data_as(_lib.c_dbl_p); d.dev_of_bus = dev.ctypes.data_as(_lib.c_int_p)
+    d.Y_N = Y_N.view(np.float64).ctypes.data_as(_lib.c_dbl_p); d.I_N = I_N.view(np.float64).ctypes.data_as(_lib.c_dbl_p)
+    path = os.path.join(tempfile.mkdtemp(), "plan.txt")
+    assert _lib.load().hpf_tree_plan(C.byref(d), path.encode()) == 0
+    plan = {int(x.split()[0]): [int(v) for v in x.split()] for x in open(path) if not x.startswith("#")}
+    par = np.full(nn, -1)
+    for i in range(nn):
+        for e2 in range(rowptr[i], rowptr[i + 1]):
+            pass
+    print("m = %d (buses >= m are nonlinear), c = %d (buses 1 .. c-1 are PV)" % (m, c))
+    print("worst residual rows by bus:   bus  residual  error   plan record [k pard height depth kind vector_only hbm_children via_chain compress ...] or 2x2 algebra")
+    for i in np.argsort(-per_bus_r)[:12]:
+        print("   %4d  %.1e  %.1e   %s" % (i, per_bus_r[i], per_bus_e[i], plan.get(int(i), "2x2 algebra (linear subtree / chain)")))
+    print("worst errors by bus:")
+    for i in np.argsort(-per_bus_e)[:8]:
+        print("   %4d  %.1e  %.1e   %s" % (i, per_bus_r[i], per_bus_e[i], plan.get(int(i), "2x2 algebra (linear subtree / chain)")))
