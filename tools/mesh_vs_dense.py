@@ -13,6 +13,7 @@ import harmonic_power_flow_amd as hp              # noqa: E402
 from harmonic_power_flow_amd import api, synth    # noqa: E402
 
 INPUTS = os.path.join(REPO, "tests", "golden", "inputs")
+COUPLED = os.environ.get("MESH_COUPLED", "1") != "0"     # MESH_COUPLED=0: the reference's uncoupled Norton model
 for n, hmax, k in ((40, 11, 1), (40, 51, 2), (100, 27, 3), (100, 51, 3), (150, 51, 5), (300, 27, 8), (300, 51, 4)):
     tmp = tempfile.mkdtemp()
     fb, fl = synth.gen(n, seed=1, outdir=tmp)
@@ -20,10 +21,10 @@ for n, hmax, k in ((40, 11, 1), (40, 51, 2), (100, 27, 3), (100, 51, 3), (150, 5
     st = hp.Settings(H_MAX=hmax)
     buses, lines, m, nn, c = hp.init_network(fb, fl, settings=st)
     Y = hp.build_admittance_matrices(buses, lines, st.HARMONICS)
-    NE = hp.import_Norton_Equivalents(buses, True, st, INPUTS)
+    NE = hp.import_Norton_Equivalents(buses, COUPLED, st, INPUTS)
     row = []
     for solver in ("dense", "block_tree"):
-        dm = api._device_model(buses, Y, NE, True, st.HARMONICS, solver=solver)
+        dm = api._device_model(buses, Y, NE, COUPLED, st.HARMONICS, solver=solver)
         dm.set_loads(buses["P"].to_numpy(float), buses["Q"].to_numpy(float))
         dm.set_state(None, None, n_scen=1)
         dm.fund_pf(1e-6, 30)
@@ -36,4 +37,4 @@ for n, hmax, k in ((40, 11, 1), (40, 51, 2), (100, 27, 3), (100, 51, 3), (150, 5
         row.append("%s %2d it %.2f ms/it" % (solver, it[0], 1e3 * t / max(int(it[0]), 1)))
         N = dm.N
         dm.close()
-    print("n = %3d, K = %2d, %d ties (N = %5d): %s" % (n, (hmax + 1) // 2, k, N, "   ".join(row)))
+    print("n = %3d, K = %2d, %d ties (N = %5d, %s): %s" % (n, (hmax + 1) // 2, k, N, "coupled" if COUPLED else "uncoupled", "   ".join(row)))
